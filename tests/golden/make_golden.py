@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Capture golden vectors FROM THE REFERENCE ITSELF (run in the build container only).
+
+    python tests/golden/make_golden.py          # writes tests/golden/*.npz
+
+Imports /root/reference/{TriPlane,InfoInv}/models read-only (torch CPU), loads seeded
+parameters from ``ngf_amd.synth`` into the reference modules by attribute assignment (the same
+way the reference's own ``up_sampling`` replaces planes, TriPlane/models/Field.py:110-112), runs
+the reference ``forward`` and a few of its sub-functions, and stores inputs + outputs.
+
+The fixtures hold DATA only: rays, scalar configuration, parameter checksums (the parameters
+themselves are regenerated bit-exactly from the seed by ``synth``) and the reference's outputs.
+/root/reference never travels to the GPU box; these files do.
+"""
+import contextlib
+import importlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import ngf_amd  # noqa: E402
+from ngf_amd import synth  # noqa: E402
+
+REF = "/root/reference"
+
+
+def _import_ref(subdir):
+    """Import <subdir>/models.Field from the reference with a clean ``models`` namespace."""
+    for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[k]
+    sys.path.insert(0, os.path.join(REF, subdir))
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            mod = importlib.import_module("models.Field")
+    finally:
+        sys.path.pop(0)
+    return mod
+
+
+def _checksums(params):
+    out = {}
+    for k, v in params.items():
+        v64 = v.astype(np.float64).reshape(-1)
+        out["chk." + k] = np.array([v64.sum(), np.abs(v64).sum(), v64[:: max(1, v64.size // 7)][:7].sum()])
+    return out
+
+
+def _load_params(field, params):
+    for k, v in params.items():
+        obj = field
+        parts = k.split(".")
+        for p in parts[:-1]:
+            obj = getattr(obj, p) if not p.isdigit() else obj[int(p)]
+        setattr(obj, parts[-1], torch.nn.Parameter(torch.from_numpy(v.copy())))
+
+
+def _rays_for_case(seed, n_frame=160, n_edge=64):
+    frame = synth.lookat_rays(40, 40)
+    pick = (synth.hash_uniform(seed, 400, (n_frame,)) * np.float32(frame.shape[0])).astype(np.int64)
+    return np.concatenate([frame[pick], synth.edge_rays(seed, n_edge)], 0)
+
+
+def capture_triplane(name, seed, preset, gauge_on, gauge_std, with_mask, S, white_bg=True):
+    F = _import_ref("TriPlane")
+    aabb = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
+    grid = [24, 20, 18]
+    plane_hw = ((20, 24), (18, 20), (18, 24))   # plane_xy [Ny,Nx], plane_yz [Nz,Ny], plane_xz [Nz,Nx]
+    gauge_hw = (12, 14)
+    params = synth.triplane_params(seed, plane_hw, gauge_hw, preset=preset, gauge_std=gauge_std)
+    with contextlib.redirect_stdout(io.StringIO()):
+        field = F.TriPlane(aabb, grid, "cpu", near_far=[2.0, 6.0], alphaMask_thres=1e-4, distance_scale=25,
+                           rayMarch_weight_thres=1e-4, step_ratio=0.5, gauge_start=0)
+    _load_params(field, params)
+    extra = {}
+    if with_mask:
+        dhw = (10, 12, 14)
+        vol, bits = synth.alpha_mask_bits(seed, dhw)
+        maabb = torch.tensor([[-1.4, -1.3, -1.45], [1.35, 1.5, 1.2]])
+        field.alphaMask = F.AlphaGridMask("cpu", maabb, torch.from_numpy(vol.astype(np.float32)))
+        extra = {"mask_bits": bits, "mask_dhw": np.array(dhw), "mask_aabb": maabb.numpy()}
+    rays = _rays_for_case(seed)
+    iteration = 30001 if gauge_on else -1
+    field.gauge_start = 0
+    with torch.no_grad():
+        out = field(torch.from_numpy(rays), white_bg=white_bg, is_train=False, N_samples=S, iteration=iteration)
+        # intermediates of the first 8 rays through the reference's own sub-functions
+        r8 = torch.from_numpy(rays[:8])
+        pts, z, valid = field.sample_ray(r8[:, :3], r8[:, 3:6], is_train=False, N_samples=S)
+        if with_mask:
+            a = field.alphaMask.sample_alpha(pts[valid])
+            inv = ~valid
+            inv[valid] |= ~(a > 0)
+            valid = ~inv
+        xyzn = field.normalize_coord(pts)
+        sigma = torch.zeros(pts.shape[:-1])
+        coords = torch.zeros((*pts.shape[:2], 6))
+        if valid.any():
+            txy, tyz, txz = field.compute_gauge(xyzn[valid], iteration=iteration)
+            sigma[valid] = field.compute_density(txy, tyz, txz)
+            coords[valid] = torch.cat([txy, tyz, txz], -1)
+        dists = torch.cat((z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])), -1)
+        alpha, weight, _ = F.raw2alpha(sigma, dists * field.distance_scale)
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"), model="triplane", seed=seed, preset=preset, gauge_on=int(gauge_on),
+        gauge_std=np.float32(gauge_std), S=S, white_bg=int(white_bg), aabb=aabb.numpy(), grid=np.array(grid),
+        plane_hw=np.array(plane_hw), gauge_hw=np.array(gauge_hw), near_far=np.array([2.0, 6.0], np.float32),
+        step_ratio=np.float32(0.5), distance_scale=np.float32(25), thr=np.float32(1e-4),
+        stepSize=field.stepSize.numpy(), nSamples=field.nSamples, rays=rays,
+        rgb_map=out["rgb_map"].numpy(), depth_map=out["depth_map"].numpy(),
+        i_z=z.numpy(), i_valid=valid.numpy(), i_sigma=sigma.numpy(), i_coords=coords.numpy(),
+        i_alpha=alpha.numpy(), i_weight=weight.numpy(), **_checksums(params), **extra)
+    act = float((weight > 1e-4).float().mean())
+    print(f"{name}: rays {rays.shape[0]} S {S} mean rgb {out['rgb_map'].mean():.5f} active(first 8) {act:.3f}")
+
+
+def capture_infoinv(name, seed, preset, infoinv, S):
+    F = _import_ref("InfoInv")
+    aabb = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
+    grid = [22, 22, 22]
+    plane_hw = ((16, 18), (14, 16), (14, 18))
+    params = synth.infoinv_params(seed, plane_hw, preset=preset)
+    with contextlib.redirect_stdout(io.StringIO()):
+        field = F.TriPlane(aabb, grid, "cpu", near_far=[2.0, 6.0], alphaMask_thres=1e-4, distance_scale=25,
+                           rayMarch_weight_thres=1e-4, step_ratio=0.5)
+    _load_params(field, params)
+    rays = _rays_for_case(seed, 96, 32)
+    with torch.no_grad():
+        out = field(torch.from_numpy(rays), white_bg=True, is_train=False, N_samples=S, infoinv=infoinv)
+        r8 = torch.from_numpy(rays[:8])
+        pts, z, valid = field.sample_ray(r8[:, :3], r8[:, 3:6], is_train=False, N_samples=S)
+        xyzn = field.normalize_coord(pts)
+        sigma = torch.zeros(pts.shape[:-1])
+        if valid.any():
+            txy, tyz, txz = field.transform(xyzn[valid])
+            sigma[valid] = field.compute_density(txy, tyz, txz, infoinv=infoinv)
+        dists = torch.cat((z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])), -1)
+        alpha, weight, _ = F.raw2alpha(sigma, dists * field.distance_scale)
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"), model="infoinv", seed=seed, preset=preset, infoinv=int(infoinv), S=S,
+        white_bg=1, aabb=aabb.numpy(), grid=np.array(grid), plane_hw=np.array(plane_hw),
+        near_far=np.array([2.0, 6.0], np.float32), step_ratio=np.float32(0.5), distance_scale=np.float32(25),
+        thr=np.float32(1e-4), stepSize=field.stepSize.numpy(), nSamples=field.nSamples, rays=rays,
+        rgb_map=out["rgb_map"].numpy(), depth_map=out["depth_map"].numpy(),
+        i_z=z.numpy(), i_valid=valid.numpy(), i_sigma=sigma.numpy(), i_alpha=alpha.numpy(),
+        i_weight=weight.numpy(), **_checksums(params))
+    print(f"{name}: rays {rays.shape[0]} S {S} mean rgb {out['rgb_map'].mean():.5f}")
+
+
+def capture_ops(name="ops_grid_sample"):
+    """Pin the two ATen samplers on their own: rectangular plane, out-of-range coordinates."""
+    import torch.nn.functional as Fn
+    plane = synth.hash_normal(5, 1, (1, 5, 7, 9))
+    uv = (synth.hash_uniform(5, 2, (300, 2)) * np.float32(2.6) - np.float32(1.3))
+    uv[:8] = np.array([[-1, -1], [1, 1], [1, -1], [-1, 1], [0, 0], [1.0000001, 0], [-1.0000001, 0.5], [0.999999, 1]])
+    out2 = Fn.grid_sample(torch.from_numpy(plane), torch.from_numpy(uv).view(1, -1, 1, 2), align_corners=True)
+    out2 = out2.view(5, -1).T.contiguous().numpy()
+    vol, bits = synth.alpha_mask_bits(6, (5, 6, 7))
+    q = (synth.hash_uniform(5, 3, (400, 3)) * np.float32(2.4) - np.float32(1.2))
+    q[:4] = np.array([[-1, -1, -1], [1, 1, 1], [0, 0, 0], [1, -1, 0.5]])
+    out3 = Fn.grid_sample(torch.from_numpy(vol.astype(np.float32)).view(1, 1, 5, 6, 7),
+                          torch.from_numpy(q).view(1, -1, 1, 1, 3), align_corners=True).view(-1).numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), plane=plane, uv=uv, out2=out2,
+                        mask_bits=bits, mask_dhw=np.array([5, 6, 7]), q=q, out3=out3)
+    print(f"{name}: 2-D {out2.shape}, 3-D {out3.shape} (positive {int((out3 > 0).sum())})")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    capture_ops()
+    capture_triplane("triplane_r1_gauge", seed=11, preset="R1", gauge_on=True, gauge_std=0.05, with_mask=False, S=48)
+    capture_triplane("triplane_r2_nogauge", seed=12, preset="R2", gauge_on=False, gauge_std=0.05, with_mask=False, S=40,
+                     white_bg=False)
+    capture_triplane("triplane_r1_mask", seed=13, preset="R1", gauge_on=True, gauge_std=0.02, with_mask=True, S=48)
+    capture_triplane("triplane_r0", seed=14, preset="R0", gauge_on=True, gauge_std=0.01, with_mask=False, S=32)
+    capture_infoinv("infoinv_r1_on", seed=21, preset="R1", infoinv=True, S=40)
+    capture_infoinv("infoinv_r1_off", seed=22, preset="R1", infoinv=False, S=40)

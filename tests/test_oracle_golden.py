@@ -1,0 +1,65 @@
+"""Pins the CPU restatement (oracle/ngf_oracle.c) against outputs of the reference itself.
+
+The reference has no tests or golden vectors of its own; the fixtures in
+tests/golden/ were captured by importing /root/reference with torch 2.10.0 CPU
+(tests/golden/make_golden.py).  Tolerance: 1e-6 abs on pixels --
+the only differences are summation order and libm-vs-SLEEF last-ulp effects.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import load_case, oracle_for_case
+from oracle import oracle as O
+
+TRIPLANE = ["triplane_r1_gauge", "triplane_r2_nogauge", "triplane_r1_mask", "triplane_r0"]
+INFOINV = ["infoinv_r1_on", "infoinv_r1_off"]
+
+
+@pytest.mark.parametrize("name", TRIPLANE + INFOINV)
+def test_render_matches_reference(name):
+    g, params, step, mask = load_case(name)
+    assert np.float32(step) == np.float32(g["stepSize"]), "init_para stepSize restatement differs"
+    orc = oracle_for_case(g, params, step, mask)
+    rgb, depth, dbg = orc.render(g["rays"], int(g["S"]), white_bg=bool(int(g["white_bg"])), debug_rays=8)
+    assert np.max(np.abs(rgb - g["rgb_map"])) <= 2e-6
+    assert np.max(np.abs(depth - g["depth_map"])) <= 5e-6
+    # intermediates of the first 8 rays: positions and masks are bit-exact, the rest to rounding
+    assert np.array_equal(dbg["z"], g["i_z"])
+    assert np.array_equal(dbg["valid"].astype(bool), g["i_valid"])
+    np.testing.assert_allclose(dbg["sigma"], g["i_sigma"], rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(dbg["alpha"], g["i_alpha"], rtol=1e-4, atol=2e-7)
+    np.testing.assert_allclose(dbg["weight"], g["i_weight"], rtol=1e-4, atol=2e-7)
+    if "i_coords" in g:
+        np.testing.assert_allclose(dbg["coords"], g["i_coords"], rtol=0, atol=5e-7)
+
+
+def test_nsamples_restatement():
+    from ngf_amd import geometry
+    for name in TRIPLANE[:1] + INFOINV[:1]:
+        g, _, step, _ = load_case(name)
+        assert geometry.n_samples(g["aabb"], step) == int(g["nSamples"])
+    # headline geometry: 256^3 grid, +-1.5 box, step_ratio 0.5
+    aabb = [[-1.5] * 3, [1.5] * 3]
+    s = geometry.step_size(aabb, [256] * 3, 0.5)
+    assert abs(float(s) - 0.0058823532) < 1e-9 and geometry.n_samples(aabb, s) == 884
+
+
+def test_samplers_match_aten(golden_dir):
+    g = np.load(golden_dir + "/ops_grid_sample.npz")
+    lib = O.lib()
+    plane = np.ascontiguousarray(g["plane"][0])
+    uv = np.ascontiguousarray(g["uv"])
+    out = np.zeros((uv.shape[0], plane.shape[0]), np.float32)
+    lib.ngf_oracle_bilerp2d(plane.ctypes.data_as(C.c_void_p), plane.shape[1], plane.shape[2], plane.shape[0],
+                            uv.ctypes.data_as(C.c_void_p), C.c_int64(uv.shape[0]), out.ctypes.data_as(C.c_void_p))
+    assert np.max(np.abs(out - g["out2"])) <= 5e-7
+    q = np.ascontiguousarray(g["q"])
+    bits = np.ascontiguousarray(g["mask_bits"])
+    d, h, w = (int(v) for v in g["mask_dhw"])
+    out3 = np.zeros((q.shape[0],), np.float32)
+    lib.ngf_oracle_mask_sample(bits.ctypes.data_as(C.c_void_p), d, h, w, q.ctypes.data_as(C.c_void_p),
+                               C.c_int64(q.shape[0]), out3.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(out3 > 0, g["out3"] > 0)       # the path only uses the sign (FieldBase.py:264)
+    assert np.max(np.abs(out3 - g["out3"])) <= 5e-7
