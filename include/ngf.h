@@ -1,0 +1,122 @@
+/*
+ * ngf.h -- C ABI of libngf_hip.so: the MI355X (gfx950) implementation of the reference's
+ * TriPlane / InfoInv ray-march hot path (fnzhan/Neural-Gauge-Fields).
+ *
+ * The reference has no native code and no FFI: its boundary for this path is the Python call
+ *     field(rays_chunk, white_bg, is_train, N_samples, iteration)  -> {'rgb_map','depth_map'}
+ *         TriPlane/models/FieldBase.py:251-312   (InfoInv/models/FieldBase.py:228-282)
+ *     renderer(rays, field, chunk, N_samples, white_bg, is_train, device) -> (rgb, depth)
+ *         TriPlane/main.py:60-71                 (InfoInv/main.py:61-72)
+ * over parameters created by TriPlane.init_model (TriPlane/models/Field.py:17-32;
+ * InfoInv/models/Field.py:14-24) and stored in the checkpoint dict of Base.save/load
+ * (TriPlane/models/FieldBase.py:94-116).  Each entry point below names the piece of that
+ * boundary it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds on the
+ * reference side.
+ *
+ * Conventions: plain pointers and sizes only; every data pointer is a DEVICE pointer unless
+ * stated otherwise; all work is enqueued on the caller's HIP stream (hipStream_t passed as
+ * void*) and nothing synchronises except ngf_field_create (which copies ~150 KB of MLP weights
+ * to the host once to pre-compose them).  Return value 0 = success, otherwise an NGF_E_* code
+ * and ngf_last_error() holds a message for the calling thread.  No C++ exception crosses the ABI.
+ */
+#ifndef NGF_H
+#define NGF_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGF_ABI_VERSION 1
+
+enum { NGF_OK = 0, NGF_E_ARG = 1, NGF_E_HIP = 2, NGF_E_UNSUPPORTED = 3 };
+enum { NGF_MODEL_TRIPLANE = 0, NGF_MODEL_INFOINV = 1 };
+
+/* ngf_field_desc.flags */
+enum {
+    NGF_F_BAKE_DENSITY = 1 /* TriPlane: pre-compose density_decoder Linear(48,1) with the 16 density
+                              channels of each plane (exact algebra: a Linear commutes with bilinear
+                              interpolation); the march then gathers 1 instead of 16 channels per tap */
+};
+
+/* Parameter set of one field, in the reference's own tensor layouts (NCHW planes, nn.Linear
+ * weights [out,in], all float32, contiguous).  Mirrors TriPlane.init_model (Field.py:17-32) /
+ * InfoInv init_model (InfoInv/models/Field.py:14-24) + the scalars of Base.__init__/init_para
+ * (FieldBase.py:45-74) + the optional AlphaGridMask (FieldBase.py:22-40, ckpt keys
+ * 'alphaMask.shape' / 'alphaMask.mask' (np.packbits) / 'alphaMask.aabb', FieldBase.py:104-108). */
+typedef struct ngf_field_desc {
+    int32_t model;                 /* NGF_MODEL_* */
+    int32_t flags;                 /* NGF_F_* */
+    int32_t plane_c;               /* 64 (TriPlane) | 96 (InfoInv) */
+    int32_t dens_dim;              /* 16 | 24: leading channels of each plane that feed density */
+    const float *plane[3];         /* plane_xy [1,C,Ny,Nx], plane_yz [1,C,Nz,Ny], plane_xz [1,C,Nz,Nx] */
+    int32_t plane_h[3], plane_w[3];
+    const float *gauge[3];         /* gauge_xy, gauge_yz, gauge_xz [1,2,H,W]; NULL for InfoInv */
+    int32_t gauge_h[3], gauge_w[3];
+    /* density decoder: TriPlane Linear(48,1) -> (dens_w1 [1,48], dens_b1 [1]), others NULL;
+       InfoInv density_decoder.mlp.{0,2,4}: [32,72],[32]; [32,32],[32]; [1,32],[1] */
+    const float *dens_w1, *dens_b1, *dens_w2, *dens_b2, *dens_w3, *dens_b3;
+    /* rgb_decoder: basis.weight [F,F] (F = 3*(plane_c-dens_dim)); mlp.0 [64,F+15],[64];
+       mlp.2 [64,64],[64]; mlp.4 [3,64],[3]   (networks.py:12-32) */
+    const float *basis, *w1, *b1, *w2, *b2, *w3, *b3;
+    float aabb[6];                 /* aabb[0] xyz, aabb[1] xyz */
+    float near_, far_;             /* near_far */
+    float step;                    /* stepSize (FieldBase.py:70) -- computed by the caller in float32 */
+    float distance_scale;          /* 25 */
+    float weight_thres;            /* rayMarch_weight_thres, 1e-4 */
+    /* optional alpha mask: the checkpoint's np.packbits image of the [D,H,W] volume (bit = occupied) */
+    const uint8_t *mask_bits;      /* NULL = no mask */
+    int32_t mask_d, mask_h, mask_w;
+    float mask_aabb[6];
+} ngf_field_desc;
+
+typedef struct ngf_field ngf_field; /* opaque: packed (channel-last, zero-bordered) textures + MLP image */
+
+/* Replaces: model construction + load_state_dict (TriPlane/main.py:34-38, FieldBase.py:111-116).
+ * Re-packs the parameters into the kernel's HBM layout (DESIGN.md "Data layout"); the source
+ * tensors are only read during this call and may be freed afterwards.  Call again (and destroy
+ * the old handle) whenever the parameters change. */
+int ngf_field_create(const ngf_field_desc *desc, ngf_field **out, void *hip_stream);
+int ngf_field_destroy(ngf_field *f);
+
+/* Replaces: Base.forward (FieldBase.py:251-312 / InfoInv FieldBase.py:228-282) for n rays, i.e. also
+ * the whole chunk loop of renderer (main.py:60-71) when n is the full frame.
+ *   rays      [n,6] float32 (origin, direction) row-major
+ *   n_samples S > 0 (the caller resolves N_samples<=0 to nSamples)
+ *   white_bg  rgb += 1 - acc                                       (FieldBase.py:299-300)
+ *   mode      TriPlane: 1 = gauge on (iteration >= gauge_start), 0 = identity split (Field.py:58,73)
+ *             InfoInv : 1 = infoinv sinusoidal modulation on, 0 = off  (InfoInv Field.py:63,83)
+ *   jitter    NULL (eval) or [n] per-ray U[0,1) offsets of the sample index (is_train, FieldBase.py:128-130)
+ *   rgb [n,3], depth [n]  outputs
+ *   stats     NULL or 4 x uint64: += {in-box samples, active (weight>thr) samples, MLP passes, rays}
+ */
+int ngf_field_render(const ngf_field *f, const float *rays, int64_t n, int32_t n_samples, int32_t white_bg,
+                     int32_t mode, const float *jitter, float *rgb, float *depth, uint64_t *stats,
+                     void *hip_stream);
+
+/* Pieces of the path exposed for parity tests (same device code as ngf_field_render):
+ *   ngf_field_decode_rgb : compute_rgb + rgb_decoder (Field.py:93-105, networks.py:25-32) for n samples
+ *                          given their (gauge-shifted) plane coordinates [n,6] and view directions [n,3]
+ *   ngf_field_march      : per-sample sigma and weight [n,S] (sample_ray .. raw2alpha) */
+int ngf_field_decode_rgb(const ngf_field *f, const float *coords, const float *dirs, int64_t n, int32_t mode,
+                         float *rgb, void *hip_stream);
+int ngf_field_march(const ngf_field *f, const float *rays, int64_t n, int32_t n_samples, int32_t mode,
+                    const float *jitter, float *sigma, float *weight, void *hip_stream);
+
+/* Replaces: get_ray_directions + get_rays for a pin-hole camera (TriPlane/dataLoader/ray_utils.py:24-42,
+ * 66-87; blender.py:46-53,84-85): rays [rows*W,6] for image rows [row0,row0+rows), c2w = HOST float[12]
+ * (3x4 row-major, OpenCV axes), directions normalised as blender.py:52. */
+int ngf_generate_rays(int32_t H, int32_t W, float focal, const float *c2w_host, int32_t row0, int32_t rows,
+                      float *rays, void *hip_stream);
+
+const char *ngf_last_error(void);
+int ngf_abi_version(void);
+/* sizeof(ngf_field_desc) as compiled into the library (binding self-check) */
+int ngf_sizeof_field_desc(void);
+/* bytes of HBM the handle owns (packed textures + MLP image) */
+int64_t ngf_field_bytes(const ngf_field *f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

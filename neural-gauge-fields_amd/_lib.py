@@ -1,0 +1,72 @@
+"""ctypes binding of libngf_hip.so (include/ngf.h).  There is no fallback: if the HIP library is
+missing or fails to load, importing a field and rendering raises -- the product path never routes
+through the CPU oracle."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+SO_PATH = os.path.join(_CSRC, "libngf_hip.so")
+_LIB = None
+
+MODEL_TRIPLANE, MODEL_INFOINV = 0, 1
+F_BAKE_DENSITY = 1
+
+SYMBOLS = ["ngf_field_create", "ngf_field_destroy", "ngf_field_render", "ngf_field_decode_rgb", "ngf_field_march",
+           "ngf_generate_rays", "ngf_last_error", "ngf_abi_version", "ngf_field_bytes", "ngf_sizeof_field_desc"]
+
+
+class FieldDesc(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("flags", C.c_int32), ("plane_c", C.c_int32), ("dens_dim", C.c_int32),
+        ("plane", C.c_void_p * 3), ("plane_h", C.c_int32 * 3), ("plane_w", C.c_int32 * 3),
+        ("gauge", C.c_void_p * 3), ("gauge_h", C.c_int32 * 3), ("gauge_w", C.c_int32 * 3),
+        ("dens_w1", C.c_void_p), ("dens_b1", C.c_void_p), ("dens_w2", C.c_void_p),
+        ("dens_b2", C.c_void_p), ("dens_w3", C.c_void_p), ("dens_b3", C.c_void_p),
+        ("basis", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p),
+        ("b2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p),
+        ("aabb", C.c_float * 6), ("near_", C.c_float), ("far_", C.c_float), ("step", C.c_float),
+        ("distance_scale", C.c_float), ("weight_thres", C.c_float),
+        ("mask_bits", C.c_void_p), ("mask_d", C.c_int32), ("mask_h", C.c_int32), ("mask_w", C.c_int32),
+        ("mask_aabb", C.c_float * 6),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile libngf_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", _CSRC, "libngf_hip.so"] + (["-B"] if force else [])
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return SO_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the HIP extension is the only render path; there is no CPU fallback)")
+        L = C.CDLL(SO_PATH)
+        L.ngf_last_error.restype = C.c_char_p
+        L.ngf_abi_version.restype = C.c_int
+        L.ngf_field_bytes.restype = C.c_int64
+        L.ngf_field_bytes.argtypes = [C.c_void_p]
+        L.ngf_field_create.argtypes = [C.POINTER(FieldDesc), C.POINTER(C.c_void_p), C.c_void_p]
+        L.ngf_field_destroy.argtypes = [C.c_void_p]
+        L.ngf_field_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ngf_field_decode_rgb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+        L.ngf_field_march.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
+        L.ngf_generate_rays.argtypes = [C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                        C.c_void_p]
+        if L.ngf_abi_version() != 1 or L.ngf_sizeof_field_desc() != C.sizeof(FieldDesc):
+            raise RuntimeError("libngf_hip.so ABI mismatch (version or ngf_field_desc layout)")
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError("libngf_hip: " + (lib().ngf_last_error() or b"?").decode())

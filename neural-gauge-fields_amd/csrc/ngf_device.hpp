@@ -1,0 +1,140 @@
+// ngf_device.hpp -- shared device-side definitions of the gfx950 ray-march kernels.
+//
+// Build note: the translation unit is compiled with -ffp-contract=off.  Every fused multiply-add
+// in this code is an explicit fmaf(); everything written as a*b+c is two roundings.  That keeps
+// the sample positions, the in-box test and the bilinear cell selection bit-identical to the
+// reference's eager fp32 arithmetic (SURVEY.md section 7 hazard 1), which is what makes the
+// threshold masks (valid, weight > thr) flip-free.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace ngf {
+
+constexpr int kWave = 64;
+constexpr int kRing = 128;          // wave-private queue of active samples (records)
+constexpr int kRecFloats = 8;       // {ray lane, weight, t_xy(2), t_yz(2), t_xz(2)}
+constexpr int kBatch = 32;          // samples per MLP pass = one 32-wide MFMA column tile
+constexpr int kViewFeat = 16;       // [d(3), sin(6), cos(6), 0]
+
+// A packed texture: channel-last texels with a one-texel zero border (zeros padding of
+// grid_sample becomes an in-bounds read of a zero texel).  p points at padded texel (0,0).
+struct Tex {
+    const float *p;
+    int32_t W, H;       // un-padded size; u indexes W, v indexes H
+    int32_t stride;     // W + 2 (texels per padded row)
+};
+
+struct MaskVol {
+    const uint8_t *bits;  // np.packbits image of [D,H,W]; NULL = none
+    int32_t D, H, W;
+    float a0[3], inv[3];  // mask aabb[0], invgridSize = 1/(aabb1-aabb0)*2
+};
+
+struct RenderArgs {
+    const float *rays;     // [n,6]
+    const float *jitter;   // [n] or NULL
+    float *rgb;            // [n,3]
+    float *depth;          // [n]
+    float *dbg_sigma;      // [n,S] or NULL   (ngf_field_march)
+    float *dbg_weight;     // [n,S] or NULL
+    unsigned long long *stats;  // 4 counters or NULL
+    unsigned int *tile_counter; // zeroed before the launch
+    int64_t n;
+    int32_t S, white_bg, mode, skip_rgb;
+    float a0[3], a1[3], inv[3];
+    float near_, far_, step, dscale, thr;
+    Tex dens[3];           // TriPlane: 16-ch (faithful) or 1-ch (baked) density texels
+    Tex app[3];            // colour texels (48 | 72 channels)
+    Tex gau[3];            // 2-ch gauge offsets (TriPlane)
+    MaskVol mask;
+    const float *blob;     // packed MLP image (copied into LDS by every workgroup)
+    int32_t blob_floats;
+    float wd[48];          // TriPlane faithful density_decoder.weight
+    float bd;              // density_decoder.bias
+};
+
+// ---- bilinear cell: ATen grid_sampler_2d, align_corners=True, padding_mode='zeros' -------------
+struct Bil {
+    int32_t idx;                 // padded texel index of the (x0,y0) tap; +1, +stride, +stride+1 are the others
+    float w00, w10, w01, w11;    // (1-fx)(1-fy), fx(1-fy), (1-fx)fy, fx*fy ; all 0 when the cell is out of range
+};
+
+__device__ __forceinline__ Bil bil_setup(float u, float v, const Tex &t)
+{
+    float px = ((u + 1.0f) / 2.0f) * (float)(t.W - 1);
+    float py = ((v + 1.0f) / 2.0f) * (float)(t.H - 1);
+    float fx = floorf(px), fy = floorf(py);
+    float wx1 = px - fx, wx0 = 1.0f - wx1;
+    float wy1 = py - fy, wy0 = 1.0f - wy1;
+    // x0 in [-1, W-1] <=> at least one of the taps x0, x0+1 can be inside; border texels are zero
+    bool in = (fx >= -1.0f) && (fx <= (float)(t.W - 1)) && (fy >= -1.0f) && (fy <= (float)(t.H - 1));
+    float cx = fminf(fmaxf(fx, -1.0f), (float)(t.W - 1));
+    float cy = fminf(fmaxf(fy, -1.0f), (float)(t.H - 1));
+    Bil b;
+    b.idx = ((int)cy + 1) * t.stride + ((int)cx + 1);
+    b.w00 = in ? wx0 * wy0 : 0.0f;
+    b.w10 = in ? wx1 * wy0 : 0.0f;
+    b.w01 = in ? wx0 * wy1 : 0.0f;
+    b.w11 = in ? wx1 * wy1 : 0.0f;
+    return b;
+}
+
+__device__ __forceinline__ float bil_mix(const Bil &b, float v00, float v10, float v01, float v11)
+{
+    return fmaf(b.w11, v11, fmaf(b.w01, v01, fmaf(b.w10, v10, b.w00 * v00)));
+}
+
+// ---- alpha mask: sign of ATen grid_sampler_3d on a {0,1} volume (FieldBase.py:33-40, 263-267) ----
+__device__ __forceinline__ int mask_bit(const MaskVol &m, int z, int y, int x)
+{
+    if (x < 0 || y < 0 || z < 0 || x >= m.W || y >= m.H || z >= m.D) return 0;
+    size_t idx = ((size_t)z * m.H + y) * m.W + x;
+    return (m.bits[idx >> 3] >> (7 - (int)(idx & 7))) & 1;
+}
+
+__device__ __forceinline__ bool mask_occupied(const MaskVol &m, const float p[3])
+{
+    float q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) q[k] = (p[k] - m.a0[k]) * m.inv[k] - 1.0f;
+    float ix = ((q[0] + 1.0f) / 2.0f) * (float)(m.W - 1);
+    float iy = ((q[1] + 1.0f) / 2.0f) * (float)(m.H - 1);
+    float iz = ((q[2] + 1.0f) / 2.0f) * (float)(m.D - 1);
+    float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    if (!(fx >= -2.0f && fx <= (float)m.W + 1.0f && fy >= -2.0f && fy <= (float)m.H + 1.0f && fz >= -2.0f &&
+          fz <= (float)m.D + 1.0f))
+        return false;
+    int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    float wx[2] = {(fx + 1.0f) - ix, ix - fx}, wy[2] = {(fy + 1.0f) - iy, iy - fy}, wz[2] = {(fz + 1.0f) - iz, iz - fz};
+    float acc = 0.0f;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+                if (mask_bit(m, z0 + dz, y0 + dy, x0 + dx)) acc += wx[dx] * wy[dy] * wz[dz];
+    return acc > 0.0f;
+}
+
+// feature2density (Field.py:48-50): F.softplus(x - 10), threshold 20
+__device__ __forceinline__ float softplus_shift(float f)
+{
+    float u = f + (-10.0f);
+    return u > 20.0f ? u : log1pf(expf(u));
+}
+
+// MFMA bookkeeping.  v_mfma_f32_32x32x2_f32 computes D[32x32] += A[32x2] * B[2x32]:
+//   lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+//   lane l, register r holds D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].
+// The MLP is evaluated transposed (rows = hidden units from LDS-resident weights, columns =
+// samples), so a lane's 16 accumulator registers are 16 hidden activations OF ITS OWN SAMPLE and
+// feed the next layer's B operand directly -- no transposition or cross-lane traffic between layers.
+__device__ __forceinline__ int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+}  // namespace ngf

@@ -1,0 +1,383 @@
+// ngf_hip.hip -- C ABI (include/ngf.h) + host side of the gfx950 ray-march library.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC ngf_hip.hip -o libngf_hip.so
+// (see Makefile).  No torch, no CPU fallback: every entry point runs HIP kernels or fails.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/ngf.h"
+#include "ngf_infoinv.hpp"
+#include "ngf_render.hpp"
+
+using namespace ngf;
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(NGF_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+struct ngf_field {
+    int32_t model = 0, flags = 0, plane_c = 0, dens_dim = 0, app = 0;
+    float *tex[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // dens[3], app[3], gau[3]
+    float *blob = nullptr;
+    uint8_t *mask = nullptr;
+    unsigned int *counters = nullptr;
+    mutable std::atomic<unsigned> next_counter{0};
+    RenderArgs proto;
+    int64_t bytes = 0;
+    int num_cus = 256;
+};
+static constexpr int kCounters = 256;
+
+// ---- packing kernels -----------------------------------------------------------------------------
+// NCHW [C,H,W] channels [c0,c0+nc) -> zero-bordered channel-last [(H+2)][(W+2)][nc]
+__global__ void pack_plane_kernel(const float *__restrict__ src, int H, int W, int c0, int nc, float *__restrict__ dst)
+{
+    const size_t total = (size_t)(H + 2) * (W + 2) * nc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nc);
+        const size_t tx = i / nc;
+        const int x = (int)(tx % (W + 2)), y = (int)(tx / (W + 2));
+        float v = 0.0f;
+        if (x >= 1 && x <= W && y >= 1 && y <= H) v = src[((size_t)(c0 + c) * H + (y - 1)) * W + (x - 1)];
+        dst[i] = v;
+    }
+}
+
+// density_decoder Linear(48,1) pre-composed with the density channels of one plane (fp64 accumulate)
+__global__ void bake_density_kernel(const float *__restrict__ src, int H, int W, int nc, const float *__restrict__ wd,
+                                    float *__restrict__ dst)
+{
+    const size_t total = (size_t)(H + 2) * (W + 2);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % (W + 2)), y = (int)(i / (W + 2));
+        double v = 0.0;
+        if (x >= 1 && x <= W && y >= 1 && y <= H)
+            for (int c = 0; c < nc; ++c) v += (double)wd[c] * (double)src[((size_t)c * H + (y - 1)) * W + (x - 1)];
+        dst[i] = (float)v;
+    }
+}
+
+// get_ray_directions + get_rays (ray_utils.py:24-42, 66-87; blender.py:52)
+__global__ void generate_rays_kernel(int H, int W, float focal, float r00, float r01, float r02, float r10, float r11,
+                                     float r12, float r20, float r21, float r22, float ox, float oy, float oz, int row0,
+                                     int rows, float *__restrict__ rays)
+{
+    const int64_t total = (int64_t)rows * W;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(q % W), row = row0 + (int)(q / W);
+        const float i = (float)col + 0.5f, j = (float)row + 0.5f;
+        float dx = (i - (float)W / 2) / focal, dy = (j - (float)H / 2) / focal, dz = 1.0f;
+        const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz);
+        dx = dx / nrm; dy = dy / nrm; dz = dz / nrm;
+        float *r = rays + q * 6;
+        r[0] = ox; r[1] = oy; r[2] = oz;
+        r[3] = (dx * r00 + dy * r01) + dz * r02;
+        r[4] = (dx * r10 + dy * r11) + dz * r12;
+        r[5] = (dx * r20 + dy * r21) + dz * r22;
+    }
+}
+
+// ---- MLP image -------------------------------------------------------------------------------------
+// Builds the LDS image described in ngf_render.hpp (MlpLayout) from the reference's rgb_decoder
+// weights.  basis (no bias, no activation; networks.py:17,26) is pre-composed with layer 1 in fp64:
+// W1' = W1[:, :F] @ basis.  Row/column permutations put every MFMA operand at [k-step][lane].
+static void build_rgb_image(int F, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
+                            const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3,
+                            const std::vector<float> &b3, float *img)
+{
+    const int IN = F + 15, HALF = F / 6, KT = 3 * HALF + 8;
+    std::vector<double> w1f((size_t)64 * (F + 16), 0.0);
+    for (int n = 0; n < 64; ++n) {
+        for (int k = 0; k < F; ++k) {
+            double s = 0.0;
+            for (int j = 0; j < F; ++j) s += (double)w1[(size_t)n * IN + j] * (double)basis[(size_t)j * F + k];
+            w1f[(size_t)n * (F + 16) + k] = s;
+        }
+        for (int k = 0; k < 15; ++k) w1f[(size_t)n * (F + 16) + F + k] = w1[(size_t)n * IN + F + k];
+    }
+    auto kmap = [&](int t, int hi) {
+        if (t < 3 * HALF) return (t / HALF) * (2 * HALF) + hi * HALF + (t % HALF);
+        return F + hi * 8 + (t - 3 * HALF);
+    };
+    const int oW1 = 0, oW2 = oW1 + 2 * KT * 64, oB1 = oW2 + 2 * 32 * 64, oB2 = oB1 + 64, oW3 = oB2 + 64, oB3 = oW3 + 192;
+    for (int nt = 0; nt < 2; ++nt)
+        for (int t = 0; t < KT; ++t)
+            for (int l = 0; l < 64; ++l)
+                img[oW1 + ((size_t)nt * KT + t) * 64 + l] = (float)w1f[(size_t)(nt * 32 + (l & 31)) * (F + 16) + kmap(t, l >> 5)];
+    for (int mt = 0; mt < 2; ++mt)
+        for (int k = 0; k < 32; ++k)
+            for (int l = 0; l < 64; ++l) {
+                const int n = (k >> 4) * 32 + ((k & 15) & 3) + 8 * ((k & 15) >> 2) + 4 * (l >> 5);
+                img[oW2 + ((size_t)mt * 32 + k) * 64 + l] = w2[(size_t)(mt * 32 + (l & 31)) * 64 + n];
+            }
+    for (int hi = 0; hi < 2; ++hi)
+        for (int k = 0; k < 32; ++k) {
+            const int n = (k >> 4) * 32 + ((k & 15) & 3) + 8 * ((k & 15) >> 2) + 4 * hi;
+            img[oB1 + hi * 32 + k] = b1[n];
+            img[oB2 + hi * 32 + k] = b2[n];
+            for (int c = 0; c < 3; ++c) img[oW3 + c * 64 + hi * 32 + k] = w3[(size_t)c * 64 + n];
+        }
+    for (int c = 0; c < 3; ++c) img[oB3 + c] = b3[c];
+    img[oB3 + 3] = 0.0f;
+}
+
+static int d2h(std::vector<float> &dst, const float *src, size_t n, hipStream_t st)
+{
+    dst.resize(n);
+    if (!src) return fail(NGF_E_ARG, "missing weight tensor");
+    HIP_TRY(hipMemcpyAsync(dst.data(), src, n * sizeof(float), hipMemcpyDeviceToHost, st));
+    return NGF_OK;
+}
+
+static int alloc_f(float **p, size_t n, ngf_field *f)
+{
+    HIP_TRY(hipMalloc((void **)p, n * sizeof(float)));
+    f->bytes += (int64_t)(n * sizeof(float));
+    return NGF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int ngf_abi_version(void) { return NGF_ABI_VERSION; }
+extern "C" int ngf_sizeof_field_desc(void) { return (int)sizeof(ngf_field_desc); }
+extern "C" const char *ngf_last_error(void) { return g_err; }
+extern "C" int64_t ngf_field_bytes(const ngf_field *f) { return f ? f->bytes : 0; }
+
+extern "C" int ngf_field_destroy(ngf_field *f)
+{
+    if (!f) return NGF_OK;
+    for (float *t : f->tex)
+        if (t) (void)hipFree(t);
+    if (f->blob) (void)hipFree(f->blob);
+    if (f->mask) (void)hipFree(f->mask);
+    if (f->counters) (void)hipFree(f->counters);
+    delete f;
+    return NGF_OK;
+}
+
+extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *hip_stream)
+{
+    if (!d || !out) return fail(NGF_E_ARG, "ngf_field_create: null argument");
+    *out = nullptr;
+    const bool tri = d->model == NGF_MODEL_TRIPLANE;
+    if (!tri && d->model != NGF_MODEL_INFOINV) return fail(NGF_E_ARG, "unknown model %d", d->model);
+    if (tri && (d->plane_c != 64 || d->dens_dim != 16)) return fail(NGF_E_UNSUPPORTED, "TriPlane expects 64-channel planes with 16 density channels");
+    if (!tri && (d->plane_c != 96 || d->dens_dim != 24)) return fail(NGF_E_UNSUPPORTED, "InfoInv expects 96-channel planes with 24 density channels");
+    for (int p = 0; p < 3; ++p) {
+        if (!d->plane[p] || d->plane_h[p] < 2 || d->plane_w[p] < 2) return fail(NGF_E_ARG, "plane %d missing or smaller than 2x2", p);
+        if (tri && (!d->gauge[p] || d->gauge_h[p] < 2 || d->gauge_w[p] < 2)) return fail(NGF_E_ARG, "gauge plane %d missing or smaller than 2x2", p);
+    }
+    if (!(d->step > 0.0f)) return fail(NGF_E_ARG, "step must be > 0");
+    hipStream_t st = (hipStream_t)hip_stream;
+    ngf_field *f = new (std::nothrow) ngf_field();
+    if (!f) return fail(NGF_E_HIP, "out of host memory");
+    f->model = d->model; f->flags = d->flags; f->plane_c = d->plane_c; f->dens_dim = d->dens_dim;
+    f->app = d->plane_c - d->dens_dim;
+    const int F = 3 * f->app;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) f->num_cus = prop.multiProcessorCount;
+
+    int rc = NGF_OK;
+    RenderArgs &A = f->proto;
+    memset(&A, 0, sizeof(A));
+    auto bail = [&](int code) { ngf_field_destroy(f); return code; };
+
+    const bool bake = tri && (d->flags & NGF_F_BAKE_DENSITY);
+    std::vector<float> wd, bd;
+    float *wd_dev = nullptr;
+    for (int p = 0; p < 3; ++p) {
+        const int H = d->plane_h[p], W = d->plane_w[p];
+        const size_t texels = (size_t)(H + 2) * (W + 2);
+        const int dc = bake ? 1 : d->dens_dim;
+        if ((rc = alloc_f(&f->tex[p], texels * dc, f))) return bail(rc);
+        if ((rc = alloc_f(&f->tex[3 + p], texels * f->app, f))) return bail(rc);
+        if (bake) {
+            bake_density_kernel<<<1024, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, d->dens_w1 + p * d->dens_dim, f->tex[p]);
+        } else {
+            pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, 0, d->dens_dim, f->tex[p]);
+        }
+        pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, f->tex[3 + p]);
+        A.dens[p] = Tex{f->tex[p], W, H, W + 2};
+        A.app[p] = Tex{f->tex[3 + p], W, H, W + 2};
+        if (tri) {
+            const int gh = d->gauge_h[p], gw = d->gauge_w[p];
+            if ((rc = alloc_f(&f->tex[6 + p], (size_t)(gh + 2) * (gw + 2) * 2, f))) return bail(rc);
+            pack_plane_kernel<<<256, 256, 0, st>>>(d->gauge[p], gh, gw, 0, 2, f->tex[6 + p]);
+            A.gau[p] = Tex{f->tex[6 + p], gw, gh, gw + 2};
+        }
+    }
+    (void)wd_dev;
+    if (hipGetLastError() != hipSuccess) return bail(fail(NGF_E_HIP, "packing kernels failed to launch"));
+
+    // MLP weights: to the host once, pre-compose, permute, back to HBM as one LDS image
+    std::vector<float> basis, w1, b1, w2, b2, w3, b3;
+    if ((rc = d2h(basis, d->basis, (size_t)F * F, st)) || (rc = d2h(w1, d->w1, (size_t)64 * (F + 15), st)) ||
+        (rc = d2h(b1, d->b1, 64, st)) || (rc = d2h(w2, d->w2, 64 * 64, st)) || (rc = d2h(b2, d->b2, 64, st)) ||
+        (rc = d2h(w3, d->w3, 3 * 64, st)) || (rc = d2h(b3, d->b3, 3, st)))
+        return bail(rc);
+    std::vector<float> dw1, db1, dw2, db2, dw3, db3;
+    if (tri) {
+        if ((rc = d2h(dw1, d->dens_w1, 48, st)) || (rc = d2h(db1, d->dens_b1, 1, st))) return bail(rc);
+    } else {
+        if ((rc = d2h(dw1, d->dens_w1, 32 * 72, st)) || (rc = d2h(db1, d->dens_b1, 32, st)) ||
+            (rc = d2h(dw2, d->dens_w2, 32 * 32, st)) || (rc = d2h(db2, d->dens_b2, 32, st)) ||
+            (rc = d2h(dw3, d->dens_w3, 32, st)) || (rc = d2h(db3, d->dens_b3, 1, st)))
+            return bail(rc);
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "hipStreamSynchronize failed in ngf_field_create"));
+
+    const int rgb_floats = tri ? MlpLayout<48>::TOTAL : MlpLayout<72>::TOTAL;
+    const int dens_floats = tri ? 0 : InfoInvDensLayout::TOTAL;
+    std::vector<float> img((size_t)rgb_floats + dens_floats, 0.0f);
+    build_rgb_image(F, basis, w1, b1, w2, b2, w3, b3, img.data());
+    if (!tri) build_infoinv_density_image(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
+    if ((rc = alloc_f(&f->blob, img.size(), f))) return bail(rc);
+    if (hipMemcpyAsync(f->blob, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return bail(fail(NGF_E_HIP, "uploading the MLP image failed"));
+    A.blob = f->blob;
+    A.blob_floats = (int)img.size();
+    if (tri) {
+        for (int i = 0; i < 48; ++i) A.wd[i] = dw1[i];
+        A.bd = db1[0];
+    }
+
+    for (int k = 0; k < 3; ++k) {
+        A.a0[k] = d->aabb[k];
+        A.a1[k] = d->aabb[3 + k];
+        A.inv[k] = 2.0f / (d->aabb[3 + k] - d->aabb[k]);      // invaabbSize (FieldBase.py:67)
+    }
+    A.near_ = d->near_; A.far_ = d->far_; A.step = d->step; A.dscale = d->distance_scale; A.thr = d->weight_thres;
+    if (d->mask_bits) {
+        const size_t nbytes = ((size_t)d->mask_d * d->mask_h * d->mask_w + 7) / 8;
+        if (hipMalloc((void **)&f->mask, nbytes) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(mask) failed"));
+        f->bytes += (int64_t)nbytes;
+        if (hipMemcpyAsync(f->mask, d->mask_bits, nbytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return bail(fail(NGF_E_HIP, "copying the alpha mask failed"));
+        A.mask.bits = f->mask;
+        A.mask.D = d->mask_d; A.mask.H = d->mask_h; A.mask.W = d->mask_w;
+        for (int k = 0; k < 3; ++k) {
+            A.mask.a0[k] = d->mask_aabb[k];
+            A.mask.inv[k] = 1.0f / (d->mask_aabb[3 + k] - d->mask_aabb[k]) * 2;   // invgridSize (FieldBase.py:29)
+        }
+    }
+    if (hipMalloc((void **)&f->counters, kCounters * sizeof(unsigned)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(counters) failed"));
+    if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "packing failed: %s", hipGetErrorString(hipGetLastError())));
+    *out = f;
+    return NGF_OK;
+}
+
+// ---- launches ------------------------------------------------------------------------------------
+template <typename K>
+static int launch_render(K kernel, const ngf_field *f, RenderArgs &A, int threads, size_t lds_bytes, hipStream_t st)
+{
+    const unsigned slot = f->next_counter.fetch_add(1) % kCounters;
+    A.tile_counter = f->counters + slot;
+    HIP_TRY(hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned), st));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const int64_t tiles = (A.n + kWave - 1) / kWave;
+    const int waves = threads / kWave;
+    int64_t grid = (tiles + waves - 1) / waves;
+    if (grid > f->num_cus) grid = f->num_cus;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds_bytes, st, A);
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+static int render_common(const ngf_field *f, RenderArgs &A, hipStream_t st)
+{
+    if (f->model == NGF_MODEL_TRIPLANE) {
+        const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + 8 * kWaveLdsFloats) * sizeof(float);
+        if (f->flags & NGF_F_BAKE_DENSITY) return launch_render(render_kernel<TriPlanePolicy<true>>, f, A, 512, lds, st);
+        return launch_render(render_kernel<TriPlanePolicy<false>>, f, A, 512, lds, st);
+    }
+    const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + kInfoInvWaves * kWaveLdsFloats) * sizeof(float);
+    return launch_render(render_kernel<InfoInvPolicy>, f, A, kInfoInvWaves * kWave, lds, st);
+}
+
+extern "C" int ngf_field_render(const ngf_field *f, const float *rays, int64_t n, int32_t n_samples, int32_t white_bg,
+                                int32_t mode, const float *jitter, float *rgb, float *depth, uint64_t *stats, void *hip_stream)
+{
+    if (!f || !rays || !rgb || !depth) return fail(NGF_E_ARG, "ngf_field_render: null argument");
+    if (n < 0 || n_samples <= 0) return fail(NGF_E_ARG, "ngf_field_render: n=%lld n_samples=%d", (long long)n, n_samples);
+    if (n == 0) return NGF_OK;
+    RenderArgs A = f->proto;
+    A.rays = rays; A.jitter = jitter; A.rgb = rgb; A.depth = depth; A.n = n; A.S = n_samples;
+    A.white_bg = white_bg ? 1 : 0; A.mode = mode ? 1 : 0; A.stats = (unsigned long long *)stats;
+    return render_common(f, A, (hipStream_t)hip_stream);
+}
+
+extern "C" int ngf_field_march(const ngf_field *f, const float *rays, int64_t n, int32_t n_samples, int32_t mode,
+                               const float *jitter, float *sigma, float *weight, void *hip_stream)
+{
+    if (!f || !rays || !sigma || !weight) return fail(NGF_E_ARG, "ngf_field_march: null argument");
+    if (n <= 0 || n_samples <= 0) return fail(NGF_E_ARG, "ngf_field_march: n=%lld n_samples=%d", (long long)n, n_samples);
+    hipStream_t st = (hipStream_t)hip_stream;
+    float *scratch = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&scratch, (size_t)n * 4 * sizeof(float), st));
+    RenderArgs A = f->proto;
+    A.rays = rays; A.jitter = jitter; A.rgb = scratch; A.depth = scratch + 3 * n; A.n = n; A.S = n_samples;
+    A.white_bg = 0; A.mode = mode ? 1 : 0; A.skip_rgb = 1; A.dbg_sigma = sigma; A.dbg_weight = weight;
+    int rc = render_common(f, A, st);
+    (void)hipFreeAsync(scratch, st);
+    return rc;
+}
+
+extern "C" int ngf_field_decode_rgb(const ngf_field *f, const float *coords, const float *dirs, int64_t n, int32_t mode,
+                                    float *rgb, void *hip_stream)
+{
+    if (!f || !coords || !dirs || !rgb) return fail(NGF_E_ARG, "ngf_field_decode_rgb: null argument");
+    if (n <= 0) return fail(NGF_E_ARG, "ngf_field_decode_rgb: n=%lld", (long long)n);
+    hipStream_t st = (hipStream_t)hip_stream;
+    RenderArgs A = f->proto;
+    A.mode = mode ? 1 : 0;
+    const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + 4 * kBatch * kViewFeat) * sizeof(float);
+    const int64_t nb = (n + kBatch - 1) / kBatch;
+    int grid = (int)((nb + 3) / 4);
+    if (grid > 4 * f->num_cus) grid = 4 * f->num_cus;
+    if (f->model == NGF_MODEL_TRIPLANE) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decode_rgb_kernel<48, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((decode_rgb_kernel<48, false>), dim3(grid), dim3(256), lds, st, A, coords, dirs, n, rgb);
+    } else {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decode_rgb_kernel<72, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((decode_rgb_kernel<72, true>), dim3(grid), dim3(256), lds, st, A, coords, dirs, n, rgb);
+    }
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+extern "C" int ngf_generate_rays(int32_t H, int32_t W, float focal, const float *c, int32_t row0, int32_t rows, float *rays,
+                                 void *hip_stream)
+{
+    if (!c || !rays || H <= 0 || W <= 0 || rows < 0 || row0 < 0 || row0 + rows > H) return fail(NGF_E_ARG, "ngf_generate_rays: bad argument");
+    if (rows == 0) return NGF_OK;
+    const int64_t total = (int64_t)rows * W;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(generate_rays_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, H, W, focal, c[0], c[1], c[2], c[4],
+                       c[5], c[6], c[8], c[9], c[10], c[3], c[7], c[11], row0, rows, rays);
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}

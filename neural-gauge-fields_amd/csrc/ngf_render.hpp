@@ -1,0 +1,403 @@
+// ngf_render.hpp -- the fused TriPlane ray-march kernel for gfx950 (MI355X).
+//
+// One persistent workgroup per CU; its waves are independent workers (no workgroup barrier after
+// the MLP image has been staged into LDS).  A wave repeatedly takes a tile of 64 consecutive rays
+// (one ray per lane) from a global counter and, per tile, alternates between two wave-uniform
+// phases:
+//
+//   march  one sample step for all 64 rays: position, in-box / alpha-mask test, three gauge
+//          fetches, three density fetches, sigma, alpha, transmittance, weight
+//          (FieldBase.py:118-137, 251-288; Field.py:53-91).  Lanes whose weight exceeds the
+//          threshold append a 32-byte record to the wave's LDS queue (ballot + prefix popcount),
+//          so the queue is ordered by (step, lane).
+//   shade  when >= 32 records are queued (or the march has ended): the colour path for 32
+//          samples (Field.py:93-105, networks.py:25-32).  Two lanes share a sample: lane (s, hi)
+//          gathers channels [hi*24, hi*24+24) of the four bilinear taps of each colour plane and
+//          is column s / k-slice hi of the B operand of v_mfma_f32_32x32x2_f32; the A operand is
+//          the pre-composed layer-1 matrix read from LDS.  Layer 2 consumes the accumulators in
+//          place, layer 3 (64->3) is a 32-term VALU dot per lane + one cross-half add.  The
+//          weighted colours go to a 32-entry LDS result list and every lane, as ray owner, adds
+//          the entries that carry its lane id in queue order -- the per-ray sum over samples is
+//          sequential in the sample index, deterministic, and uses no atomics.
+//
+// Nothing of size [n,S,*] is ever materialised in HBM.
+#pragma once
+#include "ngf_device.hpp"
+
+namespace ngf {
+
+// LDS carve (floats): [blob | per wave: ring, result list, view features]
+constexpr int kWaveLdsFloats = kRing * kRecFloats + kBatch * 4 + kWave * kViewFeat;
+
+template <int APP>
+struct MlpLayout {                        // offsets into the packed MLP image (floats)
+    static constexpr int HALF = APP / 2;          // colour channels per plane per lane-half
+    static constexpr int KT = 3 * HALF + 8;       // layer-1 k-steps (2 inputs per step): 80 | 116
+    static constexpr int W1 = 0;                  // [2 ntile][KT][64 lanes]
+    static constexpr int W2 = W1 + 2 * KT * 64;   // [2 mtile][32][64 lanes]
+    static constexpr int B1 = W2 + 2 * 32 * 64;   // [2 hi][32]
+    static constexpr int B2 = B1 + 64;            // [2 hi][32]
+    static constexpr int W3 = B2 + 64;            // [3][2 hi][32]
+    static constexpr int B3 = W3 + 192;           // [4]
+    static constexpr int TOTAL = B3 + 4;
+};
+
+// ---- shade: rgb_decoder on 32 queued samples ---------------------------------------------------
+// rec: this lane's record (lane s = lane&31 of the batch), vf: the owner ray's 16 view features.
+// Returns sigmoid colour of the lane's sample (identical in both halves).
+template <int APP, bool INFOINV>
+__device__ __forceinline__ void mlp_pass(const RenderArgs &A, const float *__restrict__ blob, const float rec[kRecFloats],
+                                         const float *__restrict__ vf, int lane, int mode, float rgb[3])
+{
+    using L = MlpLayout<APP>;
+    const int hi = lane >> 5;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc0[r] = blob[L::B1 + hi * 32 + r];
+        acc1[r] = blob[L::B1 + hi * 32 + 16 + r];
+    }
+    const float *w1a = blob + L::W1 + lane;
+    const float *w1b = blob + L::W1 + L::KT * 64 + lane;
+
+    float pe_xyz[3];
+    if (INFOINV) { pe_xyz[0] = rec[2]; pe_xyz[1] = rec[3]; pe_xyz[2] = rec[5]; }   // xyz = cat(xy, yz[:,1:])
+
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const Tex &t = A.app[p];
+        Bil b = bil_setup(rec[2 + 2 * p], rec[3 + 2 * p], t);
+        const f32x4 *t00 = reinterpret_cast<const f32x4 *>(t.p + (size_t)b.idx * APP + hi * L::HALF);
+        const f32x4 *t10 = t00 + APP / 4;
+        const f32x4 *t01 = t00 + (size_t)t.stride * (APP / 4);
+        const f32x4 *t11 = t01 + APP / 4;
+        float feat[L::HALF];
+#pragma unroll
+        for (int q = 0; q < L::HALF / 4; ++q) {
+            f32x4 v00 = t00[q], v10 = t10[q], v01 = t01[q], v11 = t11[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) feat[4 * q + e] = bil_mix(b, v00[e], v10[e], v01[e], v11[e]);
+        }
+        if (INFOINV) {
+            // plane_feature * PE_12(xyz): channel c = hi*36 + j ; c < 36 -> sin(x_{c/12} * 2^(c%12)), else cos
+            if (mode) {
+#pragma unroll
+                for (int j = 0; j < L::HALF; ++j) {
+                    float a = pe_xyz[j / 12] * (float)(1 << (j % 12));
+                    feat[j] = feat[j] * (hi ? cosf(a) : sinf(a));
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < L::HALF; ++j) {
+            const int t_ = p * L::HALF + j;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[t_ * 64], feat[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[t_ * 64], feat[j], acc1, 0, 0, 0);
+        }
+    }
+    {   // view-direction inputs [d, sin(d*{1,2}), cos(d*{1,2}), 0]: lane-half hi supplies entries hi*8 .. hi*8+7
+        const f32x4 *v = reinterpret_cast<const f32x4 *>(vf + hi * 8);
+        f32x4 va = v[0], vb = v[1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t_ = 3 * L::HALF + j;
+            float x = j < 4 ? va[j] : vb[j - 4];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[t_ * 64], x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[t_ * 64], x, acc1, 0, 0, 0);
+        }
+    }
+    // layer 2: B operand = ReLU(layer-1 accumulators) of the own sample, A = W2 rows permuted to match
+    f32x16 c0, c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        c0[r] = blob[L::B2 + hi * 32 + r];
+        c1[r] = blob[L::B2 + hi * 32 + 16 + r];
+    }
+    const float *w2a = blob + L::W2 + lane;
+    const float *w2b = blob + L::W2 + 32 * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        float h = fmaxf(k < 16 ? acc0[k & 15] : acc1[k & 15], 0.0f);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[k * 64], h, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2b[k * 64], h, c1, 0, 0, 0);
+    }
+    // layer 3 on the VALU: each half holds 32 of the 64 hidden activations of its sample
+    const float *w3 = blob + L::W3 + hi * 32;
+    float o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            float h = fmaxf(k < 16 ? c0[k & 15] : c1[k & 15], 0.0f);
+            s = fmaf(w3[c * 64 + k], h, s);
+        }
+        s = s + __shfl_xor(s, 32);
+        s = s + blob[L::B3 + c];
+        o[c] = 1.0f / (1.0f + expf(-s));
+    }
+    rgb[0] = o[0]; rgb[1] = o[1]; rgb[2] = o[2];
+}
+
+// ---- TriPlane density at the gauge-shifted coordinates ------------------------------------------
+template <bool BAKED>
+__device__ __forceinline__ float triplane_density_feature(const RenderArgs &A, const float t[6])
+{
+    float f = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const Tex &tx = A.dens[p];
+        Bil b = bil_setup(t[2 * p], t[2 * p + 1], tx);
+        if (BAKED) {
+            const float *q = tx.p + b.idx;
+            f += bil_mix(b, q[0], q[1], q[tx.stride], q[tx.stride + 1]);
+        } else {
+            const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + (size_t)b.idx * 16);
+            const f32x4 *q01 = q00 + (size_t)tx.stride * 4;
+            float d00 = 0.0f, d10 = 0.0f, d01 = 0.0f, d11 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v00 = q00[q], v10 = q00[4 + q], v01 = q01[q], v11 = q01[4 + q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float w = A.wd[p * 16 + 4 * q + e];
+                    d00 = fmaf(w, v00[e], d00);
+                    d10 = fmaf(w, v10[e], d10);
+                    d01 = fmaf(w, v01[e], d01);
+                    d11 = fmaf(w, v11[e], d11);
+                }
+            }
+            f += bil_mix(b, d00, d10, d01, d11);
+        }
+    }
+    return f + A.bd;
+}
+
+// compute_gauge (Field.py:53-75): three 2-channel bilinear fetches + the reference's add order
+__device__ __forceinline__ void triplane_gauge(const RenderArgs &A, const float x[3], int gauge_on, float t[6])
+{
+    const float u[3] = {x[0], x[1], x[0]}, v[3] = {x[1], x[2], x[2]};   // xy, yz, xz
+    if (gauge_on) {
+        float d[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const Tex &tx = A.gau[p];
+            Bil b = bil_setup(u[p], v[p], tx);
+            const f32x2 *g = reinterpret_cast<const f32x2 *>(tx.p) + b.idx;
+            f32x2 g00 = g[0], g10 = g[1], g01 = g[tx.stride], g11 = g[tx.stride + 1];
+            d[p][0] = bil_mix(b, g00[0], g10[0], g01[0], g11[0]);
+            d[p][1] = bil_mix(b, g00[1], g10[1], g01[1], g11[1]);
+        }
+        // d[0] = dxy, d[1] = dyz, d[2] = dxz
+        t[0] = (u[0] + d[0][0]) + d[2][0];  t[1] = (v[0] + d[0][1]) + d[1][0];
+        t[2] = (u[1] + d[1][0]) + d[0][1];  t[3] = (v[1] + d[1][1]) + d[2][1];
+        t[4] = (u[2] + d[2][0]) + d[0][0];  t[5] = (v[2] + d[2][1]) + d[1][1];
+    } else {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { t[2 * p] = u[p]; t[2 * p + 1] = v[p]; }
+    }
+}
+
+// Field policy of the fused kernel: TriPlane (learned gauge + Linear(48,1) density on the VALU).
+// sigma() is called by ALL lanes of the wave (wave-uniform call site); invalid lanes return 0.
+template <bool BAKED>
+struct TriPlanePolicy {
+    static constexpr int APP = 48;
+    static constexpr bool INFOINV = false;
+    static constexpr int WAVES = 8;
+    __device__ static __forceinline__ float sigma(const RenderArgs &A, const float *, bool valid, const float x[3], int, float t[6])
+    {
+        float sg = 0.0f;
+        if (valid) {
+            triplane_gauge(A, x, A.mode, t);
+            sg = softplus_shift(triplane_density_feature<BAKED>(A, t));
+        }
+        return sg;
+    }
+};
+
+// ---- the fused kernel ---------------------------------------------------------------------------
+template <typename P>
+__global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs A)
+{
+    constexpr int APP = P::APP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    for (int i = threadIdx.x; i < A.blob_floats; i += blockDim.x) smem[i] = A.blob[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *wl = smem + ((A.blob_floats + 3) & ~3) + wave * kWaveLdsFloats;
+    float *ring = wl;
+    float *res = wl + kRing * kRecFloats;
+    float *vfeat = res + kBatch * 4;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int S = A.S;
+    unsigned long long st_valid = 0, st_active = 0, st_pass = 0, st_rays = 0;
+
+    for (;;) {
+        unsigned int tile = 0;
+        if (lane == 0) tile = atomicAdd(A.tile_counter, 1u);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        const int64_t base = (int64_t)tile * kWave;
+        if (base >= A.n) break;
+        const int64_t ray = base + lane;
+        const bool live = ray < A.n;
+        const int64_t rr = live ? ray : A.n - 1;
+        float o[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { o[k] = A.rays[rr * 6 + k]; d[k] = A.rays[rr * 6 + 3 + k]; }
+        const float jit = A.jitter ? A.jitter[rr] : 0.0f;
+
+        // sample_ray (FieldBase.py:122-125)
+        float tmin = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float vec = (d[k] == 0.0f) ? 1e-6f : d[k];
+            float ra = (A.a1[k] - o[k]) / vec, rb = (A.a0[k] - o[k]) / vec;
+            tmin = fmaxf(tmin, fminf(ra, rb));
+        }
+        tmin = fminf(fmaxf(tmin, A.near_), A.far_);
+
+        // view features of this lane's ray: [d, sin(d_x), sin(2 d_x), sin(d_y), .., cos(..), 0]  (networks.py:205-216)
+        {
+            float *v = vfeat + lane * kViewFeat;
+            v[0] = d[0]; v[1] = d[1]; v[2] = d[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                v[3 + 2 * k] = sinf(d[k]);         v[4 + 2 * k] = sinf(d[k] * 2.0f);
+                v[9 + 2 * k] = cosf(d[k]);         v[10 + 2 * k] = cosf(d[k] * 2.0f);
+            }
+            v[15] = 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+        float T = 1.0f, acc = 0.0f, dep = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        int i = 0, head = 0, count = 0;
+        for (;;) {
+            if (count < kBatch && i < S) {
+                // ---------------- march one step -------------------------------------------------
+                const float z = tmin + A.step * ((float)i + jit);
+                const float zn = tmin + A.step * ((float)(i + 1) + jit);
+                const float dist = (i < S - 1) ? (zn - z) : 0.0f;
+                float p[3];
+                bool valid = live;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    p[k] = o[k] + d[k] * z;
+                    valid = valid && !(A.a0[k] > p[k] || p[k] > A.a1[k]);
+                }
+                if (A.mask.bits && valid) valid = mask_occupied(A.mask, p);
+                float t[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, x[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) x[k] = (p[k] - A.a0[k]) * A.inv[k] - 1.0f;   // normalize_coord (FieldBase.py:88-89)
+                const float sigma = P::sigma(A, smem, valid, x, lane, t);
+                // raw2alpha (FieldBase.py:12-19)
+                const float alpha = 1.0f - expf(-sigma * (dist * A.dscale));
+                const float w = alpha * T;
+                T = T * ((1.0f - alpha) + 1e-10f);
+                acc += w;
+                dep += w * z;
+                if (A.dbg_weight && live) {
+                    A.dbg_weight[ray * S + i] = w;
+                    A.dbg_sigma[ray * S + i] = sigma;
+                }
+                const bool active = (w > A.thr) && !A.skip_rgb;
+                const unsigned long long m = __ballot(active);
+                if (active) {
+                    const int slot = (head + count + __popcll(m & lt_mask)) & (kRing - 1);
+                    f32x4 *r = reinterpret_cast<f32x4 *>(ring + slot * kRecFloats);
+                    r[0] = f32x4{__int_as_float(lane), w, t[0], t[1]};
+                    r[1] = f32x4{t[2], t[3], t[4], t[5]};
+                }
+                count += __popcll(m);
+                st_valid += __popcll(__ballot(valid));
+                st_active += __popcll(m);
+                ++i;
+            } else if (count > 0) {
+                // ---------------- shade up to 32 queued samples ----------------------------------
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int nb = count < kBatch ? count : kBatch;
+                const int s = lane & 31;
+                const int slot = (head + (s < nb ? s : 0)) & (kRing - 1);
+                const f32x4 *r = reinterpret_cast<const f32x4 *>(ring + slot * kRecFloats);
+                const f32x4 r0 = r[0], r1 = r[1];
+                const float rec[kRecFloats] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+                const int owner = __float_as_int(r0[0]);
+                float c[3];
+                mlp_pass<APP, P::INFOINV>(A, smem, rec, vfeat + owner * kViewFeat, lane, A.mode, c);
+                if (lane < nb) *reinterpret_cast<f32x4 *>(res + lane * 4) = f32x4{r0[0], r0[1] * c[0], r0[1] * c[1], r0[1] * c[2]};
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // every lane, as ray owner, collects its entries in queue (= sample) order
+                for (int j = 0; j < nb; ++j) {
+                    const f32x4 e = *reinterpret_cast<const f32x4 *>(res + j * 4);
+                    if (__float_as_int(e[0]) == lane) { cr += e[1]; cg += e[2]; cb += e[3]; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                head = (head + nb) & (kRing - 1);
+                count -= nb;
+                ++st_pass;
+            } else {
+                break;
+            }
+        }
+        if (live) {
+            // compositing tail (FieldBase.py:296-306)
+            float out[3] = {cr, cg, cb};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v = out[c];
+                if (A.white_bg) v = v + (1.0f - acc);
+                A.rgb[ray * 3 + c] = fminf(fmaxf(v, 0.0f), 1.0f);
+            }
+            A.depth[ray] = dep + (1.0f - acc) * d[2];
+        }
+        st_rays += __popcll(__ballot(live));
+    }
+    if (A.stats && lane == 0) {
+        atomicAdd(A.stats + 0, st_valid);
+        atomicAdd(A.stats + 1, st_active);
+        atomicAdd(A.stats + 2, st_pass);
+        atomicAdd(A.stats + 3, st_rays);
+    }
+}
+
+// ---- compute_rgb alone on caller-supplied samples (parity-test entry point) ----------------------
+template <int APP, bool INFOINV>
+__global__ void __launch_bounds__(256) decode_rgb_kernel(const RenderArgs A, const float *coords, const float *dirs,
+                                                         int64_t n, float *out)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    for (int i = threadIdx.x; i < A.blob_floats; i += blockDim.x) smem[i] = A.blob[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float *vfeat = smem + ((A.blob_floats + 3) & ~3) + wave * (kBatch * kViewFeat);
+    const int64_t nbatch = (n + kBatch - 1) / kBatch;
+    for (int64_t bt = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; bt < nbatch; bt += (int64_t)gridDim.x * (blockDim.x >> 6)) {
+        const int s = lane & 31;
+        int64_t q = bt * kBatch + s;
+        const bool ok = q < n;
+        if (!ok) q = n - 1;
+        float rec[kRecFloats] = {0.0f, 1.0f, coords[q * 6 + 0], coords[q * 6 + 1], coords[q * 6 + 2],
+                                 coords[q * 6 + 3], coords[q * 6 + 4], coords[q * 6 + 5]};
+        if (lane < 32) {
+            float *v = vfeat + s * kViewFeat;
+            float d[3] = {dirs[q * 3], dirs[q * 3 + 1], dirs[q * 3 + 2]};
+            v[0] = d[0]; v[1] = d[1]; v[2] = d[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                v[3 + 2 * k] = sinf(d[k]);  v[4 + 2 * k] = sinf(d[k] * 2.0f);
+                v[9 + 2 * k] = cosf(d[k]);  v[10 + 2 * k] = cosf(d[k] * 2.0f);
+            }
+            v[15] = 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float c[3];
+        mlp_pass<APP, INFOINV>(A, smem, rec, vfeat + s * kViewFeat, lane, A.mode, c);
+        if (lane < 32 && ok) { out[q * 3] = c[0]; out[q * 3 + 1] = c[1]; out[q * 3 + 2] = c[2]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+}  // namespace ngf

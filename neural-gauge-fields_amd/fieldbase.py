@@ -1,0 +1,270 @@
+"""Drop-in counterparts of the reference's ``Base`` / ``AlphaGridMask`` (TriPlane/models/FieldBase.py:22-116,
+251-312; InfoInv/models/FieldBase.py) and ``renderer`` (TriPlane/main.py:60-71).
+
+Same constructor arguments, attribute and parameter names, checkpoint dictionary and ``forward``
+signature; ``forward`` hands the whole ray batch to the gfx950 library (include/ngf.h) in ONE launch
+instead of running ~40 ATen ops per chunk.  PyTorch is used for device memory, streams and the
+``nn.Module`` / ``state_dict`` plumbing only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, geometry
+
+
+class AlphaGridMask(torch.nn.Module):
+    """Occupancy volume container (FieldBase.py:22-40); the kernel consumes its np.packbits image."""
+
+    def __init__(self, device, aabb, alpha_volume):
+        super().__init__()
+        self.device = device
+        self.aabb = aabb.to(self.device)
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invgridSize = 1.0 / self.aabbSize * 2
+        self.alpha_volume = alpha_volume.view(1, 1, *alpha_volume.shape[-3:])
+        self.gridSize = torch.LongTensor([alpha_volume.shape[-1], alpha_volume.shape[-2], alpha_volume.shape[-3]]).to(self.device)
+
+    def packed_bits(self) -> np.ndarray:
+        return np.packbits(self.alpha_volume.bool().cpu().numpy().reshape(-1))
+
+
+class Base(torch.nn.Module):
+    MODEL = _lib.MODEL_TRIPLANE
+    PLANE_C = 64
+    DENS_DIM = 16
+
+    def __init__(self, aabb, gridSize, device, alphaMask=None, near_far=[2.0, 6.0], alphaMask_thres=0.001,
+                 distance_scale=25, rayMarch_weight_thres=0.0001, step_ratio=2.0, gauge_start=0, bake_density=False):
+        super().__init__()
+        self.aabb = aabb if torch.is_tensor(aabb) else torch.tensor(aabb, dtype=torch.float32)
+        self.alphaMask = alphaMask
+        self.device = device
+        self.alphaMask_thres = alphaMask_thres
+        self.distance_scale = distance_scale
+        self.rayMarch_weight_thres = rayMarch_weight_thres
+        self.near_far = near_far
+        self.step_ratio = step_ratio
+        self.bake_density = bool(bake_density)
+        self._handle = None
+        self._handle_key = None
+        self.last_stats = None
+        self.init_para(gridSize)
+        self.init_model(device=device, gauge_start=gauge_start)
+
+    # --- init_para (FieldBase.py:63-74): same attributes, arithmetic restated in geometry.py ------
+    def init_para(self, gridSize):
+        aabb = self.aabb.detach().cpu().numpy().astype(np.float32)
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invaabbSize = 2.0 / self.aabbSize
+        self.gridSize = torch.LongTensor([int(g) for g in gridSize]).to(self.device)
+        self.units = self.aabbSize.to(self.device) / (self.gridSize - 1)
+        step = geometry.step_size(aabb, [int(g) for g in gridSize], self.step_ratio)
+        self.stepSize = torch.tensor(step, dtype=torch.float32)
+        self.aabbDiag = torch.sqrt(torch.sum(torch.square(self.aabbSize)))
+        self.nSamples = geometry.n_samples(aabb, step)
+        self._handle_key = None
+
+    def init_model(self, device=None, gauge_start=0):
+        raise NotImplementedError
+
+    # --- checkpoint format (FieldBase.py:94-116) ---------------------------------------------------
+    def save(self, path):
+        kwargs = {'aabb': self.aabb, 'gridSize': self.gridSize.tolist(), 'alphaMask_thres': self.alphaMask_thres,
+                  'distance_scale': self.distance_scale, 'rayMarch_weight_thres': self.rayMarch_weight_thres,
+                  'near_far': self.near_far, 'step_ratio': self.step_ratio}
+        ckpt = {'kwargs': kwargs, 'state_dict': self.state_dict()}
+        if self.alphaMask is not None:
+            alpha_volume = self.alphaMask.alpha_volume.bool().cpu().numpy()
+            ckpt.update({'alphaMask.shape': alpha_volume.shape})
+            ckpt.update({'alphaMask.mask': np.packbits(alpha_volume.reshape(-1))})
+            ckpt.update({'alphaMask.aabb': self.alphaMask.aabb.cpu()})
+        torch.save(ckpt, path)
+
+    def load(self, ckpt):
+        if 'alphaMask.aabb' in ckpt.keys():
+            length = int(np.prod(ckpt['alphaMask.shape']))
+            vol = torch.from_numpy(np.unpackbits(ckpt['alphaMask.mask'])[:length].reshape(ckpt['alphaMask.shape']))
+            self.alphaMask = AlphaGridMask(self.device, ckpt['alphaMask.aabb'].to(self.device), vol.float().to(self.device))
+        sd = ckpt['state_dict']
+        # planes of a trained checkpoint were up-sampled / shrunk (Field.py:108-132): size them from the
+        # state_dict (the reference's own loader raises a size mismatch here)
+        for name in ('plane_xy', 'plane_yz', 'plane_xz', 'gauge_xy', 'gauge_yz', 'gauge_xz'):
+            if name in sd and hasattr(self, name) and getattr(self, name).shape != sd[name].shape:
+                setattr(self, name, torch.nn.Parameter(torch.empty_like(sd[name], device=self.device)))
+        self.load_state_dict(sd)
+        self._handle_key = None
+
+    def load_params(self, params: dict):
+        """Assign parameters from a dict of numpy arrays keyed by state_dict names (test / bench plumbing)."""
+        sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()}
+        self.load({'state_dict': sd})
+
+    # --- the HIP handle ----------------------------------------------------------------------------
+    def _param_key(self):
+        ps = [(n, p.data_ptr(), p._version, tuple(p.shape)) for n, p in self.named_parameters()]
+        m = None if self.alphaMask is None else (self.alphaMask.alpha_volume.data_ptr(), self.alphaMask.alpha_volume._version)
+        return (tuple(ps), m, float(self.stepSize), tuple(self.aabb.reshape(-1).tolist()), self.bake_density,
+                tuple(self.near_far), float(self.distance_scale), float(self.rayMarch_weight_thres))
+
+    def _fill_desc(self, d: _lib.FieldDesc, keep: list):
+        raise NotImplementedError
+
+    def release(self):
+        if self._handle is not None:
+            _lib.lib().ngf_field_destroy(self._handle)
+            self._handle = None
+            self._handle_key = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def handle(self):
+        """(Re)build the packed device image when parameters changed since the last call."""
+        key = self._param_key()
+        if self._handle is not None and key == self._handle_key:
+            return self._handle
+        L = _lib.lib()
+        dev = torch.device(self.device)
+        if dev.type != 'cuda':
+            raise RuntimeError("ngf_amd fields render on the GPU only (device='cuda'); there is no CPU path")
+        d = _lib.FieldDesc()
+        keep = []
+        d.model, d.plane_c, d.dens_dim = self.MODEL, self.PLANE_C, self.DENS_DIM
+        d.flags = _lib.F_BAKE_DENSITY if (self.bake_density and self.MODEL == _lib.MODEL_TRIPLANE) else 0
+
+        def dp(t):
+            t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        for k, name in enumerate(('plane_xy', 'plane_yz', 'plane_xz')):
+            pl = getattr(self, name)
+            d.plane[k] = dp(pl)
+            d.plane_h[k], d.plane_w[k] = pl.shape[2], pl.shape[3]
+        self._fill_desc(d, dp)
+        rd = self.rgb_decoder
+        d.basis = dp(rd.basis.weight)
+        d.w1, d.b1 = dp(rd.mlp[0].weight), dp(rd.mlp[0].bias)
+        d.w2, d.b2 = dp(rd.mlp[2].weight), dp(rd.mlp[2].bias)
+        d.w3, d.b3 = dp(rd.mlp[4].weight), dp(rd.mlp[4].bias)
+        d.aabb = (C.c_float * 6)(*self.aabb.reshape(-1).tolist())
+        d.near_, d.far_ = float(self.near_far[0]), float(self.near_far[1])
+        d.step = float(self.stepSize)
+        d.distance_scale = float(self.distance_scale)
+        d.weight_thres = float(np.float32(self.rayMarch_weight_thres))
+        if self.alphaMask is not None:
+            bits = torch.from_numpy(self.alphaMask.packed_bits()).to(dev)
+            keep.append(bits)
+            d.mask_bits = bits.data_ptr()
+            shp = self.alphaMask.alpha_volume.shape
+            d.mask_d, d.mask_h, d.mask_w = int(shp[-3]), int(shp[-2]), int(shp[-1])
+            d.mask_aabb = (C.c_float * 6)(*self.alphaMask.aabb.reshape(-1).tolist())
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            out = C.c_void_p()
+            _lib.check(L.ngf_field_create(C.byref(d), C.byref(out), C.c_void_p(stream)))
+        self.release()
+        self._handle, self._handle_key = out, key
+        return out
+
+    def _mode(self, **kw) -> int:
+        raise NotImplementedError
+
+    # --- Base.forward (FieldBase.py:251-312) ---------------------------------------------------------
+    @torch.no_grad()
+    def _render(self, rays_chunk, white_bg, is_train, N_samples, mode, collect_stats=False):
+        dev = torch.device(self.device)
+        rays = rays_chunk.to(device=dev, dtype=torch.float32).contiguous()
+        if rays.dim() != 2 or rays.shape[1] != 6:
+            raise ValueError(f"rays_chunk must be [n,6], got {tuple(rays.shape)}")
+        n = rays.shape[0]
+        S = int(N_samples) if N_samples > 0 else int(self.nSamples)
+        h = self.handle()
+        rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        depth = torch.empty((n,), device=dev, dtype=torch.float32)
+        jitter = torch.rand((n,), device=dev) if is_train else None
+        if not (white_bg or (is_train and torch.rand((1,)) < 0.5)):
+            white_bg = False
+        else:
+            white_bg = True
+        stats = torch.zeros(4, dtype=torch.int64, device=dev) if collect_stats else None
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().ngf_field_render(
+                h, rays.data_ptr(), n, S, int(white_bg), int(mode), None if jitter is None else jitter.data_ptr(),
+                rgb.data_ptr(), depth.data_ptr(), None if stats is None else stats.data_ptr(), C.c_void_p(stream)))
+        if collect_stats:
+            self.last_stats = stats
+        return {'rgb_map': rgb, 'depth_map': depth}
+
+    @torch.no_grad()
+    def march(self, rays, N_samples, mode=1):
+        """Per-sample (sigma, weight) [n,S] -- parity-test hook (sample_ray .. raw2alpha)."""
+        dev = torch.device(self.device)
+        rays = rays.to(device=dev, dtype=torch.float32).contiguous()
+        n, S = rays.shape[0], int(N_samples)
+        sigma = torch.empty((n, S), device=dev)
+        weight = torch.empty((n, S), device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().ngf_field_march(self.handle(), rays.data_ptr(), n, S, int(mode), None, sigma.data_ptr(),
+                                                  weight.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return sigma, weight
+
+    @torch.no_grad()
+    def decode_rgb(self, coords, dirs, mode=1):
+        """compute_rgb for explicit samples: coords [n,6] = (t_xy, t_yz, t_xz), dirs [n,3] -- parity-test hook."""
+        dev = torch.device(self.device)
+        coords = coords.to(device=dev, dtype=torch.float32).contiguous()
+        dirs = dirs.to(device=dev, dtype=torch.float32).contiguous()
+        out = torch.empty((coords.shape[0], 3), device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().ngf_field_decode_rgb(self.handle(), coords.data_ptr(), dirs.data_ptr(), coords.shape[0],
+                                                       int(mode), out.data_ptr(),
+                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
+
+
+class rgb_decoder(torch.nn.Module):
+    """Parameter container with the reference's names (networks.py:12-32); evaluated inside the kernel."""
+
+    def __init__(self, feat_dim, view_pe=6, middle_dim=128):
+        super().__init__()
+        if view_pe != 2 or middle_dim != 64:
+            raise ValueError("the gfx950 kernel implements rgb_decoder(view_pe=2, middle_dim=64) (Field.py:28)")
+        self.input_dim = feat_dim + 3 + 2 * view_pe * 3
+        self.view_pe = view_pe
+        self.basis = torch.nn.Linear(feat_dim, feat_dim, bias=False)
+        self.mlp = torch.nn.Sequential(torch.nn.Linear(self.input_dim, middle_dim), torch.nn.ReLU(inplace=True),
+                                       torch.nn.Linear(middle_dim, middle_dim), torch.nn.ReLU(inplace=True),
+                                       torch.nn.Linear(middle_dim, 3))
+        torch.nn.init.constant_(self.mlp[-1].bias, 0)
+
+
+class density_decoder(torch.nn.Module):
+    """InfoInv density MLP container (InfoInv/models/networks.py:34-54)."""
+
+    def __init__(self, feat_dim, middle_dim=32):
+        super().__init__()
+        self.input_dim = feat_dim
+        self.mlp = torch.nn.Sequential(torch.nn.Linear(feat_dim, middle_dim), torch.nn.ReLU(inplace=True),
+                                       torch.nn.Linear(middle_dim, middle_dim), torch.nn.ReLU(inplace=True),
+                                       torch.nn.Linear(middle_dim, 1))
+        torch.nn.init.constant_(self.mlp[-1].bias, 0)
+
+
+def renderer(rays, field, chunk=1024, N_samples=-1, white_bg=True, is_train=False, device='cuda', **field_kw):
+    """TriPlane/main.py:60-71 (InfoInv/main.py:61-72).  ``chunk`` existed to bound the reference's
+    [chunk, S, C] intermediates; the fused kernel has none, so the whole batch goes down in one launch
+    (``chunk`` is accepted and ignored).  Extra keyword arguments (``infoinv=...``) reach the field."""
+    kw = dict(field_kw)
+    if 'infoinv' not in kw and 'iteration' not in kw and field.MODEL == _lib.MODEL_TRIPLANE:
+        kw['iteration'] = 30001
+    out = field(rays.to(device), is_train=is_train, white_bg=white_bg, N_samples=N_samples, **kw)
+    return out['rgb_map'], out['depth_map']

@@ -304,3 +304,22 @@ void ngf_oracle_rgb_decode(const ngf_oracle_model *m, const float *feat, const f
 {
     for (int64_t i = 0; i < n; ++i) rgb_decode(m, feat + (size_t)i * m->app_feat, dirs + 3 * i, rgb + 3 * i);
 }
+
+/* compute_rgb / compute_density for explicit (already gauge-shifted) plane coordinates [n,6] */
+void ngf_oracle_color_at(const ngf_oracle_model *m, const float *coords, const float *dirs, int64_t n, float *rgb)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float t[3][2];
+        for (int k = 0; k < 6; ++k) t[k / 2][k % 2] = coords[6 * i + k];
+        color_at(m, t, dirs + 3 * i, rgb + 3 * i);
+    }
+}
+
+void ngf_oracle_density_at(const ngf_oracle_model *m, const float *coords, int64_t n, float *sigma)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float t[3][2];
+        for (int k = 0; k < 6; ++k) t[k / 2][k % 2] = coords[6 * i + k];
+        sigma[i] = density_at(m, t);
+    }
+}

@@ -52,6 +52,8 @@ int ngf_oracle_render(const ngf_oracle_model *m, const float *rays, int64_t n, i
                       const float *jitter, float *rgb, float *depth, ngf_oracle_debug *dbg, int32_t threads);
 void ngf_oracle_bilerp2d(const float *plane, int H, int W, int C, const float *uv, int64_t n, float *out);
 void ngf_oracle_mask_sample(const uint8_t *bits, int D, int H, int W, const float *q, int64_t n, float *out);
+void ngf_oracle_color_at(const ngf_oracle_model *m, const float *coords, const float *dirs, int64_t n, float *rgb);
+void ngf_oracle_density_at(const ngf_oracle_model *m, const float *coords, int64_t n, float *sigma);
 void ngf_oracle_rgb_decode(const ngf_oracle_model *m, const float *feat, const float *dirs, int64_t n, float *rgb);
 
 #ifdef __cplusplus

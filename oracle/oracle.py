@@ -144,3 +144,15 @@ class OracleField:
         if debug_rays:
             return rgb, depth, out
         return rgb, depth
+
+    def color_at(self, coords, dirs):
+        coords, dirs = _f32(coords), _f32(dirs)
+        out = np.empty((coords.shape[0], 3), np.float32)
+        lib().ngf_oracle_color_at(C.byref(self._m), _ptr(coords), _ptr(dirs), C.c_int64(coords.shape[0]), _ptr(out))
+        return out
+
+    def density_at(self, coords):
+        coords = _f32(coords)
+        out = np.empty((coords.shape[0],), np.float32)
+        lib().ngf_oracle_density_at(C.byref(self._m), _ptr(coords), C.c_int64(coords.shape[0]), _ptr(out))
+        return out
