@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- Mray/s of the TriPlane ray-march hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one 800x800 frame (640 000 rays, 192 samples/ray, seeded
+synthetic camera + weights, SURVEY.md section 8 D2, dense preset R1): at N=1 the whole frame on one GPU;
+at N>1 the frame's rays are sharded in contiguous row blocks (strong scaling of ONE frame, as
+BASELINE.json's north_star asks) and every step ends with one RCCL all-gather of the composited pixels.
+Rays and parameters are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+H = W = 800
+S = 192
+
+
+def alg_bytes_per_ray(s_active: float, model: str) -> float:
+    """every bilinear tap counted once, no cache credit."""
+    if model == "triplane":
+        return 24 + 16 + S * 864.0 + s_active * 2304.0
+    return 24 + 16 + S * 1152.0 + s_active * 3456.0
+
+
+def build_field(model, preset, device, bake):
+    from helpers import big_case, field_for_case
+    g, params, step = big_case(model, preset)
+    f = field_for_case(g, params, None, device=device, bake=bake)
+    f.handle()
+    return f, g, params, step
+
+
+def time_steps(fn, steps, warmup, device, dist_on):
+    import torch.distributed as dist
+    for _ in range(warmup):
+        fn()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(device)
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    el = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el
+
+
+def kernel_ms(fn, steps, device):
+    """Average duration of the render launch, HIP events on the stream it is launched on."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize(device)
+    return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+def cpu_baseline(params, g, step, rays_np, budget_s, f, kw):
+    """The reference's CPU eager path (torch port, oracle/eager.py) on a bounded sample of the same frame."""
+    from oracle.eager import EagerField
+    e = EagerField(params, g["aabb"], step, g["near_far"], float(g["distance_scale"]), float(g["thr"]), str(g["model"]))
+    chunk = 4096
+    n_chunks = rays_np.shape[0] // chunk
+    order = [(i * 37) % n_chunks for i in range(n_chunks)]          # spread over the frame
+    # torch's intra-op pool degrades badly when oversubscribed on a many-core host (256 threads on the
+    # MI355X box: >10 s per chunk vs <1 s with 16-32): pick the fastest thread count on a warm-up
+    # chunk and report the count actually used.
+    warm = torch.from_numpy(rays_np[:chunk])
+    best = (None, 1e30)
+    ncpu = os.cpu_count() or 1
+    for nt in sorted({min(ncpu, k) for k in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        e.forward(warm[:512], S)
+        t0 = time.perf_counter()
+        e.forward(warm, S)
+        dt = time.perf_counter() - t0
+        if dt < best[1]:
+            best = (nt, dt)
+    torch.set_num_threads(best[0])
+    done, t_used, worst, sq, cnt, act = 0, 0.0, 0.0, 0.0, 0, []
+    for ci in order[:64]:
+        r = torch.from_numpy(rays_np[ci * chunk:(ci + 1) * chunk])
+        t0 = time.perf_counter()
+        rgb, depth, a = e.forward(r, S)
+        t_used += time.perf_counter() - t0
+        act.append(a)
+        done += 1
+        got = f(r.to(f.device), N_samples=S, **kw)["rgb_map"].cpu()
+        diff = (got - rgb).abs()
+        worst = max(worst, float(diff.max()))
+        sq += float((diff.double() ** 2).sum())
+        cnt += diff.numel()
+        if t_used >= budget_s:
+            break
+    mse = sq / max(cnt, 1)
+    return {"value": done * chunk / t_used / 1e6, "unit": "Mray/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} chunks x {chunk} rays of the same frame, torch-eager port of Base.forward, {t_used:.1f} s"}, \
+           {"max_abs_err_vs_cpu_port": worst, "psnr_vs_cpu_port_db": (200.0 if mse == 0 else -10 * np.log10(mse)),
+            "cpu_active_fraction": float(np.mean(act))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preset", default="R1", choices=["R0", "R1", "R2"])
+    ap.add_argument("--model", default="triplane", choices=["triplane", "infoinv"])
+    ap.add_argument("--bake-density", type=int, default=0, help="1 = NGF_F_BAKE_DENSITY (pre-composed density planes)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--extras", type=int, default=1, help="N=1 only: also time the other presets / variants (untimed region)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import ngf_amd  # noqa: F401
+    from ngf_amd import dist as ndist
+    from ngf_amd import synth
+
+    model = args.model
+    kw = {"iteration": 30001} if model == "triplane" else {"infoinv": True}
+    f, g, params, step = build_field(model, args.preset, device, bool(args.bake_density))
+    n_total = H * W
+    lo, hi, per = ndist.shard_bounds(n_total, world, rank)
+    assert lo % W == 0 and hi % W == 0, "row-block sharding expects H divisible by the world size"
+    rays_np = synth.lookat_rays(H, W, rows=(lo // W, hi // W))
+    rays = torch.from_numpy(rays_np).to(device)
+    send, rgb_view, depth_view = ndist.shard_buffers(per, device)
+    recv = torch.empty((world * 4 * per,), device=device) if dist_on else None
+    out = (rgb_view[: hi - lo], depth_view[: hi - lo])
+
+    def render_only():
+        f(rays, N_samples=S, white_bg=True, out=out, **kw)
+
+    def step_fn():
+        render_only()
+        if dist_on:
+            ndist.gather_pixels(None, None, n_total, per, world, send=send, recv=recv)
+
+    elapsed = time_steps(step_fn, args.steps, args.warmup, device, dist_on)
+    ms_step = elapsed / args.steps * 1e3
+    value = n_total * args.steps / elapsed / 1e6
+
+    # dominant kernel: duration by HIP events on the launch stream; algorithmic bytes from the measured active count
+    k_ms = kernel_ms(render_only, max(5, args.steps), device)
+    f(rays, N_samples=S, white_bg=True, collect_stats=True, **kw)
+    torch.cuda.synchronize(device)
+    st = f.last_stats.cpu().numpy().astype(np.float64)
+    n_local = hi - lo
+    s_active = st[1] / n_local
+    bytes_launch = alg_bytes_per_ray(s_active, model) * n_local
+    achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "ngf::render_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
+                "active_samples_per_ray": s_active, "in_box_samples_per_ray": st[0] / n_local, "mlp_passes": st[2],
+                "note": "algorithmic bytes count every bilinear tap (no cache credit, SURVEY 8 D3); the 52 MB texture set is "
+                        "Infinity-Cache resident, so this is a gather-throughput figure, not DRAM traffic"}
+
+    result = {
+        "metric": "Mray/sec (800x800 lego-style frame, 192 samples/ray)", "value": value, "unit": "Mray/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{'TriPlane' if model == 'triplane' else 'InfoInv'} 800x800 frame, S=192, preset {args.preset} "
+                               f"(seeded random planes 256^2, dense density preset), gauge on, white_bg",
+                   "rays_per_step": n_total, "samples_per_ray": S, "sharding": f"rays x{world} (row blocks) + all_gather",
+                   "bake_density": int(args.bake_density)},
+        "roofline": roofline,
+    }
+
+    if world == 1 and rank == 0:
+        if args.cpu_seconds > 0:
+            cb, par = cpu_baseline(params, g, step, rays_np, args.cpu_seconds, f, kw)
+            result["cpu_baseline"] = cb
+            result["parity"] = par
+            result["speedup_vs_cpu_port"] = value / cb["value"]
+        if args.extras:
+            extras = {}
+            for mdl, preset, bake in (("triplane", "R0", 0), ("triplane", "R2", 0), ("triplane", args.preset, 1 - int(args.bake_density)),
+                                      ("infoinv", "R1", 0)):
+                try:
+                    fx, _, _, _ = build_field(mdl, preset, device, bool(bake))
+                    kx = {"iteration": 30001} if mdl == "triplane" else {"infoinv": True}
+                    ms = kernel_ms(lambda: fx(rays, N_samples=S, white_bg=True, **kx), 5, device)      # includes 1st-call warm-up
+                    ms = kernel_ms(lambda: fx(rays, N_samples=S, white_bg=True, **kx), 10, device)
+                    fx(rays, N_samples=S, collect_stats=True, **kx)
+                    sx = fx.last_stats.cpu().numpy().astype(np.float64)
+                    sa = sx[1] / n_total
+                    extras[f"{mdl}_{preset}{'_baked' if bake else ''}"] = {
+                        "Mray/s": n_total / ms / 1e3, "kernel_ms": ms, "active_samples_per_ray": sa,
+                        "alg_GBps": alg_bytes_per_ray(sa, mdl) * n_total / (ms * 1e-3) / 1e9}
+                    fx.release()
+                except Exception as ex:  # an extra must never take the headline number down with it
+                    extras[f"{mdl}_{preset}"] = {"error": repr(ex)}
+            result["extras"] = extras
+    if rank == 0:
+        print(json.dumps(result))
+    if dist_on:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,10 +33,26 @@ def render_sharded(render_fn, rays, group=None, gather: bool = True):
     rgb, depth = render_fn(rays[lo:hi])
     if not gather or world == 1:
         return rgb, depth
-    packed = torch.zeros((per, 4), device=rgb.device, dtype=torch.float32)
-    packed[: hi - lo, :3] = rgb
-    packed[: hi - lo, 3] = depth
-    full = torch.empty((world * per, 4), device=rgb.device, dtype=torch.float32)
-    dist.all_gather_into_tensor(full, packed, group=group)
-    full = full[:n]
-    return full[:, :3].contiguous(), full[:, 3].contiguous()
+    return gather_pixels(rgb, depth, n, per, world, group)
+
+
+def shard_buffers(per: int, device):
+    """One [4*per] float32 send buffer whose first 3*per floats are the rgb view and last per the depth
+    view, so a field can render straight into the all-gather operand (no packing copy)."""
+    buf = torch.zeros((4 * per,), device=device, dtype=torch.float32)
+    return buf, buf[: 3 * per].view(per, 3), buf[3 * per:]
+
+
+def gather_pixels(rgb, depth, n: int, per: int, world: int, group=None, send=None, recv=None):
+    """All-gather of the composited pixels.  ``send`` (from shard_buffers) avoids the packing copy."""
+    if send is None:
+        send, r_view, d_view = shard_buffers(per, rgb.device)
+        r_view[: rgb.shape[0]] = rgb
+        d_view[: depth.shape[0]] = depth
+    if recv is None:
+        recv = torch.empty((world * 4 * per,), device=send.device, dtype=torch.float32)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    blocks = recv.view(world, 4 * per)
+    full_rgb = blocks[:, : 3 * per].reshape(world * per, 3)[:n]
+    full_depth = blocks[:, 3 * per:].reshape(world * per)[:n]
+    return full_rgb, full_depth

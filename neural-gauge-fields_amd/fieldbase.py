@@ -179,7 +179,7 @@ class Base(torch.nn.Module):
 
     # --- Base.forward (FieldBase.py:251-312) ---------------------------------------------------------
     @torch.no_grad()
-    def _render(self, rays_chunk, white_bg, is_train, N_samples, mode, collect_stats=False):
+    def _render(self, rays_chunk, white_bg, is_train, N_samples, mode, collect_stats=False, out=None):
         dev = torch.device(self.device)
         rays = rays_chunk.to(device=dev, dtype=torch.float32).contiguous()
         if rays.dim() != 2 or rays.shape[1] != 6:
@@ -187,8 +187,14 @@ class Base(torch.nn.Module):
         n = rays.shape[0]
         S = int(N_samples) if N_samples > 0 else int(self.nSamples)
         h = self.handle()
-        rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
-        depth = torch.empty((n,), device=dev, dtype=torch.float32)
+        if out is not None:
+            rgb, depth = out                      # caller-provided device buffers ([n,3], [n], contiguous float32)
+            assert rgb.is_contiguous() and depth.is_contiguous() and rgb.shape == (n, 3) and depth.shape == (n,)
+        else:
+            rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
+            depth = torch.empty((n,), device=dev, dtype=torch.float32)
+        if n == 0:
+            return {'rgb_map': rgb, 'depth_map': depth}
         jitter = torch.rand((n,), device=dev) if is_train else None
         if not (white_bg or (is_train and torch.rand((1,)) < 0.5)):
             white_bg = False
