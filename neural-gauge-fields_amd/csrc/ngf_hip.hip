@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -309,9 +310,20 @@ static int launch_render(K kernel, const ngf_field *f, RenderArgs &A, int thread
 static int render_common(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
     if (f->model == NGF_MODEL_TRIPLANE) {
-        const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + 8 * kWaveLdsFloats) * sizeof(float);
-        if (f->flags & NGF_F_BAKE_DENSITY) return launch_render(render_kernel<TriPlanePolicy<true>>, f, A, 512, lds, st);
-        return launch_render(render_kernel<TriPlanePolicy<false>>, f, A, 512, lds, st);
+        // waves per workgroup (= per CU): tuning knob, NGF_WAVES in {8,12,16}; default picked from measurements
+        int W = 8;   // measured (profiles/): 8 waves x 248 VGPRs beats 12/16 waves, which spill the pipelined gathers
+        if (const char *e = getenv("NGF_WAVES")) W = atoi(e);
+        const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + W * kWaveLdsFloats) * sizeof(float);
+        const bool bk = f->flags & NGF_F_BAKE_DENSITY;
+        switch (W) {
+        case 8: return bk ? launch_render(render_kernel<TriPlanePolicy<true, 8>>, f, A, 512, lds, st)
+                          : launch_render(render_kernel<TriPlanePolicy<false, 8>>, f, A, 512, lds, st);
+        case 12: return bk ? launch_render(render_kernel<TriPlanePolicy<true, 12>>, f, A, 768, lds, st)
+                           : launch_render(render_kernel<TriPlanePolicy<false, 12>>, f, A, 768, lds, st);
+        case 16: return bk ? launch_render(render_kernel<TriPlanePolicy<true, 16>>, f, A, 1024, lds, st)
+                           : launch_render(render_kernel<TriPlanePolicy<false, 16>>, f, A, 1024, lds, st);
+        default: return fail(NGF_E_ARG, "NGF_WAVES must be 8, 12 or 16");
+        }
     }
     const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + kInfoInvWaves * kWaveLdsFloats) * sizeof(float);
     return launch_render(render_kernel<InfoInvPolicy>, f, A, kInfoInvWaves * kWave, lds, st);
@@ -353,7 +365,7 @@ extern "C" int ngf_field_decode_rgb(const ngf_field *f, const float *coords, con
     hipStream_t st = (hipStream_t)hip_stream;
     RenderArgs A = f->proto;
     A.mode = mode ? 1 : 0;
-    const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + 4 * kBatch * kViewFeat) * sizeof(float);
+    const size_t lds = ((size_t)((A.blob_floats + 3) & ~3)) * sizeof(float);
     const int64_t nb = (n + kBatch - 1) / kBatch;
     int grid = (int)((nb + 3) / 4);
     if (grid > 4 * f->num_cus) grid = 4 * f->num_cus;

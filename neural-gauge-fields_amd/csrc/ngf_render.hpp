@@ -26,8 +26,29 @@
 
 namespace ngf {
 
-// LDS carve (floats): [blob | per wave: ring, result list, view features]
-constexpr int kWaveLdsFloats = kRing * kRecFloats + kBatch * 4 + kWave * kViewFeat;
+// LDS carve (floats): [blob | per wave: ring, result list]
+constexpr int kWaveLdsFloats = kRing * kRecFloats + kBatch * 4;
+
+// The 16 view-direction inputs of rgb_decoder layer 1 (networks.py:27-29, 205-216):
+//   u[F..F+14] = [d(3), sin(d_x), sin(2 d_x), sin(d_y), sin(2 d_y), sin(d_z), sin(2 d_z), cos(same 6)], u[F+15] = 0 (pad)
+// lane-half hi supplies entries hi*8 .. hi*8+7.
+__device__ __forceinline__ void view_inputs(const float d[3], int hi, float v[8])
+{
+    float s[6], c[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        sincosf(d[k], &s[2 * k], &c[2 * k]);
+        sincosf(d[k] * 2.0f, &s[2 * k + 1], &c[2 * k + 1]);
+    }
+    v[0] = hi ? s[5] : d[0];
+    v[1] = hi ? c[0] : d[1];
+    v[2] = hi ? c[1] : d[2];
+    v[3] = hi ? c[2] : s[0];
+    v[4] = hi ? c[3] : s[1];
+    v[5] = hi ? c[4] : s[2];
+    v[6] = hi ? c[5] : s[3];
+    v[7] = hi ? 0.0f : s[4];
+}
 
 template <int APP>
 struct MlpLayout {                        // offsets into the packed MLP image (floats)
@@ -45,65 +66,91 @@ struct MlpLayout {                        // offsets into the packed MLP image (
 // ---- shade: rgb_decoder on 32 queued samples ---------------------------------------------------
 // rec: this lane's record (lane s = lane&31 of the batch), vf: the owner ray's 16 view features.
 // Returns sigmoid colour of the lane's sample (identical in both halves).
-template <int APP, bool INFOINV>
+template <int APP, bool INFOINV, int CH = (APP == 48 ? 6 : 3)>
 __device__ __forceinline__ void mlp_pass(const RenderArgs &A, const float *__restrict__ blob, const float rec[kRecFloats],
-                                         const float *__restrict__ vf, int lane, int mode, float rgb[3])
+                                         const float od[3], int lane, int mode, float rgb[3])
 {
     using L = MlpLayout<APP>;
+    constexpr int NQ = L::HALF / 4;          // float4 loads per tap per lane (6 | 9)
+    constexpr int CPP = NQ / CH;             // pipeline stages per plane
+    constexpr int NST = 3 * CPP;
+    static_assert(NQ % CH == 0, "chunk size must divide the per-tap load count");
     const int hi = lane >> 5;
+    const float *w1a = blob + L::W1 + lane;
+    const float *w1b = blob + L::W1 + L::KT * 64 + lane;
+
+    // Explicit software pipeline (hipcc otherwise issues the gathers just-in-time, 4 loads per 8 MFMAs,
+    // and exposes ~18 memory latencies per pass): the 4 taps x CH float4 of stage s+1 are requested
+    // before the 8*CH MFMAs of stage s are issued, so one gather is always in flight behind the matrix
+    // work.  sched_barrier(0) pins the stage order.
+    f32x4 raw[4][CH];
+    auto issue = [&](int st) {
+        const int p = st / CPP, q0 = (st % CPP) * CH;
+        const Tex &t = A.app[p];
+        const Bil b = bil_setup(rec[2 + 2 * p], rec[3 + 2 * p], t);
+        const f32x4 *t00 = reinterpret_cast<const f32x4 *>(t.p + (size_t)b.idx * APP + hi * L::HALF) + q0;
+        const f32x4 *t01 = t00 + (size_t)t.stride * (APP / 4);
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            raw[0][q] = t00[q];
+            raw[1][q] = t00[APP / 4 + q];
+            raw[2][q] = t01[q];
+            raw[3][q] = t01[APP / 4 + q];
+        }
+    };
+    issue(0);
+    __builtin_amdgcn_sched_barrier(0);
+
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         acc0[r] = blob[L::B1 + hi * 32 + r];
         acc1[r] = blob[L::B1 + hi * 32 + 16 + r];
     }
-    const float *w1a = blob + L::W1 + lane;
-    const float *w1b = blob + L::W1 + L::KT * 64 + lane;
-
+    {   // view-direction inputs first (their sincos chain overlaps the first gather)
+        float vin[8];
+        view_inputs(od, hi, vin);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t_ = 3 * L::HALF + j;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[t_ * 64], vin[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[t_ * 64], vin[j], acc1, 0, 0, 0);
+        }
+    }
     float pe_xyz[3];
     if (INFOINV) { pe_xyz[0] = rec[2]; pe_xyz[1] = rec[3]; pe_xyz[2] = rec[5]; }   // xyz = cat(xy, yz[:,1:])
 
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const Tex &t = A.app[p];
-        Bil b = bil_setup(rec[2 + 2 * p], rec[3 + 2 * p], t);
-        const f32x4 *t00 = reinterpret_cast<const f32x4 *>(t.p + (size_t)b.idx * APP + hi * L::HALF);
-        const f32x4 *t10 = t00 + APP / 4;
-        const f32x4 *t01 = t00 + (size_t)t.stride * (APP / 4);
-        const f32x4 *t11 = t01 + APP / 4;
-        float feat[L::HALF];
+    for (int st = 0; st < NST; ++st) {
+        const int p = st / CPP, q0 = (st % CPP) * CH;
+        __builtin_amdgcn_sched_barrier(0);
+        float feat[4 * CH];
+        {
+            const Bil b = bil_setup(rec[2 + 2 * p], rec[3 + 2 * p], A.app[p]);
 #pragma unroll
-        for (int q = 0; q < L::HALF / 4; ++q) {
-            f32x4 v00 = t00[q], v10 = t10[q], v01 = t01[q], v11 = t11[q];
+            for (int q = 0; q < CH; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) feat[4 * q + e] = bil_mix(b, v00[e], v10[e], v01[e], v11[e]);
+                for (int e = 0; e < 4; ++e) feat[4 * q + e] = bil_mix(b, raw[0][q][e], raw[1][q][e], raw[2][q][e], raw[3][q][e]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < NST) issue(st + 1);
+        __builtin_amdgcn_sched_barrier(0);
         if (INFOINV) {
             // plane_feature * PE_12(xyz): channel c = hi*36 + j ; c < 36 -> sin(x_{c/12} * 2^(c%12)), else cos
             if (mode) {
 #pragma unroll
-                for (int j = 0; j < L::HALF; ++j) {
+                for (int jj = 0; jj < 4 * CH; ++jj) {
+                    const int j = 4 * q0 + jj;
                     float a = pe_xyz[j / 12] * (float)(1 << (j % 12));
-                    feat[j] = feat[j] * (hi ? cosf(a) : sinf(a));
+                    feat[jj] = feat[jj] * (hi ? cosf(a) : sinf(a));
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < L::HALF; ++j) {
-            const int t_ = p * L::HALF + j;
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[t_ * 64], feat[j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[t_ * 64], feat[j], acc1, 0, 0, 0);
-        }
-    }
-    {   // view-direction inputs [d, sin(d*{1,2}), cos(d*{1,2}), 0]: lane-half hi supplies entries hi*8 .. hi*8+7
-        const f32x4 *v = reinterpret_cast<const f32x4 *>(vf + hi * 8);
-        f32x4 va = v[0], vb = v[1];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int t_ = 3 * L::HALF + j;
-            float x = j < 4 ? va[j] : vb[j - 4];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[t_ * 64], x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[t_ * 64], x, acc1, 0, 0, 0);
+        for (int jj = 0; jj < 4 * CH; ++jj) {
+            const int t_ = p * L::HALF + 4 * q0 + jj;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[t_ * 64], feat[jj], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[t_ * 64], feat[jj], acc1, 0, 0, 0);
         }
     }
     // layer 2: B operand = ReLU(layer-1 accumulators) of the own sample, A = W2 rows permuted to match
@@ -200,11 +247,11 @@ __device__ __forceinline__ void triplane_gauge(const RenderArgs &A, const float 
 
 // Field policy of the fused kernel: TriPlane (learned gauge + Linear(48,1) density on the VALU).
 // sigma() is called by ALL lanes of the wave (wave-uniform call site); invalid lanes return 0.
-template <bool BAKED>
+template <bool BAKED, int WAVES_ = 16>
 struct TriPlanePolicy {
     static constexpr int APP = 48;
     static constexpr bool INFOINV = false;
-    static constexpr int WAVES = 8;
+    static constexpr int WAVES = WAVES_;
     __device__ static __forceinline__ float sigma(const RenderArgs &A, const float *, bool valid, const float x[3], int, float t[6])
     {
         float sg = 0.0f;
@@ -230,7 +277,6 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
     float *wl = smem + ((A.blob_floats + 3) & ~3) + wave * kWaveLdsFloats;
     float *ring = wl;
     float *res = wl + kRing * kRecFloats;
-    float *vfeat = res + kBatch * 4;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int S = A.S;
     unsigned long long st_valid = 0, st_active = 0, st_pass = 0, st_rays = 0;
@@ -258,19 +304,6 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
             tmin = fmaxf(tmin, fminf(ra, rb));
         }
         tmin = fminf(fmaxf(tmin, A.near_), A.far_);
-
-        // view features of this lane's ray: [d, sin(d_x), sin(2 d_x), sin(d_y), .., cos(..), 0]  (networks.py:205-216)
-        {
-            float *v = vfeat + lane * kViewFeat;
-            v[0] = d[0]; v[1] = d[1]; v[2] = d[2];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                v[3 + 2 * k] = sinf(d[k]);         v[4 + 2 * k] = sinf(d[k] * 2.0f);
-                v[9 + 2 * k] = cosf(d[k]);         v[10 + 2 * k] = cosf(d[k] * 2.0f);
-            }
-            v[15] = 0.0f;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
         float T = 1.0f, acc = 0.0f, dep = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
         int i = 0, head = 0, count = 0;
@@ -324,8 +357,9 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 const f32x4 r0 = r[0], r1 = r[1];
                 const float rec[kRecFloats] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
                 const int owner = __float_as_int(r0[0]);
+                const float od[3] = {__shfl(d[0], owner), __shfl(d[1], owner), __shfl(d[2], owner)};
                 float c[3];
-                mlp_pass<APP, P::INFOINV>(A, smem, rec, vfeat + owner * kViewFeat, lane, A.mode, c);
+                mlp_pass<APP, P::INFOINV>(A, smem, rec, od, lane, A.mode, c);
                 if (lane < nb) *reinterpret_cast<f32x4 *>(res + lane * 4) = f32x4{r0[0], r0[1] * c[0], r0[1] * c[1], r0[1] * c[2]};
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // every lane, as ray owner, collects its entries in queue (= sample) order
@@ -372,7 +406,6 @@ __global__ void __launch_bounds__(256) decode_rgb_kernel(const RenderArgs A, con
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float *vfeat = smem + ((A.blob_floats + 3) & ~3) + wave * (kBatch * kViewFeat);
     const int64_t nbatch = (n + kBatch - 1) / kBatch;
     for (int64_t bt = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; bt < nbatch; bt += (int64_t)gridDim.x * (blockDim.x >> 6)) {
         const int s = lane & 31;
@@ -381,22 +414,10 @@ __global__ void __launch_bounds__(256) decode_rgb_kernel(const RenderArgs A, con
         if (!ok) q = n - 1;
         float rec[kRecFloats] = {0.0f, 1.0f, coords[q * 6 + 0], coords[q * 6 + 1], coords[q * 6 + 2],
                                  coords[q * 6 + 3], coords[q * 6 + 4], coords[q * 6 + 5]};
-        if (lane < 32) {
-            float *v = vfeat + s * kViewFeat;
-            float d[3] = {dirs[q * 3], dirs[q * 3 + 1], dirs[q * 3 + 2]};
-            v[0] = d[0]; v[1] = d[1]; v[2] = d[2];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                v[3 + 2 * k] = sinf(d[k]);  v[4 + 2 * k] = sinf(d[k] * 2.0f);
-                v[9 + 2 * k] = cosf(d[k]);  v[10 + 2 * k] = cosf(d[k] * 2.0f);
-            }
-            v[15] = 0.0f;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const float dq[3] = {dirs[q * 3], dirs[q * 3 + 1], dirs[q * 3 + 2]};
         float c[3];
-        mlp_pass<APP, INFOINV>(A, smem, rec, vfeat + s * kViewFeat, lane, A.mode, c);
+        mlp_pass<APP, INFOINV>(A, smem, rec, dq, lane, A.mode, c);
         if (lane < 32 && ok) { out[q * 3] = c[0]; out[q * 3 + 1] = c[1]; out[q * 3 + 2] = c[2]; }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
 
