@@ -38,10 +38,10 @@ def alg_bytes_per_ray(s_active: float, model: str) -> float:
     return 24 + 16 + S * 1152.0 + s_active * 3456.0
 
 
-def build_field(model, preset, device, bake):
+def build_field(model, preset, device, bake, bake_color=False):
     from helpers import big_case, field_for_case
     g, params, step = big_case(model, preset)
-    f = field_for_case(g, params, None, device=device, bake=bake)
+    f = field_for_case(g, params, None, device=device, bake=bake, bake_color=bake_color)
     f.handle()
     return f, g, params, step
 
@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--preset", default="R1", choices=["R0", "R1", "R2"])
     ap.add_argument("--model", default="triplane", choices=["triplane", "infoinv"])
     ap.add_argument("--bake-density", type=int, default=0, help="1 = NGF_F_BAKE_DENSITY (pre-composed density planes)")
+    ap.add_argument("--bake-color", type=int, default=0, help="1 = NGF_F_BAKE_COLOR (pre-composed layer-1 colour planes)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="N=1 only: also time the other presets / variants (untimed region)")
     args = ap.parse_args()
@@ -156,7 +157,7 @@ def main():
 
     model = args.model
     kw = {"iteration": 30001} if model == "triplane" else {"infoinv": True}
-    f, g, params, step = build_field(model, args.preset, device, bool(args.bake_density))
+    f, g, params, step = build_field(model, args.preset, device, bool(args.bake_density), bool(args.bake_color))
     n_total = H * W
     lo, hi, per = ndist.shard_bounds(n_total, world, rank)
     assert lo % W == 0 and hi % W == 0, "row-block sharding expects H divisible by the world size"
@@ -200,7 +201,7 @@ def main():
         "config": {"workload": f"{'TriPlane' if model == 'triplane' else 'InfoInv'} 800x800 frame, S=192, preset {args.preset} "
                                f"(seeded random planes 256^2, dense density preset), gauge on, white_bg",
                    "rays_per_step": n_total, "samples_per_ray": S, "sharding": f"rays x{world} (row blocks) + all_gather",
-                   "bake_density": int(args.bake_density)},
+                   "bake_density": int(args.bake_density), "bake_color": int(args.bake_color)},
         "roofline": roofline,
     }
 
@@ -212,17 +213,18 @@ def main():
             result["speedup_vs_cpu_port"] = value / cb["value"]
         if args.extras:
             extras = {}
-            for mdl, preset, bake in (("triplane", "R0", 0), ("triplane", "R2", 0), ("triplane", args.preset, 1 - int(args.bake_density)),
-                                      ("infoinv", "R1", 0)):
+            for mdl, preset, bake in (("triplane", "R0", 0), ("triplane", "R2", 0), ("triplane", args.preset, 1), ("triplane", args.preset, 3),
+                                      ("triplane", "R0", 1), ("triplane", "R2", 3), ("infoinv", "R1", 0)):
                 try:
-                    fx, _, _, _ = build_field(mdl, preset, device, bool(bake))
+                    fx, _, _, _ = build_field(mdl, preset, device, bool(bake & 1), bool(bake & 2))
                     kx = {"iteration": 30001} if mdl == "triplane" else {"infoinv": True}
                     ms = kernel_ms(lambda: fx(rays, N_samples=S, white_bg=True, **kx), 5, device)      # includes 1st-call warm-up
                     ms = kernel_ms(lambda: fx(rays, N_samples=S, white_bg=True, **kx), 10, device)
                     fx(rays, N_samples=S, collect_stats=True, **kx)
                     sx = fx.last_stats.cpu().numpy().astype(np.float64)
                     sa = sx[1] / n_total
-                    extras[f"{mdl}_{preset}{'_baked' if bake else ''}"] = {
+                    tag = {0: "", 1: "_bake_density", 2: "_bake_color", 3: "_bake_density_color"}[bake]
+                    extras[f"{mdl}_{preset}{tag}"] = {
                         "Mray/s": n_total / ms / 1e3, "kernel_ms": ms, "active_samples_per_ray": sa,
                         "alg_GBps": alg_bytes_per_ray(sa, mdl) * n_total / (ms * 1e-3) / 1e9}
                     fx.release()

@@ -34,9 +34,13 @@ enum { NGF_MODEL_TRIPLANE = 0, NGF_MODEL_INFOINV = 1 };
 
 /* ngf_field_desc.flags */
 enum {
-    NGF_F_BAKE_DENSITY = 1 /* TriPlane: pre-compose density_decoder Linear(48,1) with the 16 density
+    NGF_F_BAKE_DENSITY = 1, /* TriPlane: pre-compose density_decoder Linear(48,1) with the 16 density
                               channels of each plane (exact algebra: a Linear commutes with bilinear
                               interpolation); the march then gathers 1 instead of 16 channels per tap */
+    NGF_F_BAKE_COLOR = 2    /* pre-compose rgb_decoder layer 1 (W1[:, :F] . basis, no activation in between:
+                              networks.py:17,26-30) with the colour channels of each plane: colour planes
+                              become 64-channel layer-1 pre-activation planes, the shade pass keeps only the
+                              view-direction inputs and layers 2-3 on the matrix pipe.  Same algebra. */
 };
 
 /* Parameter set of one field, in the reference's own tensor layouts (NCHW planes, nn.Linear

@@ -27,6 +27,8 @@ struct Tex {
     const float *p;
     int32_t W, H;       // un-padded size; u indexes W, v indexes H
     int32_t stride;     // W + 2 (texels per padded row)
+    float fw, fh;       // (float)(W-1), (float)(H-1): host-computed so they live in SGPRs (a v_cvt of a
+                        // uniform int is a VALU op whose loop-invariant result the compiler pins in a VGPR)
 };
 
 struct MaskVol {
@@ -66,15 +68,15 @@ struct Bil {
 
 __device__ __forceinline__ Bil bil_setup(float u, float v, const Tex &t)
 {
-    float px = ((u + 1.0f) / 2.0f) * (float)(t.W - 1);
-    float py = ((v + 1.0f) / 2.0f) * (float)(t.H - 1);
+    float px = ((u + 1.0f) / 2.0f) * t.fw;
+    float py = ((v + 1.0f) / 2.0f) * t.fh;
     float fx = floorf(px), fy = floorf(py);
     float wx1 = px - fx, wx0 = 1.0f - wx1;
     float wy1 = py - fy, wy0 = 1.0f - wy1;
     // x0 in [-1, W-1] <=> at least one of the taps x0, x0+1 can be inside; border texels are zero
-    bool in = (fx >= -1.0f) && (fx <= (float)(t.W - 1)) && (fy >= -1.0f) && (fy <= (float)(t.H - 1));
-    float cx = fminf(fmaxf(fx, -1.0f), (float)(t.W - 1));
-    float cy = fminf(fmaxf(fy, -1.0f), (float)(t.H - 1));
+    bool in = (fx >= -1.0f) && (fx <= t.fw) && (fy >= -1.0f) && (fy <= t.fh);
+    float cx = fminf(fmaxf(fx, -1.0f), t.fw);
+    float cy = fminf(fmaxf(fy, -1.0f), t.fh);
     Bil b;
     b.idx = ((int)cy + 1) * t.stride + ((int)cx + 1);
     b.w00 = in ? wx0 * wy0 : 0.0f;

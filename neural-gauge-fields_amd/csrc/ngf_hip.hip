@@ -79,6 +79,23 @@ __global__ void bake_density_kernel(const float *__restrict__ src, int H, int W,
     }
 }
 
+// rgb_decoder layer 1 (pre-composed with basis) applied per texel: dst[(y,x)][j] = sum_c wp[j][c] * src[c0+c][y][x]
+// (fp64 accumulate); wp is [64][nc] with rows already in accumulator order (MlpLayout16Baked).
+__global__ void bake_color_kernel(const float *__restrict__ src, int H, int W, int c0, int nc, const float *__restrict__ wp,
+                                  float *__restrict__ dst)
+{
+    const size_t total = (size_t)(H + 2) * (W + 2) * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 63);
+        const size_t tx = i >> 6;
+        const int x = (int)(tx % (W + 2)), y = (int)(tx / (W + 2));
+        double v = 0.0;
+        if (x >= 1 && x <= W && y >= 1 && y <= H)
+            for (int c = 0; c < nc; ++c) v += (double)wp[j * nc + c] * (double)src[((size_t)(c0 + c) * H + (y - 1)) * W + (x - 1)];
+        dst[i] = (float)v;
+    }
+}
+
 // get_ray_directions + get_rays (ray_utils.py:24-42, 66-87; blender.py:52)
 __global__ void generate_rays_kernel(int H, int W, float focal, float r00, float r01, float r02, float r10, float r11,
                                      float r12, float r20, float r21, float r22, float ox, float oy, float oz, int row0,
@@ -138,6 +155,66 @@ static void build_rgb_image(int F, const std::vector<float> &basis, const std::v
             img[oB1 + hi * 32 + k] = b1[n];
             img[oB2 + hi * 32 + k] = b2[n];
             for (int c = 0; c < 3; ++c) img[oW3 + c * 64 + hi * 32 + k] = w3[(size_t)c * 64 + n];
+        }
+    for (int c = 0; c < 3; ++c) img[oB3 + c] = b3[c];
+    img[oB3 + 3] = 0.0f;
+}
+
+// 16-wide (v_mfma_f32_16x16x4_f32) image of rgb_decoder for TriPlane (ngf_shade16.hpp).  Lane (s, kq): hidden
+// unit of accumulator (mt, r) is n = mt*16 + 4*kq + r.  With bake = true the plane part of layer 1 goes to the
+// texture baker instead: wp[p][kq*16 + mt*4 + r][c] = W1'[n][p*APPc + c].
+static void build_rgb_image16(int F, bool bake, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
+                              const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3,
+                              const std::vector<float> &b3, float *img, std::vector<float> &wp)
+{
+    const int IN = F + 15, APPc = F / 3, QCH = APPc / 4, KT = 3 * QCH + 4;
+    std::vector<double> w1f((size_t)64 * (F + 16), 0.0);       // W1' = [W1[:, :F] . basis | W1[:, F:F+15] | 0]
+    for (int n = 0; n < 64; ++n) {
+        for (int k = 0; k < F; ++k) {
+            double s = 0.0;
+            for (int j = 0; j < F; ++j) s += (double)w1[(size_t)n * IN + j] * (double)basis[(size_t)j * F + k];
+            w1f[(size_t)n * (F + 16) + k] = s;
+        }
+        for (int k = 0; k < 15; ++k) w1f[(size_t)n * (F + 16) + F + k] = w1[(size_t)n * IN + F + k];
+    }
+    auto hidden = [](int mt, int r, int kq) { return mt * 16 + 4 * kq + r; };
+    int oW1, oW2, oB1, oB2, oW3, oB3;
+    if (bake) {
+        using L = MlpLayout16Baked;
+        oW1 = L::W1V; oW2 = L::W2; oB1 = L::B1; oB2 = L::B2; oW3 = L::W3; oB3 = L::B3;
+        wp.assign((size_t)3 * 64 * APPc, 0.0f);
+        for (int kq = 0; kq < 4; ++kq)
+            for (int mt = 0; mt < 4; ++mt)
+                for (int r = 0; r < 4; ++r)
+                    for (int kk = 0; kk < F; ++kk)
+                        wp[((size_t)(kk / APPc) * 64 + kq * 16 + mt * 4 + r) * APPc + (kk % APPc)] =
+                            (float)w1f[(size_t)hidden(mt, r, kq) * (F + 16) + kk];
+        for (int mt = 0; mt < 4; ++mt)
+            for (int j = 0; j < 4; ++j)
+                for (int l = 0; l < 64; ++l)
+                    img[oW1 + ((size_t)mt * 4 + j) * 64 + l] = (float)w1f[(size_t)(mt * 16 + (l & 15)) * (F + 16) + F + (l >> 4) * 4 + j];
+    } else {
+        using L = MlpLayout16<48>;
+        oW1 = L::W1; oW2 = L::W2; oB1 = L::B1; oB2 = L::B2; oW3 = L::W3; oB3 = L::B3;
+        auto kmap = [&](int t, int kq) {
+            if (t < 3 * QCH) return (t / QCH) * APPc + kq * QCH + (t % QCH);
+            return F + kq * 4 + (t - 3 * QCH);
+        };
+        for (int mt = 0; mt < 4; ++mt)
+            for (int t = 0; t < KT; ++t)
+                for (int l = 0; l < 64; ++l)
+                    img[oW1 + ((size_t)mt * KT + t) * 64 + l] = (float)w1f[(size_t)(mt * 16 + (l & 15)) * (F + 16) + kmap(t, l >> 4)];
+    }
+    for (int mt = 0; mt < 4; ++mt)
+        for (int t = 0; t < 16; ++t)
+            for (int l = 0; l < 64; ++l)
+                img[oW2 + ((size_t)mt * 16 + t) * 64 + l] = w2[(size_t)(mt * 16 + (l & 15)) * 64 + hidden(t >> 2, t & 3, l >> 4)];
+    for (int kq = 0; kq < 4; ++kq)
+        for (int k = 0; k < 16; ++k) {
+            const int n = hidden(k >> 2, k & 3, kq);
+            img[oB1 + kq * 16 + k] = b1[n];
+            img[oB2 + kq * 16 + k] = b2[n];
+            for (int c = 0; c < 3; ++c) img[oW3 + c * 64 + kq * 16 + k] = w3[(size_t)c * 64 + n];
         }
     for (int c = 0; c < 3; ++c) img[oB3 + c] = b3[c];
     img[oB3 + 3] = 0.0f;
@@ -205,31 +282,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     auto bail = [&](int code) { ngf_field_destroy(f); return code; };
 
     const bool bake = tri && (d->flags & NGF_F_BAKE_DENSITY);
-    std::vector<float> wd, bd;
-    float *wd_dev = nullptr;
-    for (int p = 0; p < 3; ++p) {
-        const int H = d->plane_h[p], W = d->plane_w[p];
-        const size_t texels = (size_t)(H + 2) * (W + 2);
-        const int dc = bake ? 1 : d->dens_dim;
-        if ((rc = alloc_f(&f->tex[p], texels * dc, f))) return bail(rc);
-        if ((rc = alloc_f(&f->tex[3 + p], texels * f->app, f))) return bail(rc);
-        if (bake) {
-            bake_density_kernel<<<1024, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, d->dens_w1 + p * d->dens_dim, f->tex[p]);
-        } else {
-            pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, 0, d->dens_dim, f->tex[p]);
-        }
-        pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, f->tex[3 + p]);
-        A.dens[p] = Tex{f->tex[p], W, H, W + 2};
-        A.app[p] = Tex{f->tex[3 + p], W, H, W + 2};
-        if (tri) {
-            const int gh = d->gauge_h[p], gw = d->gauge_w[p];
-            if ((rc = alloc_f(&f->tex[6 + p], (size_t)(gh + 2) * (gw + 2) * 2, f))) return bail(rc);
-            pack_plane_kernel<<<256, 256, 0, st>>>(d->gauge[p], gh, gw, 0, 2, f->tex[6 + p]);
-            A.gau[p] = Tex{f->tex[6 + p], gw, gh, gw + 2};
-        }
-    }
-    (void)wd_dev;
-    if (hipGetLastError() != hipSuccess) return bail(fail(NGF_E_HIP, "packing kernels failed to launch"));
+    const bool bake_c = tri && (d->flags & NGF_F_BAKE_COLOR);
 
     // MLP weights: to the host once, pre-compose, permute, back to HBM as one LDS image
     std::vector<float> basis, w1, b1, w2, b2, w3, b3;
@@ -248,21 +301,59 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     }
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "hipStreamSynchronize failed in ngf_field_create"));
 
-    const int rgb_floats = tri ? MlpLayout<48>::TOTAL : MlpLayout<72>::TOTAL;
+    const int rgb_floats = tri ? (bake_c ? MlpLayout16Baked::TOTAL : MlpLayout16<48>::TOTAL) : MlpLayout<72>::TOTAL;
     const int dens_floats = tri ? 0 : InfoInvDensLayout::TOTAL;
-    std::vector<float> img((size_t)rgb_floats + dens_floats, 0.0f);
-    build_rgb_image(F, basis, w1, b1, w2, b2, w3, b3, img.data());
+    std::vector<float> img((size_t)rgb_floats + dens_floats, 0.0f), wp;
+    if (tri) build_rgb_image16(F, bake_c, basis, w1, b1, w2, b2, w3, b3, img.data(), wp);
+    else build_rgb_image(F, basis, w1, b1, w2, b2, w3, b3, img.data());
     if (!tri) build_infoinv_density_image(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
     if ((rc = alloc_f(&f->blob, img.size(), f))) return bail(rc);
-    if (hipMemcpyAsync(f->blob, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
+    if (hipMemcpyAsync(f->blob, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess)
         return bail(fail(NGF_E_HIP, "uploading the MLP image failed"));
+    float *wp_dev = nullptr;
+    if (bake_c) {
+        if (hipMalloc((void **)&wp_dev, wp.size() * sizeof(float)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(wp) failed"));
+        if (hipMemcpyAsync(wp_dev, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) {
+            (void)hipFree(wp_dev);
+            return bail(fail(NGF_E_HIP, "uploading the pre-composed layer-1 matrix failed"));
+        }
+    }
     A.blob = f->blob;
     A.blob_floats = (int)img.size();
     if (tri) {
         for (int i = 0; i < 48; ++i) A.wd[i] = dw1[i];
         A.bd = db1[0];
     }
+
+    // textures: channel-last, zero-bordered
+    const int app_c = bake_c ? 64 : f->app;
+    for (int p = 0; p < 3; ++p) {
+        const int H = d->plane_h[p], W = d->plane_w[p];
+        const size_t texels = (size_t)(H + 2) * (W + 2);
+        const int dc = bake ? 1 : d->dens_dim;
+        if ((rc = alloc_f(&f->tex[p], texels * dc, f)) || (rc = alloc_f(&f->tex[3 + p], texels * app_c, f))) {
+            if (wp_dev) (void)hipFree(wp_dev);
+            return bail(rc);
+        }
+        if (bake) bake_density_kernel<<<1024, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, d->dens_w1 + p * d->dens_dim, f->tex[p]);
+        else pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, 0, d->dens_dim, f->tex[p]);
+        if (bake_c) bake_color_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, wp_dev + (size_t)p * 64 * f->app, f->tex[3 + p]);
+        else pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, f->tex[3 + p]);
+        A.dens[p] = Tex{f->tex[p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
+        A.app[p] = Tex{f->tex[3 + p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
+        if (tri) {
+            const int gh = d->gauge_h[p], gw = d->gauge_w[p];
+            if ((rc = alloc_f(&f->tex[6 + p], (size_t)(gh + 2) * (gw + 2) * 2, f))) {
+                if (wp_dev) (void)hipFree(wp_dev);
+                return bail(rc);
+            }
+            pack_plane_kernel<<<256, 256, 0, st>>>(d->gauge[p], gh, gw, 0, 2, f->tex[6 + p]);
+            A.gau[p] = Tex{f->tex[6 + p], gw, gh, gw + 2, (float)(gw - 1), (float)(gh - 1)};
+        }
+    }
+    const bool launch_ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    if (wp_dev) (void)hipFree(wp_dev);
+    if (!launch_ok) return bail(fail(NGF_E_HIP, "packing kernels failed"));
 
     for (int k = 0; k < 3; ++k) {
         A.a0[k] = d->aabb[k];
@@ -307,26 +398,38 @@ static int launch_render(K kernel, const ngf_field *f, RenderArgs &A, int thread
     return NGF_OK;
 }
 
+template <typename P>
+static int launch_policy(const ngf_field *f, RenderArgs &A, hipStream_t st)
+{
+    const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + P::WAVES * wave_lds_floats<P>()) * sizeof(float);
+    return launch_render(render_kernel<P>, f, A, P::WAVES * kWave, lds, st);
+}
+
+template <bool BD, bool BC>
+static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
+{
+    // tuning knobs (measurements in profiles/): waves per CU and march steps in flight per lane
+    int w = BC ? 8 : 12, ns = 1;          // measured best (profiles/r01_sweep.txt)
+    if (const char *e = getenv("NGF_WAVES")) w = atoi(e);
+    if (const char *e = getenv("NGF_NSTEP")) ns = atoi(e);
+    if (ns == 2) {
+        if (w == 8) return launch_policy<TriPlanePolicy<BD, BC, 8, 2>>(f, A, st);
+        return fail(NGF_E_ARG, "NGF_NSTEP=2 is built for NGF_WAVES=8 only");
+    }
+    switch (w) {
+    case 8: return launch_policy<TriPlanePolicy<BD, BC, 8, 1>>(f, A, st);
+    case 12: return launch_policy<TriPlanePolicy<BD, BC, 12, 1>>(f, A, st);
+    case 16: return launch_policy<TriPlanePolicy<BD, BC, 16, 1>>(f, A, st);
+    default: return fail(NGF_E_ARG, "NGF_WAVES must be 8, 12 or 16");
+    }
+}
+
 static int render_common(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
-    if (f->model == NGF_MODEL_TRIPLANE) {
-        // waves per workgroup (= per CU): tuning knob, NGF_WAVES in {8,12,16}; default picked from measurements
-        int W = 8;   // measured (profiles/): 8 waves x 248 VGPRs beats 12/16 waves, which spill the pipelined gathers
-        if (const char *e = getenv("NGF_WAVES")) W = atoi(e);
-        const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + W * kWaveLdsFloats) * sizeof(float);
-        const bool bk = f->flags & NGF_F_BAKE_DENSITY;
-        switch (W) {
-        case 8: return bk ? launch_render(render_kernel<TriPlanePolicy<true, 8>>, f, A, 512, lds, st)
-                          : launch_render(render_kernel<TriPlanePolicy<false, 8>>, f, A, 512, lds, st);
-        case 12: return bk ? launch_render(render_kernel<TriPlanePolicy<true, 12>>, f, A, 768, lds, st)
-                           : launch_render(render_kernel<TriPlanePolicy<false, 12>>, f, A, 768, lds, st);
-        case 16: return bk ? launch_render(render_kernel<TriPlanePolicy<true, 16>>, f, A, 1024, lds, st)
-                           : launch_render(render_kernel<TriPlanePolicy<false, 16>>, f, A, 1024, lds, st);
-        default: return fail(NGF_E_ARG, "NGF_WAVES must be 8, 12 or 16");
-        }
-    }
-    const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + kInfoInvWaves * kWaveLdsFloats) * sizeof(float);
-    return launch_render(render_kernel<InfoInvPolicy>, f, A, kInfoInvWaves * kWave, lds, st);
+    if (f->model == NGF_MODEL_INFOINV) return launch_policy<InfoInvPolicy>(f, A, st);
+    const bool bd = f->flags & NGF_F_BAKE_DENSITY, bc = f->flags & NGF_F_BAKE_COLOR;
+    if (bd) return bc ? launch_triplane<true, true>(f, A, st) : launch_triplane<true, false>(f, A, st);
+    return bc ? launch_triplane<false, true>(f, A, st) : launch_triplane<false, false>(f, A, st);
 }
 
 extern "C" int ngf_field_render(const ngf_field *f, const float *rays, int64_t n, int32_t n_samples, int32_t white_bg,
@@ -365,17 +468,20 @@ extern "C" int ngf_field_decode_rgb(const ngf_field *f, const float *coords, con
     hipStream_t st = (hipStream_t)hip_stream;
     RenderArgs A = f->proto;
     A.mode = mode ? 1 : 0;
-    const size_t lds = ((size_t)((A.blob_floats + 3) & ~3)) * sizeof(float);
-    const int64_t nb = (n + kBatch - 1) / kBatch;
+    const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + 4 * 32 * kViewFeat) * sizeof(float);
+    const int64_t nb = (n + 15) / 16;
     int grid = (int)((nb + 3) / 4);
     if (grid > 4 * f->num_cus) grid = 4 * f->num_cus;
-    if (f->model == NGF_MODEL_TRIPLANE) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decode_rgb_kernel<48, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((decode_rgb_kernel<48, false>), dim3(grid), dim3(256), lds, st, A, coords, dirs, n, rgb);
-    } else {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decode_rgb_kernel<72, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((decode_rgb_kernel<72, true>), dim3(grid), dim3(256), lds, st, A, coords, dirs, n, rgb);
-    }
+    auto go = [&](auto kern) -> int {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, coords, dirs, n, rgb);
+        return NGF_OK;
+    };
+    int rc;
+    if (f->model == NGF_MODEL_INFOINV) rc = go(decode_rgb_kernel<InfoInvPolicy>);
+    else if (f->flags & NGF_F_BAKE_COLOR) rc = go(decode_rgb_kernel<TriPlanePolicy<false, true, 8, 1>>);
+    else rc = go(decode_rgb_kernel<TriPlanePolicy<false, false, 8, 1>>);
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return NGF_OK;
 }

@@ -57,13 +57,16 @@ struct InfoInvPolicy {
     static constexpr int APP = 72;
     static constexpr bool INFOINV = true;
     static constexpr int WAVES = kInfoInvWaves;
+    static constexpr int NSTEP = 1;
+    static constexpr int BATCH = kBatch;
+    static constexpr int RING = 128;
 
     // called by all 64 lanes; returns sigma of the lane's own sample (0 when !valid)
     __device__ static __forceinline__ float sigma(const RenderArgs &A, const float *smem, bool valid, const float x[3], int lane,
                                                   float t[6])
     {
         using D = InfoInvDensLayout;
-        const float *img = smem + MlpLayout<72>::TOTAL;
+        const float *img = per_pass(smem) + MlpLayout<72>::TOTAL;
         const int hi = lane >> 5;
         // transform (Field.py:43-50): identity split
         t[0] = x[0]; t[1] = x[1]; t[2] = x[1]; t[3] = x[2]; t[4] = x[0]; t[5] = x[2];
@@ -137,6 +140,11 @@ struct InfoInvPolicy {
         s1 = s1 + __shfl_xor(s1, 32);
         const float f = (hi ? s1 : s0) + img[D::B3];
         return valid ? softplus_shift(f) : 0.0f;
+    }
+    __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
+                                                 int lane, float c[3])
+    {
+        mlp_pass<72, true, 3>(A, smem, rec, vf, lane, A.mode, c);
     }
 };
 

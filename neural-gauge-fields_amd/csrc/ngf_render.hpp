@@ -23,31 +23,25 @@
 // Nothing of size [n,S,*] is ever materialised in HBM.
 #pragma once
 #include "ngf_device.hpp"
+#include "ngf_shade16.hpp"
 
 namespace ngf {
 
-// LDS carve (floats): [blob | per wave: ring, result list]
-constexpr int kWaveLdsFloats = kRing * kRecFloats + kBatch * 4;
+// LDS carve (floats): [blob | per wave: ring of RING records, result list, view inputs of the 64 rays]
+template <typename P> constexpr int wave_lds_floats() { return P::RING * kRecFloats + P::BATCH * 4 + kWave * kViewFeat; }
 
 // The 16 view-direction inputs of rgb_decoder layer 1 (networks.py:27-29, 205-216):
 //   u[F..F+14] = [d(3), sin(d_x), sin(2 d_x), sin(d_y), sin(2 d_y), sin(d_z), sin(2 d_z), cos(same 6)], u[F+15] = 0 (pad)
-// lane-half hi supplies entries hi*8 .. hi*8+7.
-__device__ __forceinline__ void view_inputs(const float d[3], int hi, float v[8])
+// lane-half hi supplies entries hi*8 .. hi*8+7.  Computed once per ray per tile into LDS.
+__device__ __forceinline__ void view_inputs(const float d[3], float v[16])
 {
-    float s[6], c[6];
+    v[0] = d[0]; v[1] = d[1]; v[2] = d[2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        sincosf(d[k], &s[2 * k], &c[2 * k]);
-        sincosf(d[k] * 2.0f, &s[2 * k + 1], &c[2 * k + 1]);
+        v[3 + 2 * k] = sinf(d[k]);   v[4 + 2 * k] = sinf(d[k] * 2.0f);
+        v[9 + 2 * k] = cosf(d[k]);   v[10 + 2 * k] = cosf(d[k] * 2.0f);
     }
-    v[0] = hi ? s[5] : d[0];
-    v[1] = hi ? c[0] : d[1];
-    v[2] = hi ? c[1] : d[2];
-    v[3] = hi ? c[2] : s[0];
-    v[4] = hi ? c[3] : s[1];
-    v[5] = hi ? c[4] : s[2];
-    v[6] = hi ? c[5] : s[3];
-    v[7] = hi ? 0.0f : s[4];
+    v[15] = 0.0f;
 }
 
 template <int APP>
@@ -63,14 +57,61 @@ struct MlpLayout {                        // offsets into the packed MLP image (
     static constexpr int TOTAL = B3 + 4;
 };
 
+// The MLP image in LDS is read-only after the initial barrier, so LICM would hoist every per-lane weight /
+// bias read (160+ values) out of the persistent loops and pin them in VGPRs for the whole kernel (they
+// then spill).  Adding an opaque zero to the pointer once per pass keeps those reads inside the pass.
+__device__ __forceinline__ const float *per_pass(const float *blob)
+{
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    return blob + z;
+}
+
+// layers 2 and 3 of rgb_decoder, shared by both shade variants
+__device__ __forceinline__ void mlp_tail(const float *__restrict__ blob, int oW2, int oB2, int oW3, int oB3, int lane,
+                                         const f32x16 &acc0, const f32x16 &acc1, float rgb[3])
+{
+    const int hi = lane >> 5;
+    // layer 2: B operand = ReLU(layer-1 accumulators) of the own sample, A = W2 rows permuted to match
+    f32x16 c0, c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        c0[r] = blob[oB2 + hi * 32 + r];
+        c1[r] = blob[oB2 + hi * 32 + 16 + r];
+    }
+    const float *w2a = blob + oW2 + lane;
+    const float *w2b = blob + oW2 + 32 * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        float h = fmaxf(k < 16 ? acc0[k & 15] : acc1[k & 15], 0.0f);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[k * 64], h, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2b[k * 64], h, c1, 0, 0, 0);
+    }
+    // layer 3 on the VALU: each half holds 32 of the 64 hidden activations of its sample
+    const float *w3 = blob + oW3 + hi * 32;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            float h = fmaxf(k < 16 ? c0[k & 15] : c1[k & 15], 0.0f);
+            s = fmaf(w3[c * 64 + k], h, s);
+        }
+        s = s + __shfl_xor(s, 32);
+        s = s + blob[oB3 + c];
+        rgb[c] = 1.0f / (1.0f + expf(-s));
+    }
+}
+
 // ---- shade: rgb_decoder on 32 queued samples ---------------------------------------------------
 // rec: this lane's record (lane s = lane&31 of the batch), vf: the owner ray's 16 view features.
 // Returns sigmoid colour of the lane's sample (identical in both halves).
 template <int APP, bool INFOINV, int CH = (APP == 48 ? 6 : 3)>
-__device__ __forceinline__ void mlp_pass(const RenderArgs &A, const float *__restrict__ blob, const float rec[kRecFloats],
-                                         const float od[3], int lane, int mode, float rgb[3])
+__device__ __forceinline__ void mlp_pass(const RenderArgs &A, const float *blob, const float rec[kRecFloats],
+                                         const float *vf, int lane, int mode, float rgb[3])
 {
     using L = MlpLayout<APP>;
+    blob = per_pass(blob);
     constexpr int NQ = L::HALF / 4;          // float4 loads per tap per lane (6 | 9)
     constexpr int CPP = NQ / CH;             // pipeline stages per plane
     constexpr int NST = 3 * CPP;
@@ -107,14 +148,14 @@ __device__ __forceinline__ void mlp_pass(const RenderArgs &A, const float *__res
         acc0[r] = blob[L::B1 + hi * 32 + r];
         acc1[r] = blob[L::B1 + hi * 32 + 16 + r];
     }
-    {   // view-direction inputs first (their sincos chain overlaps the first gather)
-        float vin[8];
-        view_inputs(od, hi, vin);
+    {   // view-direction inputs first (they overlap the first gather)
+        const f32x4 va = *reinterpret_cast<const f32x4 *>(vf + hi * 8), vb = *reinterpret_cast<const f32x4 *>(vf + hi * 8 + 4);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int t_ = 3 * L::HALF + j;
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[t_ * 64], vin[j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[t_ * 64], vin[j], acc1, 0, 0, 0);
+            const float x = j < 4 ? va[j & 3] : vb[j & 3];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[t_ * 64], x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[t_ * 64], x, acc1, 0, 0, 0);
         }
     }
     float pe_xyz[3];
@@ -153,37 +194,7 @@ __device__ __forceinline__ void mlp_pass(const RenderArgs &A, const float *__res
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[t_ * 64], feat[jj], acc1, 0, 0, 0);
         }
     }
-    // layer 2: B operand = ReLU(layer-1 accumulators) of the own sample, A = W2 rows permuted to match
-    f32x16 c0, c1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        c0[r] = blob[L::B2 + hi * 32 + r];
-        c1[r] = blob[L::B2 + hi * 32 + 16 + r];
-    }
-    const float *w2a = blob + L::W2 + lane;
-    const float *w2b = blob + L::W2 + 32 * 64 + lane;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        float h = fmaxf(k < 16 ? acc0[k & 15] : acc1[k & 15], 0.0f);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[k * 64], h, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2b[k * 64], h, c1, 0, 0, 0);
-    }
-    // layer 3 on the VALU: each half holds 32 of the 64 hidden activations of its sample
-    const float *w3 = blob + L::W3 + hi * 32;
-    float o[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            float h = fmaxf(k < 16 ? c0[k & 15] : c1[k & 15], 0.0f);
-            s = fmaf(w3[c * 64 + k], h, s);
-        }
-        s = s + __shfl_xor(s, 32);
-        s = s + blob[L::B3 + c];
-        o[c] = 1.0f / (1.0f + expf(-s));
-    }
-    rgb[0] = o[0]; rgb[1] = o[1]; rgb[2] = o[2];
+    mlp_tail(blob, L::W2, L::B2, L::W3, L::B3, lane, acc0, acc1, rgb);
 }
 
 // ---- TriPlane density at the gauge-shifted coordinates ------------------------------------------
@@ -246,20 +257,35 @@ __device__ __forceinline__ void triplane_gauge(const RenderArgs &A, const float 
 }
 
 // Field policy of the fused kernel: TriPlane (learned gauge + Linear(48,1) density on the VALU).
+//   BAKE_D  density_decoder pre-composed into 1-channel planes (NGF_F_BAKE_DENSITY)
+//   BAKE_C  rgb_decoder layer 1 pre-composed into 64-channel planes (NGF_F_BAKE_COLOR)
+//   WAVES   waves per workgroup (= per CU); NSTEP march steps evaluated per loop iteration
+//   The shade runs on v_mfma_f32_16x16x4_f32, 16 samples per pass (ngf_shade16.hpp).
 // sigma() is called by ALL lanes of the wave (wave-uniform call site); invalid lanes return 0.
-template <bool BAKED, int WAVES_ = 16>
+template <bool BAKE_D, bool BAKE_C, int WAVES_, int NSTEP_>
 struct TriPlanePolicy {
-    static constexpr int APP = 48;
     static constexpr bool INFOINV = false;
     static constexpr int WAVES = WAVES_;
+    static constexpr int NSTEP = NSTEP_;
+    static constexpr int BATCH = kBatch16;
+    static constexpr int RING = NSTEP_ == 1 ? 128 : 256;        // >= BATCH-1 + 64*NSTEP records
     __device__ static __forceinline__ float sigma(const RenderArgs &A, const float *, bool valid, const float x[3], int, float t[6])
     {
-        float sg = 0.0f;
-        if (valid) {
-            triplane_gauge(A, x, A.mode, t);
-            sg = softplus_shift(triplane_density_feature<BAKED>(A, t));
-        }
-        return sg;
+        // branch-free: out-of-box samples have out-of-range coordinates, for which bil_setup clamps the
+        // texel index and zeroes the weights, so their gathers are safe and their result is discarded.
+        // Without the branch the NSTEP independent steps share one basic block and their gathers overlap.
+        float tt[6];
+        triplane_gauge(A, x, A.mode, tt);
+        const float sg = softplus_shift(triplane_density_feature<BAKE_D>(A, tt));
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[k] = valid ? tt[k] : 0.0f;
+        return valid ? sg : 0.0f;
+    }
+    __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
+                                                 int lane, float c[3])
+    {
+        if constexpr (BAKE_C) mlp_pass16_baked(A, smem, rec, vf, lane, c);
+        else mlp_pass16<48>(A, smem, rec, vf, lane, c);
     }
 };
 
@@ -267,16 +293,17 @@ struct TriPlanePolicy {
 template <typename P>
 __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs A)
 {
-    constexpr int APP = P::APP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     for (int i = threadIdx.x; i < A.blob_floats; i += blockDim.x) smem[i] = A.blob[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *wl = smem + ((A.blob_floats + 3) & ~3) + wave * kWaveLdsFloats;
+    constexpr int RING = P::RING, NSTEP = P::NSTEP, BATCH = P::BATCH;
+    float *wl = smem + ((A.blob_floats + 3) & ~3) + wave * wave_lds_floats<P>();
     float *ring = wl;
-    float *res = wl + kRing * kRecFloats;
+    float *res = wl + RING * kRecFloats;
+    float *vfeat = res + BATCH * 4;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int S = A.S;
     unsigned long long st_valid = 0, st_active = 0, st_pass = 0, st_rays = 0;
@@ -305,61 +332,75 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         }
         tmin = fminf(fmaxf(tmin, A.near_), A.far_);
 
+        {   // view inputs of this lane's ray (networks.py:27-29), read back by the shade lanes
+            float v[16];
+            view_inputs(d, v);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(vfeat + lane * kViewFeat);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        }
         float T = 1.0f, acc = 0.0f, dep = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
         int i = 0, head = 0, count = 0;
         for (;;) {
-            if (count < kBatch && i < S) {
-                // ---------------- march one step -------------------------------------------------
-                const float z = tmin + A.step * ((float)i + jit);
-                const float zn = tmin + A.step * ((float)(i + 1) + jit);
-                const float dist = (i < S - 1) ? (zn - z) : 0.0f;
-                float p[3];
-                bool valid = live;
+            if (count < BATCH && i < S) {
+                // ---------------- march NSTEP steps (independent gathers, sequential transmittance) ----
+                float z[NSTEP], dist[NSTEP], sigma[NSTEP], t[NSTEP][6];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    p[k] = o[k] + d[k] * z;
-                    valid = valid && !(A.a0[k] > p[k] || p[k] > A.a1[k]);
-                }
-                if (A.mask.bits && valid) valid = mask_occupied(A.mask, p);
-                float t[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, x[3];
+                for (int u = 0; u < NSTEP; ++u) {
+                    z[u] = tmin + A.step * ((float)(i + u) + jit);
+                    const float zn = tmin + A.step * ((float)(i + u + 1) + jit);
+                    dist[u] = (i + u < S - 1) ? (zn - z[u]) : 0.0f;
+                    float p[3], x[3];
+                    bool valid = live && (i + u < S);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) x[k] = (p[k] - A.a0[k]) * A.inv[k] - 1.0f;   // normalize_coord (FieldBase.py:88-89)
-                const float sigma = P::sigma(A, smem, valid, x, lane, t);
-                // raw2alpha (FieldBase.py:12-19)
-                const float alpha = 1.0f - expf(-sigma * (dist * A.dscale));
-                const float w = alpha * T;
-                T = T * ((1.0f - alpha) + 1e-10f);
-                acc += w;
-                dep += w * z;
-                if (A.dbg_weight && live) {
-                    A.dbg_weight[ray * S + i] = w;
-                    A.dbg_sigma[ray * S + i] = sigma;
+                    for (int k = 0; k < 3; ++k) {
+                        p[k] = o[k] + d[k] * z[u];
+                        valid = valid && !(A.a0[k] > p[k] || p[k] > A.a1[k]);
+                    }
+                    if (A.mask.bits && valid) valid = mask_occupied(A.mask, p);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) t[u][k] = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) x[k] = (p[k] - A.a0[k]) * A.inv[k] - 1.0f;   // normalize_coord (FieldBase.py:88-89)
+                    sigma[u] = P::sigma(A, smem, valid, x, lane, t[u]);
+                    st_valid += __popcll(__ballot(valid));
                 }
-                const bool active = (w > A.thr) && !A.skip_rgb;
-                const unsigned long long m = __ballot(active);
-                if (active) {
-                    const int slot = (head + count + __popcll(m & lt_mask)) & (kRing - 1);
-                    f32x4 *r = reinterpret_cast<f32x4 *>(ring + slot * kRecFloats);
-                    r[0] = f32x4{__int_as_float(lane), w, t[0], t[1]};
-                    r[1] = f32x4{t[2], t[3], t[4], t[5]};
+#pragma unroll
+                for (int u = 0; u < NSTEP; ++u) {
+                    // raw2alpha (FieldBase.py:12-19); steps past S have sigma = 0 -> alpha = w = 0, T unchanged
+                    const float alpha = 1.0f - expf(-sigma[u] * (dist[u] * A.dscale));
+                    const float w = alpha * T;
+                    T = T * ((1.0f - alpha) + 1e-10f);
+                    acc += w;
+                    dep += w * z[u];
+                    if (A.dbg_weight && live && i + u < S) {
+                        A.dbg_weight[ray * S + i + u] = w;
+                        A.dbg_sigma[ray * S + i + u] = sigma[u];
+                    }
+                    const bool active = (w > A.thr) && !A.skip_rgb;
+                    const unsigned long long m = __ballot(active);
+                    if (active) {
+                        const int slot = (head + count + __popcll(m & lt_mask)) & (RING - 1);
+                        f32x4 *r = reinterpret_cast<f32x4 *>(ring + slot * kRecFloats);
+                        r[0] = f32x4{__int_as_float(lane), w, t[u][0], t[u][1]};
+                        r[1] = f32x4{t[u][2], t[u][3], t[u][4], t[u][5]};
+                    }
+                    count += __popcll(m);
+                    st_active += __popcll(m);
                 }
-                count += __popcll(m);
-                st_valid += __popcll(__ballot(valid));
-                st_active += __popcll(m);
-                ++i;
+                i += NSTEP;
             } else if (count > 0) {
-                // ---------------- shade up to 32 queued samples ----------------------------------
+                // ---------------- shade up to BATCH queued samples ----------------------------------
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const int nb = count < kBatch ? count : kBatch;
-                const int s = lane & 31;
-                const int slot = (head + (s < nb ? s : 0)) & (kRing - 1);
+                const int nb = count < BATCH ? count : BATCH;
+                const int s = lane & (BATCH - 1);
+                const int slot = (head + (s < nb ? s : 0)) & (RING - 1);
                 const f32x4 *r = reinterpret_cast<const f32x4 *>(ring + slot * kRecFloats);
                 const f32x4 r0 = r[0], r1 = r[1];
                 const float rec[kRecFloats] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
                 const int owner = __float_as_int(r0[0]);
-                const float od[3] = {__shfl(d[0], owner), __shfl(d[1], owner), __shfl(d[2], owner)};
                 float c[3];
-                mlp_pass<APP, P::INFOINV>(A, smem, rec, od, lane, A.mode, c);
+                P::shade(A, smem, rec, vfeat + owner * kViewFeat, lane, c);
                 if (lane < nb) *reinterpret_cast<f32x4 *>(res + lane * 4) = f32x4{r0[0], r0[1] * c[0], r0[1] * c[1], r0[1] * c[2]};
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // every lane, as ray owner, collects its entries in queue (= sample) order
@@ -368,7 +409,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     if (__float_as_int(e[0]) == lane) { cr += e[1]; cg += e[2]; cb += e[3]; }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                head = (head + nb) & (kRing - 1);
+                head = (head + nb) & (RING - 1);
                 count -= nb;
                 ++st_pass;
             } else {
@@ -397,27 +438,38 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
 }
 
 // ---- compute_rgb alone on caller-supplied samples (parity-test entry point) ----------------------
-template <int APP, bool INFOINV>
+template <typename P>
 __global__ void __launch_bounds__(256) decode_rgb_kernel(const RenderArgs A, const float *coords, const float *dirs,
                                                          int64_t n, float *out)
 {
+    constexpr int BATCH = P::BATCH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     for (int i = threadIdx.x; i < A.blob_floats; i += blockDim.x) smem[i] = A.blob[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t nbatch = (n + kBatch - 1) / kBatch;
+    float *vfeat = smem + ((A.blob_floats + 3) & ~3) + wave * (32 * kViewFeat);
+    const int64_t nbatch = (n + BATCH - 1) / BATCH;
     for (int64_t bt = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; bt < nbatch; bt += (int64_t)gridDim.x * (blockDim.x >> 6)) {
-        const int s = lane & 31;
-        int64_t q = bt * kBatch + s;
+        const int s = lane & (BATCH - 1);
+        int64_t q = bt * BATCH + s;
         const bool ok = q < n;
         if (!ok) q = n - 1;
         float rec[kRecFloats] = {0.0f, 1.0f, coords[q * 6 + 0], coords[q * 6 + 1], coords[q * 6 + 2],
                                  coords[q * 6 + 3], coords[q * 6 + 4], coords[q * 6 + 5]};
-        const float dq[3] = {dirs[q * 3], dirs[q * 3 + 1], dirs[q * 3 + 2]};
+        if (lane < BATCH) {
+            const float dq[3] = {dirs[q * 3], dirs[q * 3 + 1], dirs[q * 3 + 2]};
+            float v[16];
+            view_inputs(dq, v);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(vfeat + s * kViewFeat);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dst[k] = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         float c[3];
-        mlp_pass<APP, INFOINV>(A, smem, rec, dq, lane, A.mode, c);
-        if (lane < 32 && ok) { out[q * 3] = c[0]; out[q * 3 + 1] = c[1]; out[q * 3 + 2] = c[2]; }
+        P::shade(A, smem, rec, vfeat + s * kViewFeat, lane, c);
+        if (lane < BATCH && ok) { out[q * 3] = c[0]; out[q * 3 + 1] = c[1]; out[q * 3 + 2] = c[2]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
 

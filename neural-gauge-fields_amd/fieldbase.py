@@ -38,7 +38,8 @@ class Base(torch.nn.Module):
     DENS_DIM = 16
 
     def __init__(self, aabb, gridSize, device, alphaMask=None, near_far=[2.0, 6.0], alphaMask_thres=0.001,
-                 distance_scale=25, rayMarch_weight_thres=0.0001, step_ratio=2.0, gauge_start=0, bake_density=False):
+                 distance_scale=25, rayMarch_weight_thres=0.0001, step_ratio=2.0, gauge_start=0, bake_density=False,
+                 bake_color=False):
         super().__init__()
         self.aabb = aabb if torch.is_tensor(aabb) else torch.tensor(aabb, dtype=torch.float32)
         self.alphaMask = alphaMask
@@ -48,7 +49,8 @@ class Base(torch.nn.Module):
         self.rayMarch_weight_thres = rayMarch_weight_thres
         self.near_far = near_far
         self.step_ratio = step_ratio
-        self.bake_density = bool(bake_density)
+        self.bake_density = bool(bake_density)      # NGF_F_BAKE_DENSITY (TriPlane)
+        self.bake_color = bool(bake_color)          # NGF_F_BAKE_COLOR (TriPlane)
         self._handle = None
         self._handle_key = None
         self.last_stats = None
@@ -107,7 +109,7 @@ class Base(torch.nn.Module):
     def _param_key(self):
         ps = [(n, p.data_ptr(), p._version, tuple(p.shape)) for n, p in self.named_parameters()]
         m = None if self.alphaMask is None else (self.alphaMask.alpha_volume.data_ptr(), self.alphaMask.alpha_volume._version)
-        return (tuple(ps), m, float(self.stepSize), tuple(self.aabb.reshape(-1).tolist()), self.bake_density,
+        return (tuple(ps), m, float(self.stepSize), tuple(self.aabb.reshape(-1).tolist()), self.bake_density, self.bake_color,
                 tuple(self.near_far), float(self.distance_scale), float(self.rayMarch_weight_thres))
 
     def _fill_desc(self, d: _lib.FieldDesc, keep: list):
@@ -137,7 +139,9 @@ class Base(torch.nn.Module):
         d = _lib.FieldDesc()
         keep = []
         d.model, d.plane_c, d.dens_dim = self.MODEL, self.PLANE_C, self.DENS_DIM
-        d.flags = _lib.F_BAKE_DENSITY if (self.bake_density and self.MODEL == _lib.MODEL_TRIPLANE) else 0
+        d.flags = 0
+        if self.MODEL == _lib.MODEL_TRIPLANE:
+            d.flags = (_lib.F_BAKE_DENSITY if self.bake_density else 0) | (_lib.F_BAKE_COLOR if self.bake_color else 0)
 
         def dp(t):
             t = t.detach().to(device=dev, dtype=torch.float32).contiguous()

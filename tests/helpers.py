@@ -48,7 +48,7 @@ def psnr(a, b):
     return 200.0 if mse == 0 else -10.0 * np.log10(mse)
 
 
-def field_for_case(g, params, mask, device="cuda", bake=False):
+def field_for_case(g, params, mask, device="cuda", bake=False, bake_color=False):
     """Build the ngf_amd field (HIP path) for a golden case / parameter dict."""
     import torch
     from ngf_amd import infoinv, triplane
@@ -57,7 +57,7 @@ def field_for_case(g, params, mask, device="cuda", bake=False):
               rayMarch_weight_thres=float(g["thr"]), step_ratio=float(g["step_ratio"]))
     grid = [int(v) for v in g["grid"]]
     if str(g["model"]) == "triplane":
-        f = triplane.TriPlane(aabb, grid, device, gauge_start=0, bake_density=bake, **kw)
+        f = triplane.TriPlane(aabb, grid, device, gauge_start=0, bake_density=bake, bake_color=bake_color, **kw)
     else:
         f = infoinv.TriPlane(aabb, grid, device, **kw)
     f.load_params(params)

@@ -30,9 +30,12 @@ def _close(a, b, what, rtol=RTOL, atol=ATOL):
     return float(err.max())
 
 
+@pytest.mark.parametrize("bake_color", [False, True])
 @pytest.mark.parametrize("name", TRIPLANE + INFOINV)
-def test_decode_rgb_matches_oracle(name):
+def test_decode_rgb_matches_oracle(name, bake_color):
     g, params, step, mask = load_case(name)
+    if bake_color and str(g["model"]) != "triplane":
+        pytest.skip("baked colour is a TriPlane option")
     orc = oracle_for_case(g, params, step, mask)
     from ngf_amd import synth
     n = 1000
@@ -40,7 +43,7 @@ def test_decode_rgb_matches_oracle(name):
     dirs = synth.hash_normal(77, 2, (n, 3))
     dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
     dirs[:3] = np.eye(3, dtype=np.float32)            # zero components
-    f = field_for_case(g, params, mask)
+    f = field_for_case(g, params, mask, bake_color=bake_color)
     mode = int(g["gauge_on"]) if "gauge_on" in g else int(g["infoinv"])
     got = f.decode_rgb(torch.from_numpy(coords), torch.from_numpy(dirs), mode=mode).cpu().numpy()
     want = orc.color_at(coords, dirs)
@@ -66,16 +69,17 @@ def test_march_matches_oracle(name, bake):
     np.testing.assert_allclose(weight, dbg["weight"], rtol=1e-4, atol=2e-7)
 
 
-@pytest.mark.parametrize("bake", [False, True])
+@pytest.mark.parametrize("bake", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", TRIPLANE + INFOINV)
 def test_render_matches_oracle_and_reference(name, bake):
+    """bake: bit 0 = NGF_F_BAKE_DENSITY, bit 1 = NGF_F_BAKE_COLOR."""
     g, params, step, mask = load_case(name)
     if bake and str(g["model"]) != "triplane":
-        pytest.skip("baked density is a TriPlane option")
+        pytest.skip("baked planes are a TriPlane option")
     orc = oracle_for_case(g, params, step, mask)
     S, wb = int(g["S"]), bool(int(g["white_bg"]))
     o_rgb, o_depth = orc.render(g["rays"], S, white_bg=wb)
-    f = field_for_case(g, params, mask, bake=bake)
+    f = field_for_case(g, params, mask, bake=bool(bake & 1), bake_color=bool(bake & 2))
     out = f(torch.from_numpy(g["rays"]).cuda(), white_bg=wb, is_train=False, N_samples=S, collect_stats=True, **_mode(g))
     rgb, depth = out["rgb_map"].cpu().numpy(), out["depth_map"].cpu().numpy()
     e1 = _close(rgb, o_rgb, "rgb vs oracle")
@@ -136,6 +140,8 @@ def test_headline_geometry_chunk(model, preset):
     st = f.last_stats.cpu().numpy()
     print(f"{model} {preset}: max abs err {e:.2e}, PSNR {psnr(rgb, o_rgb):.1f} dB, active fraction {st[1] / (3200 * 192):.3f}")
     if model == "triplane":
-        fb = field_for_case(g, params, None, bake=True)
-        outb = fb(torch.from_numpy(rays).cuda(), N_samples=192, iteration=30001)
-        _close(outb["rgb_map"].cpu().numpy(), o_rgb, "rgb (baked density)")
+        for bd, bc in ((True, False), (False, True), (True, True)):
+            fb = field_for_case(g, params, None, bake=bd, bake_color=bc)
+            outb = fb(torch.from_numpy(rays).cuda(), N_samples=192, iteration=30001)
+            eb = _close(outb["rgb_map"].cpu().numpy(), o_rgb, f"rgb (bake_density={bd}, bake_color={bc})")
+            print(f"   bake_density={bd} bake_color={bc}: max abs err {eb:.2e}")
