@@ -113,6 +113,32 @@ int ngf_field_march(const ngf_field *f, const float *rays, int64_t n, int32_t n_
 int ngf_generate_rays(int32_t H, int32_t W, float focal, const float *c2w_host, int32_t row0, int32_t rows,
                       float *rays, void *hip_stream);
 
+/* ---- UV-Mapping (NeuTex) colour path: UV-Mapping/model/model.py:27-59 ----------------------------------------
+ * 29 nn.Linear layers in evaluation order, reference layouts (weight [out,in], bias [out], float32, device):
+ *   [0..11]  net_geometry_decoder.block.{0,2,..,22}   63-256, 10x 256-256, 256-1          (decoder.py:201-237)
+ *   [12..16] gauge_transform.encoder.{linear1,linear2,linear_list.0,linear_list.1,last_linear}
+ *                                                      63-64, 64-128, 128-128, 128-128, 128-(3|2) (gauge_fields.py:8-46)
+ *   [17..22] net_texture.block1.{0,2,..,10}           (63|42)-256, 5x 256-256             (decoder.py:19-25)
+ *   [23]     net_texture.color1                        256-3
+ *   [24..28] net_texture.block2.{0,2,4,6,8}            295-256, 3x 256-256, 256-3          (decoder.py:27-34)
+ * sphere: primitive_type == 'sphere' (uv = normalize(q) in R^3) else 'square' (uv = tanh(q) in R^2). */
+#define NGF_UV_LAYERS 29
+typedef struct ngf_uv_desc {
+    int32_t sphere;
+    const float *w[NGF_UV_LAYERS];
+    const float *b[NGF_UV_LAYERS];
+} ngf_uv_desc;
+typedef struct ngf_uv ngf_uv;
+int ngf_uv_create(const ngf_uv_desc *desc, ngf_uv **out, void *hip_stream);
+int ngf_uv_destroy(ngf_uv *m);
+/* Replaces NeuTex.forward's colour outputs for one camera (model.py:30-52):
+ *   campos_host float[3], bg_host float[3] or NULL (HOST pointers), raydir [R,3], jitter_u [R,S] = the uniforms
+ *   cube_ray_generation draws with torch.rand (renderer.py:112-117; jitter = 0.05 always, model.py:30);
+ *   color [R,3] (tone-mapped), transmittance [R]; dbg_sigma [R,S] / dbg_col [R,S,3] optional (NULL). */
+int ngf_uv_render(const ngf_uv *m, const float *campos_host, const float *raydir, const float *bg_host,
+                  const float *jitter_u, int64_t n_rays, int32_t n_samples, float *color, float *transmittance,
+                  float *dbg_sigma, float *dbg_col, void *hip_stream);
+
 const char *ngf_last_error(void);
 int ngf_abi_version(void);
 /* sizeof(ngf_field_desc) as compiled into the library (binding self-check) */

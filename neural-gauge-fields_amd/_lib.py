@@ -16,7 +16,8 @@ F_BAKE_DENSITY = 1
 F_BAKE_COLOR = 2
 
 SYMBOLS = ["ngf_field_create", "ngf_field_destroy", "ngf_field_render", "ngf_field_decode_rgb", "ngf_field_march",
-           "ngf_generate_rays", "ngf_last_error", "ngf_abi_version", "ngf_field_bytes", "ngf_sizeof_field_desc"]
+           "ngf_generate_rays", "ngf_last_error", "ngf_abi_version", "ngf_field_bytes", "ngf_sizeof_field_desc",
+           "ngf_uv_create", "ngf_uv_destroy", "ngf_uv_render"]
 
 
 class FieldDesc(C.Structure):
@@ -33,6 +34,13 @@ class FieldDesc(C.Structure):
         ("mask_bits", C.c_void_p), ("mask_d", C.c_int32), ("mask_h", C.c_int32), ("mask_w", C.c_int32),
         ("mask_aabb", C.c_float * 6),
     ]
+
+
+UV_LAYERS = 29
+
+
+class UvDesc(C.Structure):
+    _fields_ = [("sphere", C.c_int32), ("w", C.c_void_p * UV_LAYERS), ("b", C.c_void_p * UV_LAYERS)]
 
 
 def build(force: bool = False) -> str:
@@ -62,6 +70,10 @@ def lib():
                                       C.c_void_p, C.c_void_p]
         L.ngf_generate_rays.argtypes = [C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                         C.c_void_p]
+        L.ngf_uv_create.argtypes = [C.POINTER(UvDesc), C.POINTER(C.c_void_p), C.c_void_p]
+        L.ngf_uv_destroy.argtypes = [C.c_void_p]
+        L.ngf_uv_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         if L.ngf_abi_version() != 1 or L.ngf_sizeof_field_desc() != C.sizeof(FieldDesc):
             raise RuntimeError("libngf_hip.so ABI mismatch (version or ngf_field_desc layout)")
         _LIB = L

@@ -16,6 +16,7 @@
 #include "../../include/ngf.h"
 #include "ngf_infoinv.hpp"
 #include "ngf_render.hpp"
+#include "ngf_uv.hpp"
 
 using namespace ngf;
 
@@ -496,6 +497,184 @@ extern "C" int ngf_generate_rays(int32_t H, int32_t W, float focal, const float 
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(generate_rays_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, H, W, focal, c[0], c[1], c[2], c[4],
                        c[5], c[6], c[8], c[9], c[10], c[3], c[7], c[11], row0, rows, rays);
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+// ================================ UV-Mapping (NeuTex) ===================================================================
+struct ngf_uv {
+    float *w = nullptr;
+    unsigned int *counters = nullptr;
+    mutable std::atomic<unsigned> next_counter{0};
+    UvArgs proto;
+    int num_cus = 256;
+};
+
+extern "C" int ngf_uv_destroy(ngf_uv *m)
+{
+    if (!m) return NGF_OK;
+    if (m->w) (void)hipFree(m->w);
+    if (m->counters) (void)hipFree(m->counters);
+    delete m;
+    return NGF_OK;
+}
+
+namespace {
+struct UvPacker {
+    std::vector<float> buf;
+    static int hidden(int t, int kq) { return (t >> 2) * 16 + 4 * kq + (t & 3); }
+    int align() { while (buf.size() & 3) buf.push_back(0.0f); return (int)buf.size(); }
+    // imap(t, kq) -> input index (or -1); KT k-steps; NT unit tiles (multiple of 4)
+    template <typename F>
+    int dense(const std::vector<float> &W, int out_f, int in_f, int KT, int NT, F imap)
+    {
+        const int off = align();
+        buf.resize(off + (size_t)KT * NT * 64, 0.0f);
+        for (int t = 0; t < KT; ++t)
+            for (int g = 0; g < NT / 4; ++g)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 4; ++e) {
+                        const int o = (4 * g + e) * 16 + (l & 15), i = imap(t, l >> 4);
+                        buf[off + (((size_t)t * (NT / 4) + g) * 64 + l) * 4 + e] = (o < out_f && i >= 0 && i < in_f) ? W[(size_t)o * in_f + i] : 0.0f;
+                    }
+        return off;
+    }
+    template <typename F>
+    int out_layer(const std::vector<float> &W, int out_f, int in_f, int KT, F imap)
+    {
+        const int off = align();
+        buf.resize(off + (size_t)KT * 64, 0.0f);
+        for (int t = 0; t < KT; ++t)
+            for (int l = 0; l < 64; ++l) {
+                const int o = l & 15, i = imap(t, l >> 4);
+                buf[off + (size_t)t * 64 + l] = (o < out_f && i >= 0 && i < in_f) ? W[(size_t)o * in_f + i] : 0.0f;
+            }
+        return off;
+    }
+    int bias(const std::vector<float> &b, int out_f, int NT)
+    {
+        const int off = align();
+        buf.resize(off + (size_t)NT * 16, 0.0f);
+        for (int kq = 0; kq < 4; ++kq)
+            for (int mt = 0; mt < NT; ++mt)
+                for (int r = 0; r < 4; ++r) {
+                    const int o = mt * 16 + 4 * kq + r;
+                    buf[off + kq * (NT * 4) + mt * 4 + r] = o < out_f ? b[o] : 0.0f;
+                }
+        return off;
+    }
+    int bias4(const std::vector<float> &b, int out_f)
+    {
+        const int off = align();
+        for (int e = 0; e < 4; ++e) buf.push_back(e < out_f ? b[e] : 0.0f);
+        return off;
+    }
+};
+}  // namespace
+
+extern "C" int ngf_uv_create(const ngf_uv_desc *d, ngf_uv **out, void *hip_stream)
+{
+    if (!d || !out) return fail(NGF_E_ARG, "ngf_uv_create: null argument");
+    *out = nullptr;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int ud = d->sphere ? 3 : 2;
+    const int in_uv = ud + 20 * ud;
+    static const int kOut[NGF_UV_LAYERS] = {256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 1, 64, 128, 128, 128, 0,
+                                            256, 256, 256, 256, 256, 256, 3, 256, 256, 256, 256, 3};
+    static const int kIn[NGF_UV_LAYERS] = {63, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 63, 64, 128, 128, 128,
+                                           0, 256, 256, 256, 256, 256, 256, 295, 256, 256, 256, 256};
+    std::vector<std::vector<float>> W(NGF_UV_LAYERS), B(NGF_UV_LAYERS);
+    for (int l = 0; l < NGF_UV_LAYERS; ++l) {
+        const int o = l == 16 ? ud : kOut[l], i = l == 17 ? in_uv : kIn[l];
+        if (!d->w[l] || !d->b[l]) return fail(NGF_E_ARG, "ngf_uv_create: layer %d missing", l);
+        int rc;
+        if ((rc = d2h(W[l], d->w[l], (size_t)o * i, st)) || (rc = d2h(B[l], d->b[l], o, st))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    ngf_uv *m = new (std::nothrow) ngf_uv();
+    if (!m) return fail(NGF_E_HIP, "out of host memory");
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) m->num_cus = prop.multiProcessorCount;
+    UvArgs &A = m->proto;
+    memset(&A, 0, sizeof(A));
+    A.sphere = d->sphere ? 1 : 0;
+    UvPacker P;
+    auto nat = [](int t, int kq) { return 4 * t + kq; };                      // positional-encoding inputs: natural order
+    auto hid = [](int t, int kq) { return UvPacker::hidden(t, kq); };         // previous layer's accumulator order
+    // geometry
+    A.geo_w0 = P.dense(W[0], 256, 63, 16, 16, nat);  A.geo_b0 = P.bias(B[0], 256, 16);
+    for (int l = 0; l < 10; ++l) {
+        const int o = P.dense(W[1 + l], 256, 256, 64, 16, hid);
+        if (l == 0) A.geo_wh = o;
+    }
+    for (int l = 0; l < 10; ++l) {
+        const int o = P.bias(B[1 + l], 256, 16);
+        if (l == 0) A.geo_bh = o;
+    }
+    A.geo_wo = P.out_layer(W[11], 1, 256, 64, hid);  A.geo_bo = P.bias4(B[11], 1);
+    // gauge
+    A.ga_w0 = P.dense(W[12], 64, 63, 16, 4, nat);    A.ga_b0 = P.bias(B[12], 64, 4);
+    A.ga_w1 = P.dense(W[13], 128, 64, 16, 8, hid);   A.ga_b1 = P.bias(B[13], 128, 8);
+    A.ga_w2 = P.dense(W[14], 128, 128, 32, 8, hid);  A.ga_b2 = P.bias(B[14], 128, 8);
+    A.ga_w3 = P.dense(W[15], 128, 128, 32, 8, hid);  A.ga_b3 = P.bias(B[15], 128, 8);
+    A.ga_wo = P.out_layer(W[16], ud, 128, 32, hid);  A.ga_bo = P.bias4(B[16], ud);
+    // texture
+    A.t1_w0 = P.dense(W[17], 256, in_uv, d->sphere ? 16 : 11, 16, nat);  A.t1_b0 = P.bias(B[17], 256, 16);
+    for (int l = 0; l < 5; ++l) {
+        const int o = P.dense(W[18 + l], 256, 256, 64, 16, hid);
+        if (l == 0) A.t1_wh = o;
+    }
+    for (int l = 0; l < 5; ++l) {
+        const int o = P.bias(B[18 + l], 256, 16);
+        if (l == 0) A.t1_bh = o;
+    }
+    A.c1_w = P.out_layer(W[23], 3, 256, 64, hid);    A.c1_b = P.bias4(B[23], 3);
+    A.t2_w0 = P.dense(W[24], 256, 295, 74, 16, [](int t, int kq) { return t < 64 ? UvPacker::hidden(t, kq) : 256 + 4 * (t - 64) + kq; });
+    A.t2_b0 = P.bias(B[24], 256, 16);
+    for (int l = 0; l < 3; ++l) {
+        const int o = P.dense(W[25 + l], 256, 256, 64, 16, hid);
+        if (l == 0) A.t2_wh = o;
+    }
+    for (int l = 0; l < 3; ++l) {
+        const int o = P.bias(B[25 + l], 256, 16);
+        if (l == 0) A.t2_bh = o;
+    }
+    A.t2_wo = P.out_layer(W[28], 3, 256, 64, hid);   A.t2_bo = P.bias4(B[28], 3);
+    P.align();
+    auto bail = [&](int code) { ngf_uv_destroy(m); return code; };
+    if (hipMalloc((void **)&m->w, P.buf.size() * sizeof(float)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(uv weights) failed"));
+    if (hipMemcpyAsync(m->w, P.buf.data(), P.buf.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return bail(fail(NGF_E_HIP, "uploading the packed UV weights failed"));
+    if (hipMalloc((void **)&m->counters, kCounters * sizeof(unsigned)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(counters) failed"));
+    A.w = m->w;
+    *out = m;
+    return NGF_OK;
+}
+
+extern "C" int ngf_uv_render(const ngf_uv *m, const float *campos_host, const float *raydir, const float *bg_host, const float *jitter_u,
+                             int64_t n_rays, int32_t n_samples, float *color, float *transmittance, float *dbg_sigma, float *dbg_col,
+                             void *hip_stream)
+{
+    if (!m || !campos_host || !raydir || !jitter_u || !color || !transmittance) return fail(NGF_E_ARG, "ngf_uv_render: null argument");
+    if (n_rays < 0 || n_samples <= 0) return fail(NGF_E_ARG, "ngf_uv_render: n_rays=%lld n_samples=%d", (long long)n_rays, n_samples);
+    if ((dbg_sigma == nullptr) != (dbg_col == nullptr)) return fail(NGF_E_ARG, "ngf_uv_render: dbg_sigma and dbg_col go together");
+    if (n_rays == 0) return NGF_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    UvArgs A = m->proto;
+    A.raydir = raydir; A.U = jitter_u; A.color = color; A.trans = transmittance; A.dbg_sigma = dbg_sigma; A.dbg_col = dbg_col;
+    A.R = n_rays; A.S = n_samples;
+    for (int k = 0; k < 3; ++k) { A.campos[k] = campos_host[k]; A.bg[k] = bg_host ? bg_host[k] : 0.0f; }
+    A.has_bg = bg_host ? 1 : 0;
+    const unsigned slot = m->next_counter.fetch_add(1) % kCounters;
+    A.ray_counter = m->counters + slot;
+    HIP_TRY(hipMemsetAsync(A.ray_counter, 0, sizeof(unsigned), st));
+    int64_t grid = (n_rays + 7) / 8;
+    if (grid > (int64_t)m->num_cus) grid = m->num_cus;
+    const size_t lds = (size_t)8 * kUvWaveLds * sizeof(float);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(uv_render_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(uv_render_kernel, dim3((unsigned)grid), dim3(512), lds, st, A);
     HIP_TRY(hipGetLastError());
     return NGF_OK;
 }

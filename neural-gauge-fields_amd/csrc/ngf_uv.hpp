@@ -1,0 +1,305 @@
+// ngf_uv.hpp -- UV-Mapping (NeuTex) colour path on gfx950: UV-Mapping/model/model.py:30-50.
+//
+//   cube_ray_generation  renderer.py:79-141     GeometryMlpDecoder  decoder.py:201-237
+//   GaugeTransform       gauge_fields.py:8-74   TextureMlpDecoder   decoder.py:11-78 (un-edited texture branch)
+//   ray_march            renderer.py:176-247    simple_tone_map     renderer.py:7-8
+//
+// 1.33 M MAC per sample, no data to speak of (5.4 MB of weights): the path is bound by the fp32 matrix pipe.
+// One wave renders one ray: lane i owns sample i of a 64-sample chunk (segment jitter, prefix sum, position,
+// in-cube test).  In-cube samples are compacted and pushed through the three MLPs 16 at a time on
+// v_mfma_f32_16x16x4_f32 with FOUR lanes per sample (lane (s, kq)); the product is evaluated transposed (rows =
+// units, columns = samples) so a lane's accumulators are 64 of the 256 activations of its own sample and are the
+// B operand of the next layer without any data movement.  Weights are pre-permuted at create time into
+// [k-step][unit-tile group][lane][4] so the A operand of four MFMAs is one coalesced 16-byte load per lane,
+// streamed from L2 (they do not fit LDS).  Out-of-cube samples are skipped: their opacity is exactly 0 in the
+// reference (sigma * valid, renderer.py:222), so skipping them changes nothing.
+#pragma once
+#include "ngf_device.hpp"
+
+namespace ngf {
+
+#define NGF_UV_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+struct UvArgs {
+    const float *raydir;   // [R,3]
+    const float *U;        // [R,S] jitter uniforms
+    float *color;          // [R,3]
+    float *trans;          // [R]
+    float *dbg_sigma;      // [R,S] or NULL
+    float *dbg_col;        // [R,S,3] or NULL
+    unsigned int *ray_counter;
+    int64_t R;
+    int32_t S, sphere, has_bg, pad_;
+    float campos[3], bg[3];
+    const float *w;        // packed weights / biases (offsets below, floats)
+    // geometry
+    int32_t geo_w0, geo_b0, geo_wh, geo_bh, geo_wo, geo_bo;       // wh/bh: 10 hidden layers, strides 65536 / 256
+    // gauge
+    int32_t ga_w0, ga_b0, ga_w1, ga_b1, ga_w2, ga_b2, ga_w3, ga_b3, ga_wo, ga_bo;
+    // texture
+    int32_t t1_w0, t1_b0, t1_wh, t1_bh, c1_w, c1_b, t2_w0, t2_b0, t2_wh, t2_bh, t2_wo, t2_bo;
+};
+
+__device__ __forceinline__ float act_fn(float x, float slope) { return fmaxf(x, 0.0f) + slope * fminf(x, 0.0f); }
+
+constexpr int kUvActSteps = 80;                    // k-steps of per-wave activation storage (74 used by block2.0)
+constexpr int kUvWaveLds = kUvActSteps * 64;       // floats per wave
+
+// Activations live in a wave-private LDS array act[k-step][lane]: lane (s, kq) keeps there, for k-step t, the input
+// it supplies as B operand (unit (t>>2)*16 + 4*kq + (t&3) of its own sample).  Every lane only ever reads back what
+// it wrote itself, so there is no cross-lane hazard and no barrier; LDS is used because the k loop must be a real
+// loop (a fully unrolled 256x256 layer makes hipcc hoist ~256 16-byte weight loads and spill thousands of VGPRs)
+// and registers cannot be indexed by a loop variable.
+
+// acc[mt] <- bias (accumulator order: unit mt*16 + 4*kq + r)
+template <int NT>
+__device__ __forceinline__ void load_bias(const float *b, int kq, f32x4 acc[NT])
+{
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(b + kq * (NT * 4) + mt * 4);
+}
+
+// one k-step: NT unit tiles, A from packed weights [t][NT/4][64 lanes][4] (one coalesced 16-byte load per 4 MFMAs)
+template <int NT>
+__device__ __forceinline__ void kstep(const float *w, int t, int lane, float b, f32x4 acc[NT])
+{
+    const f32x4 *wp = reinterpret_cast<const f32x4 *>(w) + ((size_t)t * (NT / 4)) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < NT / 4; ++g) {
+        const f32x4 a = wp[g * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = NGF_UV_MFMA(a[e], b, acc[4 * g + e]);
+    }
+}
+
+template <int NT_OUT>
+__device__ __forceinline__ void dense(const float *w, const float *bias, int KT, int lane, const float *act, f32x4 out[NT_OUT])
+{
+    load_bias<NT_OUT>(bias, lane >> 4, out);
+#pragma unroll 2
+    for (int t = 0; t < KT; ++t) kstep<NT_OUT>(w, t, lane, act[t * 64 + lane], out);
+}
+
+template <int NT>
+__device__ __forceinline__ void store_act(float *act, int lane, const f32x4 acc[NT], float slope)
+{
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) act[(mt * 4 + r) * 64 + lane] = act_fn(acc[mt][r], slope);
+}
+
+// output layer with <= 3 units: packed [t][64 lanes] (rows >= n_out are zero); rows 0..3 land in lanes kq = 0
+__device__ __forceinline__ f32x4 dense_out(const float *w, const float *bias4, int KT, int lane, const float *act)
+{
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+    for (int t = 0; t < KT; ++t) acc = NGF_UV_MFMA(w[t * 64 + lane], act[t * 64 + lane], acc);
+    const int src = lane & 15;
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __shfl(acc[e], src) + bias4[e];
+    return r;
+}
+
+// positional-encoding inputs [x(D), sin(D*F), cos(D*F)] (util.py:427-438): lane-quarter kq supplies entry 4t + kq
+template <int D, int F>
+__device__ __forceinline__ float pe_entry(const float x[3], int f)
+{
+    constexpr int N = D * F;
+    if (f >= D + 2 * N) return 0.0f;
+    const int g = f - D;
+    const int gi = g < 0 ? 0 : (g >= N ? g - N : g);
+    const int dim = gi / F, fr = gi - dim * F;
+    const float xd = dim == 0 ? x[0] : (dim == 1 ? x[1] : x[2]);
+    const float arg = xd * (float)(1 << fr);
+    float s, c;
+    sincosf(arg, &s, &c);
+    const float raw = f == 0 ? x[0] : (f == 1 ? x[1] : x[2]);
+    return f < D ? raw : (g < N ? s : c);
+}
+
+template <int D, int F>
+__device__ __forceinline__ void store_pe(float *act, int t0, int KT, int lane, const float x[3])
+{
+    const int kq = lane >> 4;
+#pragma unroll 1
+    for (int t = 0; t < KT; ++t) act[(t0 + t) * 64 + lane] = pe_entry<D, F>(x, 4 * t + kq);
+}
+
+// ---- the three networks for 16 samples ------------------------------------------------------------------------------
+// p: position of the lane's sample, v: ray direction.  Returns sigma and colour (identical in the 4 lanes of a sample).
+__device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lane, const float p[3], const float v[3], float &sigma,
+                                            float col[3])
+{
+    const float *W = A.w;
+    f32x4 x[16];
+    // geometry: 63 -> 256 -> (10x) 256 -> 1, ReLU
+    store_pe<3, 10>(act, 0, 16, lane, p);
+    dense<16>(W + A.geo_w0, W + A.geo_b0, 16, lane, act, x);
+    store_act<16>(act, lane, x, 0.0f);
+#pragma unroll 1
+    for (int l = 0; l < 10; ++l) {
+        dense<16>(W + A.geo_wh + (size_t)l * 65536, W + A.geo_bh + l * 256, 64, lane, act, x);
+        store_act<16>(act, lane, x, 0.0f);
+    }
+    {
+        const f32x4 o = dense_out(W + A.geo_wo, W + A.geo_bo, 64, lane, act);
+        sigma = o[0] > 20.0f ? o[0] : log1pf(expf(o[0]));
+    }
+    // gauge: 63 -> 64 -> 128 -> 128 -> 128 -> 3|2, ReLU
+    float uv[3];
+    {
+        f32x4 g[8];
+        store_pe<3, 10>(act, 0, 16, lane, p);
+        dense<4>(W + A.ga_w0, W + A.ga_b0, 16, lane, act, g);
+        store_act<4>(act, lane, g, 0.0f);
+        dense<8>(W + A.ga_w1, W + A.ga_b1, 16, lane, act, g);
+        store_act<8>(act, lane, g, 0.0f);
+        dense<8>(W + A.ga_w2, W + A.ga_b2, 32, lane, act, g);
+        store_act<8>(act, lane, g, 0.0f);
+        dense<8>(W + A.ga_w3, W + A.ga_b3, 32, lane, act, g);
+        store_act<8>(act, lane, g, 0.0f);
+        const f32x4 q = dense_out(W + A.ga_wo, W + A.ga_bo, 32, lane, act);
+        if (A.sphere) {
+            float nrm = sqrtf((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);
+            nrm = fmaxf(nrm, 1e-12f);
+            uv[0] = q[0] / nrm; uv[1] = q[1] / nrm; uv[2] = q[2] / nrm;
+        } else {
+            uv[0] = tanhf(q[0]); uv[1] = tanhf(q[1]); uv[2] = 0.0f;
+        }
+    }
+    // texture block1: (63|42) -> 256 -> (5x) 256, LeakyReLU(0.2)
+    if (A.sphere) {
+        store_pe<3, 10>(act, 0, 16, lane, uv);
+        dense<16>(W + A.t1_w0, W + A.t1_b0, 16, lane, act, x);
+    } else {
+        store_pe<2, 10>(act, 0, 11, lane, uv);
+        dense<16>(W + A.t1_w0, W + A.t1_b0, 11, lane, act, x);
+    }
+    store_act<16>(act, lane, x, 0.2f);
+#pragma unroll 1
+    for (int l = 0; l < 5; ++l) {
+        dense<16>(W + A.t1_wh + (size_t)l * 65536, W + A.t1_bh + l * 256, 64, lane, act, x);
+        store_act<16>(act, lane, x, 0.2f);
+    }
+    // act[0..63] = block1 output h; color1 and block2 both read it
+    const f32x4 c1 = dense_out(W + A.c1_w, W + A.c1_b, 64, lane, act);
+    // block2: [h(256), v(3), PE6(v)(36)] -> 256 -> (3x) 256 -> 3
+    store_pe<3, 6>(act, 64, 10, lane, v);
+    dense<16>(W + A.t2_w0, W + A.t2_b0, 74, lane, act, x);
+    store_act<16>(act, lane, x, 0.2f);
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) {
+        dense<16>(W + A.t2_wh + (size_t)l * 65536, W + A.t2_bh + l * 256, 64, lane, act, x);
+        store_act<16>(act, lane, x, 0.2f);
+    }
+    const f32x4 c2 = dense_out(W + A.t2_wo, W + A.t2_bo, 64, lane, act);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float s1 = c1[k] > 20.0f ? c1[k] : log1pf(expf(c1[k]));      // softplus(color1) (clamp = False, decoder.py:66-67)
+        col[k] = fmaxf(s1 + c2[k], 0.0f);                                   // (color1 + color2).clamp(min=0)   decoder.py:78
+    }
+}
+
+__global__ void __launch_bounds__(512) uv_render_kernel(const UvArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    float *act = smem + (threadIdx.x >> 6) * kUvWaveLds;
+    const int S = A.S;
+    const float dt = (float)(2.0 / S), dtj = (float)((2.0 / S) * 0.05);     // renderer.py:107-117 (python floats)
+    for (;;) {
+        unsigned int ray = 0;
+        if (lane == 0) ray = atomicAdd(A.ray_counter, 1u);
+        ray = __builtin_amdgcn_readfirstlane(ray);
+        if ((int64_t)ray >= A.R) break;
+        float d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k] = A.raydir[(size_t)ray * 3 + k];
+        // slab test (renderer.py:90-105)
+        float t1[3], t2[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { t1[k] = (-1.0f - A.campos[k]) / d[k]; t2[k] = (1.0f - A.campos[k]) / d[k]; }
+        const float tmin = fmaxf(fminf(t1[0], t2[0]), fmaxf(fminf(t1[1], t2[1]), fminf(t1[2], t2[2])));
+        const float tmax = fminf(fmaxf(t1[0], t2[0]), fminf(fmaxf(t1[1], t2[1]), fmaxf(t1[2], t2[2])));
+        const float t0 = fmaxf((tmin < tmax) ? tmin : 0.0f, 0.0f);
+
+        double cum = 0.0;          // torch.cumsum accumulates float32 in double on the CPU path we are pinned to
+        float T = 1.0f, rc[3] = {0.0f, 0.0f, 0.0f};
+        for (int base = 0; base < S; base += 64) {
+            const int i = base + lane;
+            const bool in = i < S;
+            const float seg = in ? dt + dtj * (A.U[(size_t)ray * S + i] - 0.5f) : 0.0f;
+            // inclusive prefix sum over the chunk, sequential in the sample index
+            double mycum = 0.0, prev = 0.0;
+            for (int j = 0; j < 64; ++j) {
+                const double before = cum;
+                cum += (double)__shfl(seg, j);
+                if (lane == j) { mycum = cum; prev = before; }
+            }
+            const float e0 = t0 + (float)prev, e1 = t0 + (float)mycum;
+            const float mid = (e0 + e1) / 2.0f;
+            float p[3];
+            bool valid = in;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                p[k] = A.campos[k] + d[k] * mid;
+                valid = valid && (p[k] > -1.0f) && (p[k] < 1.0f);
+            }
+            const unsigned long long vm = __ballot(valid);
+            const int nv = __popcll(vm);
+            const int rank = __popcll(vm & ((1ull << lane) - 1ull));
+            float sigma = 0.0f, col[3] = {0.0f, 0.0f, 0.0f};
+            for (int g0 = 0; g0 < nv; g0 += 16) {
+                // lane (s, kq) evaluates the (g0+s)-th in-cube sample of the chunk: find its owner lane
+                const int want = g0 + (lane & 15);
+                unsigned long long m = vm;
+                int owner = 0;
+                {   // select the want-th set bit of vm (want < nv, else reuse the first)
+                    const int w2 = want < nv ? want : g0;
+                    for (int b = 0; b < w2; ++b) m &= m - 1;
+                    owner = __ffsll((long long)m) - 1;
+                }
+                float q[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) q[k] = __shfl(p[k], owner);
+                float sg, cc[3];
+                uv_networks(A, act, lane, q, d, sg, cc);
+                // owners pull their result from lane slot (kq = 0 copy)
+                const int slot = rank - g0;
+                const bool mine = valid && slot >= 0 && slot < 16;
+                const float psg = __shfl(sg, slot & 15), p0 = __shfl(cc[0], slot & 15), p1 = __shfl(cc[1], slot & 15),
+                            p2 = __shfl(cc[2], slot & 15);
+                if (mine) { sigma = psg; col[0] = p0; col[1] = p1; col[2] = p2; }
+            }
+            if (A.dbg_sigma && in) {
+                A.dbg_sigma[(size_t)ray * S + i] = sigma;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) A.dbg_col[((size_t)ray * S + i) * 3 + k] = col[k];
+            }
+            // ray_march (renderer.py:222-233): sequential in the sample index
+            const float op = 1.0f - expf(-(sigma * (valid ? 1.0f : 0.0f)) * seg);
+            for (int j = 0; j < 64; ++j) {
+                if (base + j >= S) break;
+                const float o = __shfl(op, j);
+                const float w = o * T;
+                T = T * ((1.0f - o) + 1e-10f);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) rc[k] += __shfl(col[k], j) * w;
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float c = rc[k];
+                if (A.has_bg) c += A.bg[k] * T;
+                c = powf(c * 1.0f + 1e-5f, (float)(1.0 / 2.2));          // simple_tone_map (renderer.py:7-8)
+                A.color[(size_t)ray * 3 + k] = fminf(fmaxf(c, 0.0f), 1.0f);
+            }
+            A.trans[ray] = T;
+        }
+    }
+}
+
+}  // namespace ngf

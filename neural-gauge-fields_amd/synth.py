@@ -190,3 +190,62 @@ def edge_rays(seed=0, n=64, aabb=((-1.5, -1.5, -1.5), (1.5, 1.5, 1.5))):
     d[2 * k:3 * k] = o[2 * k:3 * k]
     d = d / np.maximum(np.sqrt(np.sum(d * d, -1, keepdims=True)), np.float32(1e-12))
     return np.ascontiguousarray(np.concatenate([o, d], 1), dtype=np.float32)
+
+
+def _xavier(seed, stream, out_f, in_f, gain=1.0, bias_std=0.0):
+    """UV-Mapping's xavier-uniform (util.py:385-395): U(-a, a), a = gain*sqrt(2/(fan_in+fan_out))*sqrt(3);
+    biases are zero in the reference (util.py:408-409); bias_std > 0 makes the synthetic test stricter."""
+    a = np.float32(gain * math.sqrt(2.0 / (in_f + out_f)) * math.sqrt(3.0))
+    w = (hash_uniform(seed, stream, (out_f, in_f)) * np.float32(2.0) - np.float32(1.0)) * a
+    b = hash_normal(seed, stream + 1, (out_f,)) * np.float32(bias_std)
+    return w.astype(np.float32), b.astype(np.float32)
+
+
+def uvmapping_params(seed=0, primitive_type="sphere", bias_std=0.05):
+    """NeuTex colour-path parameters keyed by the reference's state_dict names:
+    net_geometry_decoder.block.{0..22}, gauge_transform.encoder.*, net_texture.{block1,color1,block2}.*"""
+    ud = 3 if primitive_type == "sphere" else 2
+    g_relu, g_lrelu = math.sqrt(2.0), math.sqrt(2.0 / (1 + 0.2 ** 2))
+    p = {}
+    st = 500
+
+    def put(prefix, out_f, in_f, gain):
+        nonlocal st
+        p[prefix + ".weight"], p[prefix + ".bias"] = _xavier(seed, st, out_f, in_f, gain, bias_std)
+        st += 2
+
+    put("net_geometry_decoder.block.0", 256, 63, g_relu)
+    for i in range(10):
+        put(f"net_geometry_decoder.block.{2 + 2 * i}", 256, 256, g_relu)
+    put("net_geometry_decoder.block.22", 1, 256, 1.0)
+    put("gauge_transform.encoder.linear1", 64, 63, 1.0)
+    put("gauge_transform.encoder.linear2", 128, 64, 1.0)
+    put("gauge_transform.encoder.linear_list.0", 128, 128, 1.0)
+    put("gauge_transform.encoder.linear_list.1", 128, 128, 1.0)
+    put("gauge_transform.encoder.last_linear", ud, 128, 1.0)
+    put("net_texture.block1.0", 256, ud + 20 * ud, g_lrelu)
+    for i in range(5):
+        put(f"net_texture.block1.{2 + 2 * i}", 256, 256, g_lrelu)
+    put("net_texture.color1", 3, 256, 1.0)
+    put("net_texture.block2.0", 256, 295, g_lrelu)
+    for i in range(3):
+        put(f"net_texture.block2.{2 + 2 * i}", 256, 256, g_lrelu)
+    put("net_texture.block2.8", 3, 256, 1.0)
+    return p
+
+
+def dtu_rays(H=600, W=800, campos=(1.7514, 0.0961, -4.7220), focal=(1446.17, 1441.59), center=(411.60, 309.54), rows=None):
+    """Pin-hole rays of a DTU-like view (UV-Mapping/data/dtu.py:27-37 convention: normalised directions through
+    pixel centres, camera looking at the origin).  Returns campos [3] and raydir [rows*W, 3] float32."""
+    c = np.asarray(campos, np.float64)
+    fwd = -c / np.linalg.norm(c)
+    up = np.array([0.0, -1.0, 0.0])
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    r0, r1 = (0, H) if rows is None else rows
+    i = (np.arange(W, dtype=np.float64) + 0.5)[None, :].repeat(r1 - r0, 0)
+    j = (np.arange(r0, r1, dtype=np.float64) + 0.5)[:, None].repeat(W, 1)
+    d = ((i - center[0]) / focal[0])[..., None] * right + ((j - center[1]) / focal[1])[..., None] * down + fwd
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    return c.astype(np.float32), np.ascontiguousarray(d.reshape(-1, 3).astype(np.float32))

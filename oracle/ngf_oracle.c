@@ -323,3 +323,148 @@ void ngf_oracle_density_at(const ngf_oracle_model *m, const float *coords, int64
         sigma[i] = density_at(m, t);
     }
 }
+
+/* ======================= UV-Mapping (NeuTex) colour path ======================================================
+ * cube_ray_generation   UV-Mapping/model/renderer.py:79-141  (jitter = 0.05 always, model.py:30; the uniforms are an
+ *                       input here because the reference draws them with torch.rand inside the call)
+ * GeometryMlpDecoder    UV-Mapping/model/decoder.py:219-237      GaugeTransform  UV-Mapping/model/gauge_fields.py:60-74
+ * TextureMlpDecoder     UV-Mapping/model/decoder.py:63-78 (clamp=False, no target texture: model.py:22-23)
+ * ray_march             UV-Mapping/model/renderer.py:222-247     simple_tone_map :7-8
+ * positional_encoding   UV-Mapping/util.py:427-438
+ */
+static void uv_linear(const ngf_oracle_linear *L, const float *x, float *y)
+{
+    for (int o = 0; o < L->out_f; ++o) {
+        float acc = 0.0f;
+        const float *w = L->w + (size_t)o * L->in_f;
+        for (int i = 0; i < L->in_f; ++i) acc += w[i] * x[i];
+        if (L->b) acc += L->b[o];
+        if (L->act == 1) acc = acc < 0.0f ? 0.0f : acc;
+        else if (L->act == 2) acc = acc > 0.0f ? acc : 0.2f * acc;
+        y[o] = acc;
+    }
+}
+
+static void posenc_n(const float *p, int D, int F, float *out) /* [sin(D*F), cos(D*F)], per-dimension-major */
+{
+    int n = D * F;
+    for (int k = 0; k < D; ++k)
+        for (int f = 0; f < F; ++f) {
+            float a = p[k] * (float)(1 << f);
+            out[k * F + f] = sinf(a);
+            out[n + k * F + f] = cosf(a);
+        }
+}
+
+static float softplus20(float u) { return u > 20.0f ? u : log1pf(expf(u)); }
+
+static void uv_sample(const ngf_oracle_uv_model *m, const float p[3], const float v[3], float *sigma, float uv[3], float col[3])
+{
+    float a[320], b[320];
+    /* geometry: softplus(MLP([p, PE10(p)])) */
+    a[0] = p[0]; a[1] = p[1]; a[2] = p[2];
+    posenc_n(p, 3, 10, a + 3);
+    float in63[63];
+    memcpy(in63, a, sizeof(in63));
+    float *x = a, *y = b;
+    for (int l = 0; l < 12; ++l) { uv_linear(&m->geo[l], x, y); float *t = x; x = y; y = t; }
+    *sigma = softplus20(x[0]);
+    /* gauge */
+    x = in63; y = b;
+    float g1[128], g2[128];
+    uv_linear(&m->gauge[0], in63, g1);
+    uv_linear(&m->gauge[1], g1, g2);
+    uv_linear(&m->gauge[2], g2, g1);
+    uv_linear(&m->gauge[3], g1, g2);
+    float q[3] = {0, 0, 0};
+    uv_linear(&m->gauge[4], g2, q);
+    int ud = m->sphere ? 3 : 2;
+    if (m->sphere) {
+        float nrm = sqrtf((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);
+        if (nrm < 1e-12f) nrm = 1e-12f;
+        for (int k = 0; k < 3; ++k) uv[k] = q[k] / nrm;
+    } else {
+        uv[0] = tanhf(q[0]); uv[1] = tanhf(q[1]); uv[2] = 0.0f;
+    }
+    /* texture */
+    for (int k = 0; k < ud; ++k) a[k] = uv[k];
+    posenc_n(uv, ud, 10, a + ud);
+    x = a; y = b;
+    for (int l = 0; l < 6; ++l) { uv_linear(&m->tex1[l], x, y); float *t = x; x = y; y = t; }
+    float c1[3];
+    uv_linear(&m->color1, x, c1);
+    for (int k = 0; k < 3; ++k) c1[k] = softplus20(c1[k]);
+    float in2[295];
+    memcpy(in2, x, 256 * sizeof(float));
+    in2[256] = v[0]; in2[257] = v[1]; in2[258] = v[2];
+    posenc_n(v, 3, 6, in2 + 259);
+    x = in2; y = (x == a) ? b : a;
+    float h1[256], h2[256];
+    uv_linear(&m->tex2[0], in2, h1);
+    uv_linear(&m->tex2[1], h1, h2);
+    uv_linear(&m->tex2[2], h2, h1);
+    uv_linear(&m->tex2[3], h1, h2);
+    float c2[3];
+    uv_linear(&m->tex2[4], h2, c2);
+    for (int k = 0; k < 3; ++k) { float c = c1[k] + c2[k]; col[k] = c < 0.0f ? 0.0f : c; }
+}
+
+int ngf_oracle_uv_render(const ngf_oracle_uv_model *m, const float *campos, const float *raydir, const float *bg,
+                         const float *U, int64_t R, int32_t S, float *color, float *trans, float *dbg_sigma,
+                         float *dbg_uv, float *dbg_col, uint8_t *dbg_valid, int32_t threads)
+{
+    if (!m || !campos || !raydir || !U || !color || !trans || S <= 0 || S > 1024) return 1;
+    (void)threads;
+    const float dt = (float)(1.0 * 2 / S);                 /* domain_size * 2 / point_count */
+    const float dtj = (float)((1.0 * 2 / S) * 0.05);       /* dt * jitter (python floats) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int64_t r = 0; r < R; ++r) {
+        const float *d = raydir + 3 * r;
+        float t1[3], t2[3];
+        for (int k = 0; k < 3; ++k) { t1[k] = (-1.0f - campos[k]) / d[k]; t2[k] = (1.0f - campos[k]) / d[k]; }
+        float tmin = fmaxf(fminf(t1[0], t2[0]), fmaxf(fminf(t1[1], t2[1]), fminf(t1[2], t2[2])));
+        float tmax = fminf(fmaxf(t1[0], t2[0]), fminf(fmaxf(t1[1], t2[1]), fmaxf(t1[2], t2[2])));
+        float t = (tmin < tmax) ? tmin : 0.0f;
+        if (t < 0.0f) t = 0.0f;
+        /* torch.cumsum on CPU accumulates float32 inputs in double (at::acc_type<float,false>) and rounds each
+           prefix to float; the positions feed sin(512 x), so this rounding is visible at the 1e-4 level */
+        double cum = 0.0;
+        float Tacc = 1.0f, rc[3] = {0, 0, 0};
+        float e_prev = t + 0.0f;
+        for (int i = 0; i < S; ++i) {
+            float seg = dt + dtj * (U[r * S + i] - 0.5f);
+            cum = cum + (double)seg;
+            float e_next = t + (float)cum;
+            float mid = (e_prev + e_next) / 2.0f;
+            e_prev = e_next;
+            float p[3];
+            int valid = 1;
+            for (int k = 0; k < 3; ++k) {
+                p[k] = campos[k] + d[k] * mid;
+                if (!(p[k] > -1.0f && p[k] < 1.0f)) valid = 0;
+            }
+            float sigma, uv[3], col[3];
+            uv_sample(m, p, d, &sigma, uv, col);
+            float sg = sigma * (float)valid;
+            float op = 1.0f - expf(-sg * seg);
+            float w = op * Tacc;
+            Tacc = Tacc * ((1.0f - op) + 1e-10f);
+            for (int k = 0; k < 3; ++k) rc[k] += col[k] * w;
+            size_t q = (size_t)r * S + i;
+            if (dbg_sigma) dbg_sigma[q] = sigma;
+            if (dbg_valid) dbg_valid[q] = (uint8_t)valid;
+            if (dbg_uv) for (int k = 0; k < 3; ++k) dbg_uv[3 * q + k] = uv[k];
+            if (dbg_col) for (int k = 0; k < 3; ++k) dbg_col[3 * q + k] = col[k];
+        }
+        for (int k = 0; k < 3; ++k) {
+            float c = rc[k];
+            if (bg) c += bg[k] * Tacc;
+            c = powf(c * 1.0f + 1e-5f, (float)(1.0 / 2.2));
+            color[3 * r + k] = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
+        }
+        trans[r] = Tacc;
+    }
+    return 0;
+}

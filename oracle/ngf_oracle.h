@@ -56,6 +56,28 @@ void ngf_oracle_color_at(const ngf_oracle_model *m, const float *coords, const f
 void ngf_oracle_density_at(const ngf_oracle_model *m, const float *coords, int64_t n, float *sigma);
 void ngf_oracle_rgb_decode(const ngf_oracle_model *m, const float *feat, const float *dirs, int64_t n, float *rgb);
 
+/* ---- UV-Mapping (NeuTex) colour path: UV-Mapping/model/model.py:30-50 and the sub-modules it calls ---------- */
+typedef struct ngf_oracle_linear {
+    const float *w, *b; /* nn.Linear weight [out,in], bias [out] */
+    int32_t in_f, out_f;
+    int32_t act;        /* 0 none, 1 ReLU, 2 LeakyReLU(0.2) */
+} ngf_oracle_linear;
+
+typedef struct ngf_oracle_uv_model {
+    int32_t sphere;                 /* 1: uv = normalize(q) in R^3, 0: uv = tanh(q) in R^2 (gauge_fields.py:65-74) */
+    ngf_oracle_linear geo[12];      /* GeometryMlpDecoder.block: 63-256, 10x 256-256, 256-1   (decoder.py:201-237) */
+    ngf_oracle_linear gauge[5];     /* GaugeNetwork: 63-64, 64-128, 128-128 x2, 128-(3|2)     (gauge_fields.py:8-46) */
+    ngf_oracle_linear tex1[6];      /* TextureMlpDecoder.block1: (63|42)-256, 5x 256-256     (decoder.py:19-25) */
+    ngf_oracle_linear color1;       /* 256-3 */
+    ngf_oracle_linear tex2[5];      /* block2: 295-256, 3x 256-256, 256-3                    (decoder.py:27-34) */
+} ngf_oracle_uv_model;
+
+/* campos [3], raydir [R,3], bg [3] or NULL, U [R,S] uniforms of the segment jitter (renderer.py:112-117),
+ * out: color [R,3], transmittance [R]; optional per-sample debug [R,S]: sigma, uv [R,S,3], col [R,S,3], valid */
+int ngf_oracle_uv_render(const ngf_oracle_uv_model *m, const float *campos, const float *raydir, const float *bg,
+                         const float *U, int64_t R, int32_t S, float *color, float *trans, float *dbg_sigma,
+                         float *dbg_uv, float *dbg_col, uint8_t *dbg_valid, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,3 +156,66 @@ class OracleField:
         out = np.empty((coords.shape[0],), np.float32)
         lib().ngf_oracle_density_at(C.byref(self._m), _ptr(coords), C.c_int64(coords.shape[0]), _ptr(out))
         return out
+
+
+# ---- UV-Mapping (NeuTex) colour path -------------------------------------------------------------------------------
+class _Linear(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("in_f", C.c_int32), ("out_f", C.c_int32), ("act", C.c_int32)]
+
+
+class _UvModel(C.Structure):
+    _fields_ = [("sphere", C.c_int32), ("geo", _Linear * 12), ("gauge", _Linear * 5), ("tex1", _Linear * 6),
+                ("color1", _Linear), ("tex2", _Linear * 5)]
+
+
+def uv_layer_table(primitive_type="sphere"):
+    """(state_dict prefix, activation) of every Linear on the colour path, in evaluation order, per sub-network.
+    act: 0 none, 1 ReLU, 2 LeakyReLU(0.2)."""
+    geo = [(f"net_geometry_decoder.block.{2 * i}", 1) for i in range(11)] + [("net_geometry_decoder.block.22", 0)]
+    gauge = [("gauge_transform.encoder.linear1", 1), ("gauge_transform.encoder.linear2", 1),
+             ("gauge_transform.encoder.linear_list.0", 1), ("gauge_transform.encoder.linear_list.1", 1),
+             ("gauge_transform.encoder.last_linear", 0)]
+    tex1 = [(f"net_texture.block1.{2 * i}", 2) for i in range(6)]
+    tex2 = [(f"net_texture.block2.{2 * i}", 2) for i in range(4)] + [("net_texture.block2.8", 0)]
+    return {"geo": geo, "gauge": gauge, "tex1": tex1, "color1": [("net_texture.color1", 0)], "tex2": tex2}
+
+
+class OracleUV:
+    def __init__(self, params: dict, primitive_type="sphere"):
+        self._keep = {k: _f32(v) for k, v in params.items()}
+        m = _UvModel()
+        m.sphere = int(primitive_type == "sphere")
+        tab = uv_layer_table(primitive_type)
+
+        def fill(dst, name, act):
+            w, b = self._keep[name + ".weight"], self._keep[name + ".bias"]
+            dst.w, dst.b, dst.in_f, dst.out_f, dst.act = w.ctypes.data, b.ctypes.data, w.shape[1], w.shape[0], act
+
+        for key, arr in (("geo", m.geo), ("gauge", m.gauge), ("tex1", m.tex1), ("tex2", m.tex2)):
+            for i, (name, act) in enumerate(tab[key]):
+                fill(arr[i], name, act)
+        fill(m.color1, "net_texture.color1", 0)
+        self._m = m
+        L = lib()
+        L.ngf_oracle_uv_render.restype = C.c_int
+
+    def render(self, campos, raydir, U, bg=None, debug=False, threads=None):
+        campos, raydir, U = _f32(campos).reshape(3), _f32(raydir), _f32(U)
+        R, S = U.shape
+        color = np.empty((R, 3), np.float32)
+        trans = np.empty((R,), np.float32)
+        bgp = None if bg is None else _f32(bg).reshape(3)
+        dbg = {}
+        if debug:
+            dbg = {"sigma": np.zeros((R, S), np.float32), "uv": np.zeros((R, S, 3), np.float32),
+                   "col": np.zeros((R, S, 3), np.float32), "valid": np.zeros((R, S), np.uint8)}
+        if threads is None:
+            threads = os.cpu_count() or 1
+        rc = lib().ngf_oracle_uv_render(C.byref(self._m), _ptr(campos), _ptr(raydir), None if bgp is None else _ptr(bgp),
+                                        _ptr(U), C.c_int64(R), C.c_int32(S), _ptr(color), _ptr(trans),
+                                        _ptr(dbg["sigma"]) if debug else None, _ptr(dbg["uv"]) if debug else None,
+                                        _ptr(dbg["col"]) if debug else None, _ptr(dbg["valid"]) if debug else None,
+                                        C.c_int32(int(threads)))
+        if rc != 0:
+            raise RuntimeError(f"ngf_oracle_uv_render failed: {rc}")
+        return (color, trans, dbg) if debug else (color, trans)

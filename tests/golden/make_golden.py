@@ -170,6 +170,61 @@ def capture_ops(name="ops_grid_sample"):
     print(f"{name}: 2-D {out2.shape}, 3-D {out3.shape} (positive {int((out3 > 0).sum())})")
 
 
+def capture_uv(name, seed, primitive_type, R=96, S=64):
+    """UV-Mapping colour path through the reference's own sub-modules, composed as NeuTex.forward does
+    (model.py:30-50); NeuTex.forward itself is CUDA-hardwired (gauge_fields.py:129,154) and cannot run here.
+    torch.rand inside cube_ray_generation is replaced by a stored uniform tensor so the jitter is reproducible."""
+    for k in [k for k in sys.modules if k in ("model", "util") or k.startswith("model.")]:
+        del sys.modules[k]
+    sys.path.insert(0, os.path.join(REF, "UV-Mapping"))
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            dec = importlib.import_module("model.decoder")
+            gf = importlib.import_module("model.gauge_fields")
+            rn = importlib.import_module("model.renderer")
+    finally:
+        sys.path.pop(0)
+    params = synth.uvmapping_params(seed, primitive_type)
+    with contextlib.redirect_stdout(io.StringIO()):
+        geo = dec.GeometryMlpDecoder(pos_freqs=10, hidden_size=256, num_layers=10)
+        gauge = gf.GaugeTransform(primitive_type)
+        tex = dec.TextureMlpDecoder(3, 10, 6, uv_dim=2 if primitive_type == "square" else 3, layers=[5, 3], width=256,
+                                    clamp=False, primitive_type=primitive_type, target_texture="None")
+    sd = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
+    geo.load_state_dict({k[len("net_geometry_decoder."):]: v for k, v in sd.items() if k.startswith("net_geometry_decoder.")})
+    gauge.load_state_dict({k[len("gauge_transform."):]: v for k, v in sd.items() if k.startswith("gauge_transform.")})
+    tex.load_state_dict({k[len("net_texture."):]: v for k, v in sd.items() if k.startswith("net_texture.")})
+    campos, dirs = synth.dtu_rays(600, 800)
+    pick = (synth.hash_uniform(seed, 600, (R,)) * np.float32(dirs.shape[0])).astype(np.int64)
+    raydir = dirs[pick]
+    raydir[-4:] = np.array([[0.3, 0.9, 0.3], [-0.6, 0.1, 0.79], [0, 0, 1], [0.577, 0.577, 0.578]], np.float32)  # misses etc.
+    raydir = raydir / np.linalg.norm(raydir, axis=1, keepdims=True)
+    U = synth.hash_uniform(seed, 601, (1, R, S))
+    bg = np.array([0.2, 0.5, 0.8], np.float32)
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: torch.from_numpy(U.copy())
+    try:
+        with torch.no_grad():
+            cp, rd = torch.from_numpy(campos)[None], torch.from_numpy(raydir)[None]
+            ray_pos, ray_dist, ray_valid, _ = rn.cube_ray_generation(cp, rd, S, jitter=0.05)
+    finally:
+        torch.rand = real_rand
+    with torch.no_grad():
+        density = geo(ray_pos)["density"][..., None]
+        uv = gauge(ray_pos)
+        feats = tex(uv, rd[:, :, None, :])
+        bsdf = torch.cat([density, feats[..., :3]], -1)
+        out = rn.ray_march(rd, ray_pos, ray_dist, ray_valid, bsdf, None, None, rn.radiance_render, rn.alpha_blend)
+        ray_color, bgw = out[0], out[6]
+        ray_color = ray_color + torch.from_numpy(bg)[None, None, :] * bgw[:, :, None]
+        color = rn.simple_tone_map(ray_color)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), model="uv", seed=seed, primitive_type=primitive_type, S=S,
+                        campos=campos, raydir=raydir, U=U[0], bg=bg, color=color[0].numpy(), transmittance=bgw[0].numpy(),
+                        i_sigma=density[0, :8, :, 0].numpy(), i_uv=uv[0, :8].numpy(), i_col=feats[0, :8, :, :3].numpy(),
+                        i_valid=ray_valid[0, :8].numpy(), **_checksums(params))
+    print(f"{name}: rays {R} S {S} mean color {float(color.mean()):.4f} mean T {float(bgw.mean()):.4f} valid {float(ray_valid.float().mean()):.3f}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     capture_ops()
@@ -180,3 +235,5 @@ if __name__ == "__main__":
     capture_triplane("triplane_r0", seed=14, preset="R0", gauge_on=True, gauge_std=0.01, with_mask=False, S=32)
     capture_infoinv("infoinv_r1_on", seed=21, preset="R1", infoinv=True, S=40)
     capture_infoinv("infoinv_r1_off", seed=22, preset="R1", infoinv=False, S=40)
+    capture_uv("uv_sphere", seed=31, primitive_type="sphere")
+    capture_uv("uv_square", seed=32, primitive_type="square")

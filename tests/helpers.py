@@ -81,3 +81,13 @@ def big_case(model="triplane", preset="R1", res=256, seed=3):
         params = synth.infoinv_params(seed, hw, preset=preset)
     step = geometry.step_size(g["aabb"], g["grid"], 0.5)
     return g, params, step
+
+
+def load_uv_case(name):
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    params = synth.uvmapping_params(int(g["seed"]), str(g["primitive_type"]))
+    for k, v in params.items():
+        v64 = v.astype(np.float64).reshape(-1)
+        chk = np.array([v64.sum(), np.abs(v64).sum(), v64[:: max(1, v64.size // 7)][:7].sum()])
+        assert np.array_equal(chk, g["chk." + k]), f"synth regenerated different parameters for {k}"
+    return g, params
