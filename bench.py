@@ -188,11 +188,33 @@ def main():
     s_active = st[1] / n_local
     bytes_launch = alg_bytes_per_ray(s_active, model) * n_local
     achieved = bytes_launch / (k_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "ngf::render_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
-                "active_samples_per_ray": s_active, "in_box_samples_per_ray": st[0] / n_local, "mlp_passes": st[2],
-                "note": "algorithmic bytes count every bilinear tap (no cache credit, SURVEY 8 D3); the 52 MB texture set is "
-                        "Infinity-Cache resident, so this is a gather-throughput figure, not DRAM traffic"}
+    # Executed matrix work of the launch: passes x MFMAs per 16-sample pass x 2*16*16*4 flop (v_mfma_f32_16x16x4_f32);
+    # agrees with rocprofv3's SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 (profiles/r01_pmc_*.txt).
+    mfma_per_pass = 80 if args.bake_color else 224
+    mfma_flops = st[2] * mfma_per_pass * 2048.0 if model == "triplane" else None
+    pmc = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_baked.json" if args.bake_color else "r01_pmc_faithful.json")))
+    except Exception:
+        pass
+    alg = {"unit": "GB/s", "achieved": achieved, "peak": HBM_PEAK_GBS, "frac": achieved / HBM_PEAK_GBS,
+           "bytes_per_launch": bytes_launch,
+           "note": "SURVEY 8 D3 accounting: every bilinear tap counted once, no cache credit.  The 52 MB texture set is L2 / "
+                   "Infinity-Cache resident (PMC: 5.6 GB of fabric reads per launch, L2 hit 92 %, L1 hit 92 %), so this exceeds "
+                   "the HBM peak by construction and HBM is not the binding resource."}
+    if mfma_flops is not None:
+        tf = mfma_flops / (k_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                    "traffic": None if pmc is None or model != "triplane" or args.preset != "R1" else pmc.get("hbm_traffic_bytes_per_launch"),
+                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, profiles/r01_pmc_*.txt",
+                    "flops_counted": "executed fp32 MFMA flops of the colour MLP (layer 1 pre-composed with `basis`): the binding "
+                                     "resource per PMC (MFMA pipe 46 % busy, TA 62 %, HBM 6 % of peak)",
+                    "flops_per_launch": mfma_flops}
+    else:
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None}
+    roofline.update({"kernel": "ngf::render_kernel", "kernel_ms": k_ms, "active_samples_per_ray": s_active,
+                     "in_box_samples_per_ray": st[0] / n_local, "mlp_passes": st[2], "algorithmic_hbm": alg,
+                     "algorithmic_flops_per_launch": (S * 550.0 + s_active * 71400.0) * n_local if model == "triplane" else None})
 
     result = {
         "metric": "Mray/sec (800x800 lego-style frame, 192 samples/ray)", "value": value, "unit": "Mray/s", "n_gpus": world,
@@ -230,6 +252,27 @@ def main():
                     fx.release()
                 except Exception as ex:  # an extra must never take the headline number down with it
                     extras[f"{mdl}_{preset}"] = {"error": repr(ex)}
+            try:    # BASELINE config 4: UV-Mapping (NeuTex) colour path, DTU-like 800x600 view, 64 samples/ray, sphere gauge
+                from ngf_amd import uvmapping
+                up = synth.uvmapping_params(5, "sphere")
+                net = uvmapping.NeuTex(primitive_type="sphere", sample_num=64, device=device)
+                net.load_params(up)
+                cam, dirs = synth.dtu_rays(600, 800, rows=(252, 348))                 # 96 rows through the object: 76 800 rays
+                cam_t, dirs_t = torch.from_numpy(cam)[None], torch.from_numpy(dirs)[None].to(device)
+                Uj = torch.rand((1, dirs.shape[0], 64), device=device)
+                net(cam_t, dirs_t, None, jitter_u=Uj)
+                ms = kernel_ms(lambda: net(cam_t, dirs_t, None, jitter_u=Uj), 3, device)
+                net(cam_t, dirs_t, None, jitter_u=Uj, collect_stats=True)
+                us = net.last_stats.cpu().numpy().astype(np.float64)
+                flops = us[1] * 16 * 2 * 1334592.0                                    # executed: passes x 16 samples x 2 x MAC/sample
+                extras["uvmapping_sphere"] = {
+                    "Mray/s": dirs.shape[0] / ms / 1e3, "kernel_ms": ms, "rays": int(dirs.shape[0]),
+                    "in_cube_samples_per_ray": us[0] / dirs.shape[0], "executed_TFLOPs": flops / (ms * 1e-3) / 1e12,
+                    "mfma_frac_of_157.3": flops / (ms * 1e-3) / 157.3e12,
+                    "algorithmic_TFLOPs_all_64_samples": dirs.shape[0] * 64 * 2 * 1334592.0 / (ms * 1e-3) / 1e12}
+                net.release()
+            except Exception as ex:
+                extras["uvmapping_sphere"] = {"error": repr(ex)}
             result["extras"] = extras
     if rank == 0:
         print(json.dumps(result))

@@ -134,10 +134,11 @@ int ngf_uv_destroy(ngf_uv *m);
 /* Replaces NeuTex.forward's colour outputs for one camera (model.py:30-52):
  *   campos_host float[3], bg_host float[3] or NULL (HOST pointers), raydir [R,3], jitter_u [R,S] = the uniforms
  *   cube_ray_generation draws with torch.rand (renderer.py:112-117; jitter = 0.05 always, model.py:30);
- *   color [R,3] (tone-mapped), transmittance [R]; dbg_sigma [R,S] / dbg_col [R,S,3] optional (NULL). */
+ *   color [R,3] (tone-mapped), transmittance [R]; dbg_sigma [R,S] / dbg_col [R,S,3] optional (NULL);
+ *   stats NULL or 2 x uint64: += {in-cube samples evaluated, MLP passes of 16 samples}. */
 int ngf_uv_render(const ngf_uv *m, const float *campos_host, const float *raydir, const float *bg_host,
                   const float *jitter_u, int64_t n_rays, int32_t n_samples, float *color, float *transmittance,
-                  float *dbg_sigma, float *dbg_col, void *hip_stream);
+                  float *dbg_sigma, float *dbg_col, uint64_t *stats, void *hip_stream);
 
 const char *ngf_last_error(void);
 int ngf_abi_version(void);

@@ -73,7 +73,7 @@ def lib():
         L.ngf_uv_create.argtypes = [C.POINTER(UvDesc), C.POINTER(C.c_void_p), C.c_void_p]
         L.ngf_uv_destroy.argtypes = [C.c_void_p]
         L.ngf_uv_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
-                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         if L.ngf_abi_version() != 1 or L.ngf_sizeof_field_desc() != C.sizeof(FieldDesc):
             raise RuntimeError("libngf_hip.so ABI mismatch (version or ngf_field_desc layout)")
         _LIB = L

@@ -48,6 +48,7 @@ struct RenderArgs {
     unsigned int *tile_counter; // zeroed before the launch
     int64_t n;
     int32_t S, white_bg, mode, skip_rgb;
+    int32_t ablate;        // profiling only (NGF_ABLATE): 1 skip collect, 2 skip layers 2-3, 4 cached gathers, 16 raise wave priority in the shade pass
     float a0[3], a1[3], inv[3];
     float near_, far_, step, dscale, thr;
     Tex dens[3];           // TriPlane: 16-ch (faithful) or 1-ch (baked) density texels
@@ -74,7 +75,9 @@ __device__ __forceinline__ Bil bil_setup(float u, float v, const Tex &t)
     float wx1 = px - fx, wx0 = 1.0f - wx1;
     float wy1 = py - fy, wy0 = 1.0f - wy1;
     // x0 in [-1, W-1] <=> at least one of the taps x0, x0+1 can be inside; border texels are zero
-    bool in = (fx >= -1.0f) && (fx <= t.fw) && (fy >= -1.0f) && (fy <= t.fh);
+    // bitwise &, not &&: the short-circuit form compiles to branches, which splits every gather stage into basic
+    // blocks and makes hipcc spill hundreds of VGPRs in the shade pipeline (measured: 139 spills -> 0)
+    bool in = (fx >= -1.0f) & (fx <= t.fw) & (fy >= -1.0f) & (fy <= t.fh);
     float cx = fminf(fmaxf(fx, -1.0f), t.fw);
     float cy = fminf(fmaxf(fy, -1.0f), t.fh);
     Bil b;

@@ -163,7 +163,7 @@ static void build_rgb_image(int F, const std::vector<float> &basis, const std::v
 
 // 16-wide (v_mfma_f32_16x16x4_f32) image of rgb_decoder for TriPlane (ngf_shade16.hpp).  Lane (s, kq): hidden
 // unit of accumulator (mt, r) is n = mt*16 + 4*kq + r.  With bake = true the plane part of layer 1 goes to the
-// texture baker instead: wp[p][kq*16 + mt*4 + r][c] = W1'[n][p*APPc + c].
+// texture baker instead: wp[p][n][c] = W1'[n][p*APPc + c] (natural unit order: channel n of a baked texel = unit n).
 static void build_rgb_image16(int F, bool bake, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
                               const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3,
                               const std::vector<float> &b3, float *img, std::vector<float> &wp)
@@ -188,7 +188,7 @@ static void build_rgb_image16(int F, bool bake, const std::vector<float> &basis,
             for (int mt = 0; mt < 4; ++mt)
                 for (int r = 0; r < 4; ++r)
                     for (int kk = 0; kk < F; ++kk)
-                        wp[((size_t)(kk / APPc) * 64 + kq * 16 + mt * 4 + r) * APPc + (kk % APPc)] =
+                        wp[((size_t)(kk / APPc) * 64 + hidden(mt, r, kq)) * APPc + (kk % APPc)] =
                             (float)w1f[(size_t)hidden(mt, r, kq) * (F + 16) + kk];
         for (int mt = 0; mt < 4; ++mt)
             for (int j = 0; j < 4; ++j)
@@ -198,7 +198,7 @@ static void build_rgb_image16(int F, bool bake, const std::vector<float> &basis,
         using L = MlpLayout16<48>;
         oW1 = L::W1; oW2 = L::W2; oB1 = L::B1; oB2 = L::B2; oW3 = L::W3; oB3 = L::B3;
         auto kmap = [&](int t, int kq) {
-            if (t < 3 * QCH) return (t / QCH) * APPc + kq * QCH + (t % QCH);
+            if (t < 3 * QCH) return (t / QCH) * APPc + 16 * ((t % QCH) / 4) + 4 * kq + ((t % QCH) & 3);   // channel 16q + 4kq + e
             return F + kq * 4 + (t - 3 * QCH);
         };
         for (int mt = 0; mt < 4; ++mt)
@@ -403,6 +403,7 @@ template <typename P>
 static int launch_policy(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
     const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + P::WAVES * wave_lds_floats<P>()) * sizeof(float);
+    if (lds > 160 * 1024) return fail(NGF_E_ARG, "this waves-per-CU setting needs %zu bytes of LDS (> 160 KiB)", lds);
     return launch_render(render_kernel<P>, f, A, P::WAVES * kWave, lds, st);
 }
 
@@ -410,7 +411,7 @@ template <bool BD, bool BC>
 static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
     // tuning knobs (measurements in profiles/): waves per CU and march steps in flight per lane
-    int w = BC ? 8 : 12, ns = 1;          // measured best (profiles/r01_sweep.txt)
+    int w = 12, ns = 1;                   // measured best (profiles/r01_sweep.txt)
     if (const char *e = getenv("NGF_WAVES")) w = atoi(e);
     if (const char *e = getenv("NGF_NSTEP")) ns = atoi(e);
     if (ns == 2) {
@@ -442,6 +443,7 @@ extern "C" int ngf_field_render(const ngf_field *f, const float *rays, int64_t n
     RenderArgs A = f->proto;
     A.rays = rays; A.jitter = jitter; A.rgb = rgb; A.depth = depth; A.n = n; A.S = n_samples;
     A.white_bg = white_bg ? 1 : 0; A.mode = mode ? 1 : 0; A.stats = (unsigned long long *)stats;
+    if (const char *e = getenv("NGF_ABLATE")) A.ablate = atoi(e);     // profiling only: results are wrong when set
     return render_common(f, A, (hipStream_t)hip_stream);
 }
 
@@ -655,7 +657,7 @@ extern "C" int ngf_uv_create(const ngf_uv_desc *d, ngf_uv **out, void *hip_strea
 
 extern "C" int ngf_uv_render(const ngf_uv *m, const float *campos_host, const float *raydir, const float *bg_host, const float *jitter_u,
                              int64_t n_rays, int32_t n_samples, float *color, float *transmittance, float *dbg_sigma, float *dbg_col,
-                             void *hip_stream)
+                             uint64_t *stats, void *hip_stream)
 {
     if (!m || !campos_host || !raydir || !jitter_u || !color || !transmittance) return fail(NGF_E_ARG, "ngf_uv_render: null argument");
     if (n_rays < 0 || n_samples <= 0) return fail(NGF_E_ARG, "ngf_uv_render: n_rays=%lld n_samples=%d", (long long)n_rays, n_samples);
@@ -664,7 +666,7 @@ extern "C" int ngf_uv_render(const ngf_uv *m, const float *campos_host, const fl
     hipStream_t st = (hipStream_t)hip_stream;
     UvArgs A = m->proto;
     A.raydir = raydir; A.U = jitter_u; A.color = color; A.trans = transmittance; A.dbg_sigma = dbg_sigma; A.dbg_col = dbg_col;
-    A.R = n_rays; A.S = n_samples;
+    A.R = n_rays; A.S = n_samples; A.stats = (unsigned long long *)stats;
     for (int k = 0; k < 3; ++k) { A.campos[k] = campos_host[k]; A.bg[k] = bg_host ? bg_host[k] : 0.0f; }
     A.has_bg = bg_host ? 1 : 0;
     const unsigned slot = m->next_counter.fetch_add(1) % kCounters;

@@ -400,11 +400,13 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 const float rec[kRecFloats] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
                 const int owner = __float_as_int(r0[0]);
                 float c[3];
+                if (A.ablate & 16) __builtin_amdgcn_s_setprio(1);
                 P::shade(A, smem, rec, vfeat + owner * kViewFeat, lane, c);
+                if (A.ablate & 16) __builtin_amdgcn_s_setprio(0);
                 if (lane < nb) *reinterpret_cast<f32x4 *>(res + lane * 4) = f32x4{r0[0], r0[1] * c[0], r0[1] * c[1], r0[1] * c[2]};
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // every lane, as ray owner, collects its entries in queue (= sample) order
-                for (int j = 0; j < nb; ++j) {
+                for (int j = 0; j < ((A.ablate & 1) ? 1 : nb); ++j) {
                     const f32x4 e = *reinterpret_cast<const f32x4 *>(res + j * 4);
                     if (__float_as_int(e[0]) == lane) { cr += e[1]; cg += e[2]; cb += e[3]; }
                 }

@@ -90,34 +90,44 @@ __device__ __forceinline__ void gather16_issue(const RenderArgs &A, const float 
     constexpr int NQ = APP / 16;
     const Tex &t = A.app[P];
     g.b = bil_setup(rec[2 + 2 * P], rec[3 + 2 * P], t);
-    const f32x4 *t00 = reinterpret_cast<const f32x4 *>(t.p + (size_t)g.b.idx * APP + kq * (APP / 4));
+    if (A.ablate & 4) g.b.idx = 64 + (kq << 2);        // profiling: every lane reads the same few (cached) texels
+    // lane-quarter kq owns channels [16q + 4kq, 16q + 4kq + 4), q = 0..NQ-1: the four lanes of a sample read one
+    // contiguous 64-byte piece per load instruction, so a wave-wide load touches 16 cache lines instead of ~32
+    const f32x4 *t00 = reinterpret_cast<const f32x4 *>(t.p + (size_t)g.b.idx * APP) + kq;
     const f32x4 *t01 = t00 + (size_t)t.stride * (APP / 4);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        g.raw[0][q] = t00[q];
-        g.raw[1][q] = t00[APP / 4 + q];
-        g.raw[2][q] = t01[q];
-        g.raw[3][q] = t01[APP / 4 + q];
+        g.raw[0][q] = t00[4 * q];
+        g.raw[1][q] = t00[APP / 4 + 4 * q];
+        g.raw[2][q] = t01[4 * q];
+        g.raw[3][q] = t01[APP / 4 + 4 * q];
     }
 }
 
-template <int APP, int P>
-__device__ __forceinline__ void layer1_plane16(const float *blob, int lane, const Gather16<APP> &g, f32x4 acc[4])
+template <int APP>
+__device__ __forceinline__ void mix16(const Gather16<APP> &g, float feat[APP / 4])
 {
-    using L = MlpLayout16<APP>;
-    constexpr int NQ = APP / 16;
-    const float *w1 = blob + L::W1 + lane;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+    for (int q = 0; q < APP / 16; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float f = bil_mix(g.b, g.raw[0][q][e], g.raw[1][q][e], g.raw[2][q][e], g.raw[3][q][e]);
-            const int t = P * L::QCH + 4 * q + e;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt] = NGF_MFMA16(w1[(mt * L::KT + t) * 64], f, acc[mt]);
-        }
+        for (int e = 0; e < 4; ++e) feat[4 * q + e] = bil_mix(g.b, g.raw[0][q][e], g.raw[1][q][e], g.raw[2][q][e], g.raw[3][q][e]);
 }
 
+template <int APP, int P>
+__device__ __forceinline__ void layer1_plane16(const float *blob, int lane, const float feat[APP / 4], f32x4 acc[4])
+{
+    using L = MlpLayout16<APP>;
+    const float *w1 = blob + L::W1 + lane;
+#pragma unroll
+    for (int j = 0; j < L::QCH; ++j) {
+        const int t = P * L::QCH + j;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = NGF_MFMA16(w1[(mt * L::KT + t) * 64], feat[j], acc[mt]);
+    }
+}
+
+// One gather buffer (48 VGPRs) + 12 interpolated features: plane p is interpolated into feat[], the buffer is
+// re-issued for plane p+1 at once, and plane p's 48 MFMAs run while that gather is in flight.
 template <int APP>
 __device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const float *vf,
                                            int lane, float rgb[3])
@@ -125,8 +135,9 @@ __device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blo
     using L = MlpLayout16<APP>;
     blob = per_pass16(blob);
     const int kq = lane >> 4;
-    Gather16<APP> ga, gb;
-    gather16_issue<APP, 0>(A, rec, kq, ga);
+    Gather16<APP> g;
+    float feat[L::QCH];
+    gather16_issue<APP, 0>(A, rec, kq, g);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[4];
 #pragma unroll
@@ -140,57 +151,101 @@ __device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blo
             for (int mt = 0; mt < 4; ++mt) acc[mt] = NGF_MFMA16(w1[(mt * L::KT + 3 * L::QCH + j) * 64], v[j], acc[mt]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    gather16_issue<APP, 1>(A, rec, kq, gb);            // plane 1 in flight behind plane 0's MFMAs
+    mix16<APP>(g, feat);
     __builtin_amdgcn_sched_barrier(0);
-    layer1_plane16<APP, 0>(blob, lane, ga, acc);
+    gather16_issue<APP, 1>(A, rec, kq, g);
     __builtin_amdgcn_sched_barrier(0);
-    gather16_issue<APP, 2>(A, rec, kq, ga);
+    layer1_plane16<APP, 0>(blob, lane, feat, acc);
     __builtin_amdgcn_sched_barrier(0);
-    layer1_plane16<APP, 1>(blob, lane, gb, acc);
+    mix16<APP>(g, feat);
     __builtin_amdgcn_sched_barrier(0);
-    layer1_plane16<APP, 2>(blob, lane, ga, acc);
+    gather16_issue<APP, 2>(A, rec, kq, g);
+    __builtin_amdgcn_sched_barrier(0);
+    layer1_plane16<APP, 1>(blob, lane, feat, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    mix16<APP>(g, feat);
+    __builtin_amdgcn_sched_barrier(0);
+    layer1_plane16<APP, 2>(blob, lane, feat, acc);
+    if (A.ablate & 2) { rgb[0] = acc[0][0]; rgb[1] = acc[1][1]; rgb[2] = acc[2][2] + acc[3][3]; return; }
     mlp_tail16(blob, L::W2, L::B2, L::W3, L::B3, lane, acc, rgb);
 }
 
-// ---- NGF_F_BAKE_COLOR: 64-channel layer-1 pre-activation planes, channel kq*16 + mt*4 + r ----------------------
-template <int P>
-__device__ __forceinline__ void baked16_issue(const RenderArgs &A, const float rec[kRecFloats], int kq, Gather16<64> &g)
+// ---- NGF_F_BAKE_COLOR: 64-channel layer-1 pre-activation planes, channel = hidden unit mt*16 + 4*kq + r ----------------------
+struct BakedHalf {                // half a plane: 4 taps x 2 float4 = accumulator tiles 2h, 2h+1
+    f32x4 raw[4][2];
+    Bil b;
+};
+
+template <int ST>                 // stage = plane * 2 + half
+__device__ __forceinline__ void baked16_issue(const RenderArgs &A, const float rec[kRecFloats], int kq, BakedHalf &g)
 {
+    constexpr int P = ST >> 1, H = ST & 1;
     const Tex &t = A.app[P];
     g.b = bil_setup(rec[2 + 2 * P], rec[3 + 2 * P], t);
-    const f32x4 *t00 = reinterpret_cast<const f32x4 *>(t.p + (size_t)g.b.idx * 64 + kq * 16);
+    // channel 16*mt + 4*kq + r = hidden unit of accumulator (mt, r): natural order; 4 lanes read 64 contiguous bytes
+    const f32x4 *t00 = reinterpret_cast<const f32x4 *>(t.p + (size_t)g.b.idx * 64) + kq + 8 * H;
     const f32x4 *t01 = t00 + (size_t)t.stride * 16;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        g.raw[0][q] = t00[q];
-        g.raw[1][q] = t00[16 + q];
-        g.raw[2][q] = t01[q];
-        g.raw[3][q] = t01[16 + q];
+    for (int q = 0; q < 2; ++q) {
+        g.raw[0][q] = t00[4 * q];
+        g.raw[1][q] = t00[16 + 4 * q];
+        g.raw[2][q] = t01[4 * q];
+        g.raw[3][q] = t01[16 + 4 * q];
     }
 }
 
-__device__ __forceinline__ void baked16_consume(const Gather16<64> &g, f32x4 acc[4])
+template <int ST>
+__device__ __forceinline__ void baked16_consume(const BakedHalf &g, float sum[16])
 {
+    constexpr int H = ST & 1;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[mt][e] += bil_mix(g.b, g.raw[0][mt][e], g.raw[1][mt][e], g.raw[2][mt][e], g.raw[3][mt][e]);
+        for (int e = 0; e < 4; ++e)
+            sum[(2 * H + q) * 4 + e] += bil_mix(g.b, g.raw[0][q][e], g.raw[1][q][e], g.raw[2][q][e], g.raw[3][q][e]);
 }
 
+// Two half-plane buffers (32 VGPRs each): stage s+1 is in flight while stage s is accumulated.  The interpolated
+// pre-activations are summed in plain VGPRs first and only then become the MFMA accumulator of the 16 view-input
+// MFMAs (updating MFMA accumulators with VALU adds in between made hipcc spill heavily).
 __device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const float *vf,
                                                  int lane, float rgb[3])
 {
     using L = MlpLayout16Baked;
     blob = per_pass16(blob);
     const int kq = lane >> 4;
-    Gather16<64> ga, gb;
+    BakedHalf ga, gb;
     baked16_issue<0>(A, rec, kq, ga);
     __builtin_amdgcn_sched_barrier(0);
     baked16_issue<1>(A, rec, kq, gb);
     __builtin_amdgcn_sched_barrier(0);
+    float sum[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum[k] = blob[L::B1 + kq * 16 + k];
+    __builtin_amdgcn_sched_barrier(0);
+    baked16_consume<0>(ga, sum);
+    __builtin_amdgcn_sched_barrier(0);
+    baked16_issue<2>(A, rec, kq, ga);
+    __builtin_amdgcn_sched_barrier(0);
+    baked16_consume<1>(gb, sum);
+    __builtin_amdgcn_sched_barrier(0);
+    baked16_issue<3>(A, rec, kq, gb);
+    __builtin_amdgcn_sched_barrier(0);
+    baked16_consume<2>(ga, sum);
+    __builtin_amdgcn_sched_barrier(0);
+    baked16_issue<4>(A, rec, kq, ga);
+    __builtin_amdgcn_sched_barrier(0);
+    baked16_consume<3>(gb, sum);
+    __builtin_amdgcn_sched_barrier(0);
+    baked16_issue<5>(A, rec, kq, gb);
+    __builtin_amdgcn_sched_barrier(0);
+    baked16_consume<4>(ga, sum);
+    __builtin_amdgcn_sched_barrier(0);
+    baked16_consume<5>(gb, sum);
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(blob + L::B1 + kq * 16 + mt * 4);
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{sum[4 * mt], sum[4 * mt + 1], sum[4 * mt + 2], sum[4 * mt + 3]};
     {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(vf + kq * 4);
         const float *w1 = blob + L::W1V + lane;
@@ -199,14 +254,7 @@ __device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const floa
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc[mt] = NGF_MFMA16(w1[(mt * 4 + j) * 64], v[j], acc[mt]);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    baked16_consume(ga, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    baked16_issue<2>(A, rec, kq, ga);
-    __builtin_amdgcn_sched_barrier(0);
-    baked16_consume(gb, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    baked16_consume(ga, acc);
+    if (A.ablate & 2) { rgb[0] = acc[0][0]; rgb[1] = acc[1][1]; rgb[2] = acc[2][2] + acc[3][3]; return; }
     mlp_tail16(blob, L::W2, L::B2, L::W3, L::B3, lane, acc, rgb);
 }
 

@@ -28,6 +28,7 @@ struct UvArgs {
     float *dbg_sigma;      // [R,S] or NULL
     float *dbg_col;        // [R,S,3] or NULL
     unsigned int *ray_counter;
+    unsigned long long *stats;  // {in-cube samples, passes} or NULL
     int64_t R;
     int32_t S, sphere, has_bg, pad_;
     float campos[3], bg[3];
@@ -208,6 +209,7 @@ __global__ void __launch_bounds__(512) uv_render_kernel(const UvArgs A)
     const int lane = threadIdx.x & 63;
     float *act = smem + (threadIdx.x >> 6) * kUvWaveLds;
     const int S = A.S;
+    unsigned long long st_samples = 0, st_pass = 0;
     const float dt = (float)(2.0 / S), dtj = (float)((2.0 / S) * 0.05);     // renderer.py:107-117 (python floats)
     for (;;) {
         unsigned int ray = 0;
@@ -249,6 +251,8 @@ __global__ void __launch_bounds__(512) uv_render_kernel(const UvArgs A)
             }
             const unsigned long long vm = __ballot(valid);
             const int nv = __popcll(vm);
+            st_samples += nv;
+            st_pass += (nv + 15) / 16;
             const int rank = __popcll(vm & ((1ull << lane) - 1ull));
             float sigma = 0.0f, col[3] = {0.0f, 0.0f, 0.0f};
             for (int g0 = 0; g0 < nv; g0 += 16) {
@@ -299,6 +303,10 @@ __global__ void __launch_bounds__(512) uv_render_kernel(const UvArgs A)
             }
             A.trans[ray] = T;
         }
+    }
+    if (A.stats && lane == 0) {
+        atomicAdd(A.stats + 0, st_samples);
+        atomicAdd(A.stats + 1, st_pass);
     }
 }
 

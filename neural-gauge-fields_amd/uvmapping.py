@@ -133,7 +133,8 @@ class NeuTex(nn.Module):
         return out
 
     @torch.no_grad()
-    def forward(self, camera_position=None, ray_direction=None, background_color=None, jitter_u=None, debug=False):
+    def forward(self, camera_position=None, ray_direction=None, background_color=None, jitter_u=None, debug=False,
+                collect_stats=False):
         """model.py:27: camera_position [N,3], ray_direction [N,R,3] (normalised), background_color [N,3] or None."""
         dev = torch.device(self.device)
         N, R = ray_direction.shape[0], ray_direction.shape[1]
@@ -146,6 +147,7 @@ class NeuTex(nn.Module):
         trans = torch.empty((N, R), device=dev)
         dbg_s = torch.zeros((N, R, S), device=dev) if debug else None
         dbg_c = torch.zeros((N, R, S, 3), device=dev) if debug else None
+        stats = torch.zeros(2, dtype=torch.int64, device=dev) if collect_stats else None
         h = self.handle()
         cam = camera_position.detach().cpu().to(torch.float32)
         bg = None if background_color is None else background_color.detach().cpu().to(torch.float32)
@@ -156,8 +158,11 @@ class NeuTex(nn.Module):
                 bp = None if bg is None else (C.c_float * 3)(*bg[n].tolist())
                 _lib.check(_lib.lib().ngf_uv_render(
                     h, cp, rd[n].data_ptr(), bp, U[n].data_ptr(), R, S, color[n].data_ptr(), trans[n].data_ptr(),
-                    None if dbg_s is None else dbg_s[n].data_ptr(), None if dbg_c is None else dbg_c[n].data_ptr(), st))
+                    None if dbg_s is None else dbg_s[n].data_ptr(), None if dbg_c is None else dbg_c[n].data_ptr(),
+                    None if stats is None else stats.data_ptr(), st))
         out = {"color": color, "transmittance": trans}
+        if collect_stats:
+            self.last_stats = stats
         if debug:
             out["sigma"], out["point_color"] = dbg_s, dbg_c
         return out

@@ -37,9 +37,37 @@ if "WRITE_SIZE" in m:
     print(f"WRITE_SIZE  = {m['WRITE_SIZE']*1024/1e6:.1f} MB/dispatch (uncalibrated)")
 if "TCC_HIT_sum" in m:
     print(f"L2 hit rate = {100*m['TCC_HIT_sum']/(m['TCC_HIT_sum']+m['TCC_MISS_sum']):.1f} %")
-if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
-    print(f"MFMA busy   = {100*m['SQ_VALU_MFMA_BUSY_CYCLES']/(m['GRBM_GUI_ACTIVE']*1024):.1f} % of (GRBM_GUI_ACTIVE x 1024 SIMDs)")
+out = {"kernel_ms_under_pmc": sum(durs) / max(len(durs), 1)}
+if "GRBM_GUI_ACTIVE" in m:
+    cyc = m["GRBM_GUI_ACTIVE"] / 8.0          # the counter is summed over the 8 XCDs
+    print(f"active cycles per XCD = {cyc:.4g}")
     if durs:
-        print(f"effective clock ~ {m['GRBM_GUI_ACTIVE']/(sum(durs)/len(durs)*1e-3)/1e9:.2f} GHz")
+        print(f"effective clock ~ {cyc/(sum(durs)/len(durs)*1e-3)/1e9:.2f} GHz")
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+        out["mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024)
+        print(f"MFMA busy   = {100*out['mfma_busy_frac']:.1f} % of (active cycles x 1024 SIMDs)")
+    if "TA_TA_BUSY_sum" in m:
+        out["ta_busy_frac"] = m["TA_TA_BUSY_sum"] / (cyc * 256)
+        print(f"TA busy     = {100*out['ta_busy_frac']:.1f} % of (active cycles x 256 CUs)")
+    if "SQ_ACTIVE_INST_VALU" in m:
+        out["valu_busy_frac"] = 4 * m["SQ_ACTIVE_INST_VALU"] / (cyc * 1024)
+        print(f"VALU busy   = {100*out['valu_busy_frac']:.1f} % (SQ_ACTIVE_INST_VALU quad-cycles x4 / SIMD cycles)")
+    if "SQ_WAVE_CYCLES" in m:
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if k in m:
+                print(f"{k:20s}= {100*m[k]/m['SQ_WAVE_CYCLES']:.1f} % of wave cycles")
+if "TCP_TOTAL_CACHE_ACCESSES_sum" in m and "TCP_TCC_READ_REQ_sum" in m:
+    out["l1_hit_frac"] = 1 - m["TCP_TCC_READ_REQ_sum"] / m["TCP_TOTAL_CACHE_ACCESSES_sum"]
+    print(f"L1 hit rate ~ {100*out['l1_hit_frac']:.1f} % (1 - TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES)")
 if "SQ_INSTS_VALU_MFMA_MOPS_F32" in m:
+    out["mfma_flops_per_dispatch"] = m["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512
     print(f"MFMA f32 flops/dispatch = {m['SQ_INSTS_VALU_MFMA_MOPS_F32']*512:.4g}")
+if "FETCH_SIZE" in m:
+    out["fetch_bytes_corrected"] = 2 * m["FETCH_SIZE"] * 1024
+    out["write_bytes"] = m.get("WRITE_SIZE", 0) * 1024
+    out["hbm_traffic_bytes_per_launch"] = out["fetch_bytes_corrected"] + out["write_bytes"]
+if "TCC_HIT_sum" in m:
+    out["l2_hit_frac"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
+if len(sys.argv) > 2:
+    import json
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
