@@ -145,7 +145,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    dist_on = world > 1
+    dist_on = world > 1 or os.environ.get("NGF_BENCH_FORCE_DIST") == "1"     # the env knob exercises the RCCL path on one GPU
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

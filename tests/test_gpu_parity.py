@@ -145,3 +145,40 @@ def test_headline_geometry_chunk(model, preset):
             outb = fb(torch.from_numpy(rays).cuda(), N_samples=192, iteration=30001)
             eb = _close(outb["rgb_map"].cpu().numpy(), o_rgb, f"rgb (bake_density={bd}, bake_color={bc})")
             print(f"   bake_density={bd} bake_color={bc}: max abs err {eb:.2e}")
+
+
+def test_generate_rays_matches_loader_restatement():
+    """ngf_generate_rays vs the numpy restatement of get_ray_directions/get_rays (synth.lookat_rays)."""
+    from ngf_amd import rays as nrays
+    from ngf_amd import synth
+    c2w = synth.lookat_pose()
+    want = synth.lookat_rays(800, 800, c2w, rows=(390, 410))
+    got = nrays.generate_rays(800, 800, nrays.blender_focal(800), c2w, rows=(390, 410)).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.array_equal(got[:, :3], want[:, :3])
+    assert np.abs(got[:, 3:] - want[:, 3:]).max() < 3e-7          # matmul rounding order only
+    # and the renders of both ray sets agree
+    g, params, step = big_case("triplane", "R1")
+    f = field_for_case(g, params, None)
+    a = f(torch.from_numpy(want[:4096]).cuda(), N_samples=96, iteration=30001)["rgb_map"]
+    b = f(torch.from_numpy(got[:4096]).cuda(), N_samples=96, iteration=30001)["rgb_map"]
+    # a 1-ulp change of a direction can move a sample across the box face or a texel edge (SURVEY.md section 7,
+    # hazard 1), so single pixels may differ by ~1e-3; everything else agrees to rounding
+    diff = (a - b).abs()
+    assert float(diff.max()) < 5e-3 and float((diff > 1e-5).float().mean()) < 1e-2
+
+
+def test_bench_rccl_path_single_gpu(tmp_path):
+    """The N>1 path of bench.py (nccl init, barrier, all_gather of composited pixels) on ONE GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NGF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--extras", "0",
+                        "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["value"] > 1 and d["scaling"] == "strong"
