@@ -274,11 +274,18 @@ def main():
             except Exception as ex:
                 extras["uvmapping_sphere"] = {"error": repr(ex)}
             result["extras"] = extras
-    if rank == 0:
-        print(json.dumps(result))
     if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio; flush it first so that the JSON line is the LAST line on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -23,3 +23,17 @@ def test_eager_port_matches_reference_golden(name):
     assert np.abs(depth.numpy() - g["depth_map"]).max() <= 5e-6
     o_rgb, _ = oracle_for_case(g, params, step, mask).render(g["rays"], int(g["S"]), white_bg=bool(int(g["white_bg"])))
     assert np.abs(rgb.numpy() - o_rgb).max() <= 3e-6
+
+
+def test_baseline_config0_plumbing():
+    """BASELINE.json configs[0]: TriPlane 64x64 render, 64 samples/ray, CPU eager -- port vs C oracle."""
+    from helpers import big_case
+    from ngf_amd import synth
+    g, params, step = big_case("triplane", "R1", res=64)
+    rays = synth.lookat_rays(64, 64)
+    e = EagerField(params, g["aabb"], step, g["near_far"], 25.0, 1e-4, "triplane")
+    rgb, depth = e.render(torch.from_numpy(rays), 64, chunk=4096)
+    g["gauge_on"] = np.array(1)
+    o_rgb, o_depth = oracle_for_case(g, params, step, None).render(rays, 64)
+    assert np.abs(rgb.numpy() - o_rgb).max() < 3e-6 and np.abs(depth.numpy() - o_depth).max() < 1e-5
+    assert rgb.shape == (4096, 3)
