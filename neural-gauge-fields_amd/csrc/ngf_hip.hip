@@ -389,8 +389,19 @@ static int launch_render(K kernel, const ngf_field *f, RenderArgs &A, int thread
     A.tile_counter = f->counters + slot;
     HIP_TRY(hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned), st));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    const int64_t tiles = (A.n + kWave - 1) / kWave;
+    // Small launches (one rank's shard of a frame) are bound by the latency of ONE tile, not by throughput: give
+    // every wave fewer rays (lanes >= tile_w idle in the march, the shade passes are unaffected) while the tile
+    // count still fits the resident waves.  profiles/exp_shard_latency.py
     const int waves = threads / kWave;
+    const int64_t slots = (int64_t)f->num_cus * waves;
+    int tw = 64;
+    if (const char *e = getenv("NGF_TILE_W")) tw = atoi(e);
+    else {
+        while (tw > 16 && (A.n + tw / 2 - 1) / (tw / 2) <= slots) tw /= 2;
+    }
+    if (tw != 64 && tw != 32 && tw != 16) return fail(NGF_E_ARG, "NGF_TILE_W must be 64, 32 or 16");
+    A.tile_w = tw;
+    const int64_t tiles = (A.n + tw - 1) / tw;
     int64_t grid = (tiles + waves - 1) / waves;
     if (grid > f->num_cus) grid = f->num_cus;
     if (grid < 1) grid = 1;
@@ -417,6 +428,9 @@ static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
     if (ns == 2) {
         if (w == 8) return launch_policy<TriPlanePolicy<BD, BC, 8, 2>>(f, A, st);
         return fail(NGF_E_ARG, "NGF_NSTEP=2 is built for NGF_WAVES=8 only");
+    }
+    if (getenv("NGF_PROFILE")) {      // stats[4..9] += section cycles (profiles/exp_sections.py); stats must hold 10 counters
+        if constexpr (!BC) return launch_policy<TriPlanePolicy<BD, false, 12, 1, true>>(f, A, st);
     }
     switch (w) {
     case 8: return launch_policy<TriPlanePolicy<BD, BC, 8, 1>>(f, A, st);

@@ -57,6 +57,7 @@ struct InfoInvPolicy {
     static constexpr int APP = 72;
     static constexpr bool INFOINV = true;
     static constexpr int WAVES = kInfoInvWaves;
+    static constexpr bool PROFILE = false;
     static constexpr int NSTEP = 1;
     static constexpr int BATCH = kBatch;
     static constexpr int RING = 128;

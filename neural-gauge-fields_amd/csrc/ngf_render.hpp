@@ -262,8 +262,9 @@ __device__ __forceinline__ void triplane_gauge(const RenderArgs &A, const float 
 //   WAVES   waves per workgroup (= per CU); NSTEP march steps evaluated per loop iteration
 //   The shade runs on v_mfma_f32_16x16x4_f32, 16 samples per pass (ngf_shade16.hpp).
 // sigma() is called by ALL lanes of the wave (wave-uniform call site); invalid lanes return 0.
-template <bool BAKE_D, bool BAKE_C, int WAVES_, int NSTEP_>
+template <bool BAKE_D, bool BAKE_C, int WAVES_, int NSTEP_, bool PROFILE_ = false>
 struct TriPlanePolicy {
+    static constexpr bool PROFILE = PROFILE_;
     static constexpr bool INFOINV = false;
     static constexpr int WAVES = WAVES_;
     static constexpr int NSTEP = NSTEP_;
@@ -282,10 +283,10 @@ struct TriPlanePolicy {
         return valid ? sg : 0.0f;
     }
     __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
-                                                 int lane, float c[3])
+                                                 int lane, float c[3], unsigned long long *tk = nullptr)
     {
         if constexpr (BAKE_C) mlp_pass16_baked(A, smem, rec, vf, lane, c);
-        else mlp_pass16<48>(A, smem, rec, vf, lane, c);
+        else mlp_pass16<48>(A, smem, rec, vf, lane, c, tk);
     }
 };
 
@@ -307,15 +308,16 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int S = A.S;
     unsigned long long st_valid = 0, st_active = 0, st_pass = 0, st_rays = 0;
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // PROFILE only: cycles per section, summed over the wave's life
 
     for (;;) {
         unsigned int tile = 0;
         if (lane == 0) tile = atomicAdd(A.tile_counter, 1u);
         tile = __builtin_amdgcn_readfirstlane(tile);
-        const int64_t base = (int64_t)tile * kWave;
+        const int64_t base = (int64_t)tile * A.tile_w;
         if (base >= A.n) break;
         const int64_t ray = base + lane;
-        const bool live = ray < A.n;
+        const bool live = (lane < A.tile_w) && (ray < A.n);
         const int64_t rr = live ? ray : A.n - 1;
         float o[3], d[3];
 #pragma unroll
@@ -342,6 +344,8 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         float T = 1.0f, acc = 0.0f, dep = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
         int i = 0, head = 0, count = 0;
         for (;;) {
+            [[maybe_unused]] unsigned long long t_sec = 0;
+            if constexpr (P::PROFILE) t_sec = __builtin_readcyclecounter();
             if (count < BATCH && i < S) {
                 // ---------------- march NSTEP steps (independent gathers, sequential transmittance) ----
                 float z[NSTEP], dist[NSTEP], sigma[NSTEP], t[NSTEP][6];
@@ -389,6 +393,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     st_active += __popcll(m);
                 }
                 i += NSTEP;
+                if constexpr (P::PROFILE) prof[0] += __builtin_readcyclecounter() - t_sec;
             } else if (count > 0) {
                 // ---------------- shade up to BATCH queued samples ----------------------------------
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -400,20 +405,49 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 const float rec[kRecFloats] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
                 const int owner = __float_as_int(r0[0]);
                 float c[3];
-                if (A.ablate & 16) __builtin_amdgcn_s_setprio(1);
-                P::shade(A, smem, rec, vfeat + owner * kViewFeat, lane, c);
-                if (A.ablate & 16) __builtin_amdgcn_s_setprio(0);
-                if (lane < nb) *reinterpret_cast<f32x4 *>(res + lane * 4) = f32x4{r0[0], r0[1] * c[0], r0[1] * c[1], r0[1] * c[2]};
+                if constexpr (P::PROFILE) {
+                    unsigned long long tk[5] = {0, 0, 0, 0, 0};
+                    P::shade(A, smem, rec, vfeat + owner * kViewFeat, lane, c, tk);
+                    prof[1] += tk[0] - t_sec;      // ring read, address setup, gather 0 + view MFMAs issued
+                    prof[2] += tk[1] - tk[0];      // wait for plane 0 + interpolate
+                    prof[3] += tk[2] - tk[1];      // layer-1 MFMAs (planes 1, 2 gathered behind them)
+                    prof[4] += tk[4] - tk[2];      // layer 2: 64 MFMAs issued
+                    prof[6] += tk[3] - tk[4];      // layer 3 (VALU dot, 2 cross-lane adds, sigmoid)
+                    t_sec = tk[3];
+                } else {
+                    P::shade(A, smem, rec, vfeat + owner * kViewFeat, lane, c);
+                }
+                // result list, structure-of-arrays: res[0..B) owner lane ids, then weighted r, g, b
+                if (lane < BATCH) {
+                    res[lane] = lane < nb ? r0[0] : __int_as_float(-1);
+                    res[BATCH + lane] = r0[1] * c[0];
+                    res[2 * BATCH + lane] = r0[1] * c[1];
+                    res[3 * BATCH + lane] = r0[1] * c[2];
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                // every lane, as ray owner, collects its entries in queue (= sample) order
-                for (int j = 0; j < ((A.ablate & 1) ? 1 : nb); ++j) {
-                    const f32x4 e = *reinterpret_cast<const f32x4 *>(res + j * 4);
-                    if (__float_as_int(e[0]) == lane) { cr += e[1]; cg += e[2]; cb += e[3]; }
+                // every lane, as ray owner, adds its entries in queue (= sample) order; all reads are issued up front
+                // (broadcast ds_read_b128), no per-entry LDS round trip
+                if (!(A.ablate & 1)) {
+#pragma unroll
+                    for (int q = 0; q < BATCH / 4; ++q) {
+                        const f32x4 id = *reinterpret_cast<const f32x4 *>(res + 4 * q);
+                        const f32x4 vr = *reinterpret_cast<const f32x4 *>(res + BATCH + 4 * q);
+                        const f32x4 vg = *reinterpret_cast<const f32x4 *>(res + 2 * BATCH + 4 * q);
+                        const f32x4 vb = *reinterpret_cast<const f32x4 *>(res + 3 * BATCH + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bool mine = __float_as_int(id[e]) == lane;
+                            cr += mine ? vr[e] : 0.0f;
+                            cg += mine ? vg[e] : 0.0f;
+                            cb += mine ? vb[e] : 0.0f;
+                        }
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 head = (head + nb) & (RING - 1);
                 count -= nb;
                 ++st_pass;
+                if constexpr (P::PROFILE) prof[5] += __builtin_readcyclecounter() - t_sec;     // result list + owner collect
             } else {
                 break;
             }
@@ -436,6 +470,9 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         atomicAdd(A.stats + 1, st_active);
         atomicAdd(A.stats + 2, st_pass);
         atomicAdd(A.stats + 3, st_rays);
+        if constexpr (P::PROFILE) {
+            for (int k = 0; k < 7; ++k) atomicAdd(A.stats + 4 + k, prof[k]);
+        }
     }
 }
 

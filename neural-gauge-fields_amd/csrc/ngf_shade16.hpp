@@ -51,7 +51,7 @@ __device__ __forceinline__ const float *per_pass16(const float *blob)
 
 // layers 2 and 3; acc[mt][r] = layer-1 pre-activation of hidden unit mt*16 + 4*kq + r
 __device__ __forceinline__ void mlp_tail16(const float *blob, int oW2, int oB2, int oW3, int oB3, int lane, const f32x4 acc[4],
-                                           float rgb[3])
+                                           float rgb[3], unsigned long long *tk = nullptr)
 {
     const int kq = lane >> 4;
     f32x4 c[4];
@@ -64,6 +64,7 @@ __device__ __forceinline__ void mlp_tail16(const float *blob, int oW2, int oB2, 
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) c[mt] = NGF_MFMA16(w2[(mt * 16 + t) * 64], h, c[mt]);
     }
+    if (tk) { __builtin_amdgcn_sched_barrier(0); tk[4] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
     const float *w3 = blob + oW3 + kq * 16;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
@@ -128,9 +129,11 @@ __device__ __forceinline__ void layer1_plane16(const float *blob, int lane, cons
 
 // One gather buffer (48 VGPRs) + 12 interpolated features: plane p is interpolated into feat[], the buffer is
 // re-issued for plane p+1 at once, and plane p's 48 MFMAs run while that gather is in flight.
+#define NGF_TICK(i) do { if (tk) tk[i] = __builtin_readcyclecounter(); } while (0)
+
 template <int APP>
 __device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const float *vf,
-                                           int lane, float rgb[3])
+                                           int lane, float rgb[3], unsigned long long *tk = nullptr)
 {
     using L = MlpLayout16<APP>;
     blob = per_pass16(blob);
@@ -151,8 +154,10 @@ __device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blo
             for (int mt = 0; mt < 4; ++mt) acc[mt] = NGF_MFMA16(w1[(mt * L::KT + 3 * L::QCH + j) * 64], v[j], acc[mt]);
     }
     __builtin_amdgcn_sched_barrier(0);
+    NGF_TICK(0);                       // gather 0 issued + view MFMAs issued
     mix16<APP>(g, feat);
     __builtin_amdgcn_sched_barrier(0);
+    NGF_TICK(1);                       // plane 0 arrived and interpolated
     gather16_issue<APP, 1>(A, rec, kq, g);
     __builtin_amdgcn_sched_barrier(0);
     layer1_plane16<APP, 0>(blob, lane, feat, acc);
@@ -166,8 +171,12 @@ __device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blo
     mix16<APP>(g, feat);
     __builtin_amdgcn_sched_barrier(0);
     layer1_plane16<APP, 2>(blob, lane, feat, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    NGF_TICK(2);                       // all layer-1 MFMAs issued
     if (A.ablate & 2) { rgb[0] = acc[0][0]; rgb[1] = acc[1][1]; rgb[2] = acc[2][2] + acc[3][3]; return; }
-    mlp_tail16(blob, L::W2, L::B2, L::W3, L::B3, lane, acc, rgb);
+    mlp_tail16(blob, L::W2, L::B2, L::W3, L::B3, lane, acc, rgb, tk);
+    __builtin_amdgcn_sched_barrier(0);
+    NGF_TICK(3);                       // layers 2-3 done
 }
 
 // ---- NGF_F_BAKE_COLOR: 64-channel layer-1 pre-activation planes, channel = hidden unit mt*16 + 4*kq + r ----------------------

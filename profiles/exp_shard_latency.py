@@ -24,7 +24,7 @@ for rows in ((350, 450), (0, 100), (0, 800)):
     print(f"  rows {rows}: {ms:.3f} ms  ({rays.shape[0] / ms / 1e3:.1f} Mray/s)")
 ''' % (ROOT, ROOT)
 for bd in ("0", "1"):
-    for w, ns in (("12", "1"), ("8", "1"), ("8", "2"), ("16", "1")):
+    for w, ns in (("12", "1"), ("8", "1"), ("8", "2")):
         env = dict(os.environ, NGF_WAVES=w, NGF_NSTEP=ns, BD=bd)
         print(f"bake_density={bd} waves={w} nstep={ns}")
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
