@@ -107,6 +107,17 @@ int ngf_field_decode_rgb(const ngf_field *f, const float *coords, const float *d
 int ngf_field_march(const ngf_field *f, const float *rays, int64_t n, int32_t n_samples, int32_t mode,
                     const float *jitter, float *sigma, float *weight, void *hip_stream);
 
+/* Model-management helpers that reuse the march's device code:
+ *   ngf_field_alpha      : Base.compute_alpha (FieldBase.py:140-159) for n world-space points [n,3]:
+ *                          alpha = 1 - exp(-sigma * length), sigma = 0 where the alpha mask (if any) is empty;
+ *                          mode as in ngf_field_render (the reference calls it with the gauge OFF, iteration = -1).
+ *   ngf_field_ray_filter : the alpha-mask branch of Base.filtering_rays (FieldBase.py:237-239): keep[i] = 1 iff any of
+ *                          the n_samples points of ray i samples the alpha mask > 0 (requires a mask). */
+int ngf_field_alpha(const ngf_field *f, const float *xyz, int64_t n, int32_t mode, float length, float *alpha,
+                    void *hip_stream);
+int ngf_field_ray_filter(const ngf_field *f, const float *rays, int64_t n, int32_t n_samples, uint8_t *keep,
+                         void *hip_stream);
+
 /* Replaces: get_ray_directions + get_rays for a pin-hole camera (TriPlane/dataLoader/ray_utils.py:24-42,
  * 66-87; blender.py:46-53,84-85): rays [rows*W,6] for image rows [row0,row0+rows), c2w = HOST float[12]
  * (3x4 row-major, OpenCV axes), directions normalised as blender.py:52. */

@@ -17,7 +17,7 @@ F_BAKE_COLOR = 2
 
 SYMBOLS = ["ngf_field_create", "ngf_field_destroy", "ngf_field_render", "ngf_field_decode_rgb", "ngf_field_march",
            "ngf_generate_rays", "ngf_last_error", "ngf_abi_version", "ngf_field_bytes", "ngf_sizeof_field_desc",
-           "ngf_uv_create", "ngf_uv_destroy", "ngf_uv_render"]
+           "ngf_uv_create", "ngf_uv_destroy", "ngf_uv_render", "ngf_field_alpha", "ngf_field_ray_filter"]
 
 
 class FieldDesc(C.Structure):
@@ -70,6 +70,8 @@ def lib():
                                       C.c_void_p, C.c_void_p]
         L.ngf_generate_rays.argtypes = [C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                         C.c_void_p]
+        L.ngf_field_alpha.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
+        L.ngf_field_ray_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
         L.ngf_uv_create.argtypes = [C.POINTER(UvDesc), C.POINTER(C.c_void_p), C.c_void_p]
         L.ngf_uv_destroy.argtypes = [C.c_void_p]
         L.ngf_uv_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,

@@ -503,6 +503,44 @@ extern "C" int ngf_field_decode_rgb(const ngf_field *f, const float *coords, con
     return NGF_OK;
 }
 
+extern "C" int ngf_field_alpha(const ngf_field *f, const float *xyz, int64_t n, int32_t mode, float length, float *alpha, void *hip_stream)
+{
+    if (!f || !xyz || !alpha) return fail(NGF_E_ARG, "ngf_field_alpha: null argument");
+    if (n < 0) return fail(NGF_E_ARG, "ngf_field_alpha: n=%lld", (long long)n);
+    if (n == 0) return NGF_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    RenderArgs A = f->proto;
+    A.mode = mode ? 1 : 0;
+    int64_t grid = (n + 255) / 256;
+    if (grid > 8 * (int64_t)f->num_cus) grid = 8 * (int64_t)f->num_cus;
+    if (f->model == NGF_MODEL_INFOINV) {
+        const size_t lds = (size_t)((A.blob_floats + 3) & ~3) * sizeof(float);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(alpha_kernel<InfoInvPolicy>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (grid > (int64_t)f->num_cus) grid = f->num_cus;
+        hipLaunchKernelGGL(alpha_kernel<InfoInvPolicy>, dim3((unsigned)grid), dim3(256), lds, st, A, xyz, n, length, alpha);
+    } else if (f->flags & NGF_F_BAKE_DENSITY) {
+        hipLaunchKernelGGL((alpha_kernel<TriPlanePolicy<true, false, 8, 1>>), dim3((unsigned)grid), dim3(256), 0, st, A, xyz, n, length, alpha);
+    } else {
+        hipLaunchKernelGGL((alpha_kernel<TriPlanePolicy<false, false, 8, 1>>), dim3((unsigned)grid), dim3(256), 0, st, A, xyz, n, length, alpha);
+    }
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+extern "C" int ngf_field_ray_filter(const ngf_field *f, const float *rays, int64_t n, int32_t n_samples, uint8_t *keep, void *hip_stream)
+{
+    if (!f || !rays || !keep) return fail(NGF_E_ARG, "ngf_field_ray_filter: null argument");
+    if (!f->proto.mask.bits) return fail(NGF_E_ARG, "ngf_field_ray_filter: the field has no alpha mask");
+    if (n < 0 || n_samples <= 0) return fail(NGF_E_ARG, "ngf_field_ray_filter: n=%lld n_samples=%d", (long long)n, n_samples);
+    if (n == 0) return NGF_OK;
+    RenderArgs A = f->proto;
+    int64_t grid = (n + 255) / 256;
+    if (grid > 16 * (int64_t)f->num_cus) grid = 16 * (int64_t)f->num_cus;
+    hipLaunchKernelGGL(ray_filter_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)hip_stream, A, rays, n, n_samples, keep);
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
 extern "C" int ngf_generate_rays(int32_t H, int32_t W, float focal, const float *c, int32_t row0, int32_t rows, float *rays,
                                  void *hip_stream)
 {

@@ -476,6 +476,59 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
     }
 }
 
+// ---- compute_alpha for explicit world-space points (FieldBase.py:140-159) ----------------------------------------------
+template <typename P>
+__global__ void __launch_bounds__(256) alpha_kernel(const RenderArgs A, const float *xyz, int64_t n, float length, float *alpha)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if constexpr (P::INFOINV) {
+        for (int i = threadIdx.x; i < A.blob_floats; i += blockDim.x) smem[i] = A.blob[i];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n; base += stride) {
+        const int64_t i = base + lane;
+        const int64_t ii = i < n ? i : n - 1;
+        float p[3] = {xyz[ii * 3], xyz[ii * 3 + 1], xyz[ii * 3 + 2]};
+        bool valid = i < n;
+        if (A.mask.bits && valid) valid = mask_occupied(A.mask, p);
+        float x[3], t[6];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x[k] = (p[k] - A.a0[k]) * A.inv[k] - 1.0f;
+        const float sigma = P::sigma(A, smem, valid, x, lane, t);
+        if (i < n) alpha[i] = 1.0f - expf(-sigma * length);
+    }
+}
+
+// ---- filtering_rays, alpha-mask branch (FieldBase.py:237-239): one ray per thread --------------------------------------
+__global__ void __launch_bounds__(256) ray_filter_kernel(const RenderArgs A, const float *rays, int64_t n, int S, uint8_t *keep)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        float o[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { o[k] = rays[r * 6 + k]; d[k] = rays[r * 6 + 3 + k]; }
+        float tmin = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float vec = (d[k] == 0.0f) ? 1e-6f : d[k];
+            float ra = (A.a1[k] - o[k]) / vec, rb = (A.a0[k] - o[k]) / vec;
+            tmin = fmaxf(tmin, fminf(ra, rb));
+        }
+        tmin = fminf(fmaxf(tmin, A.near_), A.far_);
+        bool hit = false;
+        for (int i = 0; i < S && !hit; ++i) {
+            const float z = tmin + A.step * (float)i;
+            float p[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p[k] = o[k] + d[k] * z;
+            hit = mask_occupied(A.mask, p);
+        }
+        keep[r] = hit ? 1 : 0;
+    }
+}
+
 // ---- compute_rgb alone on caller-supplied samples (parity-test entry point) ----------------------
 template <typename P>
 __global__ void __launch_bounds__(256) decode_rgb_kernel(const RenderArgs A, const float *coords, const float *dirs,

@@ -214,6 +214,75 @@ class Base(torch.nn.Module):
             self.last_stats = stats
         return {'rgb_map': rgb, 'depth_map': depth}
 
+    # --- model management on top of the march's device code ---------------------------------
+    ALPHA_MODE = 0        # compute_alpha runs with the gauge OFF in TriPlane (iteration=-1, FieldBase.py:154)
+
+    @torch.no_grad()
+    def compute_alpha(self, xyz_locs, length=1):
+        """FieldBase.py:140-159: alpha = 1 - exp(-sigma * length) at world-space points [..., 3]."""
+        dev = torch.device(self.device)
+        pts = xyz_locs.to(device=dev, dtype=torch.float32).reshape(-1, 3).contiguous()
+        out = torch.empty((pts.shape[0],), device=dev, dtype=torch.float32)
+        if pts.shape[0]:
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().ngf_field_alpha(self.handle(), pts.data_ptr(), pts.shape[0], int(self.ALPHA_MODE),
+                                                      C.c_float(float(length)), out.data_ptr(),
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out.view(xyz_locs.shape[:-1])
+
+    @torch.no_grad()
+    def getDenseAlpha(self, gridSize=None):
+        """FieldBase.py:161-178: alpha on the [gx,gy,gz] lattice of the aabb (one launch instead of gx slices)."""
+        gridSize = self.gridSize.tolist() if gridSize is None else [int(g) for g in gridSize]
+        dev = torch.device(self.device)
+        samples = torch.stack(torch.meshgrid(torch.linspace(0, 1, gridSize[0]), torch.linspace(0, 1, gridSize[1]),
+                                             torch.linspace(0, 1, gridSize[2]), indexing='ij'), -1).to(dev)
+        aabb = self.aabb.to(dev)
+        dense_xyz = aabb[0] * (1 - samples) + aabb[1] * samples
+        alpha = self.compute_alpha(dense_xyz.view(-1, 3), float(self.stepSize)).view(gridSize)
+        return alpha, dense_xyz
+
+    @torch.no_grad()
+    def updateAlphaMask(self, gridSize=(200, 200, 200)):
+        """FieldBase.py:180-216: rebuild the occupancy volume (3x3x3 max-pool + threshold) and return the new aabb."""
+        import torch.nn.functional as F
+        gridSize = tuple(int(g) for g in gridSize)
+        alpha, dense_xyz = self.getDenseAlpha(gridSize)
+        dense_xyz = dense_xyz.transpose(0, 2).contiguous()
+        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
+        ks = 3
+        alpha = F.max_pool3d(alpha, kernel_size=ks, padding=ks // 2, stride=1).view(gridSize[::-1])
+        occ = alpha >= self.alphaMask_thres
+        alpha = occ.to(torch.float32)
+        self.alphaMask = AlphaGridMask(self.device, self.aabb, alpha)
+        self._handle_key = None
+        valid_xyz = dense_xyz[alpha > 0.5]
+        xyz_min, xyz_max = valid_xyz.amin(0), valid_xyz.amax(0)
+        return torch.stack((xyz_min, xyz_max))
+
+    @torch.no_grad()
+    def filtering_rays(self, all_rays, all_rgbs, N_samples=256, chunk=10240 * 5, bbox_only=False):
+        """FieldBase.py:218-246: drop rays that miss the box (bbox_only) or never touch an occupied voxel."""
+        dev = torch.device(self.device)
+        shape = all_rgbs.shape[:-1]
+        rays = all_rays.reshape(-1, all_rays.shape[-1]).to(device=dev, dtype=torch.float32).contiguous()
+        if bbox_only:
+            aabb = self.aabb.to(dev)
+            o, d = rays[:, :3], rays[:, 3:6]
+            vec = torch.where(d == 0, torch.full_like(d, 1e-6), d)
+            rate_a, rate_b = (aabb[1] - o) / vec, (aabb[0] - o) / vec
+            keep = torch.maximum(rate_a, rate_b).amin(-1) > torch.minimum(rate_a, rate_b).amax(-1)
+        else:
+            if self.alphaMask is None:
+                raise RuntimeError("filtering_rays(bbox_only=False) needs an alpha mask (updateAlphaMask)")
+            flags = torch.empty((rays.shape[0],), device=dev, dtype=torch.uint8)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().ngf_field_ray_filter(self.handle(), rays.data_ptr(), rays.shape[0], int(N_samples),
+                                                           flags.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            keep = flags.bool()
+        keep = keep.view(shape).to(all_rays.device)
+        return all_rays[keep], all_rgbs[keep]
+
     @torch.no_grad()
     def march(self, rays, N_samples, mode=1):
         """Per-sample (sigma, weight) [n,S] -- parity-test hook (sample_ray .. raw2alpha)."""

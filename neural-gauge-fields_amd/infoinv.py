@@ -37,6 +37,8 @@ class TriPlane(Base):
         d.dens_w2, d.dens_b2 = dp(m[2].weight), dp(m[2].bias)
         d.dens_w3, d.dens_b3 = dp(m[4].weight), dp(m[4].bias)
 
+    ALPHA_MODE = 1        # compute_alpha(..., infoinv=True) by default (InfoInv/models/FieldBase.py:140)
+
     def forward(self, rays_chunk, white_bg=True, is_train=False, N_samples=-1, infoinv=True, collect_stats=False, out=None):
         """InfoInv/models/FieldBase.py:228."""
         return self._render(rays_chunk, white_bg, is_train, N_samples, mode=int(bool(infoinv)), collect_stats=collect_stats, out=out)

@@ -170,6 +170,37 @@ def capture_ops(name="ops_grid_sample"):
     print(f"{name}: 2-D {out2.shape}, 3-D {out3.shape} (positive {int((out3 > 0).sum())})")
 
 
+def capture_alpha_mask(name="triplane_alpha_mask", seed=41):
+    """updateAlphaMask + filtering_rays of the reference on a small lattice (FieldBase.py:161-246)."""
+    F = _import_ref("TriPlane")
+    aabb = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
+    grid = [24, 20, 18]
+    plane_hw = ((20, 24), (18, 20), (18, 24))
+    gauge_hw = (12, 14)
+    params = synth.triplane_params(seed, plane_hw, gauge_hw, preset="R2", gauge_std=0.05)
+    with contextlib.redirect_stdout(io.StringIO()):
+        field = F.TriPlane(aabb, grid, "cpu", near_far=[2.0, 6.0], alphaMask_thres=0.02, distance_scale=25,
+                           rayMarch_weight_thres=1e-4, step_ratio=0.5, gauge_start=0)
+    _load_params(field, params)
+    mgrid = (14, 12, 10)
+    rays = _rays_for_case(seed, 200, 64)
+    rgbs = synth.hash_uniform(seed, 700, (rays.shape[0], 3))
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        dense_alpha, _ = field.getDenseAlpha(mgrid)
+        new_aabb = field.updateAlphaMask(mgrid)
+        vol = field.alphaMask.alpha_volume[0, 0].numpy().copy()
+        kept_rays, kept_rgbs = field.filtering_rays(torch.from_numpy(rays), torch.from_numpy(rgbs), N_samples=40)
+        kept_bbox, _ = field.filtering_rays(torch.from_numpy(rays), torch.from_numpy(rgbs), bbox_only=True)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), model="triplane", seed=seed, preset="R2", gauge_std=np.float32(0.05),
+                        aabb=aabb.numpy(), grid=np.array(grid), plane_hw=np.array(plane_hw), gauge_hw=np.array(gauge_hw),
+                        near_far=np.array([2.0, 6.0], np.float32), step_ratio=np.float32(0.5), distance_scale=np.float32(25),
+                        thr=np.float32(1e-4), alphaMask_thres=np.float32(0.02), mgrid=np.array(mgrid), rays=rays, rgbs=rgbs,
+                        dense_alpha=dense_alpha.numpy(), mask_volume=vol, new_aabb=new_aabb.numpy(),
+                        kept_rays=kept_rays.numpy(), kept_bbox=kept_bbox.numpy(), **_checksums(params))
+    print(f"{name}: occupancy {vol.mean():.3f}, new aabb {new_aabb.numpy().round(3).tolist()}, kept {kept_rays.shape[0]}/{rays.shape[0]} "
+          f"(bbox only {kept_bbox.shape[0]})")
+
+
 def capture_uv(name, seed, primitive_type, R=96, S=64):
     """UV-Mapping colour path through the reference's own sub-modules, composed as NeuTex.forward does
     (model.py:30-50); NeuTex.forward itself is CUDA-hardwired (gauge_fields.py:129,154) and cannot run here.
@@ -235,5 +266,6 @@ if __name__ == "__main__":
     capture_triplane("triplane_r0", seed=14, preset="R0", gauge_on=True, gauge_std=0.01, with_mask=False, S=32)
     capture_infoinv("infoinv_r1_on", seed=21, preset="R1", infoinv=True, S=40)
     capture_infoinv("infoinv_r1_off", seed=22, preset="R1", infoinv=False, S=40)
+    capture_alpha_mask()
     capture_uv("uv_sphere", seed=31, primitive_type="sphere")
     capture_uv("uv_square", seed=32, primitive_type="square")

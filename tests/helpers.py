@@ -25,6 +25,8 @@ def load_case(name):
         chk = np.array([v64.sum(), np.abs(v64).sum(), v64[:: max(1, v64.size // 7)][:7].sum()])
         assert np.array_equal(chk, g["chk." + k]), f"synth regenerated different parameters for {k}"
     step = geometry.step_size(g["aabb"], g["grid"], float(g["step_ratio"]))
+    if "S" not in g:
+        g["S"] = np.array(0)
     mask = None
     if "mask_bits" in g:
         mask = (g["mask_bits"], tuple(int(v) for v in g["mask_dhw"]), g["mask_aabb"])

@@ -215,3 +215,34 @@ def test_full_frame_properties():
     o_rgb, o_depth = orc.render(rays_np[pick], 192)
     _close(rgb[torch.from_numpy(pick).cuda()].cpu().numpy(), o_rgb, "full-frame rgb vs oracle")
     _close(depth[torch.from_numpy(pick).cuda()].cpu().numpy(), o_depth, "full-frame depth vs oracle", atol=5e-5)
+
+
+def test_alpha_mask_build_and_ray_filter():
+    """Row N2: getDenseAlpha / updateAlphaMask / filtering_rays against the reference's own outputs."""
+    g, params, step, _ = load_case("triplane_alpha_mask")
+    f = field_for_case(g, params, None)
+    f.alphaMask_thres = float(g["alphaMask_thres"])
+    mgrid = tuple(int(v) for v in g["mgrid"])
+    alpha, dense_xyz = f.getDenseAlpha(mgrid)
+    np.testing.assert_allclose(alpha.cpu().numpy(), g["dense_alpha"], rtol=2e-4, atol=2e-7)
+    # the same values through the C oracle (gauge off, identity split of the normalised position)
+    orc = oracle_for_case(g, params, step, None)
+    xyz = dense_xyz.view(-1, 3).cpu().numpy()
+    xn = (xyz - g["aabb"][0]) * (np.float32(2.0) / (g["aabb"][1] - g["aabb"][0])) - np.float32(1.0)
+    coords = np.stack([xn[:, 0], xn[:, 1], xn[:, 1], xn[:, 2], xn[:, 0], xn[:, 2]], 1).astype(np.float32)
+    o_alpha = 1.0 - np.exp(-orc.density_at(coords) * np.float32(step))
+    np.testing.assert_allclose(alpha.view(-1).cpu().numpy(), o_alpha, rtol=2e-4, atol=2e-7)
+    new_aabb = f.updateAlphaMask(mgrid)
+    vol = f.alphaMask.alpha_volume[0, 0].cpu().numpy()
+    near_thr = np.abs(torch.nn.functional.max_pool3d(torch.from_numpy(g["dense_alpha"]).clamp(0, 1).transpose(0, 2)[None, None], 3, 1, 1)[0, 0].numpy()
+                      - float(g["alphaMask_thres"])) < 1e-6
+    assert np.array_equal(vol[~near_thr], g["mask_volume"][~near_thr])
+    np.testing.assert_allclose(new_aabb.cpu().numpy(), g["new_aabb"], atol=1e-6)
+    rays, rgbs = torch.from_numpy(g["rays"]), torch.from_numpy(g["rgbs"])
+    kept, kept_rgb = f.filtering_rays(rays, rgbs, N_samples=40)
+    assert kept.shape == g["kept_rays"].shape and np.array_equal(kept.numpy(), g["kept_rays"])
+    kept_b, _ = f.filtering_rays(rays, rgbs, bbox_only=True)
+    assert np.array_equal(kept_b.numpy(), g["kept_bbox"])
+    # the rebuilt mask is used by the next render and by a checkpoint round trip
+    out = f(rays.cuda(), N_samples=32, iteration=30001)
+    assert bool(torch.isfinite(out["rgb_map"]).all())
