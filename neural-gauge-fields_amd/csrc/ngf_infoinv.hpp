@@ -58,6 +58,7 @@ struct InfoInvPolicy {
     static constexpr bool INFOINV = true;
     static constexpr int WAVES = kInfoInvWaves;
     static constexpr bool PROFILE = false;
+    static constexpr bool VLDS = true;
     static constexpr int NSTEP = 1;
     static constexpr int BATCH = kBatch;
     static constexpr int RING = 128;
@@ -143,7 +144,7 @@ struct InfoInvPolicy {
         return valid ? softplus_shift(f) : 0.0f;
     }
     __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
-                                                 int lane, float c[3])
+                                                 const float *, int lane, float c[3], unsigned long long * = nullptr)
     {
         mlp_pass<72, true, 3>(A, smem, rec, vf, lane, A.mode, c);
     }

@@ -28,7 +28,7 @@
 namespace ngf {
 
 // LDS carve (floats): [blob | per wave: ring of RING records, result list, view inputs of the 64 rays]
-template <typename P> constexpr int wave_lds_floats() { return P::RING * kRecFloats + P::BATCH * 4 + kWave * kViewFeat; }
+template <typename P> constexpr int wave_lds_floats() { return P::RING * kRecFloats + P::BATCH * 4 + (P::VLDS ? kWave * kViewFeat : 0); }
 
 // The 16 view-direction inputs of rgb_decoder layer 1 (networks.py:27-29, 205-216):
 //   u[F..F+14] = [d(3), sin(d_x), sin(2 d_x), sin(d_y), sin(2 d_y), sin(d_z), sin(2 d_z), cos(same 6)], u[F+15] = 0 (pad)
@@ -269,6 +269,7 @@ struct TriPlanePolicy {
     static constexpr int WAVES = WAVES_;
     static constexpr int NSTEP = NSTEP_;
     static constexpr int BATCH = kBatch16;
+    static constexpr bool VLDS = WAVES_ <= 12;                  // per-ray view inputs cached in LDS (4 KB / wave) or recomputed per pass
     static constexpr int RING = NSTEP_ == 1 ? 128 : 256;        // >= BATCH-1 + 64*NSTEP records
     __device__ static __forceinline__ float sigma(const RenderArgs &A, const float *, bool valid, const float x[3], int, float t[6])
     {
@@ -282,11 +283,13 @@ struct TriPlanePolicy {
         for (int k = 0; k < 6; ++k) t[k] = valid ? tt[k] : 0.0f;
         return valid ? sg : 0.0f;
     }
+    // vf: the owner ray's 16 cached view inputs (VLDS) or nullptr; od: the owner ray's direction
     __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
-                                                 int lane, float c[3], unsigned long long *tk = nullptr)
+                                                 const float od[3], int lane, float c[3], unsigned long long *tk = nullptr)
     {
-        if constexpr (BAKE_C) mlp_pass16_baked(A, smem, rec, vf, lane, c);
-        else mlp_pass16<48>(A, smem, rec, vf, lane, c, tk);
+        const f32x4 v = VLDS ? *reinterpret_cast<const f32x4 *>(vf + (lane >> 4) * 4) : view_entries16(od, lane >> 4);
+        if constexpr (BAKE_C) mlp_pass16_baked(A, smem, rec, v, lane, c);
+        else mlp_pass16<48>(A, smem, rec, v, lane, c, tk);
     }
 };
 
@@ -334,7 +337,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         }
         tmin = fminf(fmaxf(tmin, A.near_), A.far_);
 
-        {   // view inputs of this lane's ray (networks.py:27-29), read back by the shade lanes
+        if constexpr (P::VLDS) {   // view inputs of this lane's ray (networks.py:27-29), read back by the shade lanes
             float v[16];
             view_inputs(d, v);
             f32x4 *dst = reinterpret_cast<f32x4 *>(vfeat + lane * kViewFeat);
@@ -404,10 +407,12 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 const f32x4 r0 = r[0], r1 = r[1];
                 const float rec[kRecFloats] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
                 const int owner = __float_as_int(r0[0]);
+                float od[3] = {0.0f, 0.0f, 0.0f};
+                if constexpr (!P::VLDS) { od[0] = __shfl(d[0], owner); od[1] = __shfl(d[1], owner); od[2] = __shfl(d[2], owner); }
                 float c[3];
                 if constexpr (P::PROFILE) {
                     unsigned long long tk[5] = {0, 0, 0, 0, 0};
-                    P::shade(A, smem, rec, vfeat + owner * kViewFeat, lane, c, tk);
+                    P::shade(A, smem, rec, vfeat + owner * kViewFeat, od, lane, c, tk);
                     prof[1] += tk[0] - t_sec;      // ring read, address setup, gather 0 + view MFMAs issued
                     prof[2] += tk[1] - tk[0];      // wait for plane 0 + interpolate
                     prof[3] += tk[2] - tk[1];      // layer-1 MFMAs (planes 1, 2 gathered behind them)
@@ -415,7 +420,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     prof[6] += tk[3] - tk[4];      // layer 3 (VALU dot, 2 cross-lane adds, sigmoid)
                     t_sec = tk[3];
                 } else {
-                    P::shade(A, smem, rec, vfeat + owner * kViewFeat, lane, c);
+                    P::shade(A, smem, rec, vfeat + owner * kViewFeat, od, lane, c);
                 }
                 // result list, structure-of-arrays: res[0..B) owner lane ids, then weighted r, g, b
                 if (lane < BATCH) {
@@ -559,7 +564,8 @@ __global__ void __launch_bounds__(256) decode_rgb_kernel(const RenderArgs A, con
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         float c[3];
-        P::shade(A, smem, rec, vfeat + s * kViewFeat, lane, c);
+        const float dq2[3] = {dirs[q * 3], dirs[q * 3 + 1], dirs[q * 3 + 2]};
+        P::shade(A, smem, rec, vfeat + s * kViewFeat, dq2, lane, c);
         if (lane < BATCH && ok) { out[q * 3] = c[0]; out[q * 3 + 1] = c[1]; out[q * 3 + 2] = c[2]; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }

@@ -47,6 +47,40 @@ __device__ __forceinline__ const float *per_pass16(const float *blob)
     return blob + z;
 }
 
+// sin/cos for |x| <= 2 (view directions are unit vectors, the encoding uses d and 2d): Cody-Waite reduction by pi/2
+// + the cephes single-precision kernels, <= 2 ulp.  Used when the per-ray view inputs are not cached in LDS.
+__device__ __forceinline__ void sincos_small(float x, float &s, float &c)
+{
+    const float k = rintf(x * 0.636619772f);
+    float r = fmaf(-k, 1.5707962513e+00f, x);
+    r = fmaf(-k, 7.5497894159e-08f, r);
+    const float z = r * r;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k & 3;
+    const float s0 = (q & 1) ? cp : sp, c0 = (q & 1) ? sp : cp;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// the 4 view inputs lane-quarter kq supplies: entries kq*4 .. kq*4+3 of [d(3), sin(d_x, 2d_x, d_y, 2d_y, d_z, 2d_z), cos(same), 0]
+__device__ __forceinline__ f32x4 view_entries16(const float d[3], int kq)
+{
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int f = 4 * kq + e;                  // 0..15
+        const int g = f < 3 ? 0 : (f < 9 ? f - 3 : (f < 15 ? f - 9 : 0));     // index into [d_x, 2d_x, d_y, 2d_y, d_z, 2d_z]
+        const int dim = g >> 1;
+        const float dd = dim == 0 ? d[0] : (dim == 1 ? d[1] : d[2]);
+        float s, c;
+        sincos_small((g & 1) ? dd * 2.0f : dd, s, c);
+        const float raw = f == 0 ? d[0] : (f == 1 ? d[1] : d[2]);
+        v[e] = f < 3 ? raw : (f < 9 ? s : (f < 15 ? c : 0.0f));
+    }
+    return v;
+}
+
 #define NGF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // layers 2 and 3; acc[mt][r] = layer-1 pre-activation of hidden unit mt*16 + 4*kq + r
@@ -132,7 +166,7 @@ __device__ __forceinline__ void layer1_plane16(const float *blob, int lane, cons
 #define NGF_TICK(i) do { if (tk) tk[i] = __builtin_readcyclecounter(); } while (0)
 
 template <int APP>
-__device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const float *vf,
+__device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v,
                                            int lane, float rgb[3], unsigned long long *tk = nullptr)
 {
     using L = MlpLayout16<APP>;
@@ -145,8 +179,7 @@ __device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blo
     f32x4 acc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(blob + L::B1 + kq * 16 + mt * 4);
-    {   // view-direction inputs: lane-quarter kq supplies entries kq*4 .. kq*4+3
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(vf + kq * 4);
+    {   // view-direction inputs: lane-quarter kq supplies entries kq*4 .. kq*4+3 (v)
         const float *w1 = blob + L::W1 + lane;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -217,7 +250,7 @@ __device__ __forceinline__ void baked16_consume(const BakedHalf &g, float sum[16
 // Two half-plane buffers (32 VGPRs each): stage s+1 is in flight while stage s is accumulated.  The interpolated
 // pre-activations are summed in plain VGPRs first and only then become the MFMA accumulator of the 16 view-input
 // MFMAs (updating MFMA accumulators with VALU adds in between made hipcc spill heavily).
-__device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const float *vf,
+__device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v,
                                                  int lane, float rgb[3])
 {
     using L = MlpLayout16Baked;
@@ -256,7 +289,6 @@ __device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const floa
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{sum[4 * mt], sum[4 * mt + 1], sum[4 * mt + 2], sum[4 * mt + 3]};
     {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(vf + kq * 4);
         const float *w1 = blob + L::W1V + lane;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
