@@ -674,7 +674,7 @@ extern "C" int ngf_uv_create(const ngf_uv_desc *d, ngf_uv **out, void *hip_strea
     A.ga_w3 = P.dense(W[15], 128, 128, 32, 8, hid);  A.ga_b3 = P.bias(B[15], 128, 8);
     A.ga_wo = P.out_layer(W[16], ud, 128, 32, hid);  A.ga_bo = P.bias4(B[16], ud);
     // texture
-    A.t1_w0 = P.dense(W[17], 256, in_uv, d->sphere ? 16 : 11, 16, nat);  A.t1_b0 = P.bias(B[17], 256, 16);
+    A.t1_w0 = P.dense(W[17], 256, in_uv, d->sphere ? 16 : 12, 16, nat);  A.t1_b0 = P.bias(B[17], 256, 16);
     for (int l = 0; l < 5; ++l) {
         const int o = P.dense(W[18 + l], 256, 256, 64, 16, hid);
         if (l == 0) A.t1_wh = o;
@@ -684,7 +684,7 @@ extern "C" int ngf_uv_create(const ngf_uv_desc *d, ngf_uv **out, void *hip_strea
         if (l == 0) A.t1_bh = o;
     }
     A.c1_w = P.out_layer(W[23], 3, 256, 64, hid);    A.c1_b = P.bias4(B[23], 3);
-    A.t2_w0 = P.dense(W[24], 256, 295, 74, 16, [](int t, int kq) { return t < 64 ? UvPacker::hidden(t, kq) : 256 + 4 * (t - 64) + kq; });
+    A.t2_w0 = P.dense(W[24], 256, 295, 76, 16, [](int t, int kq) { return t < 64 ? UvPacker::hidden(t, kq) : 256 + 4 * (t - 64) + kq; });
     A.t2_b0 = P.bias(B[24], 256, 16);
     for (int l = 0; l < 3; ++l) {
         const int o = P.dense(W[25 + l], 256, 256, 64, 16, hid);

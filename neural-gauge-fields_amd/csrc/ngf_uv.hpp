@@ -60,25 +60,59 @@ __device__ __forceinline__ void load_bias(const float *b, int kq, f32x4 acc[NT])
     for (int mt = 0; mt < NT; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(b + kq * (NT * 4) + mt * 4);
 }
 
-// one k-step: NT unit tiles, A from packed weights [t][NT/4][64 lanes][4] (one coalesced 16-byte load per 4 MFMAs)
+// A operand of one k-step: NT unit tiles from packed weights [t][NT/4][64 lanes][4] (one coalesced 16-byte load per 4 MFMAs)
 template <int NT>
-__device__ __forceinline__ void kstep(const float *w, int t, int lane, float b, f32x4 acc[NT])
+struct KStepA {
+    f32x4 a[NT / 4];
+    float b;
+};
+
+template <int NT>
+__device__ __forceinline__ void kload(const float *w, const float *act, int t, int lane, KStepA<NT> &k)
 {
     const f32x4 *wp = reinterpret_cast<const f32x4 *>(w) + ((size_t)t * (NT / 4)) * 64 + lane;
 #pragma unroll
-    for (int g = 0; g < NT / 4; ++g) {
-        const f32x4 a = wp[g * 64];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[4 * g + e] = NGF_UV_MFMA(a[e], b, acc[4 * g + e]);
-    }
+    for (int g = 0; g < NT / 4; ++g) k.a[g] = wp[g * 64];
+    k.b = act[t * 64 + lane];
 }
 
+template <int NT>
+__device__ __forceinline__ void kmma(const KStepA<NT> &k, f32x4 acc[NT])
+{
+#pragma unroll
+    for (int g = 0; g < NT / 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = NGF_UV_MFMA(k.a[g][e], k.b, acc[4 * g + e]);
+}
+
+// Dense layer, KT4 k-steps (multiple of 4; padded steps have zero weights and zero inputs).  Software pipeline with
+// two k-steps of weight loads in flight behind the MFMAs (the un-pipelined loop left the waves 67 % of their cycles
+// in s_waitcnt with the matrix pipe 31 % busy: latency-, not bandwidth-bound).
 template <int NT_OUT>
-__device__ __forceinline__ void dense(const float *w, const float *bias, int KT, int lane, const float *act, f32x4 out[NT_OUT])
+__device__ __forceinline__ void dense(const float *w, const float *bias, int KT4, int lane, const float *act, f32x4 out[NT_OUT])
 {
     load_bias<NT_OUT>(bias, lane >> 4, out);
-#pragma unroll 2
-    for (int t = 0; t < KT; ++t) kstep<NT_OUT>(w, t, lane, act[t * 64 + lane], out);
+    KStepA<NT_OUT> k0, k1, k2, k3;
+    kload<NT_OUT>(w, act, 0, lane, k0);
+    kload<NT_OUT>(w, act, 1, lane, k1);
+#pragma unroll 1
+    for (int t = 0; t < KT4; t += 4) {
+        // sched_barrier(0) pins the order: without it hipcc sinks every load next to its first use and waits
+        // vmcnt(0) before each group of four MFMAs
+        kload<NT_OUT>(w, act, t + 2, lane, k2);
+        kload<NT_OUT>(w, act, t + 3, lane, k3);
+        __builtin_amdgcn_sched_barrier(0);
+        kmma<NT_OUT>(k0, out);
+        kmma<NT_OUT>(k1, out);
+        __builtin_amdgcn_sched_barrier(0);
+        const int tn = t + 4 < KT4 ? t + 4 : t;          // last iteration: harmless reload instead of a branch
+        kload<NT_OUT>(w, act, tn, lane, k0);
+        kload<NT_OUT>(w, act, tn + 1, lane, k1);
+        __builtin_amdgcn_sched_barrier(0);
+        kmma<NT_OUT>(k2, out);
+        kmma<NT_OUT>(k3, out);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 template <int NT>
@@ -175,8 +209,8 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
         store_pe<3, 10>(act, 0, 16, lane, uv);
         dense<16>(W + A.t1_w0, W + A.t1_b0, 16, lane, act, x);
     } else {
-        store_pe<2, 10>(act, 0, 11, lane, uv);
-        dense<16>(W + A.t1_w0, W + A.t1_b0, 11, lane, act, x);
+        store_pe<2, 10>(act, 0, 12, lane, uv);
+        dense<16>(W + A.t1_w0, W + A.t1_b0, 12, lane, act, x);
     }
     store_act<16>(act, lane, x, 0.2f);
 #pragma unroll 1
@@ -187,8 +221,8 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     // act[0..63] = block1 output h; color1 and block2 both read it
     const f32x4 c1 = dense_out(W + A.c1_w, W + A.c1_b, 64, lane, act);
     // block2: [h(256), v(3), PE6(v)(36)] -> 256 -> (3x) 256 -> 3
-    store_pe<3, 6>(act, 64, 10, lane, v);
-    dense<16>(W + A.t2_w0, W + A.t2_b0, 74, lane, act, x);
+    store_pe<3, 6>(act, 64, 12, lane, v);                 // 39 inputs + zero padding up to k-step 76
+    dense<16>(W + A.t2_w0, W + A.t2_b0, 76, lane, act, x);
     store_act<16>(act, lane, x, 0.2f);
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
