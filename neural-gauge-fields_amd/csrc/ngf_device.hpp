@@ -48,7 +48,8 @@ struct RenderArgs {
     unsigned int *tile_counter; // zeroed before the launch
     int64_t n;
     int32_t S, white_bg, mode, skip_rgb;
-    int32_t tile_w;        // rays per wave tile: 64, or 32 / 16 for small launches (more waves, shorter critical path)
+    int32_t tile_w;        // rays per wave tile: 64, or 32 / 16 / 8 for small launches (more waves, shorter critical path)
+    int32_t tile_shift;    // log2(tile_w); the split march gives every ray 64 >> tile_shift lanes (consecutive steps)
     int32_t ablate;        // profiling only (NGF_ABLATE): 1 skip collect, 2 skip layers 2-3, 4 cached gathers, 16 raise wave priority in the shade pass
     float a0[3], a1[3], inv[3];
     float near_, far_, step, dscale, thr;

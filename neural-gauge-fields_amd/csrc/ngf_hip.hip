@@ -383,29 +383,32 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
 
 // ---- launches ------------------------------------------------------------------------------------
 template <typename K>
-static int launch_render(K kernel, const ngf_field *f, RenderArgs &A, int threads, size_t lds_bytes, hipStream_t st)
+static int launch_render(K kernel, K kernel_split, const ngf_field *f, RenderArgs &A, int threads, size_t lds_bytes, hipStream_t st)
 {
     const unsigned slot = f->next_counter.fetch_add(1) % kCounters;
     A.tile_counter = f->counters + slot;
     HIP_TRY(hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned), st));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    // Small launches (one rank's shard of a frame) are bound by the latency of ONE tile, not by throughput: give
-    // every wave fewer rays (lanes >= tile_w idle in the march, the shade passes are unaffected) while the tile
-    // count still fits the resident waves.  profiles/exp_shard_latency.py
+    // Split march (render_kernel<P, true>): a tile holds tile_w rays and every ray is marched by 64 / tile_w lanes on
+    // consecutive steps (bit-identical results).  Small tiles shorten the critical path of a tile and even out the
+    // tiles-per-wave quantisation, which bounds small launches (one rank's shard of a frame, the reference's 4096-ray
+    // chunks) and still buys 5 % on a full frame.  Measured in profiles/r01_split_march.txt: tile_w = 8 is best from
+    // 40 000 rays to the full frame, tile_w = 4 for a 4000-ray chunk (0.31 ms vs 0.53 ms).  NGF_TILE_W / NGF_SPLIT override for experiments.
     const int waves = threads / kWave;
-    const int64_t slots = (int64_t)f->num_cus * waves;
     int tw = 64;
+    if (kernel_split) tw = A.n < 8 * (int64_t)f->num_cus * waves ? 4 : 8;      // below one 8-ray tile per resident wave: 4-ray tiles
     if (const char *e = getenv("NGF_TILE_W")) tw = atoi(e);
-    else {
-        while (tw > 16 && (A.n + tw / 2 - 1) / (tw / 2) <= slots) tw /= 2;
-    }
-    if (tw != 64 && tw != 32 && tw != 16) return fail(NGF_E_ARG, "NGF_TILE_W must be 64, 32 or 16");
+    if (tw != 64 && tw != 32 && tw != 16 && tw != 8 && tw != 4) return fail(NGF_E_ARG, "NGF_TILE_W must be 64, 32, 16, 8 or 4");
+    bool split = tw < 64 && kernel_split;
+    if (const char *e = getenv("NGF_SPLIT")) split = atoi(e) != 0 && kernel_split;
     A.tile_w = tw;
+    A.tile_shift = tw == 64 ? 6 : tw == 32 ? 5 : tw == 16 ? 4 : tw == 8 ? 3 : 2;
+    K k = split ? kernel_split : kernel;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     const int64_t tiles = (A.n + tw - 1) / tw;
     int64_t grid = (tiles + waves - 1) / waves;
     if (grid > f->num_cus) grid = f->num_cus;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds_bytes, st, A);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds_bytes, st, A);
     HIP_TRY(hipGetLastError());
     return NGF_OK;
 }
@@ -415,7 +418,8 @@ static int launch_policy(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
     const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + P::WAVES * wave_lds_floats<P>()) * sizeof(float);
     if (lds > 160 * 1024) return fail(NGF_E_ARG, "this waves-per-CU setting needs %zu bytes of LDS (> 160 KiB)", lds);
-    return launch_render(render_kernel<P>, f, A, P::WAVES * kWave, lds, st);
+    if constexpr (P::NSTEP == 1) return launch_render(render_kernel<P, false>, render_kernel<P, true>, f, A, P::WAVES * kWave, lds, st);
+    else return launch_render(render_kernel<P, false>, (decltype(&render_kernel<P, false>))nullptr, f, A, P::WAVES * kWave, lds, st);
 }
 
 template <bool BD, bool BC>

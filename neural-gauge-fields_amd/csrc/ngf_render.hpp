@@ -294,9 +294,15 @@ struct TriPlanePolicy {
 };
 
 // ---- the fused kernel ---------------------------------------------------------------------------
-template <typename P>
+// SPLIT = false: one ray per lane, tile_w (<= 64) rays per tile.  SPLIT = true (small launches: one rank's shard of a frame,
+// the reference's 4096-ray chunks): a tile holds tile_w = 64 >> k rays and every ray is marched by K = 64 / tile_w lanes that
+// take K CONSECUTIVE steps per iteration; transmittance, acc and depth are then chained lane to lane in step order, so each
+// ray sees exactly the sequential arithmetic of the unsplit march (results are bit-identical) while a tile's critical path
+// is K times shorter and all 64 lanes gather.
+template <typename P, bool SPLIT = false>
 __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs A)
 {
+    static_assert(!SPLIT || P::NSTEP == 1, "the split march is written for one step per lane per iteration");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     for (int i = threadIdx.x; i < A.blob_floats; i += blockDim.x) smem[i] = A.blob[i];
     __syncthreads();
@@ -319,8 +325,11 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         tile = __builtin_amdgcn_readfirstlane(tile);
         const int64_t base = (int64_t)tile * A.tile_w;
         if (base >= A.n) break;
-        const int64_t ray = base + lane;
-        const bool live = (lane < A.tile_w) && (ray < A.n);
+        const int seg = SPLIT ? (lane >> A.tile_shift) : 0;              // which of the K consecutive steps this lane takes
+        const int rl = SPLIT ? (lane & (A.tile_w - 1)) : lane;           // ray slot inside the tile (= owner id in the queues)
+        const int K = SPLIT ? (64 >> A.tile_shift) : 1;
+        const int64_t ray = base + rl;
+        const bool live = (rl < A.tile_w) && (ray < A.n);
         const int64_t rr = live ? ray : A.n - 1;
         float o[3], d[3];
 #pragma unroll
@@ -340,7 +349,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         if constexpr (P::VLDS) {   // view inputs of this lane's ray (networks.py:27-29), read back by the shade lanes
             float v[16];
             view_inputs(d, v);
-            f32x4 *dst = reinterpret_cast<f32x4 *>(vfeat + lane * kViewFeat);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(vfeat + rl * kViewFeat);      // split march: K lanes store the same values
 #pragma unroll
             for (int q = 0; q < 4; ++q) dst[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
         }
@@ -354,11 +363,12 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 float z[NSTEP], dist[NSTEP], sigma[NSTEP], t[NSTEP][6];
 #pragma unroll
                 for (int u = 0; u < NSTEP; ++u) {
-                    z[u] = tmin + A.step * ((float)(i + u) + jit);
-                    const float zn = tmin + A.step * ((float)(i + u + 1) + jit);
-                    dist[u] = (i + u < S - 1) ? (zn - z[u]) : 0.0f;
+                    const int si = i + u + seg;
+                    z[u] = tmin + A.step * ((float)si + jit);
+                    const float zn = tmin + A.step * ((float)(si + 1) + jit);
+                    dist[u] = (si < S - 1) ? (zn - z[u]) : 0.0f;
                     float p[3], x[3];
-                    bool valid = live && (i + u < S);
+                    bool valid = live && (si < S);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         p[k] = o[k] + d[k] * z[u];
@@ -376,26 +386,47 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 for (int u = 0; u < NSTEP; ++u) {
                     // raw2alpha (FieldBase.py:12-19); steps past S have sigma = 0 -> alpha = w = 0, T unchanged
                     const float alpha = 1.0f - expf(-sigma[u] * (dist[u] * A.dscale));
-                    const float w = alpha * T;
-                    T = T * ((1.0f - alpha) + 1e-10f);
-                    acc += w;
-                    dep += w * z[u];
-                    if (A.dbg_weight && live && i + u < S) {
-                        A.dbg_weight[ray * S + i + u] = w;
-                        A.dbg_sigma[ray * S + i + u] = sigma[u];
+                    float w;
+                    if constexpr (SPLIT) {
+                        // lane (seg, ray) needs T, acc, dep as they stand after steps i .. i+seg-1 of its ray: K-1 rounds of
+                        // "take the previous step's outputs from lane - tile_w"; after round r segments <= r are final
+                        const float f = (1.0f - alpha) + 1e-10f;
+                        float Tin = T, ain = acc, din = dep;
+                        const int prev = (lane - A.tile_w) & 63;
+                        for (int r = 1; r < K; ++r) {
+                            const float wr = alpha * Tin;
+                            const float To = Tin * f, ao = ain + wr, dz = wr * z[u];
+                            const float dn = din + dz;
+                            const float Tp = __shfl(To, prev), ap = __shfl(ao, prev), dp = __shfl(dn, prev);
+                            if (seg > 0) { Tin = Tp; ain = ap; din = dp; }
+                        }
+                        w = alpha * Tin;
+                        const float To = Tin * f, ao = ain + w, dz = w * z[u];
+                        const float dn = din + dz;
+                        const int last = 64 - A.tile_w + rl;            // the lane that took step i + K - 1 of this ray
+                        T = __shfl(To, last); acc = __shfl(ao, last); dep = __shfl(dn, last);
+                    } else {
+                        w = alpha * T;
+                        T = T * ((1.0f - alpha) + 1e-10f);
+                        acc += w;
+                        dep += w * z[u];
+                    }
+                    if (A.dbg_weight && live && i + u + seg < S) {
+                        A.dbg_weight[ray * S + i + u + seg] = w;
+                        A.dbg_sigma[ray * S + i + u + seg] = sigma[u];
                     }
                     const bool active = (w > A.thr) && !A.skip_rgb;
                     const unsigned long long m = __ballot(active);
                     if (active) {
                         const int slot = (head + count + __popcll(m & lt_mask)) & (RING - 1);
                         f32x4 *r = reinterpret_cast<f32x4 *>(ring + slot * kRecFloats);
-                        r[0] = f32x4{__int_as_float(lane), w, t[u][0], t[u][1]};
+                        r[0] = f32x4{__int_as_float(rl), w, t[u][0], t[u][1]};
                         r[1] = f32x4{t[u][2], t[u][3], t[u][4], t[u][5]};
                     }
                     count += __popcll(m);
                     st_active += __popcll(m);
                 }
-                i += NSTEP;
+                i += NSTEP * K;
                 if constexpr (P::PROFILE) prof[0] += __builtin_readcyclecounter() - t_sec;
             } else if (count > 0) {
                 // ---------------- shade up to BATCH queued samples ----------------------------------
@@ -457,7 +488,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 break;
             }
         }
-        if (live) {
+        if (live && seg == 0) {
             // compositing tail (FieldBase.py:296-306)
             float out[3] = {cr, cg, cb};
 #pragma unroll
@@ -468,7 +499,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
             }
             A.depth[ray] = dep + (1.0f - acc) * d[2];
         }
-        st_rays += __popcll(__ballot(live));
+        st_rays += __popcll(__ballot(live && seg == 0));
     }
     if (A.stats && lane == 0) {
         atomicAdd(A.stats + 0, st_valid);

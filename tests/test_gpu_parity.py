@@ -119,6 +119,27 @@ def test_deterministic_and_chunk_independent():
     assert torch.equal(a["rgb_map"][37:150], c["rgb_map"])
 
 
+@pytest.mark.parametrize("name", ["triplane_r1_gauge", "triplane_r1_mask", "infoinv_r1_on"])
+def test_split_march_is_bit_identical(name, monkeypatch):
+    """The split march (tile_w rays x 64/tile_w lanes per ray on consecutive steps, csrc/ngf_render.hpp render_kernel<P, true>)
+    chains transmittance / acc / depth from lane to lane in step order, so every tile shape gives the pixels of the
+    one-ray-per-lane march bit for bit.  S = 45 is not a multiple of any lanes-per-ray count; the batch is ragged."""
+    g, params, step, mask = load_case(name)
+    f = field_for_case(g, params, mask)
+    rays = torch.from_numpy(g["rays"]).cuda()[:203]
+    kw = {"infoinv": True} if name.startswith("infoinv") else {"iteration": 30001}
+    monkeypatch.setenv("NGF_TILE_W", "64"); monkeypatch.setenv("NGF_SPLIT", "0")
+    ref = f(rays, N_samples=45, **kw)
+    for tw in ("32", "16", "8", "4"):
+        monkeypatch.setenv("NGF_TILE_W", tw); monkeypatch.setenv("NGF_SPLIT", "1")
+        got = f(rays, N_samples=45, **kw)
+        assert torch.equal(ref["rgb_map"], got["rgb_map"]), tw
+        assert torch.equal(ref["depth_map"], got["depth_map"]), tw
+    monkeypatch.delenv("NGF_TILE_W"); monkeypatch.delenv("NGF_SPLIT")
+    got = f(rays, N_samples=45, **kw)          # the default choice
+    assert torch.equal(ref["rgb_map"], got["rgb_map"]) and torch.equal(ref["depth_map"], got["depth_map"])
+
+
 @pytest.mark.parametrize("model,preset", [("triplane", "R1"), ("triplane", "R2"), ("infoinv", "R1")])
 def test_headline_geometry_chunk(model, preset):
     """4096 rays x 192 samples of the 800x800 frame on 256^2 planes (BASELINE config 2/3 shapes)."""
