@@ -7,8 +7,9 @@
 
 A "step" is one pass of the hot path over one 800x800 frame (640 000 rays, 192 samples/ray, seeded
 synthetic camera + weights, SURVEY.md section 8 D2, dense preset R1): at N=1 the whole frame on one GPU;
-at N>1 the frame's rays are sharded in contiguous row blocks (strong scaling of ONE frame, as
-BASELINE.json's north_star asks) and every step ends with one RCCL all-gather of the composited pixels.
+at N>1 the frame's rows are dealt out to the ranks in 10-row blocks (strong scaling of ONE frame, as
+BASELINE.json's north_star asks) and every frame is followed by one RCCL all-gather of the composited pixels,
+double-buffered so that frame k's exchange overlaps frame k+1's march.
 Rays and parameters are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -46,16 +47,18 @@ def build_field(model, preset, device, bake, bake_color=False):
     return f, g, params, step
 
 
-def time_steps(fn, steps, warmup, device, dist_on):
+def time_steps(fn, steps, warmup, device, dist_on, finish=lambda: None):
     import torch.distributed as dist
     for _ in range(warmup):
         fn()
+    finish()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
+    finish()                 # the last frame's exchange + reorder belong to the timed region
     torch.cuda.synchronize(device)
     if dist_on:
         dist.barrier()
@@ -159,23 +162,41 @@ def main():
     kw = {"iteration": 30001} if model == "triplane" else {"infoinv": True}
     f, g, params, step = build_field(model, args.preset, device, bool(args.bake_density), bool(args.bake_color))
     n_total = H * W
-    lo, hi, per = ndist.shard_bounds(n_total, world, rank)
-    assert lo % W == 0 and hi % W == 0, "row-block sharding expects H divisible by the world size"
-    rays_np = synth.lookat_rays(H, W, rows=(lo // W, hi // W))
+    # rows dealt out in blocks of ROW_BLOCK, round robin over the ranks (equal work per rank, ngf_amd/dist.py)
+    ROW_BLOCK = 10
+    per = n_total // world
+    assert H % (world * ROW_BLOCK) == 0, "row-block sharding expects H divisible by world x 10"
+    my_rows = ndist.interleaved_rows(H, world, rank, ROW_BLOCK)
+    rays_np = np.concatenate([synth.lookat_rays(H, W, rows=r) for r in my_rows], 0)
     rays = torch.from_numpy(rays_np).to(device)
+    n_local = rays.shape[0]
+    assert n_local == per
+    pipe = ndist.PipelinedGather(per, world, device) if dist_on else None
     send, rgb_view, depth_view = ndist.shard_buffers(per, device)
-    recv = torch.empty((world * 4 * per,), device=device) if dist_on else None
-    out = (rgb_view[: hi - lo], depth_view[: hi - lo])
+    frame_no = [0]
+    last_frame = [None]
 
     def render_only():
-        f(rays, N_samples=S, white_bg=True, out=out, **kw)
+        f(rays, N_samples=S, white_bg=True, out=(rgb_view, depth_view), **kw)
 
     def step_fn():
-        render_only()
-        if dist_on:
-            ndist.gather_pixels(None, None, n_total, per, world, send=send, recv=recv)
+        if not dist_on:
+            render_only()
+            return
+        # frame k: march into send buffer k%2, start its all-gather on RCCL's stream, hand out frame k-1 (whose
+        # exchange overlapped this march) in image order.  Every frame is complete when the timed region ends.
+        k = frame_no[0]
+        f(rays, N_samples=S, white_bg=True, out=pipe.buffers(k), **kw)
+        pipe.submit(k)
+        if k > 0:
+            last_frame[0] = ndist.deinterleave(*pipe.frame(k - 1), H, W, world, ROW_BLOCK)
+        frame_no[0] = k + 1
 
-    elapsed = time_steps(step_fn, args.steps, args.warmup, device, dist_on)
+    def finish():
+        if dist_on and frame_no[0] > 0:
+            last_frame[0] = ndist.deinterleave(*pipe.frame(frame_no[0] - 1), H, W, world, ROW_BLOCK)
+
+    elapsed = time_steps(step_fn, args.steps, args.warmup, device, dist_on, finish)
     ms_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed / 1e6
 
@@ -184,7 +205,6 @@ def main():
     f(rays, N_samples=S, white_bg=True, collect_stats=True, **kw)
     torch.cuda.synchronize(device)
     st = f.last_stats.cpu().numpy().astype(np.float64)
-    n_local = hi - lo
     s_active = st[1] / n_local
     bytes_launch = alg_bytes_per_ray(s_active, model) * n_local
     achieved = bytes_launch / (k_ms * 1e-3) / 1e9
@@ -222,10 +242,19 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{'TriPlane' if model == 'triplane' else 'InfoInv'} 800x800 frame, S=192, preset {args.preset} "
                                f"(seeded random planes 256^2, dense density preset), gauge on, white_bg",
-                   "rays_per_step": n_total, "samples_per_ray": S, "sharding": f"rays x{world} (row blocks) + all_gather",
+                   "rays_per_step": n_total, "samples_per_ray": S, "sharding": f"rays x{world} (10-row blocks, round robin) + double-buffered RCCL all_gather",
                    "bake_density": int(args.bake_density), "bake_color": int(args.bake_color)},
         "roofline": roofline,
     }
+
+    if dist_on:
+        # untimed: the gathered, re-ordered frame of the last step against a direct render of the whole frame on this rank
+        whole = torch.from_numpy(synth.lookat_rays(H, W)).to(device)
+        ref = f(whole, N_samples=S, white_bg=True, **kw)
+        same = bool(torch.equal(ref["rgb_map"], last_frame[0][0]) and torch.equal(ref["depth_map"], last_frame[0][1]))
+        flag = torch.tensor([int(same)], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        result["gathered_frame_bit_identical_to_single_gpu_render"] = bool(flag.item())
 
     if world == 1 and rank == 0:
         if args.cpu_seconds > 0:

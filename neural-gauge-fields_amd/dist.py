@@ -19,6 +19,63 @@ def shard_bounds(n: int, world: int, rank: int):
     return lo, min(lo + per, n), per
 
 
+def interleaved_rows(H: int, world: int, rank: int, block: int):
+    """Row ranges [(r0, r1), ...] of rank ``rank`` when the frame is dealt out in blocks of ``block`` rows, round
+    robin: rank r owns blocks r, r+world, ...  Every rank then sees the same mix of cheap (background, box edge)
+    and expensive rows -- contiguous 100-row shards of the 800x800 frame differ by 7 % in render time
+    (profiles/r01_split_march.txt), and the slowest rank is what strong scaling pays for."""
+    if H % (world * block):
+        raise ValueError(f"H={H} must be a multiple of world*block={world * block}")
+    return [(b * block, (b + 1) * block) for b in range(rank, H // block, world)]
+
+
+def deinterleave(rgb, depth, H: int, W: int, world: int, block: int):
+    """Rank-major gathered pixels ([world*per, 3], [world*per], per = H*W/world, each rank's rows in
+    interleaved_rows order) -> frame order.  One strided copy on the device."""
+    nblk = H // (world * block)
+    rgb = rgb.view(world, nblk, block * W, 3).permute(1, 0, 2, 3).reshape(H * W, 3)
+    depth = depth.view(world, nblk, block * W).permute(1, 0, 2).reshape(H * W)
+    return rgb, depth
+
+
+class PipelinedGather:
+    """Double-buffered all-gather of a rank's pixels: frame k's exchange runs on RCCL's stream while frame k+1 is
+    marched on the render stream.  ``buffers(k)`` gives the (rgb, depth) views frame k must be rendered into;
+    ``submit(k)`` starts its exchange; ``frame(k)`` waits for it and returns the rank-major (rgb, depth)."""
+
+    def __init__(self, per: int, world: int, device, group=None, depth: int = 2):
+        self.per, self.world, self.group = per, world, group
+        self.send = [shard_buffers(per, device) for _ in range(depth)]
+        self.recv = [torch.empty((world * 4 * per,), device=device, dtype=torch.float32) for _ in range(depth)]
+        self.work = [None] * depth
+
+    def buffers(self, k: int):
+        i = k % len(self.send)
+        if self.work[i] is not None:          # the exchange that last read this send buffer must be done
+            self.work[i].wait()
+            self.work[i] = None
+        _, rgb, depth = self.send[i]
+        return rgb, depth
+
+    def submit(self, k: int):
+        i = k % len(self.send)
+        self.work[i] = dist.all_gather_into_tensor(self.recv[i], self.send[i][0], group=self.group, async_op=True)
+
+    def frame(self, k: int):
+        i = k % len(self.send)
+        if self.work[i] is not None:
+            self.work[i].wait()
+            self.work[i] = None
+        blocks = self.recv[i].view(self.world, 4 * self.per)
+        return blocks[:, : 3 * self.per].reshape(self.world * self.per, 3), blocks[:, 3 * self.per:].reshape(self.world * self.per)
+
+    def drain(self):
+        for i, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[i] = None
+
+
 def render_sharded(render_fn, rays, group=None, gather: bool = True):
     """``render_fn(rays_shard) -> (rgb [m,3], depth [m])`` on this rank's device.
 

@@ -205,6 +205,7 @@ def test_bench_rccl_path_single_gpu(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 1 and d["scaling"] == "strong"
+    assert d["gathered_frame_bit_identical_to_single_gpu_render"] is True
 
 
 def test_full_frame_properties():

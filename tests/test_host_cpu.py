@@ -96,6 +96,25 @@ def _worker(rank, world, port, tmp):
     ok = np.array_equal(rgb.numpy(), ref_rgb) and np.array_equal(depth.numpy(), ref_depth)
     lo, hi, per = ndist.shard_bounds(201, world, rank)
     ok = ok and (per == 101) and (hi - lo == (101 if rank == 0 else 100))
+    # interleaved row blocks + double-buffered exchange (what bench.py runs at N > 1): three 8x5 "frames"
+    H, W, blk = 8, 5, 2
+    frames = [rays[k:k + H * W] for k in (0, 40, 80)]
+    full = [orc.render(fr.numpy(), 48, threads=1) for fr in frames]
+    rows = ndist.interleaved_rows(H, world, rank, blk)
+    ok = ok and rows == [(rank * blk, rank * blk + blk), ((rank + 2) * blk, (rank + 2) * blk + blk)]
+    pipe = ndist.PipelinedGather(H * W // world, world, torch.device("cpu"))
+    got = []
+    for k, fr in enumerate(frames):
+        mine = torch.cat([fr[r0 * W:r1 * W] for r0, r1 in rows])
+        o_rgb, o_depth = pipe.buffers(k)
+        r, d = render_fn(mine)
+        o_rgb.copy_(r); o_depth.copy_(d)
+        pipe.submit(k)
+        if k > 0:
+            got.append(ndist.deinterleave(*pipe.frame(k - 1), H, W, world, blk))
+    got.append(ndist.deinterleave(*pipe.frame(len(frames) - 1), H, W, world, blk))
+    for (g_rgb, g_depth), (f_rgb, f_depth) in zip(got, full):
+        ok = ok and np.array_equal(g_rgb.numpy(), f_rgb) and np.array_equal(g_depth.numpy(), f_depth)
     open(os.path.join(tmp, f"ok{rank}"), "w").write("1" if ok else "0")
     dist.destroy_process_group()
 
