@@ -217,10 +217,15 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_baked.json" if args.bake_color else "r01_pmc_faithful.json")))
     except Exception:
         pass
+    pmc_txt = "no PMC summary under profiles/" if pmc is None else (
+        f"PMC: {pmc['hbm_traffic_bytes_per_launch'] / 1e9:.2f} GB of fabric traffic per launch, L2 hit {100 * pmc['l2_hit_frac']:.0f} %, "
+        f"L1 hit {100 * pmc['l1_hit_frac']:.0f} %")
+    busy_txt = "" if pmc is None else (f" per PMC (MFMA pipe {100 * pmc['mfma_busy_frac']:.0f} % busy, TA {100 * pmc['ta_busy_frac']:.0f} %, "
+                                        f"fabric traffic {pmc['hbm_traffic_bytes_per_launch'] / (pmc['kernel_ms_under_pmc'] * 1e-3) / 8e12 * 100:.0f} % of the HBM peak)")
     alg = {"unit": "GB/s", "achieved": achieved, "peak": HBM_PEAK_GBS, "frac": achieved / HBM_PEAK_GBS,
            "bytes_per_launch": bytes_launch,
            "note": "SURVEY 8 D3 accounting: every bilinear tap counted once, no cache credit.  The 52 MB texture set is L2 / "
-                   "Infinity-Cache resident (PMC: 5.6 GB of fabric reads per launch, L2 hit 92 %, L1 hit 92 %), so this exceeds "
+                   f"Infinity-Cache resident ({pmc_txt}), so this exceeds "
                    "the HBM peak by construction and HBM is not the binding resource."}
     if mfma_flops is not None:
         tf = mfma_flops / (k_ms * 1e-3) / 1e12
@@ -228,7 +233,7 @@ def main():
                     "traffic": None if pmc is None or model != "triplane" or args.preset != "R1" else pmc.get("hbm_traffic_bytes_per_launch"),
                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, profiles/r01_pmc_*.txt",
                     "flops_counted": "executed fp32 MFMA flops of the colour MLP (layer 1 pre-composed with `basis`): the binding "
-                                     "resource per PMC (MFMA pipe 46 % busy, TA 62 %, HBM 6 % of peak)",
+                                     "resource" + busy_txt,
                     "flops_per_launch": mfma_flops}
     else:
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None}
@@ -255,6 +260,17 @@ def main():
         flag = torch.tensor([int(same)], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         result["gathered_frame_bit_identical_to_single_gpu_render"] = bool(flag.item())
+        # untimed: the exchange alone (SURVEY 8 E1 asks for it next to the Mray/s): blocking all-gathers, HIP events
+        pipe.drain()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for a, b in ev:
+            a.record()
+            dist.all_gather_into_tensor(pipe.recv[0], pipe.send[0][0])
+            b.record()
+        torch.cuda.synchronize(device)
+        result["all_gather_ms"] = float(np.median([a.elapsed_time(b) for a, b in ev]))
+        result["all_gather_bytes_per_rank"] = 4 * per * 4
+        result["shard_kernel_ms"] = k_ms
 
     if world == 1 and rank == 0:
         if args.cpu_seconds > 0:
