@@ -318,6 +318,26 @@ def main():
                 net.release()
             except Exception as ex:
                 extras["uvmapping_sphere"] = {"error": repr(ex)}
+            # eval output stage on the headline frame: device (HIP events) next to the reference's host way
+            # (D2H of the float frame + numpy/scipy: oracle/evalout.py), one frame each
+            try:
+                from ngf_amd import evalout
+                from oracle import evalout as ev_orc
+                r = f(rays, N_samples=S, white_bg=True, **kw)
+                gt = (r["rgb_map"] * 0.95 + 0.02).clamp(0, 1)
+                run = lambda: evalout.frame_outputs(r["rgb_map"], r["depth_map"], H, W, (2.0, 6.0), gt)
+                run()
+                dev_ms = kernel_ms(run, 5, device)
+                t0 = time.perf_counter()
+                rgb_h = r["rgb_map"].clamp(0, 1).reshape(H, W, 3).cpu().numpy()
+                dep_h = r["depth_map"].reshape(H, W).cpu().numpy()
+                gt_h = gt.reshape(H, W, 3).cpu().numpy()
+                ev_orc.depth_index(dep_h, (2.0, 6.0)); ev_orc.psnr(rgb_h, gt_h); s_host = ev_orc.rgb_ssim(rgb_h, gt_h, 1); ev_orc.frame_u8(rgb_h)
+                host_ms = (time.perf_counter() - t0) * 1e3
+                extras["eval_output_stage_800x800"] = {"device_ms": dev_ms, "host_numpy_scipy_ms": host_ms,
+                                                       "ssim_device_minus_host": run()["ssim"] - s_host}
+            except Exception as ex:
+                extras["eval_output_stage_800x800"] = {"error": repr(ex)}
             result["extras"] = extras
     if dist_on:
         import torch.distributed as dist

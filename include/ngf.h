@@ -124,6 +124,29 @@ int ngf_field_ray_filter(const ngf_field *f, const float *rays, int64_t n, int32
 int ngf_generate_rays(int32_t H, int32_t W, float focal, const float *c2w_host, int32_t row0, int32_t rows,
                       float *rays, void *hip_stream);
 
+/* ---- eval output stage: what `evaluation` (TriPlane/main.py:73-138) does to every
+ * rendered frame on the host, here on the device so that a frame leaves HBM as 8-bit images and scalars.
+ * `workspace` is caller-owned device scratch of at least ngf_eval_workspace_bytes(H, W, filter_size) bytes
+ * (pass H = W = 0 for the calls that only reduce).  All results stay on the device; nothing synchronises.
+ *   ngf_eval_frame_u8       rgb_map.clamp(0,1) (main.py:98) then (rgb*255).astype('uint8') (main.py:117): truncation.
+ *   ngf_eval_depth_range    range[0] = min(x[x>0]), range[1] = max(x) of nan_to_num(depth)   (utils.py:37-40)
+ *   ngf_eval_depth_colormap visualize_depth_numpy (utils.py:32-47): x=(x-mi)/(ma-mi+1e-8) in float32, (255*x) cast to
+ *                           uint8 as numpy does on x86-64 (int32 truncation, low byte), then the 256x3 colour table
+ *                           `lut` (device, B,G,R per entry like cv2.applyColorMap) -> out [n,3].
+ *   ngf_eval_mse            mean((a-b)**2) over n float32 values -> *out (float64; PSNR = -10 log10, main.py:105-106)
+ *   ngf_eval_ssim           rgb_ssim (utils.py:109-155) of two [H,W,3] float32 images: 'valid' separable Gaussian
+ *                           blur and the SSIM map in float64; *mean_out = mean of the map, map_out (nullable)
+ *                           [H-fs+1, W-fs+1, 3]. */
+int64_t ngf_eval_workspace_bytes(int32_t H, int32_t W, int32_t filter_size);
+int ngf_eval_frame_u8(const float *rgb, int64_t n_values, uint8_t *out, void *hip_stream);
+int ngf_eval_depth_range(const float *depth, int64_t n, float *range, void *workspace, void *hip_stream);
+int ngf_eval_depth_colormap(const float *depth, int64_t n, const float *range, const uint8_t *lut, uint8_t *out,
+                            void *hip_stream);
+int ngf_eval_mse(const float *a, const float *b, int64_t n, double *out, void *workspace, void *hip_stream);
+int ngf_eval_ssim(const float *img0, const float *img1, int32_t H, int32_t W, double max_val, int32_t filter_size,
+                  double filter_sigma, double k1, double k2, double *mean_out, double *map_out, void *workspace,
+                  void *hip_stream);
+
 /* ---- UV-Mapping (NeuTex) colour path: UV-Mapping/model/model.py:27-59 ----------------------------------------
  * 29 nn.Linear layers in evaluation order, reference layouts (weight [out,in], bias [out], float32, device):
  *   [0..11]  net_geometry_decoder.block.{0,2,..,22}   63-256, 10x 256-256, 256-1          (decoder.py:201-237)

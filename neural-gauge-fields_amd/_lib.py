@@ -17,7 +17,9 @@ F_BAKE_COLOR = 2
 
 SYMBOLS = ["ngf_field_create", "ngf_field_destroy", "ngf_field_render", "ngf_field_decode_rgb", "ngf_field_march",
            "ngf_generate_rays", "ngf_last_error", "ngf_abi_version", "ngf_field_bytes", "ngf_sizeof_field_desc",
-           "ngf_uv_create", "ngf_uv_destroy", "ngf_uv_render", "ngf_field_alpha", "ngf_field_ray_filter"]
+           "ngf_uv_create", "ngf_uv_destroy", "ngf_uv_render", "ngf_field_alpha", "ngf_field_ray_filter",
+           "ngf_eval_workspace_bytes", "ngf_eval_frame_u8", "ngf_eval_depth_range", "ngf_eval_depth_colormap", "ngf_eval_mse",
+           "ngf_eval_ssim"]
 
 
 class FieldDesc(C.Structure):
@@ -76,6 +78,14 @@ def lib():
         L.ngf_uv_destroy.argtypes = [C.c_void_p]
         L.ngf_uv_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ngf_eval_workspace_bytes.restype = C.c_int64
+        L.ngf_eval_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+        L.ngf_eval_frame_u8.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.ngf_eval_depth_range.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ngf_eval_depth_colormap.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ngf_eval_mse.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ngf_eval_ssim.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_double, C.c_double,
+                                    C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         if L.ngf_abi_version() != 1 or L.ngf_sizeof_field_desc() != C.sizeof(FieldDesc):
             raise RuntimeError("libngf_hip.so ABI mismatch (version or ngf_field_desc layout)")
         _LIB = L

@@ -256,8 +256,57 @@ def capture_uv(name, seed, primitive_type, R=96, S=64):
     print(f"{name}: rays {R} S {S} mean color {float(color.mean()):.4f} mean T {float(bgw.mean()):.4f} valid {float(ray_valid.float().mean()):.3f}")
 
 
+def capture_evalout():
+    """Eval output stage: the reference's own rgb_ssim and visualize_depth_numpy (TriPlane/utils.py) run on
+    seeded inputs.  utils.py does not import here (cv2, imageio, ... are absent), so the two function definitions are
+    taken out of the module's syntax tree and executed with numpy/scipy; cv2.applyColorMap is the identity, i.e. the
+    captured depth image is the uint8 INDEX image the colour table is applied to (the table itself cannot be pinned)."""
+    import ast
+    import types
+    import scipy.signal
+    src = open(os.path.join(REF, "TriPlane", "utils.py")).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("rgb_ssim", "visualize_depth_numpy")]
+    assert len(keep) == 2
+    cv2 = types.SimpleNamespace(COLORMAP_JET=2, applyColorMap=lambda x, cmap: x)
+    import scipy
+    ns = {"np": np, "scipy": scipy, "cv2": cv2, "torch": torch}
+    # default argument cv2.COLORMAP_JET is evaluated at definition time -> cv2 must be in the namespace first
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "reference:TriPlane/utils.py", "exec"), ns)
+    H, W = 37, 45
+    img0 = synth.hash_uniform(41, 700, (H, W, 3))
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    smooth = (0.5 + 0.5 * np.sin(xx / 5.0)[..., None] * np.cos(yy / 7.0)[..., None]).astype(np.float32)
+    img0 = (0.7 * smooth + 0.3 * img0).astype(np.float32)
+    img1 = np.clip(img0 + (synth.hash_uniform(41, 701, (H, W, 3)) - np.float32(0.5)) * np.float32(0.2), 0, 1).astype(np.float32)
+    img1[:6, :8] = img0[:6, :8]                       # a patch with zero error
+    img1[-5:, -5:] = 0.25                             # constant patch: zero variance in img1
+    t0, t1 = torch.from_numpy(img0), torch.from_numpy(img1)      # the reference passes torch CPU tensors (main.py:109)
+    ssim = ns["rgb_ssim"](t0, t1, 1)
+    ssim_map = ns["rgb_ssim"](t0, t1, 1, return_map=True)
+    ssim5 = ns["rgb_ssim"](t0, t1, 1, filter_size=5, filter_sigma=0.8)
+    loss = torch.mean((t0 - t1) ** 2)
+    psnr = -10.0 * np.log(loss.item()) / np.log(10.0)
+    depth = (np.float32(2.0) + np.float32(4.5) * synth.hash_uniform(41, 702, (24, 20))).astype(np.float32)
+    depth[0, :6] = [0.0, -0.4, 1.2, 6.7, np.nan, np.inf]       # background / below near / above far / non-finite
+    depth[1, 0] = -np.inf
+    d_nf, mm_nf = ns["visualize_depth_numpy"](depth.copy(), (2.0, 6.0))
+    finite = depth.copy()
+    finite[~np.isfinite(finite)] = 3.0
+    d_auto, mm_auto = ns["visualize_depth_numpy"](finite.copy(), None)
+    rgb = (synth.hash_uniform(41, 703, (16, 12, 3)) * np.float32(1.4) - np.float32(0.2)).astype(np.float32)
+    rgb8 = (torch.from_numpy(rgb).clamp(0.0, 1.0).numpy() * 255).astype('uint8')          # main.py:98,117
+    np.savez_compressed(os.path.join(HERE, "evalout.npz"), img0=img0, img1=img1, ssim=np.float64(ssim), ssim_map=ssim_map,
+                        ssim5=np.float64(ssim5), mse=np.float64(loss.item()), psnr=np.float64(psnr), depth=depth, depth_idx_nearfar=d_nf,
+                        depth_finite=finite, depth_idx_auto=d_auto, depth_auto_range=np.asarray(mm_auto, np.float64), rgb=rgb, rgb8=rgb8)
+    print(f"evalout: ssim {ssim:.6f} ssim5 {ssim5:.6f} psnr {psnr:.4f} depth idx mean {d_nf.mean():.2f} auto range {mm_auto}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "evalout":       # regenerate one fixture without touching the others
+        capture_evalout()
+        sys.exit(0)
     capture_ops()
     capture_triplane("triplane_r1_gauge", seed=11, preset="R1", gauge_on=True, gauge_std=0.05, with_mask=False, S=48)
     capture_triplane("triplane_r2_nogauge", seed=12, preset="R2", gauge_on=False, gauge_std=0.05, with_mask=False, S=40,
@@ -269,3 +318,4 @@ if __name__ == "__main__":
     capture_alpha_mask()
     capture_uv("uv_sphere", seed=31, primitive_type="sphere")
     capture_uv("uv_square", seed=32, primitive_type="square")
+    capture_evalout()
