@@ -302,10 +302,74 @@ def capture_evalout():
     print(f"evalout: ssim {ssim:.6f} ssim5 {ssim5:.6f} psnr {psnr:.4f} depth idx mean {d_nf.mean():.2f} auto range {mm_auto}")
 
 
+def capture_train(name="train_r1", seed=51, S=40, steps=2):
+    """Training step: the reference TriPlane module in training mode -- forward(is_train=True) with the
+    per-ray jitter supplied through a patched torch.rand_like, the loss of main.py:281-291, autograd, and ``steps``
+    iterations of torch.optim.Adam over get_optparam_groups with the lr decay of main.py:298-299."""
+    F = _import_ref("TriPlane")
+    aabb = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
+    grid = [12, 10, 9]
+    plane_hw = ((10, 12), (9, 10), (9, 12))
+    gauge_hw = (7, 8)
+    params = synth.triplane_params(seed, plane_hw, gauge_hw, preset="R1", gauge_std=0.05)
+    with contextlib.redirect_stdout(io.StringIO()):
+        field = F.TriPlane(aabb, grid, "cpu", near_far=[2.0, 6.0], alphaMask_thres=1e-4, distance_scale=25,
+                           rayMarch_weight_thres=1e-4, step_ratio=0.5, gauge_start=0)
+    _load_params(field, params)
+    rays = _rays_for_case(seed, 96, 32)
+    n = rays.shape[0]
+    rgb_train = synth.hash_uniform(seed, 800, (n, 3))
+    lr_factor = 0.1 ** (1 / 30000)
+    opt = torch.optim.Adam(field.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99))
+    names = [k for k in params]
+    out = {}
+    real = torch.rand_like
+    for it in range(steps):
+        U = synth.hash_uniform(seed, 810 + it, (n, 1))
+        white = it % 2 == 0                                  # iteration 1: black background (the coin came up >= 0.5)
+        torch.rand_like = lambda *a, **k: torch.from_numpy(U.copy())
+        real_rand = torch.rand
+        torch.rand = lambda *a, **k: torch.tensor([0.7])
+        try:
+            o = field(torch.from_numpy(rays), is_train=True, white_bg=white, N_samples=S, iteration=it)
+        finally:
+            torch.rand_like = real
+            torch.rand = real_rand
+        rgb_loss = torch.mean((o["rgb_map"] - torch.from_numpy(rgb_train)) ** 2)
+        total = rgb_loss + 8e-5 * field.density_L1()
+        opt.zero_grad()
+        total.backward()
+        for k in names:
+            obj = field
+            for part in k.split(".")[:-1]:
+                obj = getattr(obj, part) if not part.isdigit() else obj[int(part)]
+            out[f"grad{it}.{k}"] = getattr(obj, k.split(".")[-1]).grad.numpy().copy()
+        out[f"jitter{it}"] = U[:, 0]
+        out[f"white{it}"] = np.array(int(white))
+        out[f"rgb_map{it}"] = o["rgb_map"].detach().numpy().copy()
+        out[f"rgb_loss{it}"] = np.float64(rgb_loss.item())
+        out[f"total_loss{it}"] = np.float64(total.item())
+        opt.step()
+        for g in opt.param_groups:
+            g["lr"] = g["lr"] * lr_factor
+    for k in names:
+        obj = field
+        for part in k.split(".")[:-1]:
+            obj = getattr(obj, part) if not part.isdigit() else obj[int(part)]
+        out[f"after.{k}"] = getattr(obj, k.split(".")[-1]).detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), model="triplane", seed=seed, preset="R1", gauge_std=np.float32(0.05), S=S,
+                        steps=steps, aabb=aabb.numpy(), grid=np.array(grid), plane_hw=np.array(plane_hw), gauge_hw=np.array(gauge_hw),
+                        near_far=np.array([2.0, 6.0], np.float32), distance_scale=np.float32(25), thr=np.float32(1e-4),
+                        stepSize=field.stepSize.numpy(), rays=rays, rgb_train=rgb_train, lr_factor=np.float64(lr_factor),
+                        **_checksums(params), **out)
+    print(f"{name}: rays {n} S {S} losses {[out[f'rgb_loss{i}'] for i in range(steps)]} |grad plane_xy| {np.abs(out['grad0.plane_xy']).mean():.3e} "
+          f"|grad gauge_xy| {np.abs(out['grad0.gauge_xy']).mean():.3e}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    if len(sys.argv) > 1 and sys.argv[1] == "evalout":       # regenerate one fixture without touching the others
-        capture_evalout()
+    if len(sys.argv) > 1:       # regenerate one fixture without touching the others
+        {"evalout": capture_evalout, "train": capture_train}[sys.argv[1]]()
         sys.exit(0)
     capture_ops()
     capture_triplane("triplane_r1_gauge", seed=11, preset="R1", gauge_on=True, gauge_std=0.05, with_mask=False, S=48)
@@ -319,3 +383,4 @@ if __name__ == "__main__":
     capture_uv("uv_sphere", seed=31, primitive_type="sphere")
     capture_uv("uv_square", seed=32, primitive_type="square")
     capture_evalout()
+    capture_train()

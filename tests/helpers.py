@@ -33,6 +33,19 @@ def load_case(name):
     return g, params, step, mask
 
 
+def load_train_case(name):
+    """Training fixture (make_golden.py capture_train): (arrays, regenerated initial parameters)."""
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    plane_hw = tuple(tuple(int(v) for v in hw) for hw in g["plane_hw"])
+    params = synth.triplane_params(int(g["seed"]), plane_hw, tuple(int(v) for v in g["gauge_hw"]), preset=str(g["preset"]),
+                                   gauge_std=float(g["gauge_std"]))
+    for k, v in params.items():
+        v64 = v.astype(np.float64).reshape(-1)
+        chk = np.array([v64.sum(), np.abs(v64).sum(), v64[:: max(1, v64.size // 7)][:7].sum()])
+        assert np.array_equal(chk, g["chk." + k]), f"synth regenerated different parameters for {k}"
+    return g, params
+
+
 def oracle_for_case(g, params, step, mask):
     return OracleField(params, g["aabb"], step, near_far=g["near_far"], distance_scale=float(g["distance_scale"]),
                        rayMarch_weight_thres=float(g["thr"]), model=str(g["model"]),
