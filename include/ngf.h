@@ -147,6 +147,51 @@ int ngf_eval_ssim(const float *img0, const float *img1, int32_t H, int32_t W, do
                   double filter_sigma, double k1, double k2, double *mean_out, double *map_out, void *workspace,
                   void *hip_stream);
 
+/* ---- one TriPlane training step: TriPlane/main.py:264-299 ----------------------------
+ * Replaces, per iteration: field(rays_train, is_train=True, ...) (FieldBase.py:251-312), rgb MSE (main.py:281),
+ * + L1_reg_weight * density_L1() (main.py:288-291, Field.py:149-152), total_loss.backward(), optimizer.step() of
+ * torch.optim.Adam(get_optparam_groups(...), betas=(0.9,0.99)) (main.py:234-242, Field.py:34-46).
+ * The parameters and the Adam moments stay caller-owned device tensors in the REFERENCE layouts and are updated IN
+ * PLACE; the trainer owns packed copies, gradient buffers and the per-sample scratch (ngf_trainer_bytes()).
+ * Parameter indices (`which`): 0-2 plane_xy/yz/xz [1,64,H,W], 3-5 gauge_xy/yz/xz [1,2,H,W], 6 density_decoder.weight
+ * [1,48], 7 .bias [1], 8 rgb_decoder.basis.weight [144,144], 9/10 mlp.0 weight [64,159] / bias, 11/12 mlp.2, 13/14 mlp.4. */
+#define NGF_TRAIN_PARAMS 15
+typedef struct ngf_train_desc {
+    float aabb[6];
+    float near_, far_, step, distance_scale, weight_thres;
+    float *plane[3];
+    int32_t plane_h[3], plane_w[3];
+    float *gauge[3];
+    int32_t gauge_h[3], gauge_w[3];
+    float *dens_w, *dens_b, *basis, *w1, *b1, *w2, *b2, *w3, *b3;
+    float *exp_avg[NGF_TRAIN_PARAMS], *exp_avg_sq[NGF_TRAIN_PARAMS]; /* Adam state, parameter layouts, zero-initialised by the caller */
+    const uint8_t *mask_bits;      /* optional alpha mask as in ngf_field_desc; NULL = none */
+    int32_t mask_d, mask_h, mask_w;
+    float mask_aabb[6];
+    int64_t max_rays;              /* largest batch (args.batch_size) */
+    int32_t max_samples;           /* largest N_samples */
+    int64_t chunk_samples;         /* active samples whose activations are kept at once; 0 = 262144 */
+} ngf_train_desc;
+typedef struct ngf_trainer ngf_trainer;
+int ngf_trainer_create(const ngf_train_desc *desc, ngf_trainer **out, void *hip_stream);
+int ngf_trainer_destroy(ngf_trainer *t);
+int64_t ngf_trainer_bytes(const ngf_trainer *t);
+int32_t ngf_sizeof_train_desc(void);
+/* forward (training mode) + backward of  mean((rgb_map - rgb_train)^2): the gradients of all 15 parameters land in the
+ * trainer's buffers (zeroed first).  jitter [n] = the per-ray U[0,1) of sample_ray (FieldBase.py:129-130; NULL = 0),
+ * white_bg = `white_bg or coin` of FieldBase.py:299, gauge_on = (iteration >= gauge_start).  *rgb_loss (DEVICE double)
+ * receives the SUM of squared residuals (divide by 3n); *n_active_host (HOST, nullable) the active-sample count.
+ * Synchronises the stream once (the colour kernels' launch geometry depends on the active count). */
+int ngf_train_backward(ngf_trainer *t, const float *rays, const float *rgb_train, const float *jitter, int64_t n,
+                       int32_t n_samples, int32_t white_bg, int32_t gauge_on, double *rgb_loss, int64_t *n_active_host,
+                       void *hip_stream);
+/* the gradient of parameter `which` in its reference layout -> out (device) */
+int ngf_train_get_grad(ngf_trainer *t, int32_t which, float *out, void *hip_stream);
+/* torch.optim.Adam's update of parameter `which` from the gradient held by the trainer; step_count >= 1 is that
+ * parameter's own step number; l1_weight (planes only) adds d/dp [l1_weight * mean(|p|)] to the gradient. */
+int ngf_train_adam(ngf_trainer *t, int32_t which, int32_t step_count, float lr, float beta1, float beta2, float eps,
+                   float l1_weight, void *hip_stream);
+
 /* ---- UV-Mapping (NeuTex) colour path: UV-Mapping/model/model.py:27-59 ----------------------------------------
  * 29 nn.Linear layers in evaluation order, reference layouts (weight [out,in], bias [out], float32, device):
  *   [0..11]  net_geometry_decoder.block.{0,2,..,22}   63-256, 10x 256-256, 256-1          (decoder.py:201-237)

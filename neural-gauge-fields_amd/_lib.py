@@ -19,7 +19,8 @@ SYMBOLS = ["ngf_field_create", "ngf_field_destroy", "ngf_field_render", "ngf_fie
            "ngf_generate_rays", "ngf_last_error", "ngf_abi_version", "ngf_field_bytes", "ngf_sizeof_field_desc",
            "ngf_uv_create", "ngf_uv_destroy", "ngf_uv_render", "ngf_field_alpha", "ngf_field_ray_filter",
            "ngf_eval_workspace_bytes", "ngf_eval_frame_u8", "ngf_eval_depth_range", "ngf_eval_depth_colormap", "ngf_eval_mse",
-           "ngf_eval_ssim"]
+           "ngf_eval_ssim", "ngf_trainer_create", "ngf_trainer_destroy", "ngf_trainer_bytes", "ngf_sizeof_train_desc", "ngf_train_backward",
+           "ngf_train_get_grad", "ngf_train_adam"]
 
 
 class FieldDesc(C.Structure):

@@ -4,6 +4,7 @@
 // (see Makefile).  No torch, no CPU fallback: every entry point runs HIP kernels or fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -18,6 +19,7 @@
 #include "ngf_render.hpp"
 #include "ngf_uv.hpp"
 #include "ngf_eval.hpp"
+#include "ngf_train.hpp"
 
 using namespace ngf;
 
@@ -644,6 +646,255 @@ extern "C" int ngf_eval_ssim(const float *img0, const float *img1, int32_t H, in
     hipLaunchKernelGGL(ssim_vertical_kernel, dim3(eval_grid(n_v)), dim3(kEvalThreads), 0, st, a, img0, img1, tmp);
     hipLaunchKernelGGL(ssim_horizontal_kernel, dim3(g), dim3(kEvalThreads), 0, st, a, (const double *)tmp, map_out, partial);
     hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(kEvalThreads), 0, st, (const double *)partial, g, (double)n_o, mean_out);
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+// ================================ training step ============================================================
+enum { TP_PLANE = 0, TP_GAUGE = 3, TP_DENS_W = 6, TP_DENS_B = 7, TP_BASIS = 8, TP_W1 = 9, TP_B1 = 10, TP_W2 = 11, TP_B2 = 12, TP_W3 = 13,
+       TP_B3 = 14, TP_COUNT = 15 };
+
+struct ngf_trainer {
+    ngf_train_desc d;
+    TrainArgs proto;
+    std::vector<void *> allocs;
+    float *tex_d[3] = {}, *tex_a[3] = {}, *tex_g[3] = {};
+    float *g_d[3] = {}, *g_a[3] = {}, *g_g[3] = {};
+    float *g_dense[TP_COUNT] = {};          // reference-layout gradient buffers of the MLP parameters (index TP_*)
+    int64_t dense_n[TP_COUNT] = {};
+    uint8_t *mask = nullptr;
+    int64_t chunk = 0;
+    int64_t bytes = 0;
+    int num_cus = 256;
+};
+
+template <typename T>
+static int tr_alloc(ngf_trainer *t, T **p, size_t count)
+{
+    void *q = nullptr;
+    if (hipMalloc(&q, count * sizeof(T) + 64) != hipSuccess) return fail(NGF_E_HIP, "hipMalloc(%zu bytes) failed for the trainer", count * sizeof(T));
+    t->allocs.push_back(q);
+    t->bytes += (int64_t)(count * sizeof(T));
+    *p = (T *)q;
+    return NGF_OK;
+}
+
+extern "C" int ngf_trainer_destroy(ngf_trainer *t)
+{
+    if (!t) return NGF_OK;
+    for (void *q : t->allocs) (void)hipFree(q);
+    delete t;
+    return NGF_OK;
+}
+
+extern "C" int64_t ngf_trainer_bytes(const ngf_trainer *t) { return t ? t->bytes : 0; }
+extern "C" int32_t ngf_sizeof_train_desc(void) { return (int32_t)sizeof(ngf_train_desc); }
+
+extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, void *hip_stream)
+{
+    if (!d || !out) return fail(NGF_E_ARG, "ngf_trainer_create: null argument");
+    if (d->max_rays <= 0 || d->max_samples <= 0) return fail(NGF_E_ARG, "ngf_trainer_create: max_rays / max_samples must be positive");
+    for (int p = 0; p < 3; ++p) {
+        if (!d->plane[p] || d->plane_h[p] < 2 || d->plane_w[p] < 2) return fail(NGF_E_ARG, "plane %d missing or smaller than 2x2", p);
+        if (!d->gauge[p] || d->gauge_h[p] < 2 || d->gauge_w[p] < 2) return fail(NGF_E_ARG, "gauge plane %d missing or smaller than 2x2", p);
+    }
+    if (!d->dens_w || !d->dens_b || !d->basis || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->w3 || !d->b3)
+        return fail(NGF_E_ARG, "ngf_trainer_create: missing MLP parameter");
+    for (int k = 0; k < TP_COUNT; ++k)
+        if (!d->exp_avg[k] || !d->exp_avg_sq[k]) return fail(NGF_E_ARG, "ngf_trainer_create: missing Adam state %d", k);
+    ngf_trainer *t = new (std::nothrow) ngf_trainer();
+    if (!t) return fail(NGF_E_HIP, "out of host memory");
+    t->d = *d;
+    auto bail = [&](int rc) { ngf_trainer_destroy(t); return rc; };
+    hipStream_t st = (hipStream_t)hip_stream;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) t->num_cus = prop.multiProcessorCount;
+    int rc;
+    TrainArgs &T = t->proto;
+    memset(&T, 0, sizeof(T));
+    RenderArgs &A = T.R;
+    for (int p = 0; p < 3; ++p) {
+        const int H = d->plane_h[p], W = d->plane_w[p], gh = d->gauge_h[p], gw = d->gauge_w[p];
+        const size_t tex = (size_t)(H + 2) * (W + 2), gtex = (size_t)(gh + 2) * (gw + 2);
+        if ((rc = tr_alloc(t, &t->tex_d[p], tex * 16)) || (rc = tr_alloc(t, &t->tex_a[p], tex * 48)) || (rc = tr_alloc(t, &t->tex_g[p], gtex * 2)) ||
+            (rc = tr_alloc(t, &t->g_d[p], tex * 16)) || (rc = tr_alloc(t, &t->g_a[p], tex * 48)) || (rc = tr_alloc(t, &t->g_g[p], gtex * 2)))
+            return bail(rc);
+        A.dens[p] = Tex{t->tex_d[p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
+        A.app[p] = Tex{t->tex_a[p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
+        A.gau[p] = Tex{t->tex_g[p], gw, gh, gw + 2, (float)(gw - 1), (float)(gh - 1)};
+        T.g_dens[p] = t->g_d[p]; T.g_app[p] = t->g_a[p]; T.g_gau[p] = t->g_g[p];
+    }
+    const int64_t dn[TP_COUNT] = {0, 0, 0, 0, 0, 0, 48, 1, 144 * 144, 64 * 159, 64, 64 * 64, 64, 3 * 64, 3};
+    for (int k = TP_DENS_W; k < TP_COUNT; ++k) {
+        t->dense_n[k] = dn[k];
+        if ((rc = tr_alloc(t, &t->g_dense[k], (size_t)dn[k]))) return bail(rc);
+    }
+    T.wd = d->dens_w; T.bd = d->dens_b; T.basis = d->basis; T.w1 = d->w1; T.b1 = d->b1; T.w2 = d->w2; T.b2 = d->b2; T.w3 = d->w3; T.b3 = d->b3;
+    T.g_wd = t->g_dense[TP_DENS_W]; T.g_bd = t->g_dense[TP_DENS_B];
+    for (int k = 0; k < 3; ++k) {
+        A.a0[k] = d->aabb[k];
+        A.a1[k] = d->aabb[3 + k];
+        A.inv[k] = 2.0f / (d->aabb[3 + k] - d->aabb[k]);
+    }
+    A.near_ = d->near_; A.far_ = d->far_; A.step = d->step; A.dscale = d->distance_scale; A.thr = d->weight_thres;
+    if (d->mask_bits) {
+        const size_t nbytes = ((size_t)d->mask_d * d->mask_h * d->mask_w + 7) / 8;
+        if ((rc = tr_alloc(t, &t->mask, nbytes))) return bail(rc);
+        if (hipMemcpyAsync(t->mask, d->mask_bits, nbytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return bail(fail(NGF_E_HIP, "copying the alpha mask failed"));
+        A.mask.bits = t->mask;
+        A.mask.D = d->mask_d; A.mask.H = d->mask_h; A.mask.W = d->mask_w;
+        for (int k = 0; k < 3; ++k) {
+            A.mask.a0[k] = d->mask_aabb[k];
+            A.mask.inv[k] = 1.0f / (d->mask_aabb[3 + k] - d->mask_aabb[k]) * 2;
+        }
+    }
+    const size_t cap = (size_t)d->max_rays * d->max_samples;
+    t->chunk = d->chunk_samples > 0 ? d->chunk_samples : 262144;
+    if ((size_t)t->chunk > cap) t->chunk = (int64_t)((cap + 15) & ~(size_t)15);
+    const size_t ch = (size_t)t->chunk;
+    if ((rc = tr_alloc(t, &T.xs, cap)) || (rc = tr_alloc(t, &T.w, cap)) || (rc = tr_alloc(t, &T.dx, cap)) || (rc = tr_alloc(t, &T.c, cap * 3)) ||
+        (rc = tr_alloc(t, &T.dt, cap * 6)) || (rc = tr_alloc(t, &T.G, (size_t)d->max_rays * 3)) || (rc = tr_alloc(t, &T.count, (size_t)d->max_rays)) ||
+        (rc = tr_alloc(t, &T.offset, (size_t)d->max_rays + 1)) || (rc = tr_alloc(t, &T.list, cap * 2)) || (rc = tr_alloc(t, &T.list_w, cap)) ||
+        (rc = tr_alloc(t, &T.F, ch * 144)) || (rc = tr_alloc(t, &T.U, ch * 160)) || (rc = tr_alloc(t, &T.H1, ch * 64)) || (rc = tr_alloc(t, &T.H2, ch * 64)) ||
+        (rc = tr_alloc(t, &T.D3, ch * 16)) || (rc = tr_alloc(t, &T.D2, ch * 64)) || (rc = tr_alloc(t, &T.D1, ch * 64)) || (rc = tr_alloc(t, &T.DG, ch * 144)) ||
+        (rc = tr_alloc(t, &T.loss, (size_t)2)))
+        return bail(rc);
+    if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "trainer setup failed: %s", hipGetErrorString(hipGetLastError())));
+    *out = t;
+    return NGF_OK;
+}
+
+static int tr_grid(const ngf_trainer *t, int64_t items, int per_block, int waves_per_cu = 8)
+{
+    int64_t g = (items + per_block - 1) / per_block;
+    const int64_t cap = (int64_t)t->num_cus * waves_per_cu;
+    if (g > cap) g = cap;
+    return g < 1 ? 1 : (int)g;
+}
+
+extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float *rgb_train, const float *jitter, int64_t n, int32_t n_samples,
+                                  int32_t white_bg, int32_t gauge_on, double *rgb_loss, int64_t *n_active_host, void *hip_stream)
+{
+    if (!t || !rays || !rgb_train || !rgb_loss) return fail(NGF_E_ARG, "ngf_train_backward: null argument");
+    if (n <= 0 || n > t->d.max_rays || n_samples <= 0 || n_samples > t->d.max_samples)
+        return fail(NGF_E_ARG, "ngf_train_backward: n=%lld (max %lld), n_samples=%d (max %d)", (long long)n, (long long)t->d.max_rays, n_samples,
+                    t->d.max_samples);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const ngf_train_desc &d = t->d;
+    TrainArgs T = t->proto;
+    RenderArgs &A = T.R;
+    A.rays = rays; A.jitter = jitter; A.n = n; A.S = n_samples; A.white_bg = white_bg ? 1 : 0; A.mode = gauge_on ? 1 : 0;
+    T.target = rgb_train;
+    T.inv_count = 1.0f / (3.0f * (float)n);
+    // parameters -> packed textures (they changed since the last step); gradient buffers -> 0
+    for (int p = 0; p < 3; ++p) {
+        const int H = d.plane_h[p], W = d.plane_w[p], gh = d.gauge_h[p], gw = d.gauge_w[p];
+        const size_t tex = (size_t)(H + 2) * (W + 2), gtex = (size_t)(gh + 2) * (gw + 2);
+        pack_plane_kernel<<<2048, 256, 0, st>>>(d.plane[p], H, W, 0, 16, t->tex_d[p]);
+        pack_plane_kernel<<<2048, 256, 0, st>>>(d.plane[p], H, W, 16, 48, t->tex_a[p]);
+        pack_plane_kernel<<<256, 256, 0, st>>>(d.gauge[p], gh, gw, 0, 2, t->tex_g[p]);
+        HIP_TRY(hipMemsetAsync(t->g_d[p], 0, tex * 16 * sizeof(float), st));
+        HIP_TRY(hipMemsetAsync(t->g_a[p], 0, tex * 48 * sizeof(float), st));
+        HIP_TRY(hipMemsetAsync(t->g_g[p], 0, gtex * 2 * sizeof(float), st));
+    }
+    for (int k = TP_DENS_W; k < TP_COUNT; ++k) HIP_TRY(hipMemsetAsync(t->g_dense[k], 0, (size_t)t->dense_n[k] * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(T.loss, 0, 2 * sizeof(double), st));
+
+    const int64_t pairs = n * n_samples;
+    hipLaunchKernelGGL(train_density_kernel, dim3(tr_grid(t, pairs, 256)), dim3(256), 0, st, T);
+    const int ray_blocks = (int)((n + 63) / 64);
+    hipLaunchKernelGGL(train_scan_kernel, dim3(ray_blocks), dim3(64), 0, st, T, 0);
+    hipLaunchKernelGGL(train_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)T.count, n, T.offset);
+    int32_t n_active = 0;
+    HIP_TRY(hipMemcpyAsync(&n_active, T.offset + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));          // the launch geometry of the colour kernels depends on the active count
+    if (n_active_host) *n_active_host = n_active;
+    hipLaunchKernelGGL(train_scan_kernel, dim3(ray_blocks), dim3(64), 0, st, T, 1);
+
+    const size_t lds_f = (size_t)kTrainWaves * kFwdTileFloats * sizeof(float), lds_b = (size_t)kTrainWaves * kBwdTileFloats * sizeof(float);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(train_color_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(train_color_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    const bool single = n_active <= t->chunk;
+    // colour forward over the whole list (activations kept when the list fits one chunk)
+    for (int64_t base = 0; base < n_active; base += t->chunk) {
+        T.chunk_base = (int32_t)base;
+        T.chunk_n = (int32_t)std::min<int64_t>(t->chunk, n_active - base);
+        T.store = single ? 1 : 0;
+        hipLaunchKernelGGL(train_color_fwd_kernel, dim3(tr_grid(t, (T.chunk_n + 15) / 16, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_f, st, T);
+    }
+    hipLaunchKernelGGL(train_composite_bwd_kernel, dim3(ray_blocks), dim3(64), 0, st, T);
+    for (int64_t base = 0; base < n_active; base += t->chunk) {
+        T.chunk_base = (int32_t)base;
+        T.chunk_n = (int32_t)std::min<int64_t>(t->chunk, n_active - base);
+        const int passes = (T.chunk_n + 15) / 16;
+        if (!single) {
+            T.store = 1;
+            hipLaunchKernelGGL(train_color_fwd_kernel, dim3(tr_grid(t, passes, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_f, st, T);
+        }
+        hipLaunchKernelGGL(train_color_bwd_kernel, dim3(tr_grid(t, passes, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_b, st, T);
+        const int rows = T.chunk_n;
+        int splits = rows / 512;
+        if (splits < 1) splits = 1;
+        if (splits > 256) splits = 256;
+        hipLaunchKernelGGL(xty_kernel, dim3(1 * 4 * splits), dim3(64), 0, st, (const float *)T.D3, 16, (const float *)T.H2, 64, rows, 1, 4, 3, 64, t->g_dense[TP_W3], 64, splits);
+        hipLaunchKernelGGL(xty_kernel, dim3(4 * 4 * splits), dim3(64), 0, st, (const float *)T.D2, 64, (const float *)T.H1, 64, rows, 4, 4, 64, 64, t->g_dense[TP_W2], 64, splits);
+        hipLaunchKernelGGL(xty_kernel, dim3(4 * 10 * splits), dim3(64), 0, st, (const float *)T.D1, 64, (const float *)T.U, 160, rows, 4, 10, 64, 159, t->g_dense[TP_W1], 159, splits);
+        hipLaunchKernelGGL(xty_kernel, dim3(9 * 9 * splits), dim3(64), 0, st, (const float *)T.DG, 144, (const float *)T.F, 144, rows, 9, 9, 144, 144, t->g_dense[TP_BASIS], 144, splits);
+        hipLaunchKernelGGL(colsum_kernel, dim3(3), dim3(256), 0, st, (const float *)T.D3, 16, rows, 3, t->g_dense[TP_B3]);
+        hipLaunchKernelGGL(colsum_kernel, dim3(64), dim3(256), 0, st, (const float *)T.D2, 64, rows, 64, t->g_dense[TP_B2]);
+        hipLaunchKernelGGL(colsum_kernel, dim3(64), dim3(256), 0, st, (const float *)T.D1, 64, rows, 64, t->g_dense[TP_B1]);
+    }
+    hipLaunchKernelGGL(train_density_bwd_kernel, dim3(tr_grid(t, pairs, 256)), dim3(256), 0, st, T);
+    HIP_TRY(hipMemcpyAsync(rgb_loss, T.loss, sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+extern "C" int ngf_train_get_grad(ngf_trainer *t, int32_t which, float *out, void *hip_stream)
+{
+    if (!t || !out || which < 0 || which >= TP_COUNT) return fail(NGF_E_ARG, "ngf_train_get_grad: bad argument");
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (which < 3) {
+        const int p = which;
+        hipLaunchKernelGGL(unpack_plane_kernel, dim3(1024), dim3(256), 0, st, (const float *)t->g_d[p], 16, (const float *)t->g_a[p], 64, t->d.plane_h[p],
+                           t->d.plane_w[p], out);
+    } else if (which < 6) {
+        const int p = which - 3;
+        hipLaunchKernelGGL(unpack_plane_kernel, dim3(256), dim3(256), 0, st, (const float *)t->g_g[p], 2, (const float *)nullptr, 2, t->d.gauge_h[p],
+                           t->d.gauge_w[p], out);
+    } else {
+        HIP_TRY(hipMemcpyAsync(out, t->g_dense[which], (size_t)t->dense_n[which] * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+extern "C" int ngf_train_adam(ngf_trainer *t, int32_t which, int32_t step_count, float lr, float beta1, float beta2, float eps, float l1_weight,
+                              void *hip_stream)
+{
+    if (!t || which < 0 || which >= TP_COUNT || step_count < 1) return fail(NGF_E_ARG, "ngf_train_adam: bad argument");
+    hipStream_t st = (hipStream_t)hip_stream;
+    const ngf_train_desc &d = t->d;
+    AdamArgs a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step_count));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step_count));
+    a.l1 = 0.0f;
+    if (which < 3) {
+        const int p = which, H = d.plane_h[p], W = d.plane_w[p];
+        a.l1 = l1_weight / (float)((int64_t)64 * H * W);             // d/dp of l1_weight * mean(|p|)
+        hipLaunchKernelGGL(adam_plane_kernel, dim3(2048), dim3(256), 0, st, d.plane[p], d.exp_avg[which], d.exp_avg_sq[which], 64, H, W,
+                           (const float *)t->g_d[p], 16, (const float *)t->g_a[p], a);
+    } else if (which < 6) {
+        const int p = which - 3;
+        hipLaunchKernelGGL(adam_plane_kernel, dim3(256), dim3(256), 0, st, d.gauge[p], d.exp_avg[which], d.exp_avg_sq[which], 2, d.gauge_h[p], d.gauge_w[p],
+                           (const float *)t->g_g[p], 2, (const float *)nullptr, a);
+    } else {
+        float *params[TP_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d.dens_w, d.dens_b, d.basis, d.w1, d.b1, d.w2, d.b2, d.w3, d.b3};
+        hipLaunchKernelGGL(adam_dense_kernel, dim3(64), dim3(256), 0, st, params[which], (const float *)t->g_dense[which], d.exp_avg[which],
+                           d.exp_avg_sq[which], t->dense_n[which], a);
+    }
     HIP_TRY(hipGetLastError());
     return NGF_OK;
 }

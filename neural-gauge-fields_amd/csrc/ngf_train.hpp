@@ -1,0 +1,716 @@
+// ngf_train.hpp -- one TriPlane training step on the device.
+//
+// What the reference does per iteration (TriPlane/main.py:264-299): field(rays, is_train=True) (FieldBase.py:251-312),
+// rgb MSE + 8e-5 * density_L1 (Field.py:149-152), autograd, torch.optim.Adam over the 8 groups of get_optparam_groups
+// (Field.py:34-46), lr decay.  Here the step is a short sequence of kernels over HBM-resident buffers (288 GB: the
+// per-sample activations of a 4096-ray batch are simply kept, 2.8 KB per active sample):
+//
+//   train_density_kernel       every (step, ray) pair in parallel: sample_ray + normalize + compute_gauge + the 48-feature
+//                              density fetch -> xs = Linear(48,1) - 10 (pre-softplus), -inf where the sample is invalid
+//   train_scan_kernel          one lane per ray, sequential raw2alpha (FieldBase.py:12-19) over the stored xs: weights,
+//                              active counts (pass 0) and the (ray, step)-ordered active list (pass 1): deterministic
+//   train_color_fwd_kernel     16 active samples per wave pass on v_mfma_f32_16x16x4_f32: 144 colour features, basis,
+//                              [g, view] -> 64 -> 64 -> 3 sigmoid; colours to the dense buffer, activations to HBM rows
+//   train_composite_bwd_kernel one lane per ray: rgb_map, clamp, residual, loss; then d loss / d xs for every sample from
+//                              the closed form of the cumprod backward (two sequential sweeps, no gathers)
+//   train_color_bwd_kernel     the data gradients of the colour MLP with the TRANSPOSED weights on the matrix pipe, the
+//                              feature gradients scattered into the packed colour planes (float atomics) and d loss / d t
+//   xty_kernel                 weight gradients as sample-reduction GEMMs  dW = Delta^T . In  (MFMA, split over samples)
+//   train_density_bwd_kernel   every valid sample: density feature scatter, d/d density_decoder, d loss / d t -> gauge planes
+//   adam_*_kernel              torch.optim.Adam's update; planes read their gradient from the packed layout and add the L1 term
+//
+// Matrix operands are read straight from the reference-layout weight tensors (150 KB, L2 resident): no per-step weight
+// packing.  Tiles of 16 samples live in wave-private LDS as [k][16] so that a lane's MFMA B operand is in[k][sample].
+#pragma once
+#include "ngf_device.hpp"
+#include "ngf_render.hpp"
+
+namespace ngf {
+
+constexpr int kTrainWaves = 4;                 // waves per workgroup in the MFMA kernels
+constexpr int kFeat = 144;                     // colour features (3 planes x 48)
+constexpr int kIn1 = 159, kIn1Pad = 160;       // [g(144), view(15)] (+1 zero pad)
+
+struct TrainArgs {
+    RenderArgs R;            // rays, jitter, n, S, mode (= gauge on), geometry, packed textures, mask, white_bg
+    float *g_dens[3], *g_app[3], *g_gau[3];     // gradient textures, same packed layouts as R.dens / R.app / R.gau
+    const float *wd, *bd;                       // density_decoder.weight [48], bias [1]
+    const float *basis, *w1, *b1, *w2, *b2, *w3, *b3;
+    float *g_wd, *g_bd;
+    // step-major dense per-sample buffers: index = step * n + ray
+    float *xs, *w, *dx;      // [S,n]
+    float *c;                // [S,n,3]
+    float *dt;               // [S,n,6]   d loss / d t from the colour path (active samples only)
+    const float *target;     // [n,3]
+    float *G;                // [n,3]   d loss / d rgb_map (before the clamp), 0 where clamped
+    int32_t *count;          // [n]     active samples per ray
+    int32_t *offset;         // [n+1]   exclusive prefix of count
+    int32_t *list;           // [cap,2] (ray, step) in (ray, step) order
+    float *list_w;           // [cap]
+    // activations of the current chunk, sample-major rows
+    float *F, *U, *H1, *H2, *D3, *D2, *D1, *DG;     // [chunk, 144|160|64|64|16|64|64|144]
+    double *loss;            // [2]: sum of squared residuals, (unused)
+    int32_t chunk_base, chunk_n;      // the slice of the active list this launch works on
+    int32_t store;           // colour forward: also write F, U, H1, H2 rows of the chunk
+    float inv_count;         // 1 / (3 n): the mean of the MSE
+};
+
+// ---- geometry of sample (ray r, step i): Base.sample_ray + normalize_coord + compute_gauge --------------------------------
+// returns valid; xn = normalised position (compute_gauge and the gauge gradient start from it)
+__device__ __forceinline__ bool sample_geometry(const RenderArgs &A, int64_t r, int i, float xn[3], float &z, float &dist)
+{
+    float o[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[k] = A.rays[r * 6 + k]; d[k] = A.rays[r * 6 + 3 + k]; }
+    const float jit = A.jitter ? A.jitter[r] : 0.0f;
+    float tmin = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float vec = (d[k] == 0.0f) ? 1e-6f : d[k];
+        float ra = (A.a1[k] - o[k]) / vec, rb = (A.a0[k] - o[k]) / vec;
+        tmin = fmaxf(tmin, fminf(ra, rb));
+    }
+    tmin = fminf(fmaxf(tmin, A.near_), A.far_);
+    z = tmin + A.step * ((float)i + jit);
+    const float zn = tmin + A.step * ((float)(i + 1) + jit);
+    dist = (i < A.S - 1) ? (zn - z) : 0.0f;
+    float p[3];
+    bool valid = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        p[k] = o[k] + d[k] * z;
+        valid = valid & !((A.a0[k] > p[k]) | (p[k] > A.a1[k]));
+    }
+    if (A.mask.bits && valid) valid = mask_occupied(A.mask, p);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xn[k] = (p[k] - A.a0[k]) * A.inv[k] - 1.0f;
+    return valid;
+}
+
+// bilinear cell with what the backward needs: tap weights, the fractions and the d(pixel)/d(coord) scales
+struct BilG {
+    int32_t idx;
+    float w00, w10, w01, w11;
+    float wx0, wx1, wy0, wy1;      // 0 when the cell is out of range
+    float sx, sy;                  // d px / d u = (W-1)/2, d py / d v = (H-1)/2
+};
+
+__device__ __forceinline__ BilG bilg_setup(float u, float v, const Tex &t)
+{
+    float px = ((u + 1.0f) / 2.0f) * t.fw;
+    float py = ((v + 1.0f) / 2.0f) * t.fh;
+    float fx = floorf(px), fy = floorf(py);
+    float wx1 = px - fx, wx0 = 1.0f - wx1;
+    float wy1 = py - fy, wy0 = 1.0f - wy1;
+    bool in = (fx >= -1.0f) & (fx <= t.fw) & (fy >= -1.0f) & (fy <= t.fh);
+    float cx = fminf(fmaxf(fx, -1.0f), t.fw);
+    float cy = fminf(fmaxf(fy, -1.0f), t.fh);
+    BilG b;
+    b.idx = ((int)cy + 1) * t.stride + ((int)cx + 1);
+    b.wx0 = in ? wx0 : 0.0f; b.wx1 = in ? wx1 : 0.0f; b.wy0 = in ? wy0 : 0.0f; b.wy1 = in ? wy1 : 0.0f;
+    b.w00 = in ? wx0 * wy0 : 0.0f;
+    b.w10 = in ? wx1 * wy0 : 0.0f;
+    b.w01 = in ? wx0 * wy1 : 0.0f;
+    b.w11 = in ? wx1 * wy1 : 0.0f;
+    b.sx = in ? t.fw * 0.5f : 0.0f;
+    b.sy = in ? t.fh * 0.5f : 0.0f;
+    return b;
+}
+
+// ---- 1. density features of every (step, ray) pair ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256) train_density_kernel(const TrainArgs T)
+{
+    const RenderArgs &A = T.R;
+    const int64_t total = (int64_t)A.S * A.n;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int i = (int)(idx / A.n);
+        const int64_t r = idx % A.n;
+        float xn[3], z, dist, tt[6];
+        const bool valid = sample_geometry(A, r, i, xn, z, dist);
+        triplane_gauge(A, xn, A.mode, tt);          // compute_gauge (Field.py:53-75), identity split when the gauge is off
+        float f = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const Tex &tx = A.dens[p];
+            Bil b = bil_setup(tt[2 * p], tt[2 * p + 1], tx);
+            const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + (size_t)b.idx * 16);
+            const f32x4 *q01 = q00 + (size_t)tx.stride * 4;
+            float d00 = 0.0f, d10 = 0.0f, d01 = 0.0f, d11 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v00 = q00[q], v10 = q00[4 + q], v01 = q01[q], v11 = q01[4 + q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float w = T.wd[p * 16 + 4 * q + e];
+                    d00 = fmaf(w, v00[e], d00);
+                    d10 = fmaf(w, v10[e], d10);
+                    d01 = fmaf(w, v01[e], d01);
+                    d11 = fmaf(w, v11[e], d11);
+                }
+            }
+            f += bil_mix(b, d00, d10, d01, d11);
+        }
+        f = (f + T.bd[0]) + (-10.0f);
+        T.xs[idx] = valid ? f : -INFINITY;
+    }
+}
+
+__device__ __forceinline__ float softplus_pre(float u)          // F.softplus, threshold 20; softplus(-inf) = 0
+{
+    return u > 20.0f ? u : log1pf(expf(u));
+}
+
+// the per-ray scalars every sequential sweep needs
+__device__ __forceinline__ float ray_tmin(const RenderArgs &A, int64_t r)
+{
+    float tmin = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float o = A.rays[r * 6 + k], d = A.rays[r * 6 + 3 + k];
+        float vec = (d == 0.0f) ? 1e-6f : d;
+        float ra = (A.a1[k] - o) / vec, rb = (A.a0[k] - o) / vec;
+        tmin = fmaxf(tmin, fminf(ra, rb));
+    }
+    return fminf(fmaxf(tmin, A.near_), A.far_);
+}
+
+// ---- 2. raw2alpha per ray; pass 0 counts the active samples, pass 1 writes weights and the ordered active list ----------
+__global__ void __launch_bounds__(64) train_scan_kernel(const TrainArgs T, int pass)
+{
+    const RenderArgs &A = T.R;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.n) return;
+    const float tmin = ray_tmin(A, r);
+    const float jit = A.jitter ? A.jitter[r] : 0.0f;
+    float Tr = 1.0f;
+    int cnt = 0;
+    const int base = pass ? T.offset[r] : 0;
+    for (int i = 0; i < A.S; ++i) {
+        const float z = tmin + A.step * ((float)i + jit);
+        const float zn = tmin + A.step * ((float)(i + 1) + jit);
+        const float dist = (i < A.S - 1) ? (zn - z) : 0.0f;
+        const float sigma = softplus_pre(T.xs[(int64_t)i * A.n + r]);
+        const float alpha = 1.0f - expf(-sigma * (dist * A.dscale));
+        const float w = alpha * Tr;
+        Tr = Tr * ((1.0f - alpha) + 1e-10f);
+        if (pass) T.w[(int64_t)i * A.n + r] = w;
+        if (w > A.thr) {
+            if (pass) {
+                T.list[2 * (int64_t)(base + cnt)] = (int)r;
+                T.list[2 * (int64_t)(base + cnt) + 1] = i;
+                T.list_w[base + cnt] = w;
+            }
+            ++cnt;
+        }
+    }
+    if (!pass) T.count[r] = cnt;
+}
+
+// exclusive prefix of count[0..n) -> offset[0..n]; one block, sequential over chunks of 1024
+__global__ void __launch_bounds__(1024) train_prefix_kernel(const int32_t *count, int64_t n, int32_t *offset)
+{
+    __shared__ int sh[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < n; b0 += 1024) {
+        const int64_t i = b0 + threadIdx.x;
+        const int v = i < n ? count[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 1; s < 1024; s <<= 1) {
+            int add = (int)threadIdx.x >= s ? sh[threadIdx.x - s] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n) offset[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offset[n] = carry;
+}
+
+// ---- MFMA building block: out[M][16] = act( W . in[K][16] + bias ) with 16 samples as the N dimension -------------------
+// v_mfma_f32_16x16x4_f32: lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; it receives D[i = 4(l>>4)+r][j = l&15].
+//   TRANS = false: Wm[m][k] = W[m*ldw + k] (forward, nn.Linear weight [out,in]);  TRANS = true: Wm[m][k] = W[k*ldw + m]
+//   ACT: 0 none, 1 relu, 2 = multiply by (mask[m][n] > 0)   (the relu backward)
+template <bool TRANS, int ACT>
+__device__ __forceinline__ void dense16(const float *__restrict__ W, int ldw, int M, int Mvalid, int K, int Kvalid,
+                                        const float *__restrict__ bias, const float *in, float *out, const float *mask, int lane)
+{
+    const int n = lane & 15, q = lane >> 4;
+    for (int mb = 0; mb < M; mb += 16) {
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int m = mb + n;                  // the A row this lane supplies
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const int k = k0 + q;
+            float a = 0.0f;
+            if (m < Mvalid && k < Kvalid) a = TRANS ? W[(size_t)k * ldw + m] : W[(size_t)m * ldw + k];
+            const float b = in[k * 16 + n];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = mb + 4 * q + r;
+            float v = acc[r];
+            if (bias && row < Mvalid) v += bias[row];
+            if (ACT == 1) v = fmaxf(v, 0.0f);
+            if (ACT == 2) v = mask[row * 16 + n] > 0.0f ? v : 0.0f;
+            out[row * 16 + n] = v;
+        }
+    }
+}
+
+// LDS tile [K][16] -> global rows [sample][ld] (and back): lane (q, n) moves rows k = q, q+4, ... of sample n
+__device__ __forceinline__ void tile_to_rows(const float *tile, int K, float *rows, int ld, int64_t slot, bool live, int lane)
+{
+    // 64 lanes write 64 consecutive k of one sample at a time: coalesced 256-byte stores
+    for (int s = 0; s < 16; ++s) {
+        const bool ok = __shfl((int)live, s) != 0;       // lane s holds sample s's liveness (lanes 0..15 = q 0)
+        if (!ok) continue;
+        const int64_t sl = __shfl((int)(slot & 0x7fffffff), s);
+        for (int k = lane; k < K; k += 64) rows[sl * ld + k] = tile[k * 16 + s];
+    }
+}
+
+__device__ __forceinline__ void rows_to_tile(const float *rows, int ld, int K, float *tile, int64_t slot, bool live, int lane)
+{
+    for (int s = 0; s < 16; ++s) {
+        const bool ok = __shfl((int)live, s) != 0;
+        const int64_t sl = __shfl((int)(slot & 0x7fffffff), s);
+        for (int k = lane; k < K; k += 64) tile[k * 16 + s] = ok ? rows[sl * ld + k] : 0.0f;
+    }
+}
+
+// gauge-shifted coordinates of a list sample (recomputed: three 2-channel fetches, cheaper than 24 bytes of HBM per valid sample)
+__device__ __forceinline__ void list_sample_coords(const RenderArgs &A, int64_t r, int i, float t[6], float xn[3])
+{
+    float z, dist;
+    (void)sample_geometry(A, r, i, xn, z, dist);
+    triplane_gauge(A, xn, A.mode, t);
+}
+
+constexpr int kFwdTileFloats = (kFeat + kIn1Pad + 64 + 64) * 16;          // F, U, H1, H2
+constexpr int kBwdTileFloats = (64 + 64 + 64 + 64 + kFeat + kFeat) * 16;  // H1, H2, D2, D1, DG, DF
+
+// ---- 3. colour forward over the active list -------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const TrainArgs T)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const RenderArgs &A = T.R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    float *Ft = smem + wave * kFwdTileFloats, *Ut = Ft + kFeat * 16, *H1t = Ut + kIn1Pad * 16, *H2t = H1t + 64 * 16;
+    const int passes = (T.chunk_n + 15) / 16;
+    for (int pass = blockIdx.x * kTrainWaves + wave; pass < passes; pass += gridDim.x * kTrainWaves) {
+        const int local = pass * 16 + n;
+        const bool live = local < T.chunk_n;
+        const int64_t slot = T.chunk_base + (live ? local : 0);
+        const int64_t r = T.list[2 * slot];
+        const int i = T.list[2 * slot + 1];
+        float t[6], xn[3];
+        list_sample_coords(A, r, i, t, xn);
+        // compute_rgb's fetch (Field.py:93-103): lane (q, n) interpolates channels 12q .. 12q+11 of every plane for sample n
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const Tex &tx = A.app[p];
+            Bil b = bil_setup(t[2 * p], t[2 * p + 1], tx);
+            const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + (size_t)b.idx * 48) + 3 * q;
+            const f32x4 *q01 = q00 + (size_t)tx.stride * 12;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                f32x4 v00 = q00[j], v10 = q00[12 + j], v01 = q01[j], v11 = q01[12 + j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Ft[(p * 48 + 12 * q + 4 * j + e) * 16 + n] = live ? bil_mix(b, v00[e], v10[e], v01[e], v11[e]) : 0.0f;
+            }
+        }
+        // the view inputs of layer 1 (networks.py:27-29): rows 144..159 of U
+        {
+            float d[3] = {A.rays[r * 6 + 3], A.rays[r * 6 + 4], A.rays[r * 6 + 5]}, v[16];
+            view_inputs(d, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Ut[(kFeat + 4 * q + j) * 16 + n] = live ? v[4 * q + j] : 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        dense16<false, 0>(T.basis, kFeat, kFeat, kFeat, kFeat, kFeat, nullptr, Ft, Ut, nullptr, lane);          // g = basis . f
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        dense16<false, 1>(T.w1, kIn1, 64, 64, kIn1Pad, kIn1, T.b1, Ut, H1t, nullptr, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        dense16<false, 1>(T.w2, 64, 64, 64, 64, 64, T.b2, H1t, H2t, nullptr, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // layer 3 + sigmoid on the VALU: lane (q, n) sums its 16 hidden units, then the four quarters meet
+        float c[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float s = 0.0f;
+            for (int k = 0; k < 16; ++k) s = fmaf(T.w3[j * 64 + 16 * q + k], H2t[(16 * q + k) * 16 + n], s);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            s += T.b3[j];
+            c[j] = 1.0f / (1.0f + expf(-s));
+        }
+        if (live && q == 0) {
+            float *dst = T.c + ((int64_t)i * A.n + r) * 3;
+            dst[0] = c[0]; dst[1] = c[1]; dst[2] = c[2];
+        }
+        if (T.store) {
+            const int64_t row = live ? local : 0;
+            tile_to_rows(Ft, kFeat, T.F, kFeat, row, live, lane);
+            tile_to_rows(Ut, kIn1Pad, T.U, kIn1Pad, row, live, lane);
+            tile_to_rows(H1t, 64, T.H1, 64, row, live, lane);
+            tile_to_rows(H2t, 64, T.H2, 64, row, live, lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+// ---- 4. compositing forward tail + backward to the pre-softplus density of every sample ------------------------------------
+__global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs T)
+{
+    const RenderArgs &A = T.R;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double sq = 0.0;
+    if (r < A.n) {
+        const float bg = A.white_bg ? 1.0f : 0.0f;
+        float acc = 0.0f, rgb[3] = {0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < A.S; ++i) {
+            const int64_t idx = (int64_t)i * A.n + r;
+            const float w = T.w[idx];
+            acc += w;
+            if (w > A.thr) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) rgb[ch] += w * T.c[idx * 3 + ch];
+            }
+        }
+        float G[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float pre = rgb[ch];
+            if (A.white_bg) pre = pre + (1.0f - acc);
+            const float out = fminf(fmaxf(pre, 0.0f), 1.0f);
+            const float res = out - T.target[r * 3 + ch];
+            sq += (double)(res * res);
+            G[ch] = (pre >= 0.0f && pre <= 1.0f) ? 2.0f * res * T.inv_count : 0.0f;      // clamp passes the gradient on [0,1]
+            T.G[r * 3 + ch] = G[ch];
+        }
+        // d loss / d alpha_i = dL/dw_i T_i - (sum_{j>i} w_j dL/dw_j) / (1 - alpha_i + 1e-10), dL/dw_j = G . (c_j [active] - bg):
+        // the cumprod backward.  The suffix sum is accumulated from the END of the ray (small terms first, in float64 like
+        // ATen's CPU cumsum), which is what autograd does; total - prefix would cancel for the late samples.
+        const float gbg = (G[0] + G[1] + G[2]) * bg;
+        const float tmin = ray_tmin(A, r);
+        const float jit = A.jitter ? A.jitter[r] : 0.0f;
+        float Tr = 1.0f;
+        for (int i = 0; i < A.S; ++i) {                         // forward sweep: park T_i in dx
+            const int64_t idx = (int64_t)i * A.n + r;
+            const float z = tmin + A.step * ((float)i + jit);
+            const float zn = tmin + A.step * ((float)(i + 1) + jit);
+            const float delta = ((i < A.S - 1) ? (zn - z) : 0.0f) * A.dscale;
+            const float alpha = 1.0f - expf(-softplus_pre(T.xs[idx]) * delta);
+            T.dx[idx] = Tr;
+            Tr = Tr * ((1.0f - alpha) + 1e-10f);
+        }
+        double suffix = 0.0;
+        for (int i = A.S - 1; i >= 0; --i) {
+            const int64_t idx = (int64_t)i * A.n + r;
+            const float x = T.xs[idx];
+            const float z = tmin + A.step * ((float)i + jit);
+            const float zn = tmin + A.step * ((float)(i + 1) + jit);
+            const float delta = ((i < A.S - 1) ? (zn - z) : 0.0f) * A.dscale;
+            const float e = expf(-softplus_pre(x) * delta);
+            const float alpha = 1.0f - e;
+            const float Ti = T.dx[idx];
+            const float w = T.w[idx];
+            float dw = -gbg;
+            if (w > A.thr) dw += G[0] * T.c[idx * 3] + G[1] * T.c[idx * 3 + 1] + G[2] * T.c[idx * 3 + 2];
+            const float keep = (1.0f - alpha) + 1e-10f;
+            const float dalpha = dw * Ti - (float)suffix / keep;
+            const float dsigma = dalpha * delta * e;                        // d alpha / d sigma = delta exp(-sigma delta)
+            const float sig = x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));   // softplus'
+            T.dx[idx] = (x == -INFINITY) ? 0.0f : dsigma * sig;
+            suffix += (double)((dw * alpha) * Ti);           // autograd's order: dL/dT_j = dL/dw_j alpha_j, then times T_j
+        }
+    }
+    // block sum of the squared residuals -> one double atomic per wave
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) sq += __shfl_xor(sq, s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(T.loss, sq);
+}
+
+// ---- 5. colour backward over the active list --------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const TrainArgs T)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const RenderArgs &A = T.R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    float *H1t = smem + wave * kBwdTileFloats, *H2t = H1t + 64 * 16, *D2t = H2t + 64 * 16, *D1t = D2t + 64 * 16, *DGt = D1t + 64 * 16,
+          *DFt = DGt + kFeat * 16;
+    const int passes = (T.chunk_n + 15) / 16;
+    for (int pass = blockIdx.x * kTrainWaves + wave; pass < passes; pass += gridDim.x * kTrainWaves) {
+        const int local = pass * 16 + n;
+        const bool live = local < T.chunk_n;
+        const int64_t row = live ? local : 0;
+        const int64_t slot = T.chunk_base + row;
+        const int64_t r = T.list[2 * slot];
+        const int i = T.list[2 * slot + 1];
+        const float w = live ? T.list_w[slot] : 0.0f;
+        rows_to_tile(T.H1, 64, 64, H1t, row, live, lane);
+        rows_to_tile(T.H2, 64, 64, H2t, row, live, lane);
+        // d3 = dL/dc * sigmoid' ; dL/dc = G_ray * w
+        float d3[3];
+        {
+            const float *cc = T.c + ((int64_t)i * A.n + r) * 3;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float c = cc[j];
+                d3[j] = live ? T.G[r * 3 + j] * w * (c * (1.0f - c)) : 0.0f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // d2 = (W3^T d3) * [h2 > 0] on the VALU (3 terms per hidden unit)
+        for (int k = 16 * q; k < 16 * q + 16; ++k) {
+            float s = T.w3[k] * d3[0] + T.w3[64 + k] * d3[1] + T.w3[128 + k] * d3[2];
+            D2t[k * 16 + n] = H2t[k * 16 + n] > 0.0f ? s : 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        dense16<true, 2>(T.w2, 64, 64, 64, 64, 64, nullptr, D2t, D1t, H1t, lane);                 // d1 = (W2^T d2) * [h1 > 0]
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        dense16<true, 0>(T.w1, kIn1, kFeat, kFeat, 64, 64, nullptr, D1t, DGt, nullptr, lane);     // dg = (W1^T d1)[:144]
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        dense16<true, 0>(T.basis, kFeat, kFeat, kFeat, kFeat, kFeat, nullptr, DGt, DFt, nullptr, lane);   // df = basis^T dg
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // rows for the weight-gradient GEMMs
+        if (live && q == 0) {
+            float *d = T.D3 + row * 16;
+            d[0] = d3[0]; d[1] = d3[1]; d[2] = d3[2];
+#pragma unroll
+            for (int j = 3; j < 16; ++j) d[j] = 0.0f;
+        }
+        tile_to_rows(D2t, 64, T.D2, 64, row, live, lane);
+        tile_to_rows(D1t, 64, T.D1, 64, row, live, lane);
+        tile_to_rows(DGt, kFeat, T.DG, kFeat, row, live, lane);
+        // feature gradients -> packed colour planes, and d loss / d t through the bilinear cell
+        float t[6], xn[3];
+        list_sample_coords(A, r, i, t, xn);
+        float dt[6];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const Tex &tx = A.app[p];
+            BilG b = bilg_setup(t[2 * p], t[2 * p + 1], tx);
+            const size_t base = (size_t)b.idx * 48 + 12 * q;
+            const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + base);
+            const f32x4 *q01 = q00 + (size_t)tx.stride * 12;
+            float *g00 = T.g_app[p] + base, *g01 = g00 + (size_t)tx.stride * 48;
+            float du = 0.0f, dv = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                f32x4 v00 = q00[j], v10 = q00[12 + j], v01 = q01[j], v11 = q01[12 + j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = DFt[(p * 48 + 12 * q + 4 * j + e) * 16 + n];
+                    if (live) {
+                        atomicAdd(g00 + 4 * j + e, b.w00 * g);
+                        atomicAdd(g00 + 48 + 4 * j + e, b.w10 * g);
+                        atomicAdd(g01 + 4 * j + e, b.w01 * g);
+                        atomicAdd(g01 + 48 + 4 * j + e, b.w11 * g);
+                    }
+                    du += g * (b.wy0 * (v10[e] - v00[e]) + b.wy1 * (v11[e] - v01[e]));
+                    dv += g * (b.wx0 * (v01[e] - v00[e]) + b.wx1 * (v11[e] - v10[e]));
+                }
+            }
+            du *= b.sx; dv *= b.sy;
+            du += __shfl_xor(du, 16); du += __shfl_xor(du, 32);
+            dv += __shfl_xor(dv, 16); dv += __shfl_xor(dv, 32);
+            dt[2 * p] = du; dt[2 * p + 1] = dv;
+        }
+        if (live && q == 0) {
+            float *d = T.dt + ((int64_t)i * A.n + r) * 6;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d[k] = dt[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+// ---- 6. weight gradients: out[M][N] += X^T . Y over `rows` samples (sample-major X [rows, ldx], Y [rows, ldy]) ------------------
+// One wave per (16x16 output tile, sample split); out is the reference-layout gradient tensor [Mvalid][ldo].
+__global__ void __launch_bounds__(64) xty_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ Y, int ldy, int rows,
+                                                 int Mt, int Nt, int Mvalid, int Nvalid, float *out, int ldo, int splits)
+{
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x % (Mt * Nt), split = blockIdx.x / (Mt * Nt);
+    const int m0 = (tile / Nt) * 16, n0 = (tile % Nt) * 16;
+    const int per = (((rows + splits - 1) / splits) + 3) & ~3;
+    const int s0 = split * per, s1 = min(rows, s0 + per);
+    const int j = lane & 15, kq = lane >> 4;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = s0; s < s1; s += 4) {
+        const int ss = s + kq;
+        float a = 0.0f, b = 0.0f;
+        if (ss < s1) {
+            a = X[(size_t)ss * ldx + m0 + j];          // rows are padded to a multiple of 16 columns
+            b = Y[(size_t)ss * ldy + n0 + j];
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * kq + r, nn = n0 + j;
+        if (m < Mvalid && nn < Nvalid) atomicAdd(out + (size_t)m * ldo + nn, acc[r]);
+    }
+}
+
+// bias gradients: column sums of a row-major [rows, ld] matrix
+__global__ void __launch_bounds__(256) colsum_kernel(const float *__restrict__ X, int ld, int rows, int cols, float *out)
+{
+    const int c = blockIdx.x;
+    if (c >= cols) return;
+    __shared__ float sh[256];
+    float s = 0.0f;
+    for (int r = threadIdx.x; r < rows; r += 256) s += X[(size_t)r * ld + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out + c, sh[0]);
+}
+
+// ---- 7. density / gauge backward for every valid sample -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs T)
+{
+    const RenderArgs &A = T.R;
+    __shared__ float s_wd[49];
+    if (threadIdx.x < 49) s_wd[threadIdx.x] = 0.0f;
+    __syncthreads();
+    const int64_t total = (int64_t)A.S * A.n;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const float dx = T.dx[idx];
+        const bool active = T.w[idx] > A.thr;
+        if (dx == 0.0f && !active) continue;
+        const int i = (int)(idx / A.n);
+        const int64_t r = idx % A.n;
+        float t[6], xn[3];
+        list_sample_coords(A, r, i, t, xn);
+        float dt[6];
+        atomicAdd(&s_wd[48], dx);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const Tex &tx = A.dens[p];
+            BilG b = bilg_setup(t[2 * p], t[2 * p + 1], tx);
+            const size_t base = (size_t)b.idx * 16;
+            const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + base);
+            const f32x4 *q01 = q00 + (size_t)tx.stride * 4;
+            float *g00 = T.g_dens[p] + base, *g01 = g00 + (size_t)tx.stride * 16;
+            float du = 0.0f, dv = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v00 = q00[j], v10 = q00[4 + j], v01 = q01[j], v11 = q01[4 + j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float wk = T.wd[p * 16 + 4 * j + e];
+                    const float g = dx * wk;                                   // d loss / d feature
+                    const float feat = fmaf(b.w11, v11[e], fmaf(b.w01, v01[e], fmaf(b.w10, v10[e], b.w00 * v00[e])));
+                    atomicAdd(&s_wd[p * 16 + 4 * j + e], dx * feat);
+                    atomicAdd(g00 + 4 * j + e, b.w00 * g);
+                    atomicAdd(g00 + 16 + 4 * j + e, b.w10 * g);
+                    atomicAdd(g01 + 4 * j + e, b.w01 * g);
+                    atomicAdd(g01 + 16 + 4 * j + e, b.w11 * g);
+                    du += g * (b.wy0 * (v10[e] - v00[e]) + b.wy1 * (v11[e] - v01[e]));
+                    dv += g * (b.wx0 * (v01[e] - v00[e]) + b.wx1 * (v11[e] - v10[e]));
+                }
+            }
+            dt[2 * p] = du * b.sx;
+            dt[2 * p + 1] = dv * b.sy;
+        }
+        if (A.mode) {
+            if (active) {
+                const float *dc = T.dt + idx * 6;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) dt[k] += dc[k];
+            }
+            // t_xy = ((x+dxy0)+dxz0, (y+dxy1)+dyz0), t_yz = ((y+dyz0)+dxy1, (z+dyz1)+dxz1), t_xz = ((x+dxz0)+dxy0, (z+dxz1)+dyz1)
+            const float dg[3][2] = {{dt[0] + dt[4], dt[1] + dt[2]}, {dt[2] + dt[1], dt[3] + dt[5]}, {dt[4] + dt[0], dt[5] + dt[3]}};
+            const float u[3] = {xn[0], xn[1], xn[0]}, v[3] = {xn[1], xn[2], xn[2]};
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const Tex &tx = A.gau[p];
+                Bil b = bil_setup(u[p], v[p], tx);
+                float *g = T.g_gau[p] + (size_t)b.idx * 2;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    atomicAdd(g + ch, b.w00 * dg[p][ch]);
+                    atomicAdd(g + 2 + ch, b.w10 * dg[p][ch]);
+                    atomicAdd(g + (size_t)tx.stride * 2 + ch, b.w01 * dg[p][ch]);
+                    atomicAdd(g + (size_t)tx.stride * 2 + 2 + ch, b.w11 * dg[p][ch]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 48) atomicAdd(T.g_wd + threadIdx.x, s_wd[threadIdx.x]);
+    if (threadIdx.x == 48) atomicAdd(T.g_bd, s_wd[48]);
+}
+
+// ---- 8. torch.optim.Adam (betas, eps, no weight decay, no amsgrad), float32 like the reference ------------------------------------
+struct AdamArgs {
+    float lr, beta1, beta2, eps;
+    float bc1, bc2_sqrt;       // 1 - beta1^t, sqrt(1 - beta2^t)
+    float l1;                  // planes: L1_reg_weight / numel, added as l1 * sign(p); 0 otherwise
+};
+
+__device__ __forceinline__ float adam_one(float p, float g, float &m, float &v, const AdamArgs &a)
+{
+    m = m + (1.0f - a.beta1) * (g - m);                   // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * a.beta2 + ((1.0f - a.beta2) * g) * g;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    const float step = a.lr / a.bc1;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    return p - step * (m / denom);
+}
+
+__global__ void __launch_bounds__(256) adam_dense_kernel(float *p, const float *g, float *m, float *v, int64_t n, const AdamArgs a)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float mi = m[i], vi = v[i];
+        p[i] = adam_one(p[i], g[i], mi, vi, a);
+        m[i] = mi; v[i] = vi;
+    }
+}
+
+// NCHW parameter [C,H,W]; gradient in the packed layouts: channels [0,cs) in ga (cs per texel), [cs,C) in gb (C-cs per texel)
+__global__ void __launch_bounds__(256) adam_plane_kernel(float *p, float *m, float *v, int C, int H, int W, const float *ga, int cs, const float *gb,
+                                                         const AdamArgs a)
+{
+    const int64_t total = (int64_t)C * H * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), c = (int)(i / ((int64_t)W * H));
+        const size_t texel = (size_t)(y + 1) * (W + 2) + (x + 1);
+        float g = c < cs ? ga[texel * cs + c] : gb[texel * (C - cs) + (c - cs)];
+        const float pv = p[i];
+        g += a.l1 * (pv > 0.0f ? 1.0f : (pv < 0.0f ? -1.0f : 0.0f));
+        float mi = m[i], vi = v[i];
+        p[i] = adam_one(pv, g, mi, vi, a);
+        m[i] = mi; v[i] = vi;
+    }
+}
+
+// packed gradient -> NCHW (inspection / tests)
+__global__ void __launch_bounds__(256) unpack_plane_kernel(const float *ga, int cs, const float *gb, int C, int H, int W, float *dst)
+{
+    const int64_t total = (int64_t)C * H * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), c = (int)(i / ((int64_t)W * H));
+        const size_t texel = (size_t)(y + 1) * (W + 2) + (x + 1);
+        dst[i] = c < cs ? ga[texel * cs + c] : gb[texel * (C - cs) + (c - cs)];
+    }
+}
+
+}  // namespace ngf

@@ -1,0 +1,208 @@
+"""One TriPlane training iteration on the device -- host-side mirror of the body of the
+reference's training loop (TriPlane/main.py:264-299):
+
+    output = field(rays_train, is_train=True, white_bg=white_bg, N_samples=nSamples, iteration=iteration)
+    total_loss = mean((rgb_map - rgb_train)**2) + L1_reg_weight * field.density_L1()
+    optimizer.zero_grad(); total_loss.backward(); optimizer.step()          # Adam(get_optparam_groups, betas=(0.9, 0.99))
+    for g in optimizer.param_groups: g['lr'] *= lr_factor
+
+``Trainer.step(rays_train, rgb_train, iteration)`` does exactly that through libngf_hip.so (csrc/ngf_train.hpp); the field's
+nn.Parameters are updated in place, like torch.optim does, so ``field(...)`` / ``field.save(...)`` see the new values.
+Random inputs of the reference (the per-ray jitter torch.rand_like of sample_ray and the white-background coin of
+FieldBase.py:299) are drawn here with torch's generators, or passed in for parity tests.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+PARAM_NAMES = ("plane_xy", "plane_yz", "plane_xz", "gauge_xy", "gauge_yz", "gauge_xz", "density_decoder.weight",
+               "density_decoder.bias", "rgb_decoder.basis.weight", "rgb_decoder.mlp.0.weight", "rgb_decoder.mlp.0.bias",
+               "rgb_decoder.mlp.2.weight", "rgb_decoder.mlp.2.bias", "rgb_decoder.mlp.4.weight", "rgb_decoder.mlp.4.bias")
+L1_REG_WEIGHT = 8e-5            # main.py:262
+
+
+class TrainDesc(C.Structure):
+    _fields_ = [
+        ("aabb", C.c_float * 6), ("near_", C.c_float), ("far_", C.c_float), ("step", C.c_float), ("distance_scale", C.c_float),
+        ("weight_thres", C.c_float),
+        ("plane", C.c_void_p * 3), ("plane_h", C.c_int32 * 3), ("plane_w", C.c_int32 * 3),
+        ("gauge", C.c_void_p * 3), ("gauge_h", C.c_int32 * 3), ("gauge_w", C.c_int32 * 3),
+        ("dens_w", C.c_void_p), ("dens_b", C.c_void_p), ("basis", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
+        ("w2", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p),
+        ("exp_avg", C.c_void_p * 15), ("exp_avg_sq", C.c_void_p * 15),
+        ("mask_bits", C.c_void_p), ("mask_d", C.c_int32), ("mask_h", C.c_int32), ("mask_w", C.c_int32), ("mask_aabb", C.c_float * 6),
+        ("max_rays", C.c_int64), ("max_samples", C.c_int32), ("chunk_samples", C.c_int64),
+    ]
+
+
+def _bind(L):
+    if getattr(L, "_ngf_train_bound", False):
+        return
+    L.ngf_trainer_create.argtypes = [C.POINTER(TrainDesc), C.POINTER(C.c_void_p), C.c_void_p]
+    L.ngf_trainer_destroy.argtypes = [C.c_void_p]
+    L.ngf_trainer_bytes.restype = C.c_int64
+    L.ngf_trainer_bytes.argtypes = [C.c_void_p]
+    L.ngf_train_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                     C.POINTER(C.c_int64), C.c_void_p]
+    L.ngf_train_get_grad.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.ngf_train_adam.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    if L.ngf_sizeof_train_desc() != C.sizeof(TrainDesc):
+        raise RuntimeError("libngf_hip.so ABI mismatch (ngf_train_desc layout)")
+    L._ngf_train_bound = True
+
+
+class Trainer:
+    """Adam state + the device trainer of one TriPlane field.
+
+    ``lr_init`` / ``lr_basis`` / ``lr_decay_*`` / ``n_iters`` are the flags of TriPlane/opt.py; ``batch_size`` and
+    ``max_samples`` size the scratch buffers (args.batch_size and the largest N_samples that will be passed)."""
+
+    def __init__(self, field, batch_size=4096, max_samples=None, lr_init=0.02, lr_basis=1e-3, lr_decay_iters=-1,
+                 lr_decay_target_ratio=0.1, n_iters=30000, L1_reg_weight=L1_REG_WEIGHT, betas=(0.9, 0.99), eps=1e-8, chunk_samples=0):
+        self.field = field
+        self.dev = torch.device(field.device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("ngf_amd.train.Trainer runs on the GPU only (device='cuda'); there is no CPU path")
+        self.L = _lib.lib()
+        _bind(self.L)
+        sd = dict(field.named_parameters())
+        self.params = []
+        for name in PARAM_NAMES:
+            p = sd[name]
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise RuntimeError(f"parameter {name} must be a contiguous float32 device tensor")
+            self.params.append(p)
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self.steps = [0] * 15                       # torch.optim.Adam keeps one step counter per parameter
+        # get_optparam_groups (Field.py:34-46)
+        net = lr_basis
+        self.lr = [lr_init] * 3 + [net * 0.1] * 3 + [net] * 9
+        if lr_decay_iters > 0:
+            self.lr_factor = lr_decay_target_ratio ** (1 / lr_decay_iters)
+        else:
+            self.lr_factor = lr_decay_target_ratio ** (1 / n_iters)
+        self.betas, self.eps, self.l1 = betas, eps, L1_reg_weight
+        self.batch_size = int(batch_size)
+        self.max_samples = int(max_samples if max_samples is not None else field.nSamples)
+        self.chunk_samples = int(chunk_samples)
+        self._h = None
+        self._loss = torch.zeros((1,), dtype=torch.float64, device=self.dev)
+        self.last_active = 0
+        self._build()
+
+    def _build(self):
+        f = self.field
+        d = TrainDesc()
+        d.aabb = (C.c_float * 6)(*f.aabb.reshape(-1).tolist())
+        d.near_, d.far_ = float(f.near_far[0]), float(f.near_far[1])
+        d.step = float(f.stepSize)
+        d.distance_scale = float(f.distance_scale)
+        d.weight_thres = float(np.float32(f.rayMarch_weight_thres))
+        for k in range(3):
+            d.plane[k] = self.params[k].data_ptr()
+            d.plane_h[k], d.plane_w[k] = self.params[k].shape[2], self.params[k].shape[3]
+            d.gauge[k] = self.params[3 + k].data_ptr()
+            d.gauge_h[k], d.gauge_w[k] = self.params[3 + k].shape[2], self.params[3 + k].shape[3]
+        (d.dens_w, d.dens_b, d.basis, d.w1, d.b1, d.w2, d.b2, d.w3, d.b3) = [p.data_ptr() for p in self.params[6:]]
+        for k in range(15):
+            d.exp_avg[k] = self.exp_avg[k].data_ptr()
+            d.exp_avg_sq[k] = self.exp_avg_sq[k].data_ptr()
+        self._keep = []
+        if f.alphaMask is not None:
+            bits = torch.from_numpy(f.alphaMask.packed_bits()).to(self.dev)
+            self._keep.append(bits)
+            d.mask_bits = bits.data_ptr()
+            shp = f.alphaMask.alpha_volume.shape
+            d.mask_d, d.mask_h, d.mask_w = int(shp[-3]), int(shp[-2]), int(shp[-1])
+            d.mask_aabb = (C.c_float * 6)(*f.alphaMask.aabb.reshape(-1).tolist())
+        d.max_rays, d.max_samples, d.chunk_samples = self.batch_size, self.max_samples, self.chunk_samples
+        out = C.c_void_p()
+        with torch.cuda.device(self.dev):
+            _lib.check(self.L.ngf_trainer_create(C.byref(d), C.byref(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        self.release()
+        self._h = out
+        self._shape_key = self._key()
+
+    def _key(self):
+        f = self.field
+        return (tuple((p.data_ptr(), tuple(p.shape)) for p in self.params), float(f.stepSize), tuple(f.aabb.reshape(-1).tolist()),
+                None if f.alphaMask is None else f.alphaMask.alpha_volume.data_ptr())
+
+    def release(self):
+        if getattr(self, "_h", None) is not None:
+            self.L.ngf_trainer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def scratch_bytes(self) -> int:
+        return int(self.L.ngf_trainer_bytes(self._h))
+
+    # ---------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def backward(self, rays_train, rgb_train, N_samples=-1, white_bg=True, iteration=0, jitter=None, coin=None):
+        """forward(is_train=True) + backward of the rgb MSE; returns the rgb loss as a 0-dim float64 device tensor.
+        ``jitter`` [n] and ``coin`` (a float in [0,1)) replace torch.rand_like / torch.rand((1,)) for parity tests."""
+        if self._key() != self._shape_key:
+            raise RuntimeError("the field's parameters were re-allocated (up_sampling / shrink / load): build a new Trainer")
+        rays = rays_train.to(device=self.dev, dtype=torch.float32).contiguous()
+        tgt = rgb_train.to(device=self.dev, dtype=torch.float32).contiguous()
+        n = rays.shape[0]
+        if rays.dim() != 2 or rays.shape[1] != 6 or tuple(tgt.shape) != (n, 3):
+            raise ValueError(f"rays_train must be [n,6] and rgb_train [n,3], got {tuple(rays.shape)} / {tuple(tgt.shape)}")
+        S = int(N_samples) if N_samples > 0 else int(self.field.nSamples)
+        if jitter is None:
+            jitter = torch.rand((n,), device=self.dev)                 # FieldBase.py:129-130
+        jitter = jitter.to(device=self.dev, dtype=torch.float32).contiguous()
+        if not white_bg:
+            c = float(torch.rand((1,))) if coin is None else float(coin)   # FieldBase.py:299
+            white_bg = c < 0.5
+        gauge_on = int(iteration >= self.field.gauge_start)
+        na = C.c_int64(0)
+        with torch.cuda.device(self.dev):
+            _lib.check(self.L.ngf_train_backward(self._h, rays.data_ptr(), tgt.data_ptr(), jitter.data_ptr(), n, S, int(bool(white_bg)), gauge_on,
+                                                 self._loss.data_ptr(), C.byref(na), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        self.last_active = int(na.value)
+        self._gauge_on = gauge_on
+        return self._loss[0] / (3.0 * n)
+
+    @torch.no_grad()
+    def gradient(self, which) -> torch.Tensor:
+        """The gradient of one parameter (index or state_dict name) in its reference layout, after ``backward``.
+        Planes exclude the L1 term (it is added inside the Adam kernel)."""
+        k = PARAM_NAMES.index(which) if isinstance(which, str) else int(which)
+        out = torch.empty_like(self.params[k])
+        with torch.cuda.device(self.dev):
+            _lib.check(self.L.ngf_train_get_grad(self._h, k, out.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
+
+    @torch.no_grad()
+    def optimizer_step(self):
+        """optimizer.step() + the lr decay of main.py:298-299.  Gauge planes without a gradient (iteration <
+        gauge_start) are skipped like torch.optim skips parameters whose .grad is None."""
+        with torch.cuda.device(self.dev):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for k in range(15):
+                if 3 <= k < 6 and not self._gauge_on:
+                    continue
+                self.steps[k] += 1
+                _lib.check(self.L.ngf_train_adam(self._h, k, self.steps[k], float(self.lr[k]), float(self.betas[0]), float(self.betas[1]),
+                                                 float(self.eps), float(self.l1), st))
+        self.field._handle_key = None      # parameters changed behind torch's back: the eval image is re-packed on the next render
+        self.lr = [x * self.lr_factor for x in self.lr]
+
+    def step(self, rays_train, rgb_train, iteration, N_samples=-1, white_bg=True, jitter=None, coin=None):
+        """One iteration of main.py:264-299.  Returns the rgb loss (0-dim float64 device tensor; ``.item()`` for PSNR)."""
+        loss = self.backward(rays_train, rgb_train, N_samples, white_bg, iteration, jitter, coin)
+        self.optimizer_step()
+        return loss

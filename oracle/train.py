@@ -87,12 +87,12 @@ class EagerTrainer(EagerField):
             v.grad = None
         total, rgb_loss, rgb_map, aux = self.loss(rays, rgb_train, S, jitter, white_bg, iteration)
         total.backward()
-        return {k: (None if v.grad is None else v.grad.detach().clone()) for k, v in self.p.items()}, float(rgb_loss), rgb_map.detach(), aux
+        return {k: (None if v.grad is None else v.grad.detach().clone()) for k, v in self.p.items()}, float(rgb_loss.detach()), rgb_map.detach(), aux
 
 
 def adam_update(p, g, m, v, t, lr, beta1=0.9, beta2=0.99, eps=1e-8):
     """torch.optim.Adam's single-tensor update (no weight decay, no amsgrad), float32: returns (p, m, v) after step t>=1."""
-    m = m * beta1 + g * (1 - beta1)
+    m = m + (1 - beta1) * (g - m)              # exp_avg.lerp_(grad, 1 - beta1)
     v = v * beta2 + g * g * (1 - beta2)
     bc1 = 1 - beta1 ** t
     bc2 = 1 - beta2 ** t

@@ -43,6 +43,7 @@ def load_train_case(name):
         v64 = v.astype(np.float64).reshape(-1)
         chk = np.array([v64.sum(), np.abs(v64).sum(), v64[:: max(1, v64.size // 7)][:7].sum()])
         assert np.array_equal(chk, g["chk." + k]), f"synth regenerated different parameters for {k}"
+    g.setdefault("step_ratio", np.float32(0.5))
     return g, params
 
 
