@@ -660,6 +660,7 @@ struct ngf_trainer {
     std::vector<void *> allocs;
     float *tex_d[3] = {}, *tex_a[3] = {}, *tex_g[3] = {};
     float *g_d[3] = {}, *g_a[3] = {}, *g_g[3] = {};
+    float *q_d[3] = {}, *d_d[3] = {};        // wd-projected density planes, scalar density-gradient images
     float *g_dense[TP_COUNT] = {};          // reference-layout gradient buffers of the MLP parameters (index TP_*)
     int64_t dense_n[TP_COUNT] = {};
     uint8_t *mask = nullptr;
@@ -718,12 +719,13 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
         const int H = d->plane_h[p], W = d->plane_w[p], gh = d->gauge_h[p], gw = d->gauge_w[p];
         const size_t tex = (size_t)(H + 2) * (W + 2), gtex = (size_t)(gh + 2) * (gw + 2);
         if ((rc = tr_alloc(t, &t->tex_d[p], tex * 16)) || (rc = tr_alloc(t, &t->tex_a[p], tex * 48)) || (rc = tr_alloc(t, &t->tex_g[p], gtex * 2)) ||
-            (rc = tr_alloc(t, &t->g_d[p], tex * 16)) || (rc = tr_alloc(t, &t->g_a[p], tex * 48)) || (rc = tr_alloc(t, &t->g_g[p], gtex * 2)))
+            (rc = tr_alloc(t, &t->q_d[p], tex)) || (rc = tr_alloc(t, &t->d_d[p], tex)) || (rc = tr_alloc(t, &t->g_d[p], tex * 16)) || (rc = tr_alloc(t, &t->g_a[p], tex * 48)) || (rc = tr_alloc(t, &t->g_g[p], gtex * 2)))
             return bail(rc);
         A.dens[p] = Tex{t->tex_d[p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
         A.app[p] = Tex{t->tex_a[p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
         A.gau[p] = Tex{t->tex_g[p], gw, gh, gw + 2, (float)(gw - 1), (float)(gh - 1)};
         T.g_dens[p] = t->g_d[p]; T.g_app[p] = t->g_a[p]; T.g_gau[p] = t->g_g[p];
+        T.q_dens[p] = t->q_d[p]; T.d_dens[p] = t->d_d[p];
     }
     const int64_t dn[TP_COUNT] = {0, 0, 0, 0, 0, 0, 48, 1, 144 * 144, 64 * 159, 64, 64 * 64, 64, 3 * 64, 3};
     for (int k = TP_DENS_W; k < TP_COUNT; ++k) {
@@ -794,7 +796,8 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         pack_plane_kernel<<<2048, 256, 0, st>>>(d.plane[p], H, W, 0, 16, t->tex_d[p]);
         pack_plane_kernel<<<2048, 256, 0, st>>>(d.plane[p], H, W, 16, 48, t->tex_a[p]);
         pack_plane_kernel<<<256, 256, 0, st>>>(d.gauge[p], gh, gw, 0, 2, t->tex_g[p]);
-        HIP_TRY(hipMemsetAsync(t->g_d[p], 0, tex * 16 * sizeof(float), st));
+        hipLaunchKernelGGL(train_project_density_kernel, dim3(256), dim3(256), 0, st, (const float *)t->tex_d[p], d.dens_w + 16 * p, (int64_t)tex, t->q_d[p]);
+        HIP_TRY(hipMemsetAsync(t->d_d[p], 0, tex * sizeof(float), st));
         HIP_TRY(hipMemsetAsync(t->g_a[p], 0, tex * 48 * sizeof(float), st));
         HIP_TRY(hipMemsetAsync(t->g_g[p], 0, gtex * 2 * sizeof(float), st));
     }
@@ -846,6 +849,11 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         hipLaunchKernelGGL(colsum_kernel, dim3(64), dim3(256), 0, st, (const float *)T.D1, 64, rows, 64, t->g_dense[TP_B1]);
     }
     hipLaunchKernelGGL(train_density_bwd_kernel, dim3(tr_grid(t, pairs, 256)), dim3(256), 0, st, T);
+    for (int p = 0; p < 3; ++p) {
+        const int64_t tex = (int64_t)(d.plane_h[p] + 2) * (d.plane_w[p] + 2);
+        hipLaunchKernelGGL(train_density_finish_kernel, dim3(256), dim3(256), 0, st, (const float *)t->d_d[p], (const float *)t->tex_d[p], d.dens_w + 16 * p, tex,
+                           t->g_d[p], t->g_dense[TP_DENS_W] + 16 * p);
+    }
     HIP_TRY(hipMemcpyAsync(rgb_loss, T.loss, sizeof(double), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipGetLastError());
     return NGF_OK;

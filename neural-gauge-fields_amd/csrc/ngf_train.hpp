@@ -16,7 +16,8 @@
 //   train_color_bwd_kernel     the data gradients of the colour MLP with the TRANSPOSED weights on the matrix pipe, the
 //                              feature gradients scattered into the packed colour planes (float atomics) and d loss / d t
 //   xty_kernel                 weight gradients as sample-reduction GEMMs  dW = Delta^T . In  (MFMA, split over samples)
-//   train_density_bwd_kernel   every valid sample: density feature scatter, d/d density_decoder, d loss / d t -> gauge planes
+//   train_density_bwd_kernel   every valid sample: ONE scalar per tap into the density-gradient images (the decoder is linear:
+//                              rank-one gradient, expanded by train_density_finish_kernel), d loss / d t -> gauge planes
 //   adam_*_kernel              torch.optim.Adam's update; planes read their gradient from the packed layout and add the L1 term
 //
 // Matrix operands are read straight from the reference-layout weight tensors (150 KB, L2 resident): no per-step weight
@@ -37,6 +38,8 @@ struct TrainArgs {
     const float *wd, *bd;                       // density_decoder.weight [48], bias [1]
     const float *basis, *w1, *b1, *w2, *b2, *w3, *b3;
     float *g_wd, *g_bd;
+    float *q_dens[3];        // wd-projected density planes (1 channel, packed): Q_p = sum_c wd[16p+c] plane_p[c]
+    float *d_dens[3];        // scalar density-gradient images: D_p[texel] = sum_samples w_tap * dx
     // step-major dense per-sample buffers: index = step * n + ray
     float *xs, *w, *dx;      // [S,n]
     float *c;                // [S,n,3]
@@ -581,12 +584,35 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float *__restrict__ X
 }
 
 // ---- 7. density / gauge backward for every valid sample -----------------------------------------------------------------------
+// density_decoder is LINEAR, so the gradient of the 16 density channels of a texel is rank one:
+//     d loss / d plane_p[c][texel] = wd[16p+c] * D_p[texel],   D_p[texel] = sum over samples of (tap weight * dx)
+// and d loss / d wd[16p+c] = sum over texels of D_p[texel] * plane_p[c][texel].  The per-sample kernel therefore scatters ONE
+// float per tap (12 atomics instead of 192) and takes the spatial derivative from the wd-projected 1-channel planes Q_p;
+// train_density_finish_kernel expands D_p afterwards.
+__global__ void __launch_bounds__(256) train_project_density_kernel(const float *__restrict__ tex16, const float *__restrict__ wd, int64_t texels,
+                                                                    float *__restrict__ q)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < texels; i += stride) {
+        const f32x4 *v = reinterpret_cast<const f32x4 *>(tex16 + i * 16);
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 x = v[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = fmaf(wd[4 * j + e], x[e], s);
+        }
+        q[i] = s;
+    }
+}
+
 __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs T)
 {
     const RenderArgs &A = T.R;
-    __shared__ float s_wd[49];
-    if (threadIdx.x < 49) s_wd[threadIdx.x] = 0.0f;
+    __shared__ float s_bd;
+    if (threadIdx.x == 0) s_bd = 0.0f;
     __syncthreads();
+    float bsum = 0.0f;
     const int64_t total = (int64_t)A.S * A.n;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
@@ -598,35 +624,20 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
         float t[6], xn[3];
         list_sample_coords(A, r, i, t, xn);
         float dt[6];
-        atomicAdd(&s_wd[48], dx);
+        bsum += dx;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const Tex &tx = A.dens[p];
             BilG b = bilg_setup(t[2 * p], t[2 * p + 1], tx);
-            const size_t base = (size_t)b.idx * 16;
-            const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + base);
-            const f32x4 *q01 = q00 + (size_t)tx.stride * 4;
-            float *g00 = T.g_dens[p] + base, *g01 = g00 + (size_t)tx.stride * 16;
-            float du = 0.0f, dv = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 v00 = q00[j], v10 = q00[4 + j], v01 = q01[j], v11 = q01[4 + j];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float wk = T.wd[p * 16 + 4 * j + e];
-                    const float g = dx * wk;                                   // d loss / d feature
-                    const float feat = fmaf(b.w11, v11[e], fmaf(b.w01, v01[e], fmaf(b.w10, v10[e], b.w00 * v00[e])));
-                    atomicAdd(&s_wd[p * 16 + 4 * j + e], dx * feat);
-                    atomicAdd(g00 + 4 * j + e, b.w00 * g);
-                    atomicAdd(g00 + 16 + 4 * j + e, b.w10 * g);
-                    atomicAdd(g01 + 4 * j + e, b.w01 * g);
-                    atomicAdd(g01 + 16 + 4 * j + e, b.w11 * g);
-                    du += g * (b.wy0 * (v10[e] - v00[e]) + b.wy1 * (v11[e] - v01[e]));
-                    dv += g * (b.wx0 * (v01[e] - v00[e]) + b.wx1 * (v11[e] - v10[e]));
-                }
-            }
-            dt[2 * p] = du * b.sx;
-            dt[2 * p + 1] = dv * b.sy;
+            const float *q = T.q_dens[p] + b.idx;
+            const float v00 = q[0], v10 = q[1], v01 = q[tx.stride], v11 = q[tx.stride + 1];
+            float *g = T.d_dens[p] + b.idx;
+            atomicAdd(g, b.w00 * dx);
+            atomicAdd(g + 1, b.w10 * dx);
+            atomicAdd(g + tx.stride, b.w01 * dx);
+            atomicAdd(g + tx.stride + 1, b.w11 * dx);
+            dt[2 * p] = dx * (b.wy0 * (v10 - v00) + b.wy1 * (v11 - v01)) * b.sx;
+            dt[2 * p + 1] = dx * (b.wx0 * (v01 - v00) + b.wx1 * (v11 - v10)) * b.sy;
         }
         if (A.mode) {
             if (active) {
@@ -652,9 +663,45 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
             }
         }
     }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) bsum += __shfl_xor(bsum, s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_bd, bsum);
     __syncthreads();
-    if (threadIdx.x < 48) atomicAdd(T.g_wd + threadIdx.x, s_wd[threadIdx.x]);
-    if (threadIdx.x == 48) atomicAdd(T.g_bd, s_wd[48]);
+    if (threadIdx.x == 0) atomicAdd(T.g_bd, s_bd);
+}
+
+// expand the scalar gradient image of plane p: g_dens[texel][c] = wd[c] * D[texel]; g_wd[c] += sum_texels D[texel] * tex16[texel][c]
+__global__ void __launch_bounds__(256) train_density_finish_kernel(const float *__restrict__ D, const float *__restrict__ tex16,
+                                                                   const float *__restrict__ wd, int64_t texels, float *__restrict__ g_dens, float *g_wd)
+{
+    __shared__ float sh[16];
+    if (threadIdx.x < 16) sh[threadIdx.x] = 0.0f;
+    __syncthreads();
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < texels; i += stride) {
+        const float d = D[i];
+        const f32x4 *v = reinterpret_cast<const f32x4 *>(tex16 + i * 16);
+        f32x4 *g = reinterpret_cast<f32x4 *>(g_dens + i * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 x = v[j];
+            g[j] = f32x4{wd[4 * j] * d, wd[4 * j + 1] * d, wd[4 * j + 2] * d, wd[4 * j + 3] * d};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * j + e] = fmaf(d, x[e], acc[4 * j + e]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float v = acc[c];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&sh[c], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) atomicAdd(g_wd + threadIdx.x, sh[threadIdx.x]);
 }
 
 // ---- 8. torch.optim.Adam (betas, eps, no weight decay, no amsgrad), float32 like the reference ------------------------------------
