@@ -844,9 +844,9 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         hipLaunchKernelGGL(xty_kernel, dim3(4 * 4 * splits), dim3(64), 0, st, (const float *)T.D2, 64, (const float *)T.H1, 64, rows, 4, 4, 64, 64, t->g_dense[TP_W2], 64, splits);
         hipLaunchKernelGGL(xty_kernel, dim3(4 * 10 * splits), dim3(64), 0, st, (const float *)T.D1, 64, (const float *)T.U, 160, rows, 4, 10, 64, 159, t->g_dense[TP_W1], 159, splits);
         hipLaunchKernelGGL(xty_kernel, dim3(9 * 9 * splits), dim3(64), 0, st, (const float *)T.DG, 144, (const float *)T.F, 144, rows, 9, 9, 144, 144, t->g_dense[TP_BASIS], 144, splits);
-        hipLaunchKernelGGL(colsum_kernel, dim3(3), dim3(256), 0, st, (const float *)T.D3, 16, rows, 3, t->g_dense[TP_B3]);
-        hipLaunchKernelGGL(colsum_kernel, dim3(64), dim3(256), 0, st, (const float *)T.D2, 64, rows, 64, t->g_dense[TP_B2]);
-        hipLaunchKernelGGL(colsum_kernel, dim3(64), dim3(256), 0, st, (const float *)T.D1, 64, rows, 64, t->g_dense[TP_B1]);
+        hipLaunchKernelGGL(colsum_kernel, dim3((rows + 1023) / 1024), dim3(256), 0, st, (const float *)T.D3, 16, rows, 3, t->g_dense[TP_B3]);
+        hipLaunchKernelGGL(colsum_kernel, dim3((rows + 1023) / 1024), dim3(256), 0, st, (const float *)T.D2, 64, rows, 64, t->g_dense[TP_B2]);
+        hipLaunchKernelGGL(colsum_kernel, dim3((rows + 1023) / 1024), dim3(256), 0, st, (const float *)T.D1, 64, rows, 64, t->g_dense[TP_B1]);
     }
     hipLaunchKernelGGL(train_density_bwd_kernel, dim3(tr_grid(t, pairs, 256)), dim3(256), 0, st, T);
     for (int p = 0; p < 3; ++p) {

@@ -240,20 +240,32 @@ __global__ void __launch_bounds__(1024) train_prefix_kernel(const int32_t *count
 // v_mfma_f32_16x16x4_f32: lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; it receives D[i = 4(l>>4)+r][j = l&15].
 //   TRANS = false: Wm[m][k] = W[m*ldw + k] (forward, nn.Linear weight [out,in]);  TRANS = true: Wm[m][k] = W[k*ldw + m]
 //   ACT: 0 none, 1 relu, 2 = multiply by (mask[m][n] > 0)   (the relu backward)
-template <bool TRANS, int ACT>
-__device__ __forceinline__ void dense16(const float *__restrict__ W, int ldw, int M, int Mvalid, int K, int Kvalid,
-                                        const float *__restrict__ bias, const float *in, float *out, const float *mask, int lane)
+template <bool TRANS, int ACT, int K, int KVALID, int OUT_T = 0>      // OUT_T > 0: out[sample][row] with row stride OUT_T
+__device__ __forceinline__ void dense16(const float *__restrict__ W, int ldw, int M, int Mvalid, const float *__restrict__ bias, const float *in,
+                                        float *out, const float *mask, int lane)
 {
+    constexpr int KS = K / 4;                   // MFMA k-steps per output row block
+    constexpr int CH = KS > 20 ? KS / 2 : KS;   // operands fetched ahead of the MFMAs (<= 20 global + 20 LDS reads in flight)
+    static_assert(KS % CH == 0, "k-steps must split evenly");
     const int n = lane & 15, q = lane >> 4;
     for (int mb = 0; mb < M; mb += 16) {
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         const int m = mb + n;                  // the A row this lane supplies
-        for (int k0 = 0; k0 < K; k0 += 4) {
-            const int k = k0 + q;
-            float a = 0.0f;
-            if (m < Mvalid && k < Kvalid) a = TRANS ? W[(size_t)k * ldw + m] : W[(size_t)m * ldw + k];
-            const float b = in[k * 16 + n];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        const bool mok = m < Mvalid;
+#pragma unroll
+        for (int c0 = 0; c0 < KS; c0 += CH) {
+            // all operands of this chunk first (independent loads: one latency), then the MFMAs back to back
+            float a[CH], b[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int k = 4 * (c0 + j) + q;
+                const bool ok = mok && (KVALID == K || k < KVALID);
+                const size_t off = TRANS ? (size_t)k * ldw + m : (size_t)m * ldw + k;
+                a[j] = ok ? W[off] : 0.0f;
+                b[j] = in[k * 16 + n];
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -262,7 +274,8 @@ __device__ __forceinline__ void dense16(const float *__restrict__ W, int ldw, in
             if (bias && row < Mvalid) v += bias[row];
             if (ACT == 1) v = fmaxf(v, 0.0f);
             if (ACT == 2) v = mask[row * 16 + n] > 0.0f ? v : 0.0f;
-            out[row * 16 + n] = v;
+            if (OUT_T) out[n * OUT_T + row] = v;
+            else out[row * 16 + n] = v;
         }
     }
 }
@@ -297,7 +310,8 @@ __device__ __forceinline__ void list_sample_coords(const RenderArgs &A, int64_t 
 }
 
 constexpr int kFwdTileFloats = (kFeat + kIn1Pad + 64 + 64) * 16;          // F, U, H1, H2
-constexpr int kBwdTileFloats = (64 + 64 + 64 + 64 + kFeat + kFeat) * 16;  // H1, H2, D2, D1, DG, DF
+constexpr int kDfStride = kFeat + 1;                                       // DF is kept sample-major (bank-conflict-free rows)
+constexpr int kBwdTileFloats = (64 + 64 + 64 + 64 + kFeat) * 16 + 16 * kDfStride + 16 * 16;  // H1, H2, D2, D1, DG, DF^T, tap table
 
 // ---- 3. colour forward over the active list -------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const TrainArgs T)
@@ -338,11 +352,11 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
             for (int j = 0; j < 4; ++j) Ut[(kFeat + 4 * q + j) * 16 + n] = live ? v[4 * q + j] : 0.0f;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<false, 0>(T.basis, kFeat, kFeat, kFeat, kFeat, kFeat, nullptr, Ft, Ut, nullptr, lane);          // g = basis . f
+        dense16<false, 0, kFeat, kFeat>(T.basis, kFeat, kFeat, kFeat, nullptr, Ft, Ut, nullptr, lane);          // g = basis . f
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<false, 1>(T.w1, kIn1, 64, 64, kIn1Pad, kIn1, T.b1, Ut, H1t, nullptr, lane);
+        dense16<false, 1, kIn1Pad, kIn1>(T.w1, kIn1, 64, 64, T.b1, Ut, H1t, nullptr, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<false, 1>(T.w2, 64, 64, 64, 64, 64, T.b2, H1t, H2t, nullptr, lane);
+        dense16<false, 1, 64, 64>(T.w2, 64, 64, 64, T.b2, H1t, H2t, nullptr, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // layer 3 + sigmoid on the VALU: lane (q, n) sums its 16 hidden units, then the four quarters meet
         float c[3];
@@ -450,7 +464,7 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     float *H1t = smem + wave * kBwdTileFloats, *H2t = H1t + 64 * 16, *D2t = H2t + 64 * 16, *D1t = D2t + 64 * 16, *DGt = D1t + 64 * 16,
-          *DFt = DGt + kFeat * 16;
+          *DFt = DGt + kFeat * 16, *tap = DFt + 16 * kDfStride;       // tap[s][p] = {texel index, w00, w10, w01, w11}
     const int passes = (T.chunk_n + 15) / 16;
     for (int pass = blockIdx.x * kTrainWaves + wave; pass < passes; pass += gridDim.x * kTrainWaves) {
         const int local = pass * 16 + n;
@@ -479,11 +493,11 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const
             D2t[k * 16 + n] = H2t[k * 16 + n] > 0.0f ? s : 0.0f;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<true, 2>(T.w2, 64, 64, 64, 64, 64, nullptr, D2t, D1t, H1t, lane);                 // d1 = (W2^T d2) * [h1 > 0]
+        dense16<true, 2, 64, 64>(T.w2, 64, 64, 64, nullptr, D2t, D1t, H1t, lane);                 // d1 = (W2^T d2) * [h1 > 0]
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<true, 0>(T.w1, kIn1, kFeat, kFeat, 64, 64, nullptr, D1t, DGt, nullptr, lane);     // dg = (W1^T d1)[:144]
+        dense16<true, 0, 64, 64>(T.w1, kIn1, kFeat, kFeat, nullptr, D1t, DGt, nullptr, lane);     // dg = (W1^T d1)[:144]
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<true, 0>(T.basis, kFeat, kFeat, kFeat, kFeat, kFeat, nullptr, DGt, DFt, nullptr, lane);   // df = basis^T dg
+        dense16<true, 0, kFeat, kFeat, kDfStride>(T.basis, kFeat, kFeat, kFeat, nullptr, DGt, DFt, nullptr, lane);   // df = basis^T dg
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // rows for the weight-gradient GEMMs
         if (live && q == 0) {
@@ -495,7 +509,7 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const
         tile_to_rows(D2t, 64, T.D2, 64, row, live, lane);
         tile_to_rows(D1t, 64, T.D1, 64, row, live, lane);
         tile_to_rows(DGt, kFeat, T.DG, kFeat, row, live, lane);
-        // feature gradients -> packed colour planes, and d loss / d t through the bilinear cell
+        // d loss / d t through the bilinear cell (lane (q, n): channels 12q..12q+11 of every plane of sample n) and the tap table
         float t[6], xn[3];
         list_sample_coords(A, r, i, t, xn);
         float dt[6];
@@ -506,20 +520,18 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const
             const size_t base = (size_t)b.idx * 48 + 12 * q;
             const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + base);
             const f32x4 *q01 = q00 + (size_t)tx.stride * 12;
-            float *g00 = T.g_app[p] + base, *g01 = g00 + (size_t)tx.stride * 48;
+            if (q == 0) {
+                float *tp = tap + (n * 3 + p) * 5;
+                tp[0] = __int_as_float(b.idx);
+                tp[1] = live ? b.w00 : 0.0f; tp[2] = live ? b.w10 : 0.0f; tp[3] = live ? b.w01 : 0.0f; tp[4] = live ? b.w11 : 0.0f;
+            }
             float du = 0.0f, dv = 0.0f;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 f32x4 v00 = q00[j], v10 = q00[12 + j], v01 = q01[j], v11 = q01[12 + j];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float g = DFt[(p * 48 + 12 * q + 4 * j + e) * 16 + n];
-                    if (live) {
-                        atomicAdd(g00 + 4 * j + e, b.w00 * g);
-                        atomicAdd(g00 + 48 + 4 * j + e, b.w10 * g);
-                        atomicAdd(g01 + 4 * j + e, b.w01 * g);
-                        atomicAdd(g01 + 48 + 4 * j + e, b.w11 * g);
-                    }
+                    const float g = DFt[n * kDfStride + p * 48 + 12 * q + 4 * j + e];
                     du += g * (b.wy0 * (v10[e] - v00[e]) + b.wy1 * (v11[e] - v01[e]));
                     dv += g * (b.wx0 * (v01[e] - v00[e]) + b.wx1 * (v11[e] - v10[e]));
                 }
@@ -528,6 +540,25 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const
             du += __shfl_xor(du, 16); du += __shfl_xor(du, 32);
             dv += __shfl_xor(dv, 16); dv += __shfl_xor(dv, 32);
             dt[2 * p] = du; dt[2 * p + 1] = dv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // feature gradients -> packed colour planes: the 48 channels of one tap are CONSECUTIVE floats, so the wave scatters
+        // (sample, plane) by (sample, plane): 4 taps x 48 channels = 3 instructions of 64 lanes over 12 cache lines, instead of
+        // every lane hitting its own line
+        for (int sp = 0; sp < 48; ++sp) {
+            const float *tp = tap + sp * 5;
+            const int smp = sp / 3, p = sp - 3 * smp;
+            const int idx = __float_as_int(tp[0]);
+            const Tex &tx = A.app[p];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int e = u * 64 + lane;                 // 0..191 = tap * 48 + channel
+                const int tp_i = e / 48, c = e - 48 * tp_i;
+                const float wt = tp[1 + tp_i];
+                const size_t off = ((size_t)idx + (tp_i & 1) + (tp_i >> 1) * (size_t)tx.stride) * 48 + c;
+                const float g = DFt[smp * kDfStride + p * 48 + c];
+                if (wt != 0.0f) atomicAdd(T.g_app[p] + off, wt * g);
+            }
         }
         if (live && q == 0) {
             float *d = T.dt + ((int64_t)i * A.n + r) * 6;
@@ -550,14 +581,17 @@ __global__ void __launch_bounds__(64) xty_kernel(const float *__restrict__ X, in
     const int s0 = split * per, s1 = min(rows, s0 + per);
     const int j = lane & 15, kq = lane >> 4;
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int s = s0; s < s1; s += 4) {
-        const int ss = s + kq;
-        float a = 0.0f, b = 0.0f;
-        if (ss < s1) {
-            a = X[(size_t)ss * ldx + m0 + j];          // rows are padded to a multiple of 16 columns
-            b = Y[(size_t)ss * ldy + n0 + j];
+    for (int s = s0; s < s1; s += 32) {             // 8 MFMA k-steps per trip: 16 independent loads, then the MFMAs
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ss = s + 4 * u + kq;
+            const bool ok = ss < s1;
+            a[u] = ok ? X[(size_t)ss * ldx + m0 + j] : 0.0f;          // rows are padded to a multiple of 16 columns
+            b[u] = ok ? Y[(size_t)ss * ldy + n0 + j] : 0.0f;
         }
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -566,21 +600,18 @@ __global__ void __launch_bounds__(64) xty_kernel(const float *__restrict__ X, in
     }
 }
 
-// bias gradients: column sums of a row-major [rows, ld] matrix
+// bias gradients: column sums of a row-major [rows, ld] matrix (cols <= 64); one block per 1024 rows
 __global__ void __launch_bounds__(256) colsum_kernel(const float *__restrict__ X, int ld, int rows, int cols, float *out)
 {
-    const int c = blockIdx.x;
-    if (c >= cols) return;
-    __shared__ float sh[256];
+    __shared__ float sh[4][64];
+    const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * 1024, r1 = min(rows, r0 + 1024);
     float s = 0.0f;
-    for (int r = threadIdx.x; r < rows; r += 256) s += X[(size_t)r * ld + c];
-    sh[threadIdx.x] = s;
+    if (c < cols)
+        for (int r = r0 + part; r < r1; r += 4) s += X[(size_t)r * ld + c];
+    sh[part][c] = s;
     __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if ((int)threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) atomicAdd(out + c, sh[0]);
+    if (part == 0 && c < cols) atomicAdd(out + c, (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]));
 }
 
 // ---- 7. density / gauge backward for every valid sample -----------------------------------------------------------------------
