@@ -806,7 +806,7 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
 
     const int64_t pairs = n * n_samples;
     hipLaunchKernelGGL(train_density_kernel, dim3(tr_grid(t, pairs, 256)), dim3(256), 0, st, T);
-    const int ray_blocks = (int)((n + 63) / 64);
+    const int ray_blocks = (int)((n + 3) / 4);        // sixteen lanes per ray
     hipLaunchKernelGGL(train_scan_kernel, dim3(ray_blocks), dim3(64), 0, st, T, 0);
     hipLaunchKernelGGL(train_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)T.count, n, T.offset);
     int32_t n_active = 0;

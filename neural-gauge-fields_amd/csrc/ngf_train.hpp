@@ -179,35 +179,61 @@ __device__ __forceinline__ float ray_tmin(const RenderArgs &A, int64_t r)
 }
 
 // ---- 2. raw2alpha per ray; pass 0 counts the active samples, pass 1 writes weights and the ordered active list ----------
+// Sixteen lanes per ray (one DPP row), each on one of 16 consecutive steps: the loads and the exp/log of a block of steps run
+// in parallel and only the transmittance product is chained lane to lane IN STEP ORDER (row_shr:1), so weights are exactly
+// those of the sequential cumprod (FieldBase.py:16) while a 4096-ray batch fills 1024 waves instead of 64.
+__device__ __forceinline__ float row_shr1(float v, float fill)      // lane (row, s) <- lane (row, s-1); lane s = 0 gets `fill`
+{
+    const int r = __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x111, 0xf, 0xf, false);
+    return __int_as_float(r);
+}
+
 __global__ void __launch_bounds__(64) train_scan_kernel(const TrainArgs T, int pass)
 {
     const RenderArgs &A = T.R;
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= A.n) return;
+    const int lane = threadIdx.x & 63, seg = lane & 15, rl = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * 4 + rl;
+    const bool live = r0 < A.n;
+    const int64_t r = live ? r0 : A.n - 1;
     const float tmin = ray_tmin(A, r);
     const float jit = A.jitter ? A.jitter[r] : 0.0f;
     float Tr = 1.0f;
     int cnt = 0;
     const int base = pass ? T.offset[r] : 0;
-    for (int i = 0; i < A.S; ++i) {
+    for (int i0 = 0; i0 < A.S; i0 += 16) {
+        const int i = i0 + seg;
+        const bool inb = i < A.S;
+        const int64_t idx = (int64_t)(inb ? i : 0) * A.n + r;
         const float z = tmin + A.step * ((float)i + jit);
         const float zn = tmin + A.step * ((float)(i + 1) + jit);
         const float dist = (i < A.S - 1) ? (zn - z) : 0.0f;
-        const float sigma = softplus_pre(T.xs[(int64_t)i * A.n + r]);
+        const float sigma = inb ? softplus_pre(T.xs[idx]) : 0.0f;
         const float alpha = 1.0f - expf(-sigma * (dist * A.dscale));
-        const float w = alpha * Tr;
-        Tr = Tr * ((1.0f - alpha) + 1e-10f);
-        if (pass) T.w[(int64_t)i * A.n + r] = w;
-        if (w > A.thr) {
-            if (pass) {
-                T.list[2 * (int64_t)(base + cnt)] = (int)r;
-                T.list[2 * (int64_t)(base + cnt) + 1] = i;
-                T.list_w[base + cnt] = w;
-            }
-            ++cnt;
+        const float keep = (1.0f - alpha) + 1e-10f;             // steps past S: alpha = 0, keep rounds to 1
+        // T entering step i0+seg = Tr * keep_0 * ... * keep_{seg-1}, multiplied in that order: after round k lanes <= k are final
+        float Tin = Tr;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            const float prev = row_shr1(Tin * keep, Tr);
+            Tin = seg > 0 ? prev : Tr;
         }
+        const float w = alpha * Tin;
+        Tr = __shfl(Tin * keep, rl * 16 + 15);
+        const bool active = live && inb && (w > A.thr);
+        const unsigned m16 = (unsigned)((__ballot(active) >> (16 * rl)) & 0xffffull);
+        if (pass && live && inb) {
+            T.w[idx] = w;
+            T.dx[idx] = Tin;                                    // parked for the compositing backward
+            if (active) {
+                const int pos = base + cnt + __popc(m16 & ((1u << seg) - 1u));
+                T.list[2 * (int64_t)pos] = (int)r;
+                T.list[2 * (int64_t)pos + 1] = i;
+                T.list_w[pos] = w;
+            }
+        }
+        cnt += __popc(m16);
     }
-    if (!pass) T.count[r] = cnt;
+    if (!pass && live && seg == 0) T.count[r] = cnt;
 }
 
 // exclusive prefix of count[0..n) -> offset[0..n]; one block, sequential over chunks of 1024
@@ -385,75 +411,82 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
 }
 
 // ---- 4. compositing forward tail + backward to the pre-softplus density of every sample ------------------------------------
+// Sixteen lanes per ray as in the scan.  d loss / d alpha_i = dL/dw_i T_i - (sum_{j>i} w_j dL/dw_j) / (1 - alpha_i + 1e-10) with
+// dL/dw_j = G . (c_j [active] - bg) is the cumprod backward; the suffix sum is accumulated from the END of the ray in float64
+// (what ATen's reverse cumsum does on the CPU), T_i was parked in dx by the scan.
 __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs T)
 {
     const RenderArgs &A = T.R;
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    double sq = 0.0;
-    if (r < A.n) {
-        const float bg = A.white_bg ? 1.0f : 0.0f;
-        float acc = 0.0f, rgb[3] = {0.0f, 0.0f, 0.0f};
-        for (int i = 0; i < A.S; ++i) {
-            const int64_t idx = (int64_t)i * A.n + r;
-            const float w = T.w[idx];
-            acc += w;
-            if (w > A.thr) {
+    const int lane = threadIdx.x & 63, seg = lane & 15, rl = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * 4 + rl;
+    const bool live = r0 < A.n;
+    const int64_t r = live ? r0 : A.n - 1;
+    const float bg = A.white_bg ? 1.0f : 0.0f;
+    float acc = 0.0f, rgb[3] = {0.0f, 0.0f, 0.0f};
+    for (int i = seg; i < A.S; i += 16) {
+        const int64_t idx = (int64_t)i * A.n + r;
+        const float w = T.w[idx];
+        acc += w;
+        if (w > A.thr) {
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) rgb[ch] += w * T.c[idx * 3 + ch];
-            }
-        }
-        float G[3];
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            float pre = rgb[ch];
-            if (A.white_bg) pre = pre + (1.0f - acc);
-            const float out = fminf(fmaxf(pre, 0.0f), 1.0f);
-            const float res = out - T.target[r * 3 + ch];
-            sq += (double)(res * res);
-            G[ch] = (pre >= 0.0f && pre <= 1.0f) ? 2.0f * res * T.inv_count : 0.0f;      // clamp passes the gradient on [0,1]
-            T.G[r * 3 + ch] = G[ch];
-        }
-        // d loss / d alpha_i = dL/dw_i T_i - (sum_{j>i} w_j dL/dw_j) / (1 - alpha_i + 1e-10), dL/dw_j = G . (c_j [active] - bg):
-        // the cumprod backward.  The suffix sum is accumulated from the END of the ray (small terms first, in float64 like
-        // ATen's CPU cumsum), which is what autograd does; total - prefix would cancel for the late samples.
-        const float gbg = (G[0] + G[1] + G[2]) * bg;
-        const float tmin = ray_tmin(A, r);
-        const float jit = A.jitter ? A.jitter[r] : 0.0f;
-        float Tr = 1.0f;
-        for (int i = 0; i < A.S; ++i) {                         // forward sweep: park T_i in dx
-            const int64_t idx = (int64_t)i * A.n + r;
-            const float z = tmin + A.step * ((float)i + jit);
-            const float zn = tmin + A.step * ((float)(i + 1) + jit);
-            const float delta = ((i < A.S - 1) ? (zn - z) : 0.0f) * A.dscale;
-            const float alpha = 1.0f - expf(-softplus_pre(T.xs[idx]) * delta);
-            T.dx[idx] = Tr;
-            Tr = Tr * ((1.0f - alpha) + 1e-10f);
-        }
-        double suffix = 0.0;
-        for (int i = A.S - 1; i >= 0; --i) {
-            const int64_t idx = (int64_t)i * A.n + r;
-            const float x = T.xs[idx];
-            const float z = tmin + A.step * ((float)i + jit);
-            const float zn = tmin + A.step * ((float)(i + 1) + jit);
-            const float delta = ((i < A.S - 1) ? (zn - z) : 0.0f) * A.dscale;
-            const float e = expf(-softplus_pre(x) * delta);
-            const float alpha = 1.0f - e;
-            const float Ti = T.dx[idx];
-            const float w = T.w[idx];
-            float dw = -gbg;
-            if (w > A.thr) dw += G[0] * T.c[idx * 3] + G[1] * T.c[idx * 3 + 1] + G[2] * T.c[idx * 3 + 2];
-            const float keep = (1.0f - alpha) + 1e-10f;
-            const float dalpha = dw * Ti - (float)suffix / keep;
-            const float dsigma = dalpha * delta * e;                        // d alpha / d sigma = delta exp(-sigma delta)
-            const float sig = x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));   // softplus'
-            T.dx[idx] = (x == -INFINITY) ? 0.0f : dsigma * sig;
-            suffix += (double)((dw * alpha) * Ti);           // autograd's order: dL/dT_j = dL/dw_j alpha_j, then times T_j
+            for (int ch = 0; ch < 3; ++ch) rgb[ch] += w * T.c[idx * 3 + ch];
         }
     }
-    // block sum of the squared residuals -> one double atomic per wave
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        acc += __shfl_xor(acc, d);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) rgb[ch] += __shfl_xor(rgb[ch], d);
+    }
+    double sq = 0.0;
+    float G[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float pre = rgb[ch];
+        if (A.white_bg) pre = pre + (1.0f - acc);
+        const float out = fminf(fmaxf(pre, 0.0f), 1.0f);
+        const float res = out - T.target[r * 3 + ch];
+        if (live && seg == 0) sq += (double)(res * res);
+        G[ch] = (pre >= 0.0f && pre <= 1.0f) ? 2.0f * res * T.inv_count : 0.0f;      // clamp passes the gradient on [0,1]
+        if (live && seg == 0) T.G[r * 3 + ch] = G[ch];
+    }
+    const float gbg = (G[0] + G[1] + G[2]) * bg;
+    const float tmin = ray_tmin(A, r);
+    const float jit = A.jitter ? A.jitter[r] : 0.0f;
+    double carry = 0.0;                                       // sum of the terms of all steps above the current block
+    for (int i0 = ((A.S - 1) / 16) * 16; i0 >= 0; i0 -= 16) {
+        const int i = i0 + seg;
+        const bool inb = i < A.S;
+        const int64_t idx = (int64_t)(inb ? i : 0) * A.n + r;
+        const float x = inb ? T.xs[idx] : -INFINITY;
+        const float z = tmin + A.step * ((float)i + jit);
+        const float zn = tmin + A.step * ((float)(i + 1) + jit);
+        const float delta = ((i < A.S - 1) ? (zn - z) : 0.0f) * A.dscale;
+        const float e = expf(-softplus_pre(x) * delta);
+        const float alpha = 1.0f - e;
+        const float Ti = inb ? T.dx[idx] : 0.0f;
+        const float w = inb ? T.w[idx] : 0.0f;
+        float dw = -gbg;
+        if (w > A.thr) dw += G[0] * T.c[idx * 3] + G[1] * T.c[idx * 3 + 1] + G[2] * T.c[idx * 3 + 2];
+        const double term = inb ? (double)((dw * alpha) * Ti) : 0.0;     // autograd's order: dL/dT_j = dL/dw_j alpha_j, then times T_j
+        double incl = term;                                              // inclusive suffix sum over the row: steps >= seg
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const double o = __shfl_down(incl, d, 16);
+            incl += (seg + d < 16) ? o : 0.0;
+        }
+        const double suffix = carry + (incl - term);
+        const float keep = (1.0f - alpha) + 1e-10f;
+        const float dalpha = dw * Ti - (float)suffix / keep;
+        const float dsigma = dalpha * delta * e;                        // d alpha / d sigma = delta exp(-sigma delta)
+        const float sig = x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));   // softplus'
+        if (live && inb) T.dx[idx] = (x == -INFINITY) ? 0.0f : dsigma * sig;
+        carry += __shfl(incl, rl * 16);
+    }
+    // one double atomic per wave for the loss
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) sq += __shfl_xor(sq, s);
-    if ((threadIdx.x & 63) == 0) atomicAdd(T.loss, sq);
+    if (lane == 0) atomicAdd(T.loss, sq);
 }
 
 // ---- 5. colour backward over the active list --------------------------------------------------------------------------------
