@@ -676,38 +676,64 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
     __shared__ float s_bd;
     if (threadIdx.x == 0) s_bd = 0.0f;
     __syncthreads();
+    const int lane = threadIdx.x & 63;
     float bsum = 0.0f;
     const int64_t total = (int64_t)A.S * A.n;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const float dx = T.dx[idx];
-        const bool active = T.w[idx] > A.thr;
-        if (dx == 0.0f && !active) continue;
+    // wave-uniform trip count: the scatter below exchanges values between lanes
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < total; base += stride) {
+        const int64_t idx0 = base + lane;
+        const bool inr = idx0 < total;
+        const int64_t idx = inr ? idx0 : total - 1;
+        float dx = inr ? T.dx[idx] : 0.0f;
+        const bool active = inr && (T.w[idx] > A.thr);
+        const bool work = (dx != 0.0f) | active;
+        if (!__any(work)) continue;
         const int i = (int)(idx / A.n);
         const int64_t r = idx % A.n;
         float t[6], xn[3];
         list_sample_coords(A, r, i, t, xn);
         float dt[6];
         bsum += dx;
+        int didx[3];
+        float dw[3][4];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const Tex &tx = A.dens[p];
             BilG b = bilg_setup(t[2 * p], t[2 * p + 1], tx);
             const float *q = T.q_dens[p] + b.idx;
             const float v00 = q[0], v10 = q[1], v01 = q[tx.stride], v11 = q[tx.stride + 1];
-            float *g = T.d_dens[p] + b.idx;
-            atomicAdd(g, b.w00 * dx);
-            atomicAdd(g + 1, b.w10 * dx);
-            atomicAdd(g + tx.stride, b.w01 * dx);
-            atomicAdd(g + tx.stride + 1, b.w11 * dx);
+            didx[p] = b.idx;
+            dw[p][0] = b.w00 * dx; dw[p][1] = b.w10 * dx; dw[p][2] = b.w01 * dx; dw[p][3] = b.w11 * dx;
             dt[2 * p] = dx * (b.wy0 * (v10 - v00) + b.wy1 * (v11 - v01)) * b.sx;
             dt[2 * p + 1] = dx * (b.wx0 * (v01 - v00) + b.wx1 * (v11 - v10)) * b.sy;
+        }
+        // density-gradient images: the two taps of a row are consecutive floats -> lane pairs write them together
+        // (32 samples x 2 floats per instruction: half as many cache lines per atomic instruction)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int strd = A.dens[p].stride;
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int src = half * 32 + (lane >> 1), e = lane & 1;
+                    const int ii = __shfl(didx[p], src);
+                    const float va = __shfl(dw[p][2 * row], src), vb = __shfl(dw[p][2 * row + 1], src);
+                    const float val = e ? vb : va;
+                    if (val != 0.0f) atomicAdd(T.d_dens[p] + (size_t)ii + (size_t)row * strd + e, val);
+                }
+            }
         }
         if (A.mode) {
             if (active) {
                 const float *dc = T.dt + idx * 6;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) dt[k] += dc[k];
+            }
+            if (!work) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) dt[k] = 0.0f;
             }
             // t_xy = ((x+dxy0)+dxz0, (y+dxy1)+dyz0), t_yz = ((y+dyz0)+dxy1, (z+dyz1)+dxz1), t_xz = ((x+dxz0)+dxy0, (z+dxz1)+dyz1)
             const float dg[3][2] = {{dt[0] + dt[4], dt[1] + dt[2]}, {dt[2] + dt[1], dt[3] + dt[5]}, {dt[4] + dt[0], dt[5] + dt[3]}};
@@ -716,20 +742,26 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
             for (int p = 0; p < 3; ++p) {
                 const Tex &tx = A.gau[p];
                 Bil b = bil_setup(u[p], v[p], tx);
-                float *g = T.g_gau[p] + (size_t)b.idx * 2;
+                const float wt[4] = {b.w00, b.w10, b.w01, b.w11};
+                // a row of the cell is 4 consecutive floats (2 texels x 2 channels): 16 samples x 4 floats per instruction
 #pragma unroll
-                for (int ch = 0; ch < 2; ++ch) {
-                    atomicAdd(g + ch, b.w00 * dg[p][ch]);
-                    atomicAdd(g + 2 + ch, b.w10 * dg[p][ch]);
-                    atomicAdd(g + (size_t)tx.stride * 2 + ch, b.w01 * dg[p][ch]);
-                    atomicAdd(g + (size_t)tx.stride * 2 + 2 + ch, b.w11 * dg[p][ch]);
+                for (int row = 0; row < 2; ++row) {
+#pragma unroll
+                    for (int sq = 0; sq < 4; ++sq) {
+                        const int src = sq * 16 + (lane >> 2), e = lane & 3;
+                        const int ii = __shfl(b.idx, src);
+                        const float wa = __shfl(wt[2 * row], src), wb = __shfl(wt[2 * row + 1], src);
+                        const float d0 = __shfl(dg[p][0], src), d1 = __shfl(dg[p][1], src);
+                        const float val = (e < 2 ? wa : wb) * ((e & 1) ? d1 : d0);
+                        if (val != 0.0f) atomicAdd(T.g_gau[p] + ((size_t)ii + (size_t)row * tx.stride) * 2 + e, val);
+                    }
                 }
             }
         }
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) bsum += __shfl_xor(bsum, s);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&s_bd, bsum);
+    if (lane == 0) atomicAdd(&s_bd, bsum);
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(T.g_bd, s_bd);
 }
