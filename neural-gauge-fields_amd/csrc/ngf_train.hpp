@@ -266,33 +266,31 @@ __global__ void __launch_bounds__(1024) train_prefix_kernel(const int32_t *count
 // v_mfma_f32_16x16x4_f32: lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; it receives D[i = 4(l>>4)+r][j = l&15].
 //   TRANS = false: Wm[m][k] = W[m*ldw + k] (forward, nn.Linear weight [out,in]);  TRANS = true: Wm[m][k] = W[k*ldw + m]
 //   ACT: 0 none, 1 relu, 2 = multiply by (mask[m][n] > 0)   (the relu backward)
-template <bool TRANS, int ACT, int K, int KVALID, int OUT_T = 0>      // OUT_T > 0: out[sample][row] with row stride OUT_T
-__device__ __forceinline__ void dense16(const float *__restrict__ W, int ldw, int M, int Mvalid, const float *__restrict__ bias, const float *in,
+template <bool TRANS, int ACT, int M, int K, int KVALID, int OUT_T = 0>      // OUT_T > 0: out[sample][row] with row stride OUT_T
+__device__ __forceinline__ void dense16(const float *__restrict__ W, int ldw, int Mvalid, const float *__restrict__ bias, const float *in,
                                         float *out, const float *mask, int lane)
 {
-    constexpr int KS = K / 4;                   // MFMA k-steps per output row block
-    constexpr int CH = KS > 20 ? KS / 2 : KS;   // operands fetched ahead of the MFMAs (<= 20 global + 20 LDS reads in flight)
-    static_assert(KS % CH == 0, "k-steps must split evenly");
+    constexpr int KS = K / 4;                   // MFMA k-steps per 16-row block
     const int n = lane & 15, q = lane >> 4;
-    for (int mb = 0; mb < M; mb += 16) {
-        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-        const int m = mb + n;                  // the A row this lane supplies
+    // the B operands (this lane's sample, k = 4j + q) are the same for every row block: read the tile once
+    float b[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) b[j] = in[(4 * j + q) * 16 + n];
+    auto load_a = [&](int mb, float (&a)[KS]) {
+        const int m = mb + n;                   // the A row this lane supplies
         const bool mok = m < Mvalid;
 #pragma unroll
-        for (int c0 = 0; c0 < KS; c0 += CH) {
-            // all operands of this chunk first (independent loads: one latency), then the MFMAs back to back
-            float a[CH], b[CH];
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int k = 4 * (c0 + j) + q;
-                const bool ok = mok && (KVALID == K || k < KVALID);
-                const size_t off = TRANS ? (size_t)k * ldw + m : (size_t)m * ldw + k;
-                a[j] = ok ? W[off] : 0.0f;
-                b[j] = in[k * 16 + n];
-            }
-#pragma unroll
-            for (int j = 0; j < CH; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+        for (int j = 0; j < KS; ++j) {
+            const int k = 4 * j + q;
+            const bool ok = mok && (KVALID == K || k < KVALID);
+            const int off = TRANS ? k * ldw + m : m * ldw + k;
+            a[j] = ok ? W[off] : 0.0f;
         }
+    };
+    auto block = [&](int mb, const float (&a)[KS]) {
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < KS; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = mb + 4 * q + r;
@@ -302,6 +300,23 @@ __device__ __forceinline__ void dense16(const float *__restrict__ W, int ldw, in
             if (ACT == 2) v = mask[row * 16 + n] > 0.0f ? v : 0.0f;
             if (OUT_T) out[n * OUT_T + row] = v;
             else out[row * 16 + n] = v;
+        }
+    };
+    // software pipeline over the row blocks, two per trip (a real loop: a full unroll hoists every block's loads and spills):
+    // the next block's weights are requested before this block's MFMAs are issued
+    float a0[KS], a1[KS];
+    load_a(0, a0);
+#pragma unroll 1
+    for (int mb = 0; mb < M; mb += 32) {
+        if (mb + 16 < M) load_a(mb + 16, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        block(mb, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (mb + 16 < M) {
+            if (mb + 32 < M) load_a(mb + 32, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            block(mb + 16, a1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -378,11 +393,11 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
             for (int j = 0; j < 4; ++j) Ut[(kFeat + 4 * q + j) * 16 + n] = live ? v[4 * q + j] : 0.0f;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<false, 0, kFeat, kFeat>(T.basis, kFeat, kFeat, kFeat, nullptr, Ft, Ut, nullptr, lane);          // g = basis . f
+        dense16<false, 0, kFeat, kFeat, kFeat>(T.basis, kFeat, kFeat, nullptr, Ft, Ut, nullptr, lane);          // g = basis . f
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<false, 1, kIn1Pad, kIn1>(T.w1, kIn1, 64, 64, T.b1, Ut, H1t, nullptr, lane);
+        dense16<false, 1, 64, kIn1Pad, kIn1>(T.w1, kIn1, 64, T.b1, Ut, H1t, nullptr, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<false, 1, 64, 64>(T.w2, 64, 64, 64, T.b2, H1t, H2t, nullptr, lane);
+        dense16<false, 1, 64, 64, 64>(T.w2, 64, 64, T.b2, H1t, H2t, nullptr, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // layer 3 + sigmoid on the VALU: lane (q, n) sums its 16 hidden units, then the four quarters meet
         float c[3];
@@ -526,11 +541,11 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const
             D2t[k * 16 + n] = H2t[k * 16 + n] > 0.0f ? s : 0.0f;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<true, 2, 64, 64>(T.w2, 64, 64, 64, nullptr, D2t, D1t, H1t, lane);                 // d1 = (W2^T d2) * [h1 > 0]
+        dense16<true, 2, 64, 64, 64>(T.w2, 64, 64, nullptr, D2t, D1t, H1t, lane);                 // d1 = (W2^T d2) * [h1 > 0]
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<true, 0, 64, 64>(T.w1, kIn1, kFeat, kFeat, nullptr, D1t, DGt, nullptr, lane);     // dg = (W1^T d1)[:144]
+        dense16<true, 0, kFeat, 64, 64>(T.w1, kIn1, kFeat, nullptr, D1t, DGt, nullptr, lane);     // dg = (W1^T d1)[:144]
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<true, 0, kFeat, kFeat, kDfStride>(T.basis, kFeat, kFeat, kFeat, nullptr, DGt, DFt, nullptr, lane);   // df = basis^T dg
+        dense16<true, 0, kFeat, kFeat, kFeat, kDfStride>(T.basis, kFeat, kFeat, nullptr, DGt, DFt, nullptr, lane);   // df = basis^T dg
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // rows for the weight-gradient GEMMs
         if (live && q == 0) {
