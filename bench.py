@@ -338,6 +338,38 @@ def main():
                                                        "ssim_device_minus_host": run()["ssim"] - s_host}
             except Exception as ex:
                 extras["eval_output_stage_800x800"] = {"error": repr(ex)}
+            # one training iteration at the reference's batch shape: 4096 random rays of the frame, the model's own
+            # nSamples, gauge on; the CPU leg is ONE forward+backward through autograd of the eager port (oracle/train.py)
+            try:
+                from ngf_amd import train as ntrain
+                ft, gt_, pt_, st_ = build_field("triplane", args.preset, device, False, False)
+                Str = int(ft.nSamples)
+                pick = (synth.hash_uniform(9, 1, (4096,)) * np.float32(rays_np.shape[0])).astype(np.int64)
+                tr_rays = torch.from_numpy(rays_np[pick]).to(device)
+                tr_rgb = torch.from_numpy(synth.hash_uniform(9, 2, (4096, 3))).to(device)
+                trn = ntrain.Trainer(ft, batch_size=4096, max_samples=Str)
+                for it in range(3):
+                    trn.step(tr_rays, tr_rgb, it, N_samples=Str)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for it in range(10):
+                    trn.step(tr_rays, tr_rgb, 3 + it, N_samples=Str)
+                torch.cuda.synchronize(device)
+                it_ms = (time.perf_counter() - t0) / 10 * 1e3
+                tr_extra = {"ms_per_iteration": it_ms, "iterations_per_s": 1e3 / it_ms, "batch_rays": 4096, "samples_per_ray": Str,
+                            "active_samples": trn.last_active, "scratch_GiB": trn.scratch_bytes() / 2 ** 30}
+                if args.cpu_seconds > 0:
+                    from oracle import train as otrain
+                    orc = otrain.EagerTrainer(pt_, gt_["aabb"], st_, gt_["near_far"], float(gt_["distance_scale"]), float(gt_["thr"]))
+                    t0 = time.perf_counter()
+                    orc.gradients(tr_rays.cpu(), tr_rgb.cpu(), Str, torch.rand(4096), True, 5)
+                    tr_extra["cpu_port_forward_backward_s"] = time.perf_counter() - t0
+                    tr_extra["cpu_threads"] = torch.get_num_threads()
+                extras["train_step_R1"] = tr_extra
+                trn.release()
+                ft.release()
+            except Exception as ex:
+                extras["train_step_R1"] = {"error": repr(ex)}
             result["extras"] = extras
     if dist_on:
         import torch.distributed as dist
