@@ -147,6 +147,11 @@ int ngf_eval_ssim(const float *img0, const float *img1, int32_t H, int32_t W, do
                   double filter_sigma, double k1, double k2, double *mean_out, double *map_out, void *workspace,
                   void *hip_stream);
 
+/* Replaces: F.interpolate(plane, size=(Ho,Wo), mode='bilinear', align_corners=True) in TriPlane.up_sampling
+ * (TriPlane/models/Field.py:108-114): src [C,Hi,Wi] -> dst [C,Ho,Wo], both device float32. */
+int ngf_resize_bilinear(const float *src, int32_t C, int32_t Hi, int32_t Wi, float *dst, int32_t Ho, int32_t Wo,
+                        void *hip_stream);
+
 /* ---- one TriPlane training step: TriPlane/main.py:264-299 ----------------------------
  * Replaces, per iteration: field(rays_train, is_train=True, ...) (FieldBase.py:251-312), rgb MSE (main.py:281),
  * + L1_reg_weight * density_L1() (main.py:288-291, Field.py:149-152), total_loss.backward(), optimizer.step() of

@@ -186,4 +186,24 @@ __global__ void __launch_bounds__(kEvalThreads) ssim_horizontal_kernel(const Ssi
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
+// F.interpolate(mode='bilinear', align_corners=True) of an NCHW tensor (TriPlane.up_sampling, Field.py:108-114):
+// ATen upsample_bilinear2d: src = dst * (in-1)/(out-1); the +1 neighbour is dropped on the last row/column.
+__global__ void __launch_bounds__(kEvalThreads) resize_bilinear_kernel(const float *__restrict__ src, int C, int Hi, int Wi, float *__restrict__ dst,
+                                                                       int Ho, int Wo)
+{
+    const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.0f;
+    const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.0f;
+    const int64_t total = (int64_t)C * Ho * Wo;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho), c = (int)(i / ((int64_t)Wo * Ho));
+        const float fy = sh * (float)y, fx = sw * (float)x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int yp = y0 < Hi - 1 ? 1 : 0, xp = x0 < Wi - 1 ? 1 : 0;
+        const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1, lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+        const float *p = src + ((int64_t)c * Hi + y0) * Wi + x0;
+        dst[i] = ly0 * (lx0 * p[0] + lx1 * p[xp]) + ly1 * (lx0 * p[(int64_t)yp * Wi] + lx1 * p[(int64_t)yp * Wi + xp]);
+    }
+}
+
 }  // namespace ngf

@@ -650,6 +650,15 @@ extern "C" int ngf_eval_ssim(const float *img0, const float *img1, int32_t H, in
     return NGF_OK;
 }
 
+extern "C" int ngf_resize_bilinear(const float *src, int32_t C, int32_t Hi, int32_t Wi, float *dst, int32_t Ho, int32_t Wo, void *hip_stream)
+{
+    if (!src || !dst || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return fail(NGF_E_ARG, "ngf_resize_bilinear: bad argument");
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(eval_grid((int64_t)C * Ho * Wo)), dim3(kEvalThreads), 0, (hipStream_t)hip_stream, src, C, Hi, Wi, dst,
+                       Ho, Wo);
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
 // ================================ training step ============================================================
 enum { TP_PLANE = 0, TP_GAUGE = 3, TP_DENS_W = 6, TP_DENS_B = 7, TP_BASIS = 8, TP_W1 = 9, TP_B1 = 10, TP_W2 = 11, TP_B2 = 12, TP_W3 = 13,
        TP_B3 = 14, TP_COUNT = 15 };

@@ -37,6 +37,43 @@ class TriPlane(Base):
                 {'params': self.gauge_xy, 'lr': lr_init_network * 0.1}, {'params': self.gauge_yz, 'lr': lr_init_network * 0.1},
                 {'params': self.gauge_xz, 'lr': lr_init_network * 0.1}]
 
+    @torch.no_grad()
+    def up_sampling(self, res):
+        """Field.py:108-114: the three planes are resampled to the new grid (bilinear, align_corners=True) on the device
+        through ngf_resize_bilinear; gauge planes keep their size.  A Trainer built on the old tensors must be rebuilt."""
+        import ctypes as C
+        L = _lib.lib()
+        for name, (h, w) in (('plane_xy', (res[1], res[0])), ('plane_yz', (res[2], res[1])), ('plane_xz', (res[2], res[0]))):
+            old = getattr(self, name).data.contiguous()
+            if not old.is_cuda:
+                raise RuntimeError("up_sampling runs on the GPU only; there is no CPU path")
+            new = torch.empty((1, old.shape[1], int(h), int(w)), device=old.device, dtype=torch.float32)
+            with torch.cuda.device(old.device):
+                _lib.check(L.ngf_resize_bilinear(old.data_ptr(), old.shape[1], old.shape[2], old.shape[3], new.data_ptr(), int(h), int(w),
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            setattr(self, name, torch.nn.Parameter(new))
+        self.init_para(res)
+
+    @torch.no_grad()
+    def shrink(self, new_aabb):
+        """Field.py:117-132: crop the planes to the grid cells covering new_aabb (pure slicing), then init_para."""
+        xyz_min, xyz_max = new_aabb
+        aabb0 = self.aabb[0].to(self.units.device)
+        t_l = (xyz_min.to(self.units.device) - aabb0) / self.units
+        b_r = (xyz_max.to(self.units.device) - aabb0) / self.units
+        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
+        b_r = torch.stack([b_r, self.gridSize]).amin(0)
+        self.plane_xy = torch.nn.Parameter(self.plane_xy.data[..., t_l[1]:b_r[1], t_l[0]:b_r[0]].contiguous())
+        self.plane_yz = torch.nn.Parameter(self.plane_yz.data[..., t_l[2]:b_r[2], t_l[1]:b_r[1]].contiguous())
+        self.plane_xz = torch.nn.Parameter(self.plane_xz.data[..., t_l[2]:b_r[2], t_l[0]:b_r[0]].contiguous())
+        newSize = b_r - t_l
+        self.aabb = torch.stack([xyz_min, xyz_max]) if not torch.is_tensor(new_aabb) else new_aabb
+        self.init_para((int(newSize[0]), int(newSize[1]), int(newSize[2])))
+
+    def density_L1(self):
+        """Field.py:149-152 (value only; its gradient is fused into the Adam kernel of ngf_amd.train.Trainer)."""
+        return torch.mean(torch.abs(self.plane_xy)) + torch.mean(torch.abs(self.plane_yz)) + torch.mean(torch.abs(self.plane_xz))
+
     def _fill_desc(self, d, dp):
         for k, name in enumerate(('gauge_xy', 'gauge_yz', 'gauge_xz')):
             g = getattr(self, name)

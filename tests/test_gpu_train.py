@@ -115,3 +115,33 @@ def test_gauge_off_before_gauge_start():
     orc = otrain.EagerTrainer(params, g["aabb"], float(g["stepSize"]), g["near_far"], float(g["distance_scale"]), float(g["thr"]), gauge_start=10)
     grads, _, _, _ = orc.gradients(torch.from_numpy(g["rays"]), torch.from_numpy(g["rgb_train"]), S, torch.from_numpy(g["jitter0"]), True, 0)
     assert grads["gauge_xy"] is None
+
+
+def test_up_sampling_and_shrink_match_aten():
+    """TriPlane.up_sampling (Field.py:108-114) against F.interpolate on the CPU (the reference's arithmetic), shrink
+    (Field.py:117-132) against the same slicing of the same tensors; the resized field renders and trains."""
+    import torch.nn.functional as F
+    g, params = load_train_case("train_r1")
+    f = field_for_case(g, params, None)
+    old = {k: f.state_dict()[k].cpu() for k in ("plane_xy", "plane_yz", "plane_xz")}
+    res = [19, 16, 13]
+    f.up_sampling(res)
+    for name, size in (("plane_xy", (res[1], res[0])), ("plane_yz", (res[2], res[1])), ("plane_xz", (res[2], res[0]))):
+        want = F.interpolate(old[name], size=size, mode="bilinear", align_corners=True)
+        got = getattr(f, name).detach().cpu()
+        assert got.shape == want.shape and (got - want).abs().max().item() < 2e-6, name
+    assert [int(v) for v in f.gridSize] == res
+    rays = torch.from_numpy(g["rays"]).cuda()
+    assert torch.isfinite(f(rays, N_samples=32, iteration=30001)["rgb_map"]).all()
+    up = {k: getattr(f, k).detach().clone() for k in old}
+    new_aabb = torch.tensor([[-1.0, -0.9, -1.1], [1.2, 1.0, 0.8]])
+    units, aabb0, grid = f.units.cpu(), f.aabb[0].cpu(), f.gridSize.cpu()
+    t_l = torch.round(torch.round((new_aabb[0] - aabb0) / units)).long()
+    b_r = torch.stack([torch.round((new_aabb[1] - aabb0) / units).long() + 1, grid]).amin(0)
+    f.shrink(new_aabb)
+    assert torch.equal(f.plane_xy.detach(), up["plane_xy"][..., t_l[1]:b_r[1], t_l[0]:b_r[0]])
+    assert torch.equal(f.plane_xz.detach(), up["plane_xz"][..., t_l[2]:b_r[2], t_l[0]:b_r[0]])
+    assert [int(v) for v in f.gridSize] == [int(v) for v in (b_r - t_l)]
+    tr = train.Trainer(f, batch_size=rays.shape[0], max_samples=32)
+    loss = tr.step(rays, torch.from_numpy(g["rgb_train"]).cuda(), 0, N_samples=32)
+    assert np.isfinite(loss.item())
