@@ -670,6 +670,7 @@ struct ngf_trainer {
     float *tex_d[3] = {}, *tex_a[3] = {}, *tex_g[3] = {};
     float *g_d[3] = {}, *g_a[3] = {}, *g_g[3] = {};
     float *q_d[3] = {}, *d_d[3] = {};        // wd-projected density planes, scalar density-gradient images
+    float *fwd_image = nullptr, *bwd_image = nullptr;      // LDS images of the colour MLP (train_fold_kernel)
     float *g_dense[TP_COUNT] = {};          // reference-layout gradient buffers of the MLP parameters (index TP_*)
     int64_t dense_n[TP_COUNT] = {};
     uint8_t *mask = nullptr;
@@ -767,8 +768,9 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
     if ((rc = tr_alloc(t, &T.xs, cap)) || (rc = tr_alloc(t, &T.w, cap)) || (rc = tr_alloc(t, &T.dx, cap)) || (rc = tr_alloc(t, &T.c, cap * 3)) ||
         (rc = tr_alloc(t, &T.dt, cap * 6)) || (rc = tr_alloc(t, &T.G, (size_t)d->max_rays * 3)) || (rc = tr_alloc(t, &T.count, (size_t)d->max_rays)) ||
         (rc = tr_alloc(t, &T.offset, (size_t)d->max_rays + 1)) || (rc = tr_alloc(t, &T.list, cap * 2)) || (rc = tr_alloc(t, &T.list_w, cap)) ||
-        (rc = tr_alloc(t, &T.F, ch * 144)) || (rc = tr_alloc(t, &T.U, ch * 160)) || (rc = tr_alloc(t, &T.H1, ch * 64)) || (rc = tr_alloc(t, &T.H2, ch * 64)) ||
-        (rc = tr_alloc(t, &T.D3, ch * 16)) || (rc = tr_alloc(t, &T.D2, ch * 64)) || (rc = tr_alloc(t, &T.D1, ch * 64)) || (rc = tr_alloc(t, &T.DG, ch * 144)) ||
+        (rc = tr_alloc(t, &T.F, ch * 144)) || (rc = tr_alloc(t, &T.V, ch * 16)) || (rc = tr_alloc(t, &T.H1, ch * 64)) || (rc = tr_alloc(t, &T.H2, ch * 64)) ||
+        (rc = tr_alloc(t, &T.D3, ch * 16)) || (rc = tr_alloc(t, &T.D2, ch * 64)) || (rc = tr_alloc(t, &T.D1, ch * 64)) || (rc = tr_alloc(t, &T.M, (size_t)64 * 144)) ||
+        (rc = tr_alloc(t, &t->fwd_image, (size_t)kFwdImage)) || (rc = tr_alloc(t, &t->bwd_image, (size_t)kBwdImage)) ||
         (rc = tr_alloc(t, &T.loss, (size_t)2)))
         return bail(rc);
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "trainer setup failed: %s", hipGetErrorString(hipGetLastError())));
@@ -812,6 +814,9 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
     }
     for (int k = TP_DENS_W; k < TP_COUNT; ++k) HIP_TRY(hipMemsetAsync(t->g_dense[k], 0, (size_t)t->dense_n[k] * sizeof(float), st));
     HIP_TRY(hipMemsetAsync(T.loss, 0, 2 * sizeof(double), st));
+    HIP_TRY(hipMemsetAsync(T.M, 0, (size_t)64 * 144 * sizeof(float), st));
+    T.fwd_image = t->fwd_image; T.bwd_image = t->bwd_image;
+    hipLaunchKernelGGL(train_fold_kernel, dim3(48), dim3(256), 0, st, T, t->fwd_image, t->bwd_image);
 
     const int64_t pairs = n * n_samples;
     hipLaunchKernelGGL(train_density_kernel, dim3(tr_grid(t, pairs, 256)), dim3(256), 0, st, T);
@@ -824,7 +829,10 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
     if (n_active_host) *n_active_host = n_active;
     hipLaunchKernelGGL(train_scan_kernel, dim3(ray_blocks), dim3(64), 0, st, T, 1);
 
-    const size_t lds_f = (size_t)kTrainWaves * kFwdTileFloats * sizeof(float), lds_b = (size_t)kTrainWaves * kBwdTileFloats * sizeof(float);
+    const size_t lds_f = (size_t)(((kFwdImage + 3) & ~3) + kTrainWaves * kFwdTileFloats) * sizeof(float),
+                 lds_b = (size_t)(((kBwdImage + 3) & ~3) + kTrainWaves * kBwdTileFloats) * sizeof(float);
+    static_assert((((kFwdImage + 3) & ~3) + kTrainWaves * kFwdTileFloats) * 4 <= 160 * 1024, "colour forward LDS");
+    static_assert((((kBwdImage + 3) & ~3) + kTrainWaves * kBwdTileFloats) * 4 <= 160 * 1024, "colour backward LDS");
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(train_color_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(train_color_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     const bool single = n_active <= t->chunk;
@@ -851,12 +859,14 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         if (splits > 256) splits = 256;
         hipLaunchKernelGGL(xty_kernel, dim3(1 * 4 * splits), dim3(64), 0, st, (const float *)T.D3, 16, (const float *)T.H2, 64, rows, 1, 4, 3, 64, t->g_dense[TP_W3], 64, splits);
         hipLaunchKernelGGL(xty_kernel, dim3(4 * 4 * splits), dim3(64), 0, st, (const float *)T.D2, 64, (const float *)T.H1, 64, rows, 4, 4, 64, 64, t->g_dense[TP_W2], 64, splits);
-        hipLaunchKernelGGL(xty_kernel, dim3(4 * 10 * splits), dim3(64), 0, st, (const float *)T.D1, 64, (const float *)T.U, 160, rows, 4, 10, 64, 159, t->g_dense[TP_W1], 159, splits);
-        hipLaunchKernelGGL(xty_kernel, dim3(9 * 9 * splits), dim3(64), 0, st, (const float *)T.DG, 144, (const float *)T.F, 144, rows, 9, 9, 144, 144, t->g_dense[TP_BASIS], 144, splits);
+        // the 15 view columns of layer 1 directly, the 144 feature columns through M = Delta1^T F (train_unfold_kernel)
+        hipLaunchKernelGGL(xty_kernel, dim3(4 * 1 * splits), dim3(64), 0, st, (const float *)T.D1, 64, (const float *)T.V, 16, rows, 4, 1, 64, 15, t->g_dense[TP_W1] + 144, 159, splits);
+        hipLaunchKernelGGL(xty_kernel, dim3(4 * 9 * splits), dim3(64), 0, st, (const float *)T.D1, 64, (const float *)T.F, 144, rows, 4, 9, 64, 144, T.M, 144, splits);
         hipLaunchKernelGGL(colsum_kernel, dim3((rows + 1023) / 1024), dim3(256), 0, st, (const float *)T.D3, 16, rows, 3, t->g_dense[TP_B3]);
         hipLaunchKernelGGL(colsum_kernel, dim3((rows + 1023) / 1024), dim3(256), 0, st, (const float *)T.D2, 64, rows, 64, t->g_dense[TP_B2]);
         hipLaunchKernelGGL(colsum_kernel, dim3((rows + 1023) / 1024), dim3(256), 0, st, (const float *)T.D1, 64, rows, 64, t->g_dense[TP_B1]);
     }
+    hipLaunchKernelGGL(train_unfold_kernel, dim3(96), dim3(256), 0, st, T, t->g_dense[TP_W1], t->g_dense[TP_BASIS]);
     hipLaunchKernelGGL(train_density_bwd_kernel, dim3(tr_grid(t, pairs, 256)), dim3(256), 0, st, T);
     for (int p = 0; p < 3; ++p) {
         const int64_t tex = (int64_t)(d.plane_h[p] + 2) * (d.plane_w[p] + 2);

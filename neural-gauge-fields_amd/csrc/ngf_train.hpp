@@ -9,19 +9,26 @@
 //                              density fetch -> xs = Linear(48,1) - 10 (pre-softplus), -inf where the sample is invalid
 //   train_scan_kernel          one lane per ray, sequential raw2alpha (FieldBase.py:12-19) over the stored xs: weights,
 //                              active counts (pass 0) and the (ray, step)-ordered active list (pass 1): deterministic
-//   train_color_fwd_kernel     16 active samples per wave pass on v_mfma_f32_16x16x4_f32: 144 colour features, basis,
-//                              [g, view] -> 64 -> 64 -> 3 sigmoid; colours to the dense buffer, activations to HBM rows
+//   train_fold_kernel          W1' = W1[:, :144] . basis and the padded / transposed LDS images of the colour MLP
+//   train_color_fwd_kernel     16 active samples per wave pass on v_mfma_f32_16x16x4_f32: [144 colour features, view] -> 64 ->
+//                              64 -> 3 sigmoid; colours to the dense buffer, activations to HBM rows
 //   train_composite_bwd_kernel one lane per ray: rgb_map, clamp, residual, loss; then d loss / d xs for every sample from
 //                              the closed form of the cumprod backward (two sequential sweeps, no gathers)
 //   train_color_bwd_kernel     the data gradients of the colour MLP with the TRANSPOSED weights on the matrix pipe, the
 //                              feature gradients scattered into the packed colour planes (float atomics) and d loss / d t
-//   xty_kernel                 weight gradients as sample-reduction GEMMs  dW = Delta^T . In  (MFMA, split over samples)
+//   xty_kernel                 weight gradients as sample-reduction GEMMs  dW = Delta^T . In  (MFMA, split over samples);
+//   train_unfold_kernel        M -> d W1[:, :144], d basis
 //   train_density_bwd_kernel   every valid sample: ONE scalar per tap into the density-gradient images (the decoder is linear:
 //                              rank-one gradient, expanded by train_density_finish_kernel), d loss / d t -> gauge planes
 //   adam_*_kernel              torch.optim.Adam's update; planes read their gradient from the packed layout and add the L1 term
 //
-// Matrix operands are read straight from the reference-layout weight tensors (150 KB, L2 resident): no per-step weight
-// packing.  Tiles of 16 samples live in wave-private LDS as [k][16] so that a lane's MFMA B operand is in[k][sample].
+// basis has neither bias nor activation (networks.py:17,26), so layer 1 acts on the features through W1' = W1[:, :144] . basis
+// (64 x 144).  train_fold_kernel rebuilds W1' from the current weights every step (float64 accumulate); forward and data
+// gradients then need ONE 160-wide layer instead of a 144x144 product plus a 160-wide layer, and by the chain rule
+//     M = Delta1^T F (64 x 144, the only big sample reduction)   ->   dW1[:, :144] = M . basis^T ,  d basis = W1[:, :144]^T . M
+// so g = basis . f is never materialised.  W1', W2 (and their transposes for the backward) are padded to bank-conflict-free
+// strides and live in LDS for the whole kernel (57-61 KB per workgroup); tiles of 16 samples live in wave-private LDS as
+// [k][16] so that a lane's MFMA B operand is in[k][sample].
 #pragma once
 #include "ngf_device.hpp"
 #include "ngf_render.hpp"
@@ -31,6 +38,12 @@ namespace ngf {
 constexpr int kTrainWaves = 4;                 // waves per workgroup in the MFMA kernels
 constexpr int kFeat = 144;                     // colour features (3 planes x 48)
 constexpr int kIn1 = 159, kIn1Pad = 160;       // [g(144), view(15)] (+1 zero pad)
+constexpr int kLd1 = 164, kLd2 = 68;           // LDS row strides == 4 (mod 32): lane (row n, k = 4j+q) -> bank 4n+q, two lanes per bank
+// forward image : W1' [64][kLd1] (cols 144..158 = W1's view columns, 159 = 0) | W2 [64][kLd2] | W3 [3][64] | b1 [64] | b2 [64] | b3 [4]
+// backward image: W1'^T [144][kLd2] | W2^T [64][kLd2] | W3 [3][64]
+constexpr int kFwdW1 = 0, kFwdW2 = kFwdW1 + 64 * kLd1, kFwdW3 = kFwdW2 + 64 * kLd2, kFwdB1 = kFwdW3 + 192, kFwdB2 = kFwdB1 + 64, kFwdB3 = kFwdB2 + 64,
+              kFwdImage = kFwdB3 + 4;
+constexpr int kBwdW1T = 0, kBwdW2T = kBwdW1T + kFeat * kLd2, kBwdW3 = kBwdW2T + 64 * kLd2, kBwdImage = kBwdW3 + 192;
 
 struct TrainArgs {
     RenderArgs R;            // rays, jitter, n, S, mode (= gauge on), geometry, packed textures, mask, white_bg
@@ -51,10 +64,12 @@ struct TrainArgs {
     int32_t *list;           // [cap,2] (ray, step) in (ray, step) order
     float *list_w;           // [cap]
     // activations of the current chunk, sample-major rows
-    float *F, *U, *H1, *H2, *D3, *D2, *D1, *DG;     // [chunk, 144|160|64|64|16|64|64|144]
+    float *F, *V, *H1, *H2, *D3, *D2, *D1;          // [chunk, 144|16|64|64|16|64|64]  (V = the 15 view inputs + 0)
+    const float *fwd_image, *bwd_image;             // LDS images built by train_fold_kernel
+    float *M;                                       // [64,144] = Delta1^T F, accumulated over the chunks
     double *loss;            // [2]: sum of squared residuals, (unused)
     int32_t chunk_base, chunk_n;      // the slice of the active list this launch works on
-    int32_t store;           // colour forward: also write F, U, H1, H2 rows of the chunk
+    int32_t store;           // colour forward: also write F, V, H1, H2 rows of the chunk
     float inv_count;         // 1 / (3 n): the mean of the MSE
 };
 
@@ -350,18 +365,74 @@ __device__ __forceinline__ void list_sample_coords(const RenderArgs &A, int64_t 
     triplane_gauge(A, xn, A.mode, t);
 }
 
-constexpr int kFwdTileFloats = (kFeat + kIn1Pad + 64 + 64) * 16;          // F, U, H1, H2
+constexpr int kFwdTileFloats = (kIn1Pad + 64 + 64) * 16;                  // [F; view], H1, H2
 constexpr int kDfStride = kFeat + 1;                                       // DF is kept sample-major (bank-conflict-free rows)
-constexpr int kBwdTileFloats = (64 + 64 + 64 + 64 + kFeat) * 16 + 16 * kDfStride + 16 * 16;  // H1, H2, D2, D1, DG, DF^T, tap table
+constexpr int kBwdTileFloats = (64 + 64 + 64) * 16 + 16 * kDfStride + 16 * 16;   // H1, H2 (then D1), D2, DF^T, tap table
+
+// ---- per-step weight images -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) train_fold_kernel(const TrainArgs T, float *fwd, float *bwd)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    for (int i = tid; i < 64 * kIn1Pad; i += nth) {                  // W1' and its transpose
+        const int m = i / kIn1Pad, k = i % kIn1Pad;
+        float v = 0.0f;
+        if (k < kFeat) {
+            double s = 0.0;
+            for (int j = 0; j < kFeat; ++j) s += (double)T.w1[m * kIn1 + j] * (double)T.basis[j * kFeat + k];
+            v = (float)s;
+            bwd[kBwdW1T + k * kLd2 + m] = v;
+        } else if (k < kIn1) {
+            v = T.w1[m * kIn1 + k];
+        }
+        fwd[kFwdW1 + m * kLd1 + k] = v;
+    }
+    for (int i = tid; i < 64 * 64; i += nth) {
+        const int m = i / 64, k = i % 64;
+        const float v = T.w2[m * 64 + k];
+        fwd[kFwdW2 + m * kLd2 + k] = v;
+        bwd[kBwdW2T + k * kLd2 + m] = v;
+    }
+    for (int i = tid; i < 192; i += nth) { fwd[kFwdW3 + i] = T.w3[i]; bwd[kBwdW3 + i] = T.w3[i]; }
+    for (int i = tid; i < 64; i += nth) { fwd[kFwdB1 + i] = T.b1[i]; fwd[kFwdB2 + i] = T.b2[i]; }
+    for (int i = tid; i < 4; i += nth) fwd[kFwdB3 + i] = i < 3 ? T.b3[i] : 0.0f;
+    // pad columns (never multiplied by a non-zero operand, but keep them defined)
+    for (int i = tid; i < 64 * (kLd1 - kIn1Pad); i += nth) fwd[kFwdW1 + (i / (kLd1 - kIn1Pad)) * kLd1 + kIn1Pad + i % (kLd1 - kIn1Pad)] = 0.0f;
+    for (int i = tid; i < 64 * (kLd2 - 64); i += nth) {
+        fwd[kFwdW2 + (i / (kLd2 - 64)) * kLd2 + 64 + i % (kLd2 - 64)] = 0.0f;
+        bwd[kBwdW2T + (i / (kLd2 - 64)) * kLd2 + 64 + i % (kLd2 - 64)] = 0.0f;
+    }
+    for (int i = tid; i < kFeat * (kLd2 - 64); i += nth) bwd[kBwdW1T + (i / (kLd2 - 64)) * kLd2 + 64 + i % (kLd2 - 64)] = 0.0f;
+}
+
+// M = Delta1^T F  ->  dW1[:, :144] += M . basis^T ,  d basis += W1[:, :144]^T . M        (chain rule through g = basis . f)
+__global__ void __launch_bounds__(256) train_unfold_kernel(const TrainArgs T, float *g_w1, float *g_basis)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    for (int i = tid; i < 64 * kFeat; i += nth) {
+        const int m = i / kFeat, j = i % kFeat;
+        float s = 0.0f;
+        for (int k = 0; k < kFeat; ++k) s = fmaf(T.M[m * kFeat + k], T.basis[j * kFeat + k], s);
+        g_w1[m * kIn1 + j] += s;
+    }
+    for (int i = tid; i < kFeat * kFeat; i += nth) {
+        const int j = i / kFeat, k = i % kFeat;
+        float s = 0.0f;
+        for (int m = 0; m < 64; ++m) s = fmaf(T.w1[m * kIn1 + j], T.M[m * kFeat + k], s);
+        g_basis[i] += s;
+    }
+}
 
 // ---- 3. colour forward over the active list -------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const TrainArgs T)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RenderArgs &A = T.R;
+    for (int i = threadIdx.x; i < kFwdImage; i += blockDim.x) smem[i] = T.fwd_image[i];
+    __syncthreads();
+    const float *img = smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
-    float *Ft = smem + wave * kFwdTileFloats, *Ut = Ft + kFeat * 16, *H1t = Ut + kIn1Pad * 16, *H2t = H1t + 64 * 16;
+    float *Ft = smem + ((kFwdImage + 3) & ~3) + wave * kFwdTileFloats, *H1t = Ft + kIn1Pad * 16, *H2t = H1t + 64 * 16;
     const int passes = (T.chunk_n + 15) / 16;
     for (int pass = blockIdx.x * kTrainWaves + wave; pass < passes; pass += gridDim.x * kTrainWaves) {
         const int local = pass * 16 + n;
@@ -385,29 +456,28 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
                 for (int e = 0; e < 4; ++e) Ft[(p * 48 + 12 * q + 4 * j + e) * 16 + n] = live ? bil_mix(b, v00[e], v10[e], v01[e], v11[e]) : 0.0f;
             }
         }
-        // the view inputs of layer 1 (networks.py:27-29): rows 144..159 of U
+        // the view inputs of layer 1 (networks.py:27-29): rows 144..159 of the input tile
         {
             float d[3] = {A.rays[r * 6 + 3], A.rays[r * 6 + 4], A.rays[r * 6 + 5]}, v[16];
             view_inputs(d, v);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) Ut[(kFeat + 4 * q + j) * 16 + n] = live ? v[4 * q + j] : 0.0f;
+            for (int j = 0; j < 4; ++j) Ft[(kFeat + 4 * q + j) * 16 + n] = live ? v[4 * q + j] : 0.0f;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<false, 0, kFeat, kFeat, kFeat>(T.basis, kFeat, kFeat, nullptr, Ft, Ut, nullptr, lane);          // g = basis . f
+        dense16<false, 1, 64, kIn1Pad, kIn1Pad>(img + kFwdW1, kLd1, 64, img + kFwdB1, Ft, H1t, nullptr, lane);      // relu(W1' f + W1v view + b1)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<false, 1, 64, kIn1Pad, kIn1>(T.w1, kIn1, 64, T.b1, Ut, H1t, nullptr, lane);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<false, 1, 64, 64, 64>(T.w2, 64, 64, T.b2, H1t, H2t, nullptr, lane);
+        dense16<false, 1, 64, 64, 64>(img + kFwdW2, kLd2, 64, img + kFwdB2, H1t, H2t, nullptr, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // layer 3 + sigmoid on the VALU: lane (q, n) sums its 16 hidden units, then the four quarters meet
         float c[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             float s = 0.0f;
-            for (int k = 0; k < 16; ++k) s = fmaf(T.w3[j * 64 + 16 * q + k], H2t[(16 * q + k) * 16 + n], s);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s = fmaf(img[kFwdW3 + j * 64 + 16 * q + k], H2t[(16 * q + k) * 16 + n], s);
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
-            s += T.b3[j];
+            s += img[kFwdB3 + j];
             c[j] = 1.0f / (1.0f + expf(-s));
         }
         if (live && q == 0) {
@@ -417,7 +487,7 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
         if (T.store) {
             const int64_t row = live ? local : 0;
             tile_to_rows(Ft, kFeat, T.F, kFeat, row, live, lane);
-            tile_to_rows(Ut, kIn1Pad, T.U, kIn1Pad, row, live, lane);
+            tile_to_rows(Ft + kFeat * 16, 16, T.V, 16, row, live, lane);
             tile_to_rows(H1t, 64, T.H1, 64, row, live, lane);
             tile_to_rows(H2t, 64, T.H2, 64, row, live, lane);
         }
@@ -509,10 +579,14 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RenderArgs &A = T.R;
+    for (int i = threadIdx.x; i < kBwdImage; i += blockDim.x) smem[i] = T.bwd_image[i];
+    __syncthreads();
+    const float *img = smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
-    float *H1t = smem + wave * kBwdTileFloats, *H2t = H1t + 64 * 16, *D2t = H2t + 64 * 16, *D1t = D2t + 64 * 16, *DGt = D1t + 64 * 16,
-          *DFt = DGt + kFeat * 16, *tap = DFt + 16 * kDfStride;       // tap[s][p] = {texel index, w00, w10, w01, w11}
+    float *H1t = smem + ((kBwdImage + 3) & ~3) + wave * kBwdTileFloats, *H2t = H1t + 64 * 16, *D2t = H2t + 64 * 16, *DFt = D2t + 64 * 16,
+          *tap = DFt + 16 * kDfStride;       // tap[s][p] = {texel index, w00, w10, w01, w11}
+    float *D1t = H2t;                        // h2 is dead once d2 exists
     const int passes = (T.chunk_n + 15) / 16;
     for (int pass = blockIdx.x * kTrainWaves + wave; pass < passes; pass += gridDim.x * kTrainWaves) {
         const int local = pass * 16 + n;
@@ -537,15 +611,13 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // d2 = (W3^T d3) * [h2 > 0] on the VALU (3 terms per hidden unit)
         for (int k = 16 * q; k < 16 * q + 16; ++k) {
-            float s = T.w3[k] * d3[0] + T.w3[64 + k] * d3[1] + T.w3[128 + k] * d3[2];
+            float s = img[kBwdW3 + k] * d3[0] + img[kBwdW3 + 64 + k] * d3[1] + img[kBwdW3 + 128 + k] * d3[2];
             D2t[k * 16 + n] = H2t[k * 16 + n] > 0.0f ? s : 0.0f;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<true, 2, 64, 64, 64>(T.w2, 64, 64, nullptr, D2t, D1t, H1t, lane);                 // d1 = (W2^T d2) * [h1 > 0]
+        dense16<false, 2, 64, 64, 64>(img + kBwdW2T, kLd2, 64, nullptr, D2t, D1t, H1t, lane);              // d1 = (W2^T d2) * [h1 > 0]
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<true, 0, kFeat, 64, 64>(T.w1, kIn1, kFeat, nullptr, D1t, DGt, nullptr, lane);     // dg = (W1^T d1)[:144]
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<true, 0, kFeat, kFeat, kFeat, kDfStride>(T.basis, kFeat, kFeat, nullptr, DGt, DFt, nullptr, lane);   // df = basis^T dg
+        dense16<false, 0, kFeat, 64, 64, kDfStride>(img + kBwdW1T, kLd2, kFeat, nullptr, D1t, DFt, nullptr, lane);   // df = W1'^T d1
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // rows for the weight-gradient GEMMs
         if (live && q == 0) {
@@ -556,7 +628,6 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const
         }
         tile_to_rows(D2t, 64, T.D2, 64, row, live, lane);
         tile_to_rows(D1t, 64, T.D1, 64, row, live, lane);
-        tile_to_rows(DGt, kFeat, T.DG, kFeat, row, live, lane);
         // d loss / d t through the bilinear cell (lane (q, n): channels 12q..12q+11 of every plane of sample n) and the tap table
         float t[6], xn[3];
         list_sample_coords(A, r, i, t, xn);
