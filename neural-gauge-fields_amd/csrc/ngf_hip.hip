@@ -862,9 +862,9 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         // the 15 view columns of layer 1 directly, the 144 feature columns through M = Delta1^T F (train_unfold_kernel)
         hipLaunchKernelGGL(xty_kernel, dim3(4 * 1 * splits), dim3(64), 0, st, (const float *)T.D1, 64, (const float *)T.V, 16, rows, 4, 1, 64, 15, t->g_dense[TP_W1] + 144, 159, splits);
         hipLaunchKernelGGL(xty_kernel, dim3(4 * 9 * splits), dim3(64), 0, st, (const float *)T.D1, 64, (const float *)T.F, 144, rows, 4, 9, 64, 144, T.M, 144, splits);
-        hipLaunchKernelGGL(colsum_kernel, dim3((rows + 1023) / 1024), dim3(256), 0, st, (const float *)T.D3, 16, rows, 3, t->g_dense[TP_B3]);
-        hipLaunchKernelGGL(colsum_kernel, dim3((rows + 1023) / 1024), dim3(256), 0, st, (const float *)T.D2, 64, rows, 64, t->g_dense[TP_B2]);
-        hipLaunchKernelGGL(colsum_kernel, dim3((rows + 1023) / 1024), dim3(256), 0, st, (const float *)T.D1, 64, rows, 64, t->g_dense[TP_B1]);
+        hipLaunchKernelGGL(colsum_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const float *)T.D3, 16, rows, 3, t->g_dense[TP_B3]);
+        hipLaunchKernelGGL(colsum_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const float *)T.D2, 64, rows, 64, t->g_dense[TP_B2]);
+        hipLaunchKernelGGL(colsum_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const float *)T.D1, 64, rows, 64, t->g_dense[TP_B1]);
     }
     hipLaunchKernelGGL(train_unfold_kernel, dim3(96), dim3(256), 0, st, T, t->g_dense[TP_W1], t->g_dense[TP_BASIS]);
     hipLaunchKernelGGL(train_density_bwd_kernel, dim3(tr_grid(t, pairs, 256)), dim3(256), 0, st, T);

@@ -719,12 +719,12 @@ __global__ void __launch_bounds__(64) xty_kernel(const float *__restrict__ X, in
     }
 }
 
-// bias gradients: column sums of a row-major [rows, ld] matrix (cols <= 64); one block per 1024 rows
+// bias gradients: column sums of a row-major [rows, ld] matrix (cols <= 64); one block per 256 rows
 __global__ void __launch_bounds__(256) colsum_kernel(const float *__restrict__ X, int ld, int rows, int cols, float *out)
 {
     __shared__ float sh[4][64];
     const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int r0 = blockIdx.x * 1024, r1 = min(rows, r0 + 1024);
+    const int r0 = blockIdx.x * 256, r1 = min(rows, r0 + 256);
     float s = 0.0f;
     if (c < cols)
         for (int r = r0 + part; r < r1; r += 4) s += X[(size_t)r * ld + c];

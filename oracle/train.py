@@ -38,8 +38,8 @@ def param_groups(params, lr_init_spatialxyz=0.02, lr_init_network=0.001):
 class EagerTrainer(EagerField):
     """EagerField with differentiable parameters and the training-mode forward."""
 
-    def __init__(self, params, aabb, step, near_far=(2.0, 6.0), distance_scale=25.0, thr=1e-4, gauge_start=0):
-        super().__init__(params, aabb, step, near_far, distance_scale, thr, "triplane")
+    def __init__(self, params, aabb, step, near_far=(2.0, 6.0), distance_scale=25.0, thr=1e-4, gauge_start=0, alpha_mask=None):
+        super().__init__(params, aabb, step, near_far, distance_scale, thr, "triplane", alpha_mask)
         self.p = {k: v.clone().requires_grad_(True) for k, v in self.p.items()}
         self.gauge_start = gauge_start
 
@@ -53,6 +53,13 @@ class EagerTrainer(EagerField):
         pts = o[:, None, :] + d[:, None, :] * z[..., None]
         valid = ~((self.aabb[0] > pts) | (pts > self.aabb[1])).any(-1)
         dists = torch.cat((z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])), -1)
+        if self.mask is not None:                                   # FieldBase.py:261-267
+            vol, maabb, minv = self.mask
+            q = (pts[valid] - maabb[0]) * minv - 1
+            a = torch.nn.functional.grid_sample(vol, q.reshape(1, -1, 1, 1, 3), align_corners=True).reshape(-1)
+            bad = ~valid
+            bad[valid] |= ~(a > 0)
+            valid = ~bad
         n = rays.shape[0]
         sigma = torch.zeros((n, S))
         coords = [torch.zeros((n, S, 2)) for _ in range(3)]

@@ -145,3 +145,40 @@ def test_up_sampling_and_shrink_match_aten():
     tr = train.Trainer(f, batch_size=rays.shape[0], max_samples=32)
     loss = tr.step(rays, torch.from_numpy(g["rgb_train"]).cuda(), 0, N_samples=32)
     assert np.isfinite(loss.item())
+
+
+@pytest.mark.parametrize("name,n_rays,S", [("triplane_r0", 37, 32), ("triplane_r1_mask", 203, 45), ("triplane_r2_nogauge", 1, 7)])
+def test_edge_batches_match_autograd_oracle(name, n_rays, S):
+    """No active sample at all (R0: the colour kernels are not launched), an alpha mask, ragged ray counts (not a multiple
+    of 4 / 16 / 64), a single ray, S not a multiple of 16."""
+    from ngf_amd import synth
+    g, params, step, mask = load_case(name)
+    if name == "triplane_r0":
+        params = dict(params)
+        params["density_decoder.bias"] = np.array([-30.0], np.float32)        # sigma ~ 0 everywhere: nothing is active
+    f = field_for_case(g, params, mask)
+    rays_np = g["rays"][:n_rays]
+    tgt_np = synth.hash_uniform(78, 1, (n_rays, 3))
+    jit_np = synth.hash_uniform(78, 2, (n_rays,))
+    am = None
+    if mask is not None:
+        bits, dhw, maabb = mask
+        vol = np.unpackbits(bits)[: int(np.prod(dhw))].reshape(dhw).astype(np.float32)
+        am = (vol, maabb)
+    orc = otrain.EagerTrainer(params, g["aabb"], step, g["near_far"], float(g["distance_scale"]), float(g["thr"]), alpha_mask=am)
+    grads, rgb_loss, _, aux = orc.gradients(torch.from_numpy(rays_np), torch.from_numpy(tgt_np), S, torch.from_numpy(jit_np), True, 3)
+    tr = train.Trainer(f, batch_size=n_rays, max_samples=S)
+    loss = tr.backward(torch.from_numpy(rays_np), torch.from_numpy(tgt_np), S, white_bg=True, iteration=3, jitter=torch.from_numpy(jit_np))
+    assert tr.last_active == int(aux["active"].sum())
+    if name == "triplane_r0":
+        assert tr.last_active == 0
+    assert abs(loss.item() - rgb_loss) < 2e-6
+    for k, pname in enumerate(train.PARAM_NAMES):
+        got = tr.gradient(k).cpu().numpy()
+        want = grads[pname].numpy() if grads[pname] is not None else np.zeros_like(got)
+        if k < 3:
+            want = want - l1_term(params[pname])
+        scale = max(float(np.abs(want).max()), 1e-12)
+        assert float(np.abs(got - want).max()) <= GRAD_TOL * scale + 1e-12, (pname, float(np.abs(got - want).max()), scale)
+    tr.optimizer_step()
+    assert all(torch.isfinite(p).all() for p in tr.params)
