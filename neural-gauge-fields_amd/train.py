@@ -63,7 +63,8 @@ class Trainer:
     ``max_samples`` size the scratch buffers (args.batch_size and the largest N_samples that will be passed)."""
 
     def __init__(self, field, batch_size=4096, max_samples=None, lr_init=0.02, lr_basis=1e-3, lr_decay_iters=-1,
-                 lr_decay_target_ratio=0.1, n_iters=30000, L1_reg_weight=L1_REG_WEIGHT, betas=(0.9, 0.99), eps=1e-8, chunk_samples=0):
+                 lr_decay_target_ratio=0.1, n_iters=30000, L1_reg_weight=L1_REG_WEIGHT, betas=(0.9, 0.99), eps=1e-8, chunk_samples=0,
+                 frozen=(), state_from=None):
         self.field = field
         self.dev = torch.device(field.device)
         if self.dev.type != "cuda":
@@ -80,6 +81,7 @@ class Trainer:
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.steps = [0] * 15                       # torch.optim.Adam keeps one step counter per parameter
+        self.frozen = set(int(k) for k in frozen)   # parameter indices optimizer_step leaves alone
         # get_optparam_groups (Field.py:34-46)
         net = lr_basis
         self.lr = [lr_init] * 3 + [net * 0.1] * 3 + [net] * 9
@@ -92,6 +94,13 @@ class Trainer:
         self.max_samples = int(max_samples if max_samples is not None else field.nSamples)
         self.chunk_samples = int(chunk_samples)
         self._h = None
+        if state_from is not None:                  # carry the optimiser state of parameters that kept their shape
+            for k in range(15):
+                if state_from.exp_avg[k].shape == self.exp_avg[k].shape:
+                    self.exp_avg[k].copy_(state_from.exp_avg[k])
+                    self.exp_avg_sq[k].copy_(state_from.exp_avg_sq[k])
+                    self.steps[k] = state_from.steps[k]
+            self.lr = list(state_from.lr)
         self._loss = torch.zeros((1,), dtype=torch.float64, device=self.dev)
         self.last_active = 0
         self._build()
@@ -193,7 +202,7 @@ class Trainer:
         with torch.cuda.device(self.dev):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             for k in range(15):
-                if 3 <= k < 6 and not self._gauge_on:
+                if (3 <= k < 6 and not self._gauge_on) or k in self.frozen:
                     continue
                 self.steps[k] += 1
                 _lib.check(self.L.ngf_train_adam(self._h, k, self.steps[k], float(self.lr[k]), float(self.betas[0]), float(self.betas[1]),
@@ -206,3 +215,78 @@ class Trainer:
         loss = self.backward(rays_train, rgb_train, N_samples, white_bg, iteration, jitter, coin)
         self.optimizer_step()
         return loss
+
+
+class SimpleSampler:
+    """TriPlane/utils.py:15-29: epoch-wise random permutation, ``batch`` indices per call."""
+
+    def __init__(self, total, batch):
+        self.total, self.batch, self.curr, self.ids = total, batch, total, None
+
+    def nextids(self):
+        self.curr += self.batch
+        if self.curr + self.batch > self.total:
+            self.ids = torch.LongTensor(np.random.permutation(self.total))
+            self.curr = 0
+        return self.ids[self.curr:self.curr + self.batch]
+
+
+def fit(field, allrays, allrgbs, args, white_bg=True, on_iteration=None):
+    """The optimisation loop of ``train`` (TriPlane/main.py:243-330) on top of ``Trainer`` -- no dataset, logging, checkpoint
+    or visualisation code (those stay with the caller; ``on_iteration(iteration, rgb_loss)`` is the hook for them).
+
+    ``args``: the reference's namespace (``opt.config_parser``): batch_size, n_iters, lr_init, lr_basis, lr_decay_iters,
+    lr_decay_target_ratio, N_voxel_init, N_voxel_final, upsamp_list, update_AlphaMask_list, nSamples, step_ratio.
+    Returns the per-iteration PSNR list.  Two behaviours of the reference that are easy to miss are kept:
+    * after ``shrink`` (first alpha-mask update) the reference's optimizer still holds the pre-shrink plane tensors and is
+      only rebuilt at the next up-sampling, so the cropped planes receive no updates in between -> the plane groups are
+      frozen until the next rebuild here too;
+    * every up-sampling resets the learning rates to their initial values and starts fresh Adam moments (main.py:316-324).
+    """
+    from . import geometry
+    dev = torch.device(field.device)
+    upsamp_list = list(args.upsamp_list or [])
+    mask_list = list(args.update_AlphaMask_list or [])
+    n_voxel_list = (torch.round(torch.exp(torch.linspace(np.log(args.N_voxel_init), np.log(args.N_voxel_final), len(upsamp_list)))).long()).tolist() \
+        if upsamp_list else []
+    reso_cur = [int(v) for v in field.gridSize]
+    nSamples = min(int(args.nSamples), geometry.cal_n_samples(reso_cur, args.step_ratio))
+    allrays, allrgbs = field.filtering_rays(allrays, allrgbs, bbox_only=True)
+    sampler = SimpleSampler(allrays.shape[0], args.batch_size)
+
+    def new_trainer(frozen=(), state_from=None, l1=L1_REG_WEIGHT):
+        return Trainer(field, batch_size=args.batch_size, max_samples=nSamples, lr_init=args.lr_init, lr_basis=args.lr_basis,
+                       lr_decay_iters=args.lr_decay_iters, lr_decay_target_ratio=args.lr_decay_target_ratio, n_iters=args.n_iters,
+                       L1_reg_weight=l1, frozen=frozen, state_from=state_from)
+
+    l1 = L1_REG_WEIGHT
+    trainer = new_trainer()
+    PSNRs = []
+    for iteration in range(args.n_iters):
+        ids = sampler.nextids()
+        rgb_loss = trainer.step(allrays[ids].to(dev), allrgbs[ids].to(dev), iteration, N_samples=nSamples, white_bg=white_bg).item()
+        PSNRs.append(-10.0 * np.log(rgb_loss) / np.log(10.0))
+        if on_iteration is not None:
+            on_iteration(iteration, rgb_loss)
+        if iteration in mask_list:
+            new_aabb = field.updateAlphaMask((256, 256, 256))
+            if iteration == mask_list[0]:
+                field.shrink(new_aabb)
+                l1 = 4e-5                                                    # main.py:306
+                allrays, allrgbs = field.filtering_rays(allrays, allrgbs)
+                sampler = SimpleSampler(allrgbs.shape[0], args.batch_size)
+                old = trainer
+                trainer = new_trainer(frozen=(0, 1, 2), state_from=old, l1=l1)
+                old.release()
+            else:
+                old = trainer
+                trainer = new_trainer(frozen=old.frozen, state_from=old, l1=l1)     # new mask -> new device image
+                old.release()
+        if iteration in upsamp_list:
+            reso_cur = geometry.N_to_reso(n_voxel_list.pop(0), field.aabb.detach().cpu().numpy())
+            nSamples = min(int(args.nSamples), geometry.cal_n_samples(reso_cur, args.step_ratio))
+            field.up_sampling(reso_cur)
+            trainer.release()
+            trainer = new_trainer(l1=l1)                                       # fresh Adam, initial learning rates
+    trainer.release()
+    return PSNRs

@@ -182,3 +182,33 @@ def test_edge_batches_match_autograd_oracle(name, n_rays, S):
         assert float(np.abs(got - want).max()) <= GRAD_TOL * scale + 1e-12, (pname, float(np.abs(got - want).max()), scale)
     tr.optimizer_step()
     assert all(torch.isfinite(p).all() for p in tr.params)
+
+
+def test_fit_loop_with_upsampling_and_alpha_mask():
+    """train.fit = the optimisation loop of TriPlane/main.py:243-330 (sampler, Trainer.step, alpha-mask update + shrink +
+    ray filtering, up-sampling with optimiser reset).  Functional: a fresh field fitted to renders of a seeded one."""
+    import types
+    from ngf_amd import synth, triplane
+    torch.manual_seed(0)
+    np.random.seed(0)
+    g, params, step, mask = load_case("triplane_r1_gauge")
+    teacher = field_for_case(g, params, None)
+    rays = torch.from_numpy(np.concatenate([synth.lookat_rays(48, 48, c2w=synth.lookat_pose(azim_deg=a)) for a in (10.0, 130.0, 250.0)])).cuda()
+    with torch.no_grad():
+        rgbs = teacher(rays, N_samples=64, iteration=30001)["rgb_map"]
+    aabb = torch.tensor(np.asarray(g["aabb"], np.float32))
+    student = triplane.TriPlane(aabb, [20, 20, 20], "cuda", near_far=[2.0, 6.0], alphaMask_thres=1e-4, distance_scale=25.0,
+                                rayMarch_weight_thres=1e-4, step_ratio=0.5, gauge_start=0)
+    with torch.no_grad():
+        student.density_decoder.bias.fill_(10.0)           # start from a visible fog so that colour gradients exist
+    args = types.SimpleNamespace(batch_size=1024, n_iters=90, lr_init=0.02, lr_basis=1e-3, lr_decay_iters=-1, lr_decay_target_ratio=0.1,
+                                 N_voxel_init=20 ** 3, N_voxel_final=32 ** 3, upsamp_list=[30, 60], update_AlphaMask_list=[40, 70],
+                                 nSamples=1e6, step_ratio=0.5)
+    shapes0 = tuple(student.plane_xy.shape)
+    seen = []
+    psnrs = train.fit(student, rays, rgbs, args, white_bg=True, on_iteration=lambda it, loss: seen.append(it))
+    assert len(psnrs) == 90 and seen == list(range(90)) and all(np.isfinite(psnrs))
+    assert np.mean(psnrs[-10:]) > np.mean(psnrs[:10]) + 1.0                # it learns
+    assert tuple(student.plane_xy.shape) != shapes0 and student.alphaMask is not None
+    out = student(rays[:512], N_samples=-1, iteration=30001)
+    assert torch.isfinite(out["rgb_map"]).all()
