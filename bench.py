@@ -230,8 +230,8 @@ def main():
     if mfma_flops is not None:
         tf = mfma_flops / (k_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
-                    "traffic": None if pmc is None or model != "triplane" or args.preset != "R1" else pmc.get("hbm_traffic_bytes_per_launch"),
-                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, profiles/r01_pmc_*.txt",
+                    "traffic": None if pmc is None or model != "triplane" or args.preset != "R1" else pmc.get("hbm_traffic_bytes_per_launch") * n_local / n_total,
+                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE of the full-frame launch (profiles/r01_pmc_*.txt), scaled to this rank's share of the rays",
                     "flops_counted": "executed fp32 MFMA flops of the colour MLP (layer 1 pre-composed with `basis`): the binding "
                                      "resource" + busy_txt,
                     "flops_per_launch": mfma_flops}
