@@ -427,6 +427,16 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     st_active += __popcll(m);
                 }
                 i += NSTEP * K;
+                // Exact early termination.  Every later sample has w <= T.  Once T < thr no later sample can be active (no colour
+                // work), and once T < 2^-26 min(acc, dep / z_max) every later `acc += w` and `dep += w z` is less than half an ulp
+                // of its accumulator, i.e. a no-op in float32: the outputs cannot change by a single bit, so the rest of the ray is
+                // skipped -- wave-uniformly, when all rays of the tile are there (8-ray tiles of adjacent pixels).  Rays behind an
+                // opaque surface stop right after it.  Off for the per-sample debug outputs and with NGF_ABLATE=32.
+                if (!A.dbg_weight && !(A.ablate & 32)) {
+                    const float zmax = tmin + A.step * (float)(S + 1);
+                    const bool done = !live || ((T < A.thr) & (zmax > 0.0f) & (T < 0x1p-26f * fminf(acc, dep / zmax)));
+                    if (!__any(!done)) i = S;
+                }
                 if constexpr (P::PROFILE) prof[0] += __builtin_readcyclecounter() - t_sec;
             } else if (count > 0) {
                 // ---------------- shade up to BATCH queued samples ----------------------------------

@@ -140,6 +140,36 @@ def test_split_march_is_bit_identical(name, monkeypatch):
     assert torch.equal(ref["rgb_map"], got["rgb_map"]) and torch.equal(ref["depth_map"], got["depth_map"])
 
 
+@pytest.mark.parametrize("name,bias", [("triplane_r1_gauge", None), ("triplane_r1_gauge", 25.0), ("triplane_r1_mask", 14.0), ("infoinv_r1_on", None)])
+def test_early_termination_is_bit_identical(name, bias, monkeypatch):
+    """The march stops a tile once, for all its rays, T is below half an ulp of acc and of depth / z_max (and below the
+    colour threshold): no later sample can change an output bit.  Checked against the full march (NGF_ABLATE=32) on the
+    golden scenes, on opaque variants of them (a surface right at the box entry: termination after a few steps) and
+    against the oracle, with and without a white background, S = 160."""
+    g, params, step, mask = load_case(name)
+    if bias is not None:
+        params = dict(params)
+        params["density_decoder.bias"] = np.array([bias], np.float32)
+    f = field_for_case(g, params, mask)
+    orc = oracle_for_case(g, params, step, mask)
+    rays = torch.from_numpy(g["rays"]).cuda()
+    kw = {"infoinv": True} if name.startswith("infoinv") else {"iteration": 30001}
+    for white in (True, False):
+        monkeypatch.setenv("NGF_ABLATE", "32")
+        full = f(rays, N_samples=160, white_bg=white, collect_stats=True, **kw)
+        n_full = int(f.last_stats[0])
+        monkeypatch.delenv("NGF_ABLATE")
+        early = f(rays, N_samples=160, white_bg=white, collect_stats=True, **kw)
+        n_early = int(f.last_stats[0])
+        assert torch.equal(full["rgb_map"], early["rgb_map"]) and torch.equal(full["depth_map"], early["depth_map"])
+        assert n_early <= n_full
+        if bias is not None:
+            assert n_early < 0.5 * n_full              # the opaque scenes really stop early
+        o_rgb, o_depth = orc.render(g["rays"], 160, white_bg=white)
+        np.testing.assert_allclose(early["rgb_map"].cpu().numpy(), o_rgb, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(early["depth_map"].cpu().numpy(), o_depth, rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("model,preset", [("triplane", "R1"), ("triplane", "R2"), ("infoinv", "R1")])
 def test_headline_geometry_chunk(model, preset):
     """4096 rays x 192 samples of the 800x800 frame on 256^2 planes (BASELINE config 2/3 shapes)."""
