@@ -238,7 +238,8 @@ def main():
     else:
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None}
     roofline.update({"kernel": "ngf::render_kernel", "kernel_ms": k_ms, "active_samples_per_ray": s_active,
-                     "in_box_samples_per_ray": st[0] / n_local, "mlp_passes": st[2], "algorithmic_hbm": alg,
+                     "evaluated_samples_per_ray": st[0] / n_local,      # in-box samples the march evaluated (exact early termination skips the rest)
+                      "mlp_passes": st[2], "algorithmic_hbm": alg,
                      "algorithmic_flops_per_launch": (S * 550.0 + s_active * 71400.0) * n_local if model == "triplane" else None})
 
     result = {

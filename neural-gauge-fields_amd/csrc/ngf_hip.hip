@@ -386,7 +386,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
 
 // ---- launches ------------------------------------------------------------------------------------
 template <typename K>
-static int launch_render(K kernel, K kernel_split, const ngf_field *f, RenderArgs &A, int threads, size_t lds_bytes, hipStream_t st)
+static int launch_render(K kernel, K kernel_split, const ngf_field *f, RenderArgs &A, int threads, size_t lds_bytes, hipStream_t st, int wide_tile)
 {
     const unsigned slot = f->next_counter.fetch_add(1) % kCounters;
     A.tile_counter = f->counters + slot;
@@ -398,7 +398,7 @@ static int launch_render(K kernel, K kernel_split, const ngf_field *f, RenderArg
     // 40 000 rays to the full frame, tile_w = 4 for a 4000-ray chunk (0.31 ms vs 0.53 ms).  NGF_TILE_W / NGF_SPLIT override for experiments.
     const int waves = threads / kWave;
     int tw = 64;
-    if (kernel_split) tw = A.n < 8 * (int64_t)f->num_cus * waves ? 4 : 8;      // below one 8-ray tile per resident wave: 4-ray tiles
+    if (kernel_split) tw = A.n < 8 * (int64_t)f->num_cus * waves ? 4 : wide_tile;      // below one 8-ray tile per resident wave: 4-ray tiles
     if (const char *e = getenv("NGF_TILE_W")) tw = atoi(e);
     if (tw != 64 && tw != 32 && tw != 16 && tw != 8 && tw != 4) return fail(NGF_E_ARG, "NGF_TILE_W must be 64, 32, 16, 8 or 4");
     bool split = tw < 64 && kernel_split;
@@ -421,8 +421,9 @@ static int launch_policy(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
     const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + P::WAVES * wave_lds_floats<P>()) * sizeof(float);
     if (lds > 160 * 1024) return fail(NGF_E_ARG, "this waves-per-CU setting needs %zu bytes of LDS (> 160 KiB)", lds);
-    if constexpr (P::NSTEP == 1) return launch_render(render_kernel<P, false>, render_kernel<P, true>, f, A, P::WAVES * kWave, lds, st);
-    else return launch_render(render_kernel<P, false>, (decltype(&render_kernel<P, false>))nullptr, f, A, P::WAVES * kWave, lds, st);
+    constexpr int wide = P::INFOINV ? 16 : 8;          // measured best full-frame tile width (profiles/r01_split_march.txt; InfoInv: 30.3 vs 29.3 Mray/s)
+    if constexpr (P::NSTEP == 1) return launch_render(render_kernel<P, false>, render_kernel<P, true>, f, A, P::WAVES * kWave, lds, st, wide);
+    else return launch_render(render_kernel<P, false>, (decltype(&render_kernel<P, false>))nullptr, f, A, P::WAVES * kWave, lds, st, wide);
 }
 
 template <bool BD, bool BC>
