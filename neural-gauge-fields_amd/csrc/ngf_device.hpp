@@ -50,7 +50,8 @@ struct RenderArgs {
     int32_t S, white_bg, mode, skip_rgb;
     int32_t tile_w;        // rays per wave tile: 64, or 32 / 16 / 8 for small launches (more waves, shorter critical path)
     int32_t tile_shift;    // log2(tile_w); the split march gives every ray 64 >> tile_shift lanes (consecutive steps)
-    int32_t ablate;        // profiling only (NGF_ABLATE): 1 skip collect, 2 skip layers 2-3, 4 cached gathers, 16 raise wave priority in the shade pass
+    int32_t ablate;        // profiling only (NGF_ABLATE): 1 skip collect, 2 skip layers 2-3, 4 cached gathers, 16 raise wave priority in the shade pass,
+                           // 32 no early termination, 64 no empty-iteration skip (both exact: A/B timing and bit-identity tests)
     float a0[3], a1[3], inv[3];
     float near_, far_, step, dscale, thr;
     Tex dens[3];           // TriPlane: 16-ch (faithful) or 1-ch (baked) density texels

@@ -361,6 +361,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
             if (count < BATCH && i < S) {
                 // ---------------- march NSTEP steps (independent gathers, sequential transmittance) ----
                 float z[NSTEP], dist[NSTEP], sigma[NSTEP], t[NSTEP][6];
+                bool empty_step = false;
 #pragma unroll
                 for (int u = 0; u < NSTEP; ++u) {
                     const int si = i + u + seg;
@@ -379,8 +380,18 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     for (int k = 0; k < 6; ++k) t[u][k] = 0.0f;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) x[k] = (p[k] - A.a0[k]) * A.inv[k] - 1.0f;   // normalize_coord (FieldBase.py:88-89)
+                    if constexpr (NSTEP == 1) {
+                        // no lane of the wave has a valid sample in this iteration (outside the box / in empty space of the alpha
+                        // mask): sigma = alpha = w = 0 for all of them, T / acc / depth keep their values -> skip the whole step
+                        if (!A.dbg_weight && !(A.ablate & 64) && !__any(valid)) { empty_step = true; break; }
+                    }
                     sigma[u] = P::sigma(A, smem, valid, x, lane, t[u]);
                     st_valid += __popcll(__ballot(valid));
+                }
+                if (empty_step) {
+                    i += NSTEP * K;
+                    if constexpr (P::PROFILE) prof[0] += __builtin_readcyclecounter() - t_sec;
+                    continue;
                 }
 #pragma unroll
                 for (int u = 0; u < NSTEP; ++u) {
