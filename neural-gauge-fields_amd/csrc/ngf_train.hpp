@@ -146,6 +146,10 @@ __global__ void __launch_bounds__(256) train_density_kernel(const TrainArgs T)
         const int64_t r = idx % A.n;
         float xn[3], z, dist, tt[6];
         const bool valid = sample_geometry(A, r, i, xn, z, dist);
+        if (!valid) {                               // outside the box / in free space of the alpha mask: sigma = 0, no fetches
+            T.xs[idx] = -INFINITY;
+            continue;
+        }
         triplane_gauge(A, xn, A.mode, tt);          // compute_gauge (Field.py:53-75), identity split when the gauge is off
         float f = 0.0f;
 #pragma unroll
@@ -170,7 +174,7 @@ __global__ void __launch_bounds__(256) train_density_kernel(const TrainArgs T)
             f += bil_mix(b, d00, d10, d01, d11);
         }
         f = (f + T.bd[0]) + (-10.0f);
-        T.xs[idx] = valid ? f : -INFINITY;
+        T.xs[idx] = f;
     }
 }
 
