@@ -212,3 +212,32 @@ def test_fit_loop_with_upsampling_and_alpha_mask():
     assert tuple(student.plane_xy.shape) != shapes0 and student.alphaMask is not None
     out = student(rays[:512], N_samples=-1, iteration=30001)
     assert torch.isfinite(out["rgb_map"]).all()
+
+
+def test_full_size_batch_matches_autograd_oracle():
+    """The reference's training shape: 256^2 planes, 4096 random rays of the 800x800 frame, the model's own nSamples (884),
+    gauge on -- every gradient against autograd of the eager port on the host (a few seconds)."""
+    from helpers import big_case
+    from ngf_amd import synth
+    g, params, step = big_case("triplane", "R1")
+    f = field_for_case(g, params, None)
+    S = int(f.nSamples)
+    frame = synth.lookat_rays(800, 800)
+    pick = (synth.hash_uniform(9, 1, (4096,)) * np.float32(frame.shape[0])).astype(np.int64)
+    rays_np = frame[pick]
+    tgt_np = synth.hash_uniform(9, 2, (4096, 3))
+    jit_np = synth.hash_uniform(9, 3, (4096,))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    orc = otrain.EagerTrainer(params, g["aabb"], step, g["near_far"], float(g["distance_scale"]), float(g["thr"]))
+    grads, rgb_loss, _, aux = orc.gradients(torch.from_numpy(rays_np), torch.from_numpy(tgt_np), S, torch.from_numpy(jit_np), True, 7)
+    tr = train.Trainer(f, batch_size=4096, max_samples=S)
+    loss = tr.backward(torch.from_numpy(rays_np), torch.from_numpy(tgt_np), S, white_bg=True, iteration=7, jitter=torch.from_numpy(jit_np))
+    n_ref = int(aux["active"].sum())
+    assert abs(tr.last_active - n_ref) <= max(2, n_ref // 50000)          # a weight within 1 ulp of the threshold may flip
+    assert abs(loss.item() - rgb_loss) < 1e-6
+    for k, name in enumerate(train.PARAM_NAMES):
+        got = tr.gradient(k).cpu().numpy()
+        want = grads[name].numpy()
+        if k < 3:
+            want = want - l1_term(params[name])
+        assert rel(got, want) < 2 * GRAD_TOL, (name, rel(got, want))
