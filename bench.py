@@ -104,7 +104,7 @@ def cpu_baseline(params, g, step, rays_np, budget_s, f, kw):
         if dt < best[1]:
             best = (nt, dt)
     torch.set_num_threads(best[0])
-    done, t_used, worst, sq, cnt, act = 0, 0.0, 0.0, 0.0, 0, []
+    done, t_used, worst, worst_rel, sq, cnt, act = 0, 0.0, 0.0, 0.0, 0.0, 0, []
     for ci in order[:64]:
         r = torch.from_numpy(rays_np[ci * chunk:(ci + 1) * chunk])
         t0 = time.perf_counter()
@@ -115,14 +115,21 @@ def cpu_baseline(params, g, step, rays_np, budget_s, f, kw):
         got = f(r.to(f.device), N_samples=S, **kw)["rgb_map"].cpu()
         diff = (got - rgb).abs()
         worst = max(worst, float(diff.max()))
+        worst_rel = max(worst_rel, float((diff / (rgb.abs() + 1e-6)).max()))      # rel with atol 1e-6
         sq += float((diff.double() ** 2).sum())
         cnt += diff.numel()
         if t_used >= budget_s:
             break
     mse = sq / max(cnt, 1)
+    cpu_model = "?"
+    try:
+        cpu_model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+    except Exception:
+        pass
     return {"value": done * chunk / t_used / 1e6, "unit": "Mray/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host": f"{cpu_model}, {os.cpu_count()} logical CPUs; thread counts tried: 8/16/32/64, fastest kept",
             "sample": f"{done} chunks x {chunk} rays of the same frame, torch-eager port of Base.forward, {t_used:.1f} s"}, \
-           {"max_abs_err_vs_cpu_port": worst, "psnr_vs_cpu_port_db": (200.0 if mse == 0 else -10 * np.log10(mse)),
+           {"max_abs_err_vs_cpu_port": worst, "max_rel_err_vs_cpu_port": worst_rel, "psnr_vs_cpu_port_db": (200.0 if mse == 0 else -10 * np.log10(mse)),
             "cpu_active_fraction": float(np.mean(act))}
 
 

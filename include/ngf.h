@@ -215,6 +215,13 @@ typedef struct ngf_uv_desc {
 typedef struct ngf_uv ngf_uv;
 int ngf_uv_create(const ngf_uv_desc *desc, ngf_uv **out, void *hip_stream);
 int ngf_uv_destroy(ngf_uv *m);
+/* Texture editing: TextureMlpDecoder with `cubemap_` set (UV-Mapping/model/decoder.py:52-58,79-121; util.py:172-238,277-282).
+ * tex = device float [6,R,R,C] cube map (sphere models) or [H,W,C] square (faces = 1), C = 3 or 4, mode = cubemap_mode_ 0..4;
+ * copied into the model.  tex = NULL switches editing off.  ngf_uv_texture_edit applies the same stage to explicit
+ * (uv [n,3], orig = color1 + color2 [n,3]) pairs -> out [n,3]. */
+int ngf_uv_set_texture(ngf_uv *m, const float *tex, int32_t faces, int32_t H, int32_t W, int32_t C, int32_t mode,
+                       void *hip_stream);
+int ngf_uv_texture_edit(const ngf_uv *m, const float *uv, const float *orig, int64_t n, float *out, void *hip_stream);
 /* Replaces NeuTex.forward's colour outputs for one camera (model.py:30-52):
  *   campos_host float[3], bg_host float[3] or NULL (HOST pointers), raydir [R,3], jitter_u [R,S] = the uniforms
  *   cube_ray_generation draws with torch.rand (renderer.py:112-117; jitter = 0.05 always, model.py:30);

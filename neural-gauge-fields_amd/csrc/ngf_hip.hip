@@ -930,6 +930,7 @@ extern "C" int ngf_train_adam(ngf_trainer *t, int32_t which, int32_t step_count,
 // ================================ UV-Mapping (NeuTex) ===================================================================
 struct ngf_uv {
     float *w = nullptr;
+    float *tex = nullptr;          // owned copy of the edit texture (ngf_uv_set_texture)
     unsigned int *counters = nullptr;
     mutable std::atomic<unsigned> next_counter{0};
     UvArgs proto;
@@ -940,6 +941,7 @@ extern "C" int ngf_uv_destroy(ngf_uv *m)
 {
     if (!m) return NGF_OK;
     if (m->w) (void)hipFree(m->w);
+    if (m->tex) (void)hipFree(m->tex);
     if (m->counters) (void)hipFree(m->counters);
     delete m;
     return NGF_OK;
@@ -1076,6 +1078,37 @@ extern "C" int ngf_uv_create(const ngf_uv_desc *d, ngf_uv **out, void *hip_strea
     if (hipMalloc((void **)&m->counters, kCounters * sizeof(unsigned)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(counters) failed"));
     A.w = m->w;
     *out = m;
+    return NGF_OK;
+}
+
+extern "C" int ngf_uv_set_texture(ngf_uv *m, const float *tex, int32_t faces, int32_t H, int32_t W, int32_t C, int32_t mode, void *hip_stream)
+{
+    if (!m) return fail(NGF_E_ARG, "ngf_uv_set_texture: null model");
+    if (m->tex) { (void)hipFree(m->tex); m->tex = nullptr; }
+    m->proto.tex = nullptr;
+    if (!tex) return NGF_OK;                       // cubemap_ = None: back to the plain texture branch
+    const bool sphere = m->proto.sphere != 0;
+    if (faces != (sphere ? 6 : 1) || H < 1 || W < 1 || C < 3 || C > 4 || (sphere && H != W) || mode < 0 || mode > 4)
+        return fail(NGF_E_ARG, "ngf_uv_set_texture: expected %s, 3-4 channels, mode 0..4 (got faces=%d %dx%dx%d mode %d)",
+                    sphere ? "a [6,R,R,C] cube map" : "a [H,W,C] square", faces, H, W, C, mode);
+    const size_t n = (size_t)faces * H * W * C;
+    HIP_TRY(hipMalloc((void **)&m->tex, n * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(m->tex, tex, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+    m->proto.tex = m->tex; m->proto.tex_h = H; m->proto.tex_w = W; m->proto.tex_c = C; m->proto.tex_mode = mode;
+    return NGF_OK;
+}
+
+extern "C" int ngf_uv_texture_edit(const ngf_uv *m, const float *uv, const float *orig, int64_t n, float *out, void *hip_stream)
+{
+    if (!m || !uv || !orig || !out || n < 0) return fail(NGF_E_ARG, "ngf_uv_texture_edit: bad argument");
+    if (!m->proto.tex) return fail(NGF_E_ARG, "ngf_uv_texture_edit: no texture set (ngf_uv_set_texture)");
+    if (n == 0) return NGF_OK;
+    int64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    const UvArgs &A = m->proto;
+    hipLaunchKernelGGL(uv_texture_edit_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)hip_stream, A.tex, A.tex_h, A.tex_w, A.tex_c, A.tex_mode, A.sphere,
+                       uv, orig, n, out);
+    HIP_TRY(hipGetLastError());
     return NGF_OK;
 }
 

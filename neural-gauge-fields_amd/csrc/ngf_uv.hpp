@@ -32,6 +32,9 @@ struct UvArgs {
     int64_t R;
     int32_t S, sphere, has_bg, pad_;
     float campos[3], bg[3];
+    // texture editing (decoder.py:79-121): cubemap_ [6,R,R,C] (sphere) or square [H,W,C], NULL = plain texture branch
+    const float *tex;
+    int32_t tex_h, tex_w, tex_c, tex_mode;
     const float *w;        // packed weights / biases (offsets below, floats)
     // geometry
     int32_t geo_w0, geo_b0, geo_wh, geo_bh, geo_wo, geo_bo;       // wh/bh: 10 hidden layers, strides 65536 / 256
@@ -42,6 +45,104 @@ struct UvArgs {
 };
 
 __device__ __forceinline__ float act_fn(float x, float slope) { return fmaxf(x, 0.0f) + slope * fminf(x, 0.0f); }
+
+// ---- texture editing: TextureMlpDecoder.forward with cubemap_ set (decoder.py:79-121) -------------------------------------
+// F.grid_sample(texture [H,W,C] as [1,C,H,W], (u,v), bilinear, padding_mode='border', align_corners=False) for one point
+__device__ __forceinline__ void tex_sample_border(const float *tex, int H, int W, int C, float u, float v, float out[4])
+{
+    float ix = ((u + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((v + 1.0f) * (float)H - 1.0f) / 2.0f;
+    ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));              // clip_coordinates
+    iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float tx = ix - fx, ty = iy - fy;
+    const float w00 = (1.0f - tx) * (1.0f - ty), w10 = tx * (1.0f - ty), w01 = (1.0f - tx) * ty, w11 = tx * ty;
+    const bool x1ok = x0 + 1 <= W - 1, y1ok = y0 + 1 <= H - 1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float s = 0.0f;
+        if (c < C && ix == ix && iy == iy) {
+            s = tex[((size_t)y0 * W + x0) * C + c] * w00;
+            if (x1ok) s += tex[((size_t)y0 * W + x0 + 1) * C + c] * w10;
+            if (y1ok) s += tex[((size_t)(y0 + 1) * W + x0) * C + c] * w01;
+            if (x1ok && y1ok) s += tex[((size_t)(y0 + 1) * W + x0 + 1) * C + c] * w11;
+        }
+        out[c] = s;
+    }
+}
+
+// sample_cubemap (util.py:172-238): the six face masks are applied in order, a later face overwrites an earlier one on ties;
+// a point that belongs to no face (NaN) keeps zeros
+__device__ __forceinline__ void cubemap_sample(const float *cube, int R, int C, const float xyz[3], float out[4])
+{
+    const float x = xyz[0], y = xyz[1], z = xyz[2];
+    const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+    const bool px = x > 0.0f, py = y > 0.0f, pz = z > 0.0f;
+    const bool mx = (ax >= ay) && (ax >= az), my = (ay >= ax) && (ay >= az), mz = (az >= ax) && (az >= ay);
+    int face = -1;
+    if (px && mx) face = 0;
+    if (!px && mx) face = 1;
+    if (py && my) face = 2;
+    if (!py && my) face = 3;
+    if (pz && mz) face = 4;
+    if (!pz && mz) face = 5;
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    if (face < 0) return;
+    float u, v;
+    switch (face) {
+    case 0: u = -z / ax; v = y / ax; break;
+    case 1: u = z / ax; v = y / ax; break;
+    case 2: u = x / ay; v = -z / ay; break;
+    case 3: u = x / ay; v = z / ay; break;
+    case 4: u = x / az; v = y / az; break;
+    default: u = -x / az; v = y / az; break;
+    }
+    tex_sample_border(cube + (size_t)face * R * R * C, R, R, C, u, v, out);
+}
+
+// orig = color1 + color2 (before any clamp), uv = the gauge output; the five cubemap_mode_ branches of decoder.py:101-121
+__device__ __forceinline__ void uv_texture_edit(const float *tex, int H, int W, int C, int mode, int sphere, const float uv[3], const float orig[3],
+                                                float col[3])
+{
+    float cc[4];
+    if (sphere) cubemap_sample(tex, H, C, uv, cc);
+    else tex_sample_border(tex, H, W, C, uv[0], uv[1], cc);
+    float o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = fminf(fmaxf(mode == 0 ? orig[k] * 8.0f : orig[k], 0.0f), 1.0f);
+    if (mode == 0) {
+        const float m = ((o[0] + o[1]) + o[2]) / 3.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) col[k] = cc[k] * m;
+    } else if (mode == 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) col[k] = cc[0] < 0.99f ? o[k] * cc[k] : o[k];
+    } else if (mode == 2) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) col[k] = cc[0] < 0.99f ? o[k] * (1.0f / cc[k]) : o[k];
+    } else if (mode == 3) {
+        const bool msk = ((cc[0] + cc[1]) + cc[2]) > 0.01f;
+        const float m2 = 2.0f * (((o[0] + o[1]) + o[2]) / 3.0f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) col[k] = (msk ? m2 * cc[k] : o[k]) + cc[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) col[k] = fminf(fmaxf(cc[k], 0.0f), 1.0f);
+    }
+}
+
+// elementwise form of the edit stage (ngf_uv_texture_edit: utility + parity hook)
+__global__ void __launch_bounds__(256) uv_texture_edit_kernel(const float *tex, int H, int W, int C, int mode, int sphere, const float *uv, const float *orig,
+                                                              int64_t n, float *out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float q[3] = {uv[i * 3], uv[i * 3 + 1], uv[i * 3 + 2]}, o[3] = {orig[i * 3], orig[i * 3 + 1], orig[i * 3 + 2]};
+        float c[3];
+        uv_texture_edit(tex, H, W, C, mode, sphere, q, o, c);
+        out[i * 3] = c[0]; out[i * 3 + 1] = c[1]; out[i * 3 + 2] = c[2];
+    }
+}
 
 constexpr int kUvActSteps = 80;                    // k-steps of per-wave activation storage (74 used by block2.0)
 constexpr int kUvWaveLds = kUvActSteps * 64;       // floats per wave
@@ -230,11 +331,14 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
         store_act<16>(act, lane, x, 0.2f);
     }
     const f32x4 c2 = dense_out(W + A.t2_wo, W + A.t2_bo, 64, lane, act);
+    float orig[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float s1 = c1[k] > 20.0f ? c1[k] : log1pf(expf(c1[k]));      // softplus(color1) (clamp = False, decoder.py:66-67)
-        col[k] = fmaxf(s1 + c2[k], 0.0f);                                   // (color1 + color2).clamp(min=0)   decoder.py:78
+        orig[k] = s1 + c2[k];
+        col[k] = fmaxf(orig[k], 0.0f);                                      // (color1 + color2).clamp(min=0)   decoder.py:78
     }
+    if (A.tex) uv_texture_edit(A.tex, A.tex_h, A.tex_w, A.tex_c, A.tex_mode, A.sphere, uv, orig, col);      // decoder.py:79-121
 }
 
 __global__ void __launch_bounds__(512) uv_render_kernel(const UvArgs A)

@@ -60,10 +60,13 @@ class GaugeTransform(nn.Module):
 
 
 class TextureMlpDecoder(nn.Module):
-    """decoder.py:11-34 (un-edited texture branch only: target_texture == 'None')."""
+    """decoder.py:11-58: the MLPs; ``cubemap_`` / ``cubemap_mode_`` (texture editing) are plain attributes as in the
+    reference and are pushed to the device by NeuTex.set_target_texture."""
 
     def __init__(self, uv_dim, width=256):
         super().__init__()
+        self.cubemap_ = None
+        self.cubemap_mode_ = 0
         self.block1 = _seq([uv_dim + 20 * uv_dim] + [width] * 6, (lambda: nn.LeakyReLU(0.2), True))
         self.color1 = nn.Linear(width, 3)
         self.block2 = _seq([width + 3 + 36] + [width] * 4 + [3], (lambda: nn.LeakyReLU(0.2), False))
@@ -99,6 +102,43 @@ class NeuTex(nn.Module):
         self.load_state_dict(sd, strict=False)
         self.to(self.device)
 
+    # --- texture editing (decoder.py:52-58, 79-121): net_texture.cubemap_ / cubemap_mode_ -------------------------------
+    def set_target_texture(self, cubemap, mode=0):
+        """``net_texture.cubemap_ = cubemap; net_texture.cubemap_mode_ = mode`` of the reference: a [6,R,R,C] cube map
+        (sphere) or an [H,W,C] image (square), values in [0,1], C = 3 or 4 (what load_cube_from_single_texture /
+        load_square return, util.py:240-275); ``None`` switches editing off."""
+        self.net_texture.cubemap_ = None if cubemap is None else torch.as_tensor(cubemap, dtype=torch.float32)
+        self.net_texture.cubemap_mode_ = int(mode)
+        if self._handle is not None:
+            self._push_texture()
+
+    def _push_texture(self):
+        t = getattr(self.net_texture, "cubemap_", None)
+        dev = torch.device(self.device)
+        with torch.cuda.device(dev):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if t is None:
+                _lib.check(_lib.lib().ngf_uv_set_texture(self._handle, None, 0, 0, 0, 0, 0, st))
+                return
+            t = t.to(dev, torch.float32).contiguous()
+            faces = 6 if t.dim() == 4 else 1
+            H, W, Cn = (t.shape[1], t.shape[2], t.shape[3]) if t.dim() == 4 else tuple(t.shape)
+            _lib.check(_lib.lib().ngf_uv_set_texture(self._handle, t.data_ptr(), faces, int(H), int(W), int(Cn), int(self.net_texture.cubemap_mode_), st))
+            torch.cuda.current_stream().synchronize()        # the library copied from `t`; it may be freed now
+
+    @torch.no_grad()
+    def texture_edit(self, uv, original_color):
+        """The edit stage alone (decoder.py:95-121): uv [n,3] (gauge output; z ignored for square models), original_color
+        = color1 + color2 [n,3] -> [n,3]."""
+        dev = torch.device(self.device)
+        uv = uv.to(dev, torch.float32).contiguous()
+        oc = original_color.to(dev, torch.float32).contiguous()
+        out = torch.empty_like(oc)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().ngf_uv_texture_edit(self.handle(), uv.data_ptr(), oc.data_ptr(), uv.shape[0], out.data_ptr(),
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
+
     def release(self):
         if self._handle is not None:
             _lib.lib().ngf_uv_destroy(self._handle)
@@ -130,6 +170,7 @@ class NeuTex(nn.Module):
             _lib.check(_lib.lib().ngf_uv_create(C.byref(d), C.byref(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         self.release()
         self._handle, self._key = out, key
+        self._push_texture()
         return out
 
     @torch.no_grad()

@@ -366,10 +366,88 @@ def capture_train(name="train_r1", seed=51, S=40, steps=2):
           f"|grad gauge_xy| {np.abs(out['grad0.gauge_xy']).mean():.3e}")
 
 
+def capture_uv_edit(name="uv_edit", seed=61, n=160):
+    """UV-Mapping texture editing: the reference TextureMlpDecoder itself with ``cubemap_`` / ``cubemap_mode_`` set
+    (decoder.py:79-121), for a sphere and a square model and all five modes.  ``orig`` (= color1 + color2, which the
+    decoder does not return) is taken from the same sub-modules the decoder calls."""
+    sys.path.insert(0, os.path.join(REF, "UV-Mapping"))
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            dec = importlib.import_module("model.decoder")
+            util = importlib.import_module("util")
+    finally:
+        sys.path.pop(0)
+    out = {}
+    for prim, uv_dim in (("sphere", 3), ("square", 2)):
+        params = synth.uvmapping_params(seed, prim)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tex = dec.TextureMlpDecoder(3, 10, 6, uv_dim=uv_dim, layers=[5, 3], width=256, clamp=False, primitive_type=prim,
+                                        target_texture="None")
+        sd = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
+        tex.load_state_dict({k[len("net_texture."):]: v for k, v in sd.items() if k.startswith("net_texture.")})
+        q = synth.hash_normal(seed, 900 + uv_dim, (n, 3))
+        if prim == "sphere":
+            uv = q / np.linalg.norm(q, axis=1, keepdims=True)
+            uv[:6] = np.eye(3, dtype=np.float32)[[0, 0, 1, 1, 2, 2]] * np.array([1, -1, 1, -1, 1, -1], np.float32)[:, None]   # face centres
+            uv[6] = [0.5, 0.5, 0.70710678]; uv[7] = [0.6, 0.6, -0.52915026]; uv[8] = [-0.57735027] * 3                        # ties / near ties
+            cube = synth.hash_uniform(seed, 910, (6, 9, 9, 3))
+            cube[:, :3, :3, 0] = 0.995                      # texels above the 0.99 mask threshold of modes 1 / 2
+            cube[2, 5:, 5:] = 0.001                         # texels below the 0.01 mask threshold of mode 3
+        else:
+            uv = np.tanh(q)[:, :2].astype(np.float32)
+            uv[:4] = [[-1, -1], [1, 1], [-1, 1], [0.999, -0.3]]
+            cube = synth.hash_uniform(seed, 911, (7, 11, 4))
+            cube[:2, :4, 0] = 0.995
+            cube[4:, 6:] = 0.001
+        uv = uv.astype(np.float32)
+        view = synth.hash_normal(seed, 920 + uv_dim, (n, 3))
+        view = (view / np.linalg.norm(view, axis=1, keepdims=True)).astype(np.float32)
+        with torch.no_grad():
+            tuv, tv = torch.from_numpy(uv[None, :, None, :uv_dim].copy()), torch.from_numpy(view[None, :, None, :].copy())
+            h = tex.block1(torch.cat([tuv, util.positional_encoding(tuv, 10)], -1))
+            c1 = torch.nn.functional.softplus(tex.color1(h))
+            c2 = tex.block2(torch.cat([h, tv, util.positional_encoding(tv, 6)], -1))
+            orig = (c1 + c2)[0, :, 0].numpy()
+            # widen the range so that the clamps of every mode are exercised
+            orig = (orig * np.float32(3.0) - np.float32(0.4)).astype(np.float32)
+            plain = tex(tuv, tv)[0, :, 0].numpy()
+            out[f"{prim}.plain"] = plain
+            out[f"{prim}.plain_orig"] = (c1 + c2)[0, :, 0].numpy()
+            tex.cubemap_ = torch.from_numpy(cube.copy())
+            # the decoder recomputes original_color = softplus(color1(h)) + block2(...) from its MLPs; to feed it the widened
+            # values the two heads are replaced by constant modules: color1 -> 0, block2 -> orig - softplus(0); what the decoder
+            # then sees (softplus(0) + (orig - softplus(0)) in float32) is what the fixture stores as `orig`
+            ln2 = torch.nn.functional.softplus(torch.zeros(()))
+            c2p = torch.from_numpy(orig.copy()) - ln2
+            orig = (ln2 + c2p).numpy().copy()
+
+            class Const(torch.nn.Module):
+                def __init__(self, value):
+                    super().__init__()
+                    self.value = value
+
+                def forward(self, z):
+                    return self.value
+
+            real_c1, real_b2 = tex.color1, tex.block2
+            tex.color1, tex.block2 = Const(torch.zeros((1, n, 1, 3))), Const(c2p[None, :, None, :])
+            try:
+                for mode in range(5):
+                    tex.cubemap_mode_ = mode
+                    out[f"{prim}.mode{mode}"] = tex(tuv, tv)[0, :, 0].numpy().copy()
+            finally:
+                tex.color1, tex.block2 = real_c1, real_b2
+        out[f"{prim}.uv"] = np.concatenate([uv, np.zeros((n, 3 - uv.shape[1]), np.float32)], 1) if uv.shape[1] < 3 else uv
+        out[f"{prim}.orig"] = orig
+        out[f"{prim}.tex"] = cube
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=seed, **out)
+    print(f"{name}: " + ", ".join(f"{k} {v.shape}" for k, v in out.items() if k.endswith("mode3")))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1:       # regenerate one fixture without touching the others
-        {"evalout": capture_evalout, "train": capture_train}[sys.argv[1]]()
+        {"evalout": capture_evalout, "train": capture_train, "uv_edit": capture_uv_edit}[sys.argv[1]]()
         sys.exit(0)
     capture_ops()
     capture_triplane("triplane_r1_gauge", seed=11, preset="R1", gauge_on=True, gauge_std=0.05, with_mask=False, S=48)
@@ -384,3 +462,4 @@ if __name__ == "__main__":
     capture_uv("uv_square", seed=32, primitive_type="square")
     capture_evalout()
     capture_train()
+    capture_uv_edit()
