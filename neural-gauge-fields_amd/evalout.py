@@ -184,3 +184,33 @@ def evaluation(test_dataset, field, args=None, savePath=None, N_vis=5, prtx='', 
         vals = [np.mean(np.asarray(PSNRs))] + ([np.mean(np.asarray(ssims))] if compute_extra_metrics else [])
         np.savetxt(f'{savePath}/{prtx}mean.txt', np.asarray(vals))
     return PSNRs
+
+
+@torch.no_grad()
+def evaluation_path(test_dataset, field, c2ws, savePath=None, N_vis=5, prtx='', N_samples=-1, white_bg=False,
+                    compute_extra_metrics=True, device='cuda', focal=None):
+    """``evaluation_path`` (TriPlane/main.py:141-183): one frame per camera pose of a path.  The rays of every pose are
+    built ON THE DEVICE from (c2w, intrinsics) (ngf_generate_rays) instead of get_rays on the host, rendered
+    in one launch and post-processed by the device output stage; returns the list of [H,W,3] uint8 frames (device tensors)
+    and the list of depth visualisations.  ``focal`` defaults to ``test_dataset.focal`` (blender.py:47).  PNGs are written
+    with PIL when ``savePath`` is given; the MP4 writers of the reference need imageio and stay with the caller."""
+    from .fieldbase import renderer
+    from .rays import generate_rays
+    if savePath is not None:
+        os.makedirs(savePath, exist_ok=True)
+        os.makedirs(savePath + "/rgbd", exist_ok=True)
+    near_far = test_dataset.near_far
+    W, H = test_dataset.img_wh
+    f = float(focal if focal is not None else test_dataset.focal)
+    rgb_maps, depth_maps = [], []
+    for idx, c2w in enumerate(c2ws):
+        rays = generate_rays(H, W, f, torch.as_tensor(c2w, dtype=torch.float32)[:3, :4], device=device)
+        rgb_map, depth_map = renderer(rays, field, chunk=8192, N_samples=N_samples, white_bg=white_bg, device=device)
+        o = frame_outputs(rgb_map, depth_map, H, W, near_far)
+        rgb_maps.append(o["rgb8"])
+        depth_maps.append(o["depth8"])
+        if savePath is not None:
+            from PIL import Image
+            Image.fromarray(o["rgb8"].cpu().numpy()).save(f'{savePath}/{prtx}{idx:03d}.png')
+            Image.fromarray(o["rgbd8"].cpu().numpy()).save(f'{savePath}/rgbd/{prtx}{idx:03d}.png')
+    return rgb_maps, depth_maps
