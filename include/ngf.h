@@ -115,6 +115,14 @@ int ngf_field_march(const ngf_field *f, const float *rays, int64_t n, int32_t n_
  *                          the n_samples points of ray i samples the alpha mask > 0 (requires a mask). */
 int ngf_field_alpha(const ngf_field *f, const float *xyz, int64_t n, int32_t mode, float length, float *alpha,
                     void *hip_stream);
+/* Replaces: getDenseAlpha + updateAlphaMask (FieldBase.py:161-216) in one pass over the [gx,gy,gz] lattice of the aabb:
+ * sx/sy/sz = the three torch.linspace(0,1,g) vectors (device), mode as ngf_field_alpha, length = stepSize, thres =
+ * alphaMask_thres.  Outputs (device): alpha_zyx [gz,gy,gx] (dense alpha, transposed like FieldBase.py:185), volume_zyx
+ * [gz,gy,gx] in {0,1} after clamp / 3x3x3 max-pool / threshold, new_aabb [2,3] = box of the occupied lattice points,
+ * *count = number of occupied voxels (0 => new_aabb is meaningless; the reference raises there). */
+int ngf_field_alpha_mask_build(const ngf_field *f, int32_t mode, const float *sx, const float *sy, const float *sz, int32_t gx,
+                               int32_t gy, int32_t gz, float length, float thres, float *alpha_zyx, float *volume_zyx,
+                               float *new_aabb, uint64_t *count, void *hip_stream);
 int ngf_field_ray_filter(const ngf_field *f, const float *rays, int64_t n, int32_t n_samples, uint8_t *keep,
                          void *hip_stream);
 
@@ -146,6 +154,10 @@ int ngf_eval_mse(const float *a, const float *b, int64_t n, double *out, void *w
 int ngf_eval_ssim(const float *img0, const float *img1, int32_t H, int32_t W, double max_val, int32_t filter_size,
                   double filter_sigma, double k1, double k2, double *mean_out, double *map_out, void *workspace,
                   void *hip_stream);
+
+/* Replaces: np.packbits(alpha_volume.bool().reshape(-1)) (FieldBase.py:104-108) on the device: volume [n] float32 (non-zero =
+ * occupied) -> bits [(n+7)/8], most significant bit first -- the mask_bits image ngf_field_create takes. */
+int ngf_pack_mask_bits(const float *volume, int64_t n, uint8_t *bits, void *hip_stream);
 
 /* Replaces: F.interpolate(plane, size=(Ho,Wo), mode='bilinear', align_corners=True) in TriPlane.up_sampling
  * (TriPlane/models/Field.py:108-114): src [C,Hi,Wi] -> dst [C,Ho,Wo], both device float32. */

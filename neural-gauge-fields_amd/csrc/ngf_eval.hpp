@@ -186,6 +186,22 @@ __global__ void __launch_bounds__(kEvalThreads) ssim_horizontal_kernel(const Ssi
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
+// np.packbits(volume.bool().reshape(-1)) (the checkpoint's alpha-mask image, FieldBase.py:104-108): MSB first, zero tail
+__global__ void __launch_bounds__(kEvalThreads) pack_mask_bits_kernel(const float *__restrict__ vol, int64_t n, uint8_t *__restrict__ bits)
+{
+    const int64_t nbytes = (n + 7) / 8;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nbytes; b += stride) {
+        unsigned v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t i = b * 8 + k;
+            v |= (unsigned)(i < n && vol[i] != 0.0f) << (7 - k);
+        }
+        bits[b] = (uint8_t)v;
+    }
+}
+
 // F.interpolate(mode='bilinear', align_corners=True) of an NCHW tensor (TriPlane.up_sampling, Field.py:108-114):
 // ATen upsample_bilinear2d: src = dst * (in-1)/(out-1); the +1 neighbour is dropped on the last row/column.
 __global__ void __launch_bounds__(kEvalThreads) resize_bilinear_kernel(const float *__restrict__ src, int C, int Hi, int Wi, float *__restrict__ dst,

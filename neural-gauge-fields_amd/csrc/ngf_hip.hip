@@ -378,7 +378,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
             A.mask.inv[k] = 1.0f / (d->mask_aabb[3 + k] - d->mask_aabb[k]) * 2;   // invgridSize (FieldBase.py:29)
         }
     }
-    if (hipMalloc((void **)&f->counters, kCounters * sizeof(unsigned)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(counters) failed"));
+    if (hipMalloc((void **)&f->counters, (kCounters + 8) * sizeof(unsigned)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(counters) failed"));      // + 6 ints for the mask build's index bounds
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "packing failed: %s", hipGetErrorString(hipGetLastError())));
     *out = f;
     return NGF_OK;
@@ -511,12 +511,8 @@ extern "C" int ngf_field_decode_rgb(const ngf_field *f, const float *coords, con
     return NGF_OK;
 }
 
-extern "C" int ngf_field_alpha(const ngf_field *f, const float *xyz, int64_t n, int32_t mode, float length, float *alpha, void *hip_stream)
+static int launch_alpha(const ngf_field *f, const float *xyz, const Lattice &L, int64_t n, int32_t mode, float length, float *alpha, hipStream_t st)
 {
-    if (!f || !xyz || !alpha) return fail(NGF_E_ARG, "ngf_field_alpha: null argument");
-    if (n < 0) return fail(NGF_E_ARG, "ngf_field_alpha: n=%lld", (long long)n);
-    if (n == 0) return NGF_OK;
-    hipStream_t st = (hipStream_t)hip_stream;
     RenderArgs A = f->proto;
     A.mode = mode ? 1 : 0;
     int64_t grid = (n + 255) / 256;
@@ -525,12 +521,45 @@ extern "C" int ngf_field_alpha(const ngf_field *f, const float *xyz, int64_t n, 
         const size_t lds = (size_t)((A.blob_floats + 3) & ~3) * sizeof(float);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(alpha_kernel<InfoInvPolicy>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (grid > (int64_t)f->num_cus) grid = f->num_cus;
-        hipLaunchKernelGGL(alpha_kernel<InfoInvPolicy>, dim3((unsigned)grid), dim3(256), lds, st, A, xyz, n, length, alpha);
+        hipLaunchKernelGGL(alpha_kernel<InfoInvPolicy>, dim3((unsigned)grid), dim3(256), lds, st, A, xyz, L, n, length, alpha);
     } else if (f->flags & NGF_F_BAKE_DENSITY) {
-        hipLaunchKernelGGL((alpha_kernel<TriPlanePolicy<true, false, 8, 1>>), dim3((unsigned)grid), dim3(256), 0, st, A, xyz, n, length, alpha);
+        hipLaunchKernelGGL((alpha_kernel<TriPlanePolicy<true, false, 8, 1>>), dim3((unsigned)grid), dim3(256), 0, st, A, xyz, L, n, length, alpha);
     } else {
-        hipLaunchKernelGGL((alpha_kernel<TriPlanePolicy<false, false, 8, 1>>), dim3((unsigned)grid), dim3(256), 0, st, A, xyz, n, length, alpha);
+        hipLaunchKernelGGL((alpha_kernel<TriPlanePolicy<false, false, 8, 1>>), dim3((unsigned)grid), dim3(256), 0, st, A, xyz, L, n, length, alpha);
     }
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+extern "C" int ngf_field_alpha(const ngf_field *f, const float *xyz, int64_t n, int32_t mode, float length, float *alpha, void *hip_stream)
+{
+    if (!f || !xyz || !alpha) return fail(NGF_E_ARG, "ngf_field_alpha: null argument");
+    if (n < 0) return fail(NGF_E_ARG, "ngf_field_alpha: n=%lld", (long long)n);
+    if (n == 0) return NGF_OK;
+    return launch_alpha(f, xyz, Lattice{nullptr, nullptr, nullptr, 0, 0, 0}, n, mode, length, alpha, (hipStream_t)hip_stream);
+}
+
+extern "C" int ngf_field_alpha_mask_build(const ngf_field *f, int32_t mode, const float *sx, const float *sy, const float *sz, int32_t gx, int32_t gy,
+                                          int32_t gz, float length, float thres, float *alpha_zyx, float *volume_zyx, float *new_aabb,
+                                          uint64_t *count, void *hip_stream)
+{
+    if (!f || !sx || !sy || !sz || !alpha_zyx || !volume_zyx || !new_aabb || !count) return fail(NGF_E_ARG, "ngf_field_alpha_mask_build: null argument");
+    if (gx < 1 || gy < 1 || gz < 1) return fail(NGF_E_ARG, "ngf_field_alpha_mask_build: grid %dx%dx%d", gx, gy, gz);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const Lattice L{sx, sy, sz, gx, gy, gz};
+    const int64_t n = (int64_t)gx * gy * gz;
+    int rc = launch_alpha(f, nullptr, L, n, mode, length, alpha_zyx, st);
+    if (rc) return rc;
+    // bounds: 6 ints in front of the caller's count word would need another buffer; the handle's counter block has room
+    int *bounds = reinterpret_cast<int *>(f->counters + kCounters);
+    const int init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1};
+    HIP_TRY(hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(count, 0, sizeof(uint64_t), st));
+    int64_t grid = (n + 255) / 256;
+    if (grid > 16 * (int64_t)f->num_cus) grid = 16 * (int64_t)f->num_cus;
+    hipLaunchKernelGGL(mask_pool_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const float *)alpha_zyx, gx, gy, gz, thres, volume_zyx, bounds,
+                       (unsigned long long *)count);
+    hipLaunchKernelGGL(mask_aabb_kernel, dim3(1), dim3(64), 0, st, f->proto, L, (const int *)bounds, new_aabb);
     HIP_TRY(hipGetLastError());
     return NGF_OK;
 }
@@ -647,6 +676,14 @@ extern "C" int ngf_eval_ssim(const float *img0, const float *img1, int32_t H, in
     hipLaunchKernelGGL(ssim_vertical_kernel, dim3(eval_grid(n_v)), dim3(kEvalThreads), 0, st, a, img0, img1, tmp);
     hipLaunchKernelGGL(ssim_horizontal_kernel, dim3(g), dim3(kEvalThreads), 0, st, a, (const double *)tmp, map_out, partial);
     hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(kEvalThreads), 0, st, (const double *)partial, g, (double)n_o, mean_out);
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+extern "C" int ngf_pack_mask_bits(const float *volume, int64_t n, uint8_t *bits, void *hip_stream)
+{
+    if (!volume || !bits || n <= 0) return fail(NGF_E_ARG, "ngf_pack_mask_bits: bad argument");
+    hipLaunchKernelGGL(pack_mask_bits_kernel, dim3(eval_grid((n + 7) / 8)), dim3(kEvalThreads), 0, (hipStream_t)hip_stream, volume, n, bits);
     HIP_TRY(hipGetLastError());
     return NGF_OK;
 }

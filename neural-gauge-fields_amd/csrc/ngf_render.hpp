@@ -533,9 +533,17 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
     }
 }
 
-// ---- compute_alpha for explicit world-space points (FieldBase.py:140-159) ----------------------------------------------
+// ---- compute_alpha for explicit world-space points (FieldBase.py:140-159) or on the lattice of getDenseAlpha (:161-178) ------------
+// Lattice form (xyz == NULL): the three 1-D linspace(0,1,g) vectors come from the host (torch's own values); point (ix,iy,iz) is
+// aabb0*(1-s) + aabb1*s per axis in float32 like the reference, and the result is written in the TRANSPOSED [gz,gy,gx] order that
+// updateAlphaMask works in (FieldBase.py:184-185) -- no [g^3,3] coordinate tensor exists.
+struct Lattice {
+    const float *sx, *sy, *sz;
+    int32_t gx, gy, gz;
+};
+
 template <typename P>
-__global__ void __launch_bounds__(256) alpha_kernel(const RenderArgs A, const float *xyz, int64_t n, float length, float *alpha)
+__global__ void __launch_bounds__(256) alpha_kernel(const RenderArgs A, const float *xyz, const Lattice L, int64_t n, float length, float *alpha)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if constexpr (P::INFOINV) {
@@ -547,7 +555,15 @@ __global__ void __launch_bounds__(256) alpha_kernel(const RenderArgs A, const fl
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n; base += stride) {
         const int64_t i = base + lane;
         const int64_t ii = i < n ? i : n - 1;
-        float p[3] = {xyz[ii * 3], xyz[ii * 3 + 1], xyz[ii * 3 + 2]};
+        float p[3];
+        if (xyz) {
+            p[0] = xyz[ii * 3]; p[1] = xyz[ii * 3 + 1]; p[2] = xyz[ii * 3 + 2];
+        } else {
+            const int ix = (int)(ii % L.gx), iy = (int)((ii / L.gx) % L.gy), iz = (int)(ii / ((int64_t)L.gx * L.gy));
+            const float s[3] = {L.sx[ix], L.sy[iy], L.sz[iz]};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p[k] = A.a0[k] * (1.0f - s[k]) + A.a1[k] * s[k];
+        }
         bool valid = i < n;
         if (A.mask.bits && valid) valid = mask_occupied(A.mask, p);
         float x[3], t[6];
@@ -556,6 +572,61 @@ __global__ void __launch_bounds__(256) alpha_kernel(const RenderArgs A, const fl
         const float sigma = P::sigma(A, smem, valid, x, lane, t);
         if (i < n) alpha[i] = 1.0f - expf(-sigma * length);
     }
+}
+
+// updateAlphaMask (FieldBase.py:180-216) after getDenseAlpha: clamp(0,1), 3x3x3 max-pool (stride 1, padding 1), threshold to a
+// {0,1} float volume [gz,gy,gx], and the index bounding box + count of the occupied voxels (integer atomics: deterministic)
+__global__ void __launch_bounds__(256) mask_pool_kernel(const float *__restrict__ alpha, int gx, int gy, int gz, float thres, float *__restrict__ vol,
+                                                        int *bounds, unsigned long long *count)
+{
+    const int64_t n = (int64_t)gx * gy * gz;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+    unsigned long long cnt = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int x = (int)(i % gx), y = (int)((i / gx) % gy), z = (int)(i / ((int64_t)gx * gy));
+        float m = -INFINITY;
+        for (int dz = -1; dz <= 1; ++dz) {
+            const int zz = z + dz;
+            if (zz < 0 || zz >= gz) continue;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= gy) continue;
+                const float *row = alpha + ((int64_t)zz * gy + yy) * gx;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= gx) continue;
+                    m = fmaxf(m, fminf(fmaxf(row[xx], 0.0f), 1.0f));
+                }
+            }
+        }
+        const bool occ = m >= thres;
+        vol[i] = occ ? 1.0f : 0.0f;
+        if (occ) {
+            ++cnt;
+            lo[0] = min(lo[0], x); lo[1] = min(lo[1], y); lo[2] = min(lo[2], z);
+            hi[0] = max(hi[0], x); hi[1] = max(hi[1], y); hi[2] = max(hi[2], z);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (hi[k] >= 0) { atomicMin(bounds + k, lo[k]); atomicMax(bounds + 3 + k, hi[k]); }
+    }
+    if (cnt) atomicAdd(count, cnt);
+}
+
+// valid_xyz.amin(0) / amax(0) (FieldBase.py:204-208): coordinates are monotone in their lattice index, so the box of the occupied
+// voxels is the lattice point of the index bounds (taken per axis with min/max to stay correct for a flipped aabb)
+__global__ void mask_aabb_kernel(const RenderArgs A, const Lattice L, const int *bounds, float *new_aabb)
+{
+    const int k = threadIdx.x;
+    if (k >= 3) return;
+    const float *s = k == 0 ? L.sx : (k == 1 ? L.sy : L.sz);
+    const float a = A.a0[k] * (1.0f - s[bounds[k]]) + A.a1[k] * s[bounds[k]];
+    const float b = A.a0[k] * (1.0f - s[bounds[3 + k]]) + A.a1[k] * s[bounds[3 + k]];
+    new_aabb[k] = fminf(a, b);
+    new_aabb[3 + k] = fmaxf(a, b);
 }
 
 // ---- filtering_rays, alpha-mask branch (FieldBase.py:237-239): one ray per thread --------------------------------------

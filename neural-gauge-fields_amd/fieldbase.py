@@ -29,7 +29,19 @@ class AlphaGridMask(torch.nn.Module):
         self.gridSize = torch.LongTensor([alpha_volume.shape[-1], alpha_volume.shape[-2], alpha_volume.shape[-3]]).to(self.device)
 
     def packed_bits(self) -> np.ndarray:
+        """The checkpoint image (FieldBase.py:104-108), on the host."""
         return np.packbits(self.alpha_volume.bool().cpu().numpy().reshape(-1))
+
+    def packed_bits_device(self) -> torch.Tensor:
+        """The same bytes built on the device (ngf_pack_mask_bits) -- what the render handle consumes."""
+        vol = self.alpha_volume
+        if not vol.is_cuda:
+            return torch.from_numpy(self.packed_bits())
+        v = vol.to(torch.float32).contiguous().view(-1)
+        bits = torch.empty(((v.numel() + 7) // 8,), dtype=torch.uint8, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().ngf_pack_mask_bits(v.data_ptr(), v.numel(), bits.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return bits
 
 
 class Base(torch.nn.Module):
@@ -164,7 +176,7 @@ class Base(torch.nn.Module):
         d.distance_scale = float(self.distance_scale)
         d.weight_thres = float(np.float32(self.rayMarch_weight_thres))
         if self.alphaMask is not None:
-            bits = torch.from_numpy(self.alphaMask.packed_bits()).to(dev)
+            bits = self.alphaMask.packed_bits_device().to(dev)
             keep.append(bits)
             d.mask_bits = bits.data_ptr()
             shp = self.alphaMask.alpha_volume.shape
@@ -244,21 +256,28 @@ class Base(torch.nn.Module):
 
     @torch.no_grad()
     def updateAlphaMask(self, gridSize=(200, 200, 200)):
-        """FieldBase.py:180-216: rebuild the occupancy volume (3x3x3 max-pool + threshold) and return the new aabb."""
-        import torch.nn.functional as F
-        gridSize = tuple(int(g) for g in gridSize)
-        alpha, dense_xyz = self.getDenseAlpha(gridSize)
-        dense_xyz = dense_xyz.transpose(0, 2).contiguous()
-        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
-        ks = 3
-        alpha = F.max_pool3d(alpha, kernel_size=ks, padding=ks // 2, stride=1).view(gridSize[::-1])
-        occ = alpha >= self.alphaMask_thres
-        alpha = occ.to(torch.float32)
-        self.alphaMask = AlphaGridMask(self.device, self.aabb, alpha)
+        """FieldBase.py:180-216 (with getDenseAlpha :161-178 inside): dense alpha on the lattice, clamp, 3x3x3 max-pool,
+        threshold, new AlphaGridMask, and the aabb of the occupied lattice points -- one C-ABI call
+        (ngf_field_alpha_mask_build); only the three torch.linspace vectors are made on the host, like the reference makes
+        its lattice, so the points are bit-identical to dense_xyz."""
+        gx, gy, gz = (int(g) for g in gridSize)
+        dev = torch.device(self.device)
+        lin = [torch.linspace(0, 1, g).to(dev) for g in (gx, gy, gz)]
+        alpha = torch.empty((gz, gy, gx), device=dev, dtype=torch.float32)
+        vol = torch.empty((gz, gy, gx), device=dev, dtype=torch.float32)
+        new_aabb = torch.empty((2, 3), device=dev, dtype=torch.float32)
+        count = torch.zeros((1,), device=dev, dtype=torch.int64)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().ngf_field_alpha_mask_build(
+                self.handle(), int(self.ALPHA_MODE), lin[0].data_ptr(), lin[1].data_ptr(), lin[2].data_ptr(), gx, gy, gz,
+                C.c_float(float(self.stepSize)), C.c_float(float(self.alphaMask_thres)), alpha.data_ptr(), vol.data_ptr(),
+                new_aabb.data_ptr(), count.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        if int(count.item()) == 0:            # the reference fails here too (amin of an empty tensor); it also prints this total
+            raise RuntimeError("updateAlphaMask: no voxel reaches alphaMask_thres")
+        self.last_dense_alpha = alpha         # [gz,gy,gx]: alpha.clamp(0,1).transpose(0,2) of the reference, before the pool
+        self.alphaMask = AlphaGridMask(self.device, self.aabb, vol)
         self._handle_key = None
-        valid_xyz = dense_xyz[alpha > 0.5]
-        xyz_min, xyz_max = valid_xyz.amin(0), valid_xyz.amax(0)
-        return torch.stack((xyz_min, xyz_max))
+        return new_aabb
 
     @torch.no_grad()
     def filtering_rays(self, all_rays, all_rgbs, N_samples=256, chunk=10240 * 5, bbox_only=False):

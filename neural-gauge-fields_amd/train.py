@@ -124,7 +124,7 @@ class Trainer:
             d.exp_avg_sq[k] = self.exp_avg_sq[k].data_ptr()
         self._keep = []
         if f.alphaMask is not None:
-            bits = torch.from_numpy(f.alphaMask.packed_bits()).to(self.dev)
+            bits = f.alphaMask.packed_bits_device().to(self.dev)
             self._keep.append(bits)
             d.mask_bits = bits.data_ptr()
             shp = f.alphaMask.alpha_volume.shape

@@ -286,6 +286,9 @@ def test_alpha_mask_build_and_ray_filter():
     o_alpha = 1.0 - np.exp(-orc.density_at(coords) * np.float32(step))
     np.testing.assert_allclose(alpha.view(-1).cpu().numpy(), o_alpha, rtol=2e-4, atol=2e-7)
     new_aabb = f.updateAlphaMask(mgrid)
+    # the one-call build evaluates the same lattice: its dense alpha is getDenseAlpha's, transposed (FieldBase.py:185)
+    assert torch.equal(f.last_dense_alpha, alpha.transpose(0, 2).contiguous())
+    assert np.array_equal(f.alphaMask.packed_bits_device().cpu().numpy(), f.alphaMask.packed_bits())      # device bit-pack = np.packbits
     vol = f.alphaMask.alpha_volume[0, 0].cpu().numpy()
     near_thr = np.abs(torch.nn.functional.max_pool3d(torch.from_numpy(g["dense_alpha"]).clamp(0, 1).transpose(0, 2)[None, None], 3, 1, 1)[0, 0].numpy()
                       - float(g["alphaMask_thres"])) < 1e-6
