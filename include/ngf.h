@@ -123,6 +123,8 @@ int ngf_field_alpha(const ngf_field *f, const float *xyz, int64_t n, int32_t mod
 int ngf_field_alpha_mask_build(const ngf_field *f, int32_t mode, const float *sx, const float *sy, const float *sz, int32_t gx,
                                int32_t gy, int32_t gz, float length, float thres, float *alpha_zyx, float *volume_zyx,
                                float *new_aabb, uint64_t *count, void *hip_stream);
+/* filtering_rays (FieldBase.py:218-246): keep[i] = 1 iff ray i touches an occupied voxel of the alpha mask within n_samples
+ * steps (n_samples > 0; the field must carry a mask), or -- n_samples <= 0 -- passes the bbox_only slab test t_max > t_min. */
 int ngf_field_ray_filter(const ngf_field *f, const float *rays, int64_t n, int32_t n_samples, uint8_t *keep,
                          void *hip_stream);
 

@@ -567,8 +567,8 @@ extern "C" int ngf_field_alpha_mask_build(const ngf_field *f, int32_t mode, cons
 extern "C" int ngf_field_ray_filter(const ngf_field *f, const float *rays, int64_t n, int32_t n_samples, uint8_t *keep, void *hip_stream)
 {
     if (!f || !rays || !keep) return fail(NGF_E_ARG, "ngf_field_ray_filter: null argument");
-    if (!f->proto.mask.bits) return fail(NGF_E_ARG, "ngf_field_ray_filter: the field has no alpha mask");
-    if (n < 0 || n_samples <= 0) return fail(NGF_E_ARG, "ngf_field_ray_filter: n=%lld n_samples=%d", (long long)n, n_samples);
+    if (n_samples > 0 && !f->proto.mask.bits) return fail(NGF_E_ARG, "ngf_field_ray_filter: the field has no alpha mask");
+    if (n < 0) return fail(NGF_E_ARG, "ngf_field_ray_filter: n=%lld", (long long)n);
     if (n == 0) return NGF_OK;
     RenderArgs A = f->proto;
     int64_t grid = (n + 255) / 256;

@@ -629,7 +629,7 @@ __global__ void mask_aabb_kernel(const RenderArgs A, const Lattice L, const int 
     new_aabb[3 + k] = fmaxf(a, b);
 }
 
-// ---- filtering_rays, alpha-mask branch (FieldBase.py:237-239): one ray per thread --------------------------------------
+// ---- filtering_rays (FieldBase.py:218-246): the alpha-mask branch (S > 0) or the bbox_only slab test (S <= 0); one ray per thread --------------------------------------
 __global__ void __launch_bounds__(256) ray_filter_kernel(const RenderArgs A, const float *rays, int64_t n, int S, uint8_t *keep)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -643,6 +643,18 @@ __global__ void __launch_bounds__(256) ray_filter_kernel(const RenderArgs A, con
             float vec = (d[k] == 0.0f) ? 1e-6f : d[k];
             float ra = (A.a1[k] - o[k]) / vec, rb = (A.a0[k] - o[k]) / vec;
             tmin = fmaxf(tmin, fminf(ra, rb));
+        }
+        if (S <= 0) {
+            // bbox_only (FieldBase.py:226-233): keep the ray iff t_max > t_min of the slab test
+            float tmax = INFINITY;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float vec = (d[k] == 0.0f) ? 1e-6f : d[k];
+                float ra = (A.a1[k] - o[k]) / vec, rb = (A.a0[k] - o[k]) / vec;
+                tmax = fminf(tmax, fmaxf(ra, rb));
+            }
+            keep[r] = tmax > tmin ? 1 : 0;
+            continue;
         }
         tmin = fminf(fmaxf(tmin, A.near_), A.far_);
         bool hit = false;

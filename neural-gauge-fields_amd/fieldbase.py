@@ -285,20 +285,14 @@ class Base(torch.nn.Module):
         dev = torch.device(self.device)
         shape = all_rgbs.shape[:-1]
         rays = all_rays.reshape(-1, all_rays.shape[-1]).to(device=dev, dtype=torch.float32).contiguous()
-        if bbox_only:
-            aabb = self.aabb.to(dev)
-            o, d = rays[:, :3], rays[:, 3:6]
-            vec = torch.where(d == 0, torch.full_like(d, 1e-6), d)
-            rate_a, rate_b = (aabb[1] - o) / vec, (aabb[0] - o) / vec
-            keep = torch.maximum(rate_a, rate_b).amin(-1) > torch.minimum(rate_a, rate_b).amax(-1)
-        else:
-            if self.alphaMask is None:
-                raise RuntimeError("filtering_rays(bbox_only=False) needs an alpha mask (updateAlphaMask)")
-            flags = torch.empty((rays.shape[0],), device=dev, dtype=torch.uint8)
+        if not bbox_only and self.alphaMask is None:
+            raise RuntimeError("filtering_rays(bbox_only=False) needs an alpha mask (updateAlphaMask)")
+        flags = torch.empty((rays.shape[0],), device=dev, dtype=torch.uint8)
+        if rays.shape[0]:
             with torch.cuda.device(dev):
-                _lib.check(_lib.lib().ngf_field_ray_filter(self.handle(), rays.data_ptr(), rays.shape[0], int(N_samples),
+                _lib.check(_lib.lib().ngf_field_ray_filter(self.handle(), rays.data_ptr(), rays.shape[0], 0 if bbox_only else int(N_samples),
                                                            flags.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-            keep = flags.bool()
+        keep = flags.bool()
         keep = keep.view(shape).to(all_rays.device)
         return all_rays[keep], all_rgbs[keep]
 
