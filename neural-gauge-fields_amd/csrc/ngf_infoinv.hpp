@@ -78,13 +78,7 @@ struct InfoInvPolicy {
         float pe[24];
         if (A.mode) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const float a = x[k] * (float)(1 << f);
-                    pe[k * 4 + f] = sinf(a);
-                    pe[12 + k * 4 + f] = cosf(a);
-                }
+            for (int k = 0; k < 3; ++k) pe_ladder<4>(x[k], pe + k * 4, pe + 12 + k * 4);
         }
         f32x16 h0, h1;   // column tile 0 (samples of lanes 0..31) and 1 (lanes 32..63)
 #pragma unroll

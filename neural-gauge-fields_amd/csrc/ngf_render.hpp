@@ -103,6 +103,27 @@ __device__ __forceinline__ void mlp_tail(const float *__restrict__ blob, int oW2
     }
 }
 
+// sin / cos of x * 2^f for f = 0..F-1 (the InfoInv positional encodings, networks.py:227-237): an accurate sincosf at every
+// fourth octave and three angle doublings from each (sin 2a = 2 sc, cos 2a = (c - s)(c + s)); a doubling at most doubles the
+// absolute error, so every value stays within ~8 ulp of 1 (5e-7) while 2F sinf/cosf calls with large-argument range reduction
+// become F/4 sincosf calls.
+template <int F>
+__device__ __forceinline__ void pe_ladder(float x, float sn[F], float cs[F])
+{
+#pragma unroll
+    for (int base = 0; base < F; base += 4) {
+        float s, c;
+        sincosf(x * (float)(1 << base), &s, &c);
+        sn[base] = s; cs[base] = c;
+#pragma unroll
+        for (int j = 1; j < 4 && base + j < F; ++j) {
+            const float s2 = 2.0f * s * c, c2 = (c - s) * (c + s);
+            s = s2; c = c2;
+            sn[base + j] = s; cs[base + j] = c;
+        }
+    }
+}
+
 // ---- shade: rgb_decoder on 32 queued samples ---------------------------------------------------
 // rec: this lane's record (lane s = lane&31 of the batch), vf: the owner ray's 16 view features.
 // Returns sigmoid colour of the lane's sample (identical in both halves).
@@ -158,8 +179,21 @@ __device__ __forceinline__ void mlp_pass(const RenderArgs &A, const float *blob,
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[t_ * 64], x, acc1, 0, 0, 0);
         }
     }
-    float pe_xyz[3];
-    if (INFOINV) { pe_xyz[0] = rec[2]; pe_xyz[1] = rec[3]; pe_xyz[2] = rec[5]; }   // xyz = cat(xy, yz[:,1:])
+    // plane_feature * PE_12(xyz) (InfoInv/models/Field.py:72-84): the same 72 factors multiply all three planes; this lane needs
+    // the 36 of its half (hi = 0: sines, hi = 1: cosines), computed once per pass
+    float pe[INFOINV ? 36 : 1];
+    if (INFOINV) {
+        const float pe_xyz[3] = {rec[2], rec[3], rec[5]};                          // xyz = cat(xy, yz[:,1:])
+        if (mode) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float sn[12], cs[12];
+                pe_ladder<12>(pe_xyz[k], sn, cs);
+#pragma unroll
+                for (int f = 0; f < 12; ++f) pe[k * 12 + f] = hi ? cs[f] : sn[f];
+            }
+        }
+    }
 
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
@@ -180,11 +214,7 @@ __device__ __forceinline__ void mlp_pass(const RenderArgs &A, const float *blob,
             // plane_feature * PE_12(xyz): channel c = hi*36 + j ; c < 36 -> sin(x_{c/12} * 2^(c%12)), else cos
             if (mode) {
 #pragma unroll
-                for (int jj = 0; jj < 4 * CH; ++jj) {
-                    const int j = 4 * q0 + jj;
-                    float a = pe_xyz[j / 12] * (float)(1 << (j % 12));
-                    feat[jj] = feat[jj] * (hi ? cosf(a) : sinf(a));
-                }
+                for (int jj = 0; jj < 4 * CH; ++jj) feat[jj] = feat[jj] * pe[4 * q0 + jj];
             }
         }
 #pragma unroll
