@@ -153,89 +153,109 @@ constexpr int kUvWaveLds = kUvActSteps * 64;       // floats per wave
 // loop (a fully unrolled 256x256 layer makes hipcc hoist ~256 16-byte weight loads and spill thousands of VGPRs)
 // and registers cannot be indexed by a loop variable.
 
+// NS = sample tiles per wave pass (16 samples each).  The weights (5.4 MB) do not fit one XCD's 4 MB L2, so every 16-sample pass
+// streams them from the Infinity Cache (PMC: 248 GB of fabric reads per 76 800-ray launch, L2 hit 81 %, MFMA 52 % busy).  With
+// NS = 2 a wave renders TWO rays at once and every weight load feeds two MFMAs: half the traffic for the same matrix work.
+
 // acc[mt] <- bias (accumulator order: unit mt*16 + 4*kq + r)
-template <int NT>
-__device__ __forceinline__ void load_bias(const float *b, int kq, f32x4 acc[NT])
+template <int NT, int NS>
+__device__ __forceinline__ void load_bias(const float *b, int kq, f32x4 acc[NS][NT])
 {
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(b + kq * (NT * 4) + mt * 4);
+    for (int mt = 0; mt < NT; ++mt) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(b + kq * (NT * 4) + mt * 4);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s][mt] = v;
+    }
 }
 
-// A operand of one k-step: NT unit tiles from packed weights [t][NT/4][64 lanes][4] (one coalesced 16-byte load per 4 MFMAs)
-template <int NT>
+// A operand of one k-step: NT unit tiles from packed weights [t][NT/4][64 lanes][4] (one coalesced 16-byte load per 4 NS MFMAs)
+template <int NT, int NS>
 struct KStepA {
     f32x4 a[NT / 4];
-    float b;
+    float b[NS];
 };
 
-template <int NT>
-__device__ __forceinline__ void kload(const float *w, const float *act, int t, int lane, KStepA<NT> &k)
+template <int NT, int NS>
+__device__ __forceinline__ void kload(const float *w, const float *act, int t, int lane, KStepA<NT, NS> &k)
 {
     const f32x4 *wp = reinterpret_cast<const f32x4 *>(w) + ((size_t)t * (NT / 4)) * 64 + lane;
 #pragma unroll
     for (int g = 0; g < NT / 4; ++g) k.a[g] = wp[g * 64];
-    k.b = act[t * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) k.b[s] = act[s * kUvWaveLds + t * 64 + lane];
 }
 
-template <int NT>
-__device__ __forceinline__ void kmma(const KStepA<NT> &k, f32x4 acc[NT])
+template <int NT, int NS>
+__device__ __forceinline__ void kmma(const KStepA<NT, NS> &k, f32x4 acc[NS][NT])
 {
 #pragma unroll
     for (int g = 0; g < NT / 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[4 * g + e] = NGF_UV_MFMA(k.a[g][e], k.b, acc[4 * g + e]);
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s][4 * g + e] = NGF_UV_MFMA(k.a[g][e], k.b[s], acc[s][4 * g + e]);
 }
 
 // Dense layer, KT4 k-steps (multiple of 4; padded steps have zero weights and zero inputs).  Software pipeline with
 // two k-steps of weight loads in flight behind the MFMAs (the un-pipelined loop left the waves 67 % of their cycles
 // in s_waitcnt with the matrix pipe 31 % busy: latency-, not bandwidth-bound).
-template <int NT_OUT>
-__device__ __forceinline__ void dense(const float *w, const float *bias, int KT4, int lane, const float *act, f32x4 out[NT_OUT])
+template <int NT_OUT, int NS>
+__device__ __forceinline__ void dense(const float *w, const float *bias, int KT4, int lane, const float *act, f32x4 out[NS][NT_OUT])
 {
-    load_bias<NT_OUT>(bias, lane >> 4, out);
-    KStepA<NT_OUT> k0, k1, k2, k3;
-    kload<NT_OUT>(w, act, 0, lane, k0);
-    kload<NT_OUT>(w, act, 1, lane, k1);
+    load_bias<NT_OUT, NS>(bias, lane >> 4, out);
+    KStepA<NT_OUT, NS> k0, k1, k2, k3;
+    kload<NT_OUT, NS>(w, act, 0, lane, k0);
+    kload<NT_OUT, NS>(w, act, 1, lane, k1);
 #pragma unroll 1
     for (int t = 0; t < KT4; t += 4) {
         // sched_barrier(0) pins the order: without it hipcc sinks every load next to its first use and waits
         // vmcnt(0) before each group of four MFMAs
-        kload<NT_OUT>(w, act, t + 2, lane, k2);
-        kload<NT_OUT>(w, act, t + 3, lane, k3);
+        kload<NT_OUT, NS>(w, act, t + 2, lane, k2);
+        kload<NT_OUT, NS>(w, act, t + 3, lane, k3);
         __builtin_amdgcn_sched_barrier(0);
-        kmma<NT_OUT>(k0, out);
-        kmma<NT_OUT>(k1, out);
+        kmma<NT_OUT, NS>(k0, out);
+        kmma<NT_OUT, NS>(k1, out);
         __builtin_amdgcn_sched_barrier(0);
         const int tn = t + 4 < KT4 ? t + 4 : t;          // last iteration: harmless reload instead of a branch
-        kload<NT_OUT>(w, act, tn, lane, k0);
-        kload<NT_OUT>(w, act, tn + 1, lane, k1);
+        kload<NT_OUT, NS>(w, act, tn, lane, k0);
+        kload<NT_OUT, NS>(w, act, tn + 1, lane, k1);
         __builtin_amdgcn_sched_barrier(0);
-        kmma<NT_OUT>(k2, out);
-        kmma<NT_OUT>(k3, out);
+        kmma<NT_OUT, NS>(k2, out);
+        kmma<NT_OUT, NS>(k3, out);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void store_act(float *act, int lane, const f32x4 acc[NT], float slope)
+template <int NT, int NS>
+__device__ __forceinline__ void store_act(float *act, int lane, const f32x4 acc[NS][NT], float slope)
 {
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt)
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) act[(mt * 4 + r) * 64 + lane] = act_fn(acc[mt][r], slope);
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) act[s * kUvWaveLds + (mt * 4 + r) * 64 + lane] = act_fn(acc[s][mt][r], slope);
 }
 
 // output layer with <= 3 units: packed [t][64 lanes] (rows >= n_out are zero); rows 0..3 land in lanes kq = 0
-__device__ __forceinline__ f32x4 dense_out(const float *w, const float *bias4, int KT, int lane, const float *act)
+template <int NS>
+__device__ __forceinline__ void dense_out(const float *w, const float *bias4, int KT, int lane, const float *act, f32x4 r[NS])
 {
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-    for (int t = 0; t < KT; ++t) acc = NGF_UV_MFMA(w[t * 64 + lane], act[t * 64 + lane], acc);
-    const int src = lane & 15;
-    f32x4 r;
+    f32x4 acc[NS];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = __shfl(acc[e], src) + bias4[e];
-    return r;
+    for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+    for (int t = 0; t < KT; ++t) {
+        const float wv = w[t * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = NGF_UV_MFMA(wv, act[s * kUvWaveLds + t * 64 + lane], acc[s]);
+    }
+    const int src = lane & 15;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[s][e] = __shfl(acc[s][e], src) + bias4[e];
 }
 
 // positional-encoding inputs [x(D), sin(D*F), cos(D*F)] (util.py:427-438): lane-quarter kq supplies entry 4t + kq
@@ -255,191 +275,254 @@ __device__ __forceinline__ float pe_entry(const float x[3], int f)
     return f < D ? raw : (g < N ? s : c);
 }
 
-template <int D, int F>
-__device__ __forceinline__ void store_pe(float *act, int t0, int KT, int lane, const float x[3])
+template <int D, int F, int NS>
+__device__ __forceinline__ void store_pe(float *act, int t0, int KT, int lane, const float x[NS][3])
 {
     const int kq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
 #pragma unroll 1
-    for (int t = 0; t < KT; ++t) act[(t0 + t) * 64 + lane] = pe_entry<D, F>(x, 4 * t + kq);
+        for (int t = 0; t < KT; ++t) act[s * kUvWaveLds + (t0 + t) * 64 + lane] = pe_entry<D, F>(x[s], 4 * t + kq);
+    }
 }
 
-// ---- the three networks for 16 samples ------------------------------------------------------------------------------
-// p: position of the lane's sample, v: ray direction.  Returns sigma and colour (identical in the 4 lanes of a sample).
-__device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lane, const float p[3], const float v[3], float &sigma,
-                                            float col[3])
+// ---- the three networks for NS x 16 samples -----------------------------------------------------------------------------
+// p: position of the lane's sample in each tile, v: its ray direction.  Returns sigma and colour (identical in the 4 lanes of a
+// sample).
+template <int NS>
+__device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lane, const float p[NS][3], const float v[NS][3], float sigma[NS],
+                                            float col[NS][3])
 {
     const float *W = A.w;
-    f32x4 x[16];
+    f32x4 x[NS][16];
     // geometry: 63 -> 256 -> (10x) 256 -> 1, ReLU
-    store_pe<3, 10>(act, 0, 16, lane, p);
-    dense<16>(W + A.geo_w0, W + A.geo_b0, 16, lane, act, x);
-    store_act<16>(act, lane, x, 0.0f);
+    store_pe<3, 10, NS>(act, 0, 16, lane, p);
+    dense<16, NS>(W + A.geo_w0, W + A.geo_b0, 16, lane, act, x);
+    store_act<16, NS>(act, lane, x, 0.0f);
 #pragma unroll 1
     for (int l = 0; l < 10; ++l) {
-        dense<16>(W + A.geo_wh + (size_t)l * 65536, W + A.geo_bh + l * 256, 64, lane, act, x);
-        store_act<16>(act, lane, x, 0.0f);
+        dense<16, NS>(W + A.geo_wh + (size_t)l * 65536, W + A.geo_bh + l * 256, 64, lane, act, x);
+        store_act<16, NS>(act, lane, x, 0.0f);
     }
     {
-        const f32x4 o = dense_out(W + A.geo_wo, W + A.geo_bo, 64, lane, act);
-        sigma = o[0] > 20.0f ? o[0] : log1pf(expf(o[0]));
+        f32x4 o[NS];
+        dense_out<NS>(W + A.geo_wo, W + A.geo_bo, 64, lane, act, o);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) sigma[s] = o[s][0] > 20.0f ? o[s][0] : log1pf(expf(o[s][0]));
     }
     // gauge: 63 -> 64 -> 128 -> 128 -> 128 -> 3|2, ReLU
-    float uv[3];
+    float uv[NS][3];
     {
-        f32x4 g[8];
-        store_pe<3, 10>(act, 0, 16, lane, p);
-        dense<4>(W + A.ga_w0, W + A.ga_b0, 16, lane, act, g);
-        store_act<4>(act, lane, g, 0.0f);
-        dense<8>(W + A.ga_w1, W + A.ga_b1, 16, lane, act, g);
-        store_act<8>(act, lane, g, 0.0f);
-        dense<8>(W + A.ga_w2, W + A.ga_b2, 32, lane, act, g);
-        store_act<8>(act, lane, g, 0.0f);
-        dense<8>(W + A.ga_w3, W + A.ga_b3, 32, lane, act, g);
-        store_act<8>(act, lane, g, 0.0f);
-        const f32x4 q = dense_out(W + A.ga_wo, W + A.ga_bo, 32, lane, act);
-        if (A.sphere) {
-            float nrm = sqrtf((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);
-            nrm = fmaxf(nrm, 1e-12f);
-            uv[0] = q[0] / nrm; uv[1] = q[1] / nrm; uv[2] = q[2] / nrm;
-        } else {
-            uv[0] = tanhf(q[0]); uv[1] = tanhf(q[1]); uv[2] = 0.0f;
+        f32x4 g4[NS][4], g[NS][8];
+        store_pe<3, 10, NS>(act, 0, 16, lane, p);
+        dense<4, NS>(W + A.ga_w0, W + A.ga_b0, 16, lane, act, g4);
+        store_act<4, NS>(act, lane, g4, 0.0f);
+        dense<8, NS>(W + A.ga_w1, W + A.ga_b1, 16, lane, act, g);
+        store_act<8, NS>(act, lane, g, 0.0f);
+        dense<8, NS>(W + A.ga_w2, W + A.ga_b2, 32, lane, act, g);
+        store_act<8, NS>(act, lane, g, 0.0f);
+        dense<8, NS>(W + A.ga_w3, W + A.ga_b3, 32, lane, act, g);
+        store_act<8, NS>(act, lane, g, 0.0f);
+        f32x4 q[NS];
+        dense_out<NS>(W + A.ga_wo, W + A.ga_bo, 32, lane, act, q);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (A.sphere) {
+                float nrm = sqrtf((q[s][0] * q[s][0] + q[s][1] * q[s][1]) + q[s][2] * q[s][2]);
+                nrm = fmaxf(nrm, 1e-12f);
+                uv[s][0] = q[s][0] / nrm; uv[s][1] = q[s][1] / nrm; uv[s][2] = q[s][2] / nrm;
+            } else {
+                uv[s][0] = tanhf(q[s][0]); uv[s][1] = tanhf(q[s][1]); uv[s][2] = 0.0f;
+            }
         }
     }
     // texture block1: (63|42) -> 256 -> (5x) 256, LeakyReLU(0.2)
     if (A.sphere) {
-        store_pe<3, 10>(act, 0, 16, lane, uv);
-        dense<16>(W + A.t1_w0, W + A.t1_b0, 16, lane, act, x);
+        store_pe<3, 10, NS>(act, 0, 16, lane, uv);
+        dense<16, NS>(W + A.t1_w0, W + A.t1_b0, 16, lane, act, x);
     } else {
-        store_pe<2, 10>(act, 0, 12, lane, uv);
-        dense<16>(W + A.t1_w0, W + A.t1_b0, 12, lane, act, x);
+        store_pe<2, 10, NS>(act, 0, 12, lane, uv);
+        dense<16, NS>(W + A.t1_w0, W + A.t1_b0, 12, lane, act, x);
     }
-    store_act<16>(act, lane, x, 0.2f);
+    store_act<16, NS>(act, lane, x, 0.2f);
 #pragma unroll 1
     for (int l = 0; l < 5; ++l) {
-        dense<16>(W + A.t1_wh + (size_t)l * 65536, W + A.t1_bh + l * 256, 64, lane, act, x);
-        store_act<16>(act, lane, x, 0.2f);
+        dense<16, NS>(W + A.t1_wh + (size_t)l * 65536, W + A.t1_bh + l * 256, 64, lane, act, x);
+        store_act<16, NS>(act, lane, x, 0.2f);
     }
     // act[0..63] = block1 output h; color1 and block2 both read it
-    const f32x4 c1 = dense_out(W + A.c1_w, W + A.c1_b, 64, lane, act);
+    f32x4 c1[NS], c2[NS];
+    dense_out<NS>(W + A.c1_w, W + A.c1_b, 64, lane, act, c1);
     // block2: [h(256), v(3), PE6(v)(36)] -> 256 -> (3x) 256 -> 3
-    store_pe<3, 6>(act, 64, 12, lane, v);                 // 39 inputs + zero padding up to k-step 76
-    dense<16>(W + A.t2_w0, W + A.t2_b0, 76, lane, act, x);
-    store_act<16>(act, lane, x, 0.2f);
+    store_pe<3, 6, NS>(act, 64, 12, lane, v);                 // 39 inputs + zero padding up to k-step 76
+    dense<16, NS>(W + A.t2_w0, W + A.t2_b0, 76, lane, act, x);
+    store_act<16, NS>(act, lane, x, 0.2f);
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
-        dense<16>(W + A.t2_wh + (size_t)l * 65536, W + A.t2_bh + l * 256, 64, lane, act, x);
-        store_act<16>(act, lane, x, 0.2f);
+        dense<16, NS>(W + A.t2_wh + (size_t)l * 65536, W + A.t2_bh + l * 256, 64, lane, act, x);
+        store_act<16, NS>(act, lane, x, 0.2f);
     }
-    const f32x4 c2 = dense_out(W + A.t2_wo, W + A.t2_bo, 64, lane, act);
-    float orig[3];
+    dense_out<NS>(W + A.t2_wo, W + A.t2_bo, 64, lane, act, c2);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float s1 = c1[k] > 20.0f ? c1[k] : log1pf(expf(c1[k]));      // softplus(color1) (clamp = False, decoder.py:66-67)
-        orig[k] = s1 + c2[k];
-        col[k] = fmaxf(orig[k], 0.0f);                                      // (color1 + color2).clamp(min=0)   decoder.py:78
+    for (int s = 0; s < NS; ++s) {
+        float orig[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float s1 = c1[s][k] > 20.0f ? c1[s][k] : log1pf(expf(c1[s][k]));      // softplus(color1) (clamp = False, decoder.py:66-67)
+            orig[k] = s1 + c2[s][k];
+            col[s][k] = fmaxf(orig[k], 0.0f);                                         // (color1 + color2).clamp(min=0)   decoder.py:78
+        }
+        if (A.tex) uv_texture_edit(A.tex, A.tex_h, A.tex_w, A.tex_c, A.tex_mode, A.sphere, uv[s], orig, col[s]);      // decoder.py:79-121
     }
-    if (A.tex) uv_texture_edit(A.tex, A.tex_h, A.tex_w, A.tex_c, A.tex_mode, A.sphere, uv, orig, col);      // decoder.py:79-121
 }
 
-__global__ void __launch_bounds__(512) uv_render_kernel(const UvArgs A)
+// One wave renders NS rays at a time: lane i owns sample i of a 64-sample chunk of each (segment jitter, prefix sum, position,
+// in-cube test); the in-cube samples of the NS rays form ONE list (ray 0's first) that is pushed through the networks NS x 16 at
+// a time.
+template <int NS>
+__global__ void __launch_bounds__(512 / NS) uv_render_kernel(const UvArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
-    float *act = smem + (threadIdx.x >> 6) * kUvWaveLds;
+    float *act = smem + (threadIdx.x >> 6) * (NS * kUvWaveLds);
     const int S = A.S;
     unsigned long long st_samples = 0, st_pass = 0;
     const float dt = (float)(2.0 / S), dtj = (float)((2.0 / S) * 0.05);     // renderer.py:107-117 (python floats)
     for (;;) {
-        unsigned int ray = 0;
-        if (lane == 0) ray = atomicAdd(A.ray_counter, 1u);
-        ray = __builtin_amdgcn_readfirstlane(ray);
-        if ((int64_t)ray >= A.R) break;
-        float d[3];
+        unsigned int ray0 = 0;
+        if (lane == 0) ray0 = atomicAdd(A.ray_counter, (unsigned)NS);
+        ray0 = __builtin_amdgcn_readfirstlane(ray0);
+        if ((int64_t)ray0 >= A.R) break;
+        float d[NS][3], t0[NS], T[NS], rc[NS][3];
+        double cum[NS];
+        bool rlive[NS];
+        size_t rayi[NS];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) d[k] = A.raydir[(size_t)ray * 3 + k];
-        // slab test (renderer.py:90-105)
-        float t1[3], t2[3];
+        for (int j = 0; j < NS; ++j) {
+            rlive[j] = (int64_t)ray0 + j < A.R;
+            rayi[j] = rlive[j] ? (size_t)ray0 + j : (size_t)ray0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { t1[k] = (-1.0f - A.campos[k]) / d[k]; t2[k] = (1.0f - A.campos[k]) / d[k]; }
-        const float tmin = fmaxf(fminf(t1[0], t2[0]), fmaxf(fminf(t1[1], t2[1]), fminf(t1[2], t2[2])));
-        const float tmax = fminf(fmaxf(t1[0], t2[0]), fminf(fmaxf(t1[1], t2[1]), fmaxf(t1[2], t2[2])));
-        const float t0 = fmaxf((tmin < tmax) ? tmin : 0.0f, 0.0f);
-
-        double cum = 0.0;          // torch.cumsum accumulates float32 in double on the CPU path we are pinned to
-        float T = 1.0f, rc[3] = {0.0f, 0.0f, 0.0f};
+            for (int k = 0; k < 3; ++k) d[j][k] = A.raydir[rayi[j] * 3 + k];
+            // slab test (renderer.py:90-105)
+            float t1[3], t2[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { t1[k] = (-1.0f - A.campos[k]) / d[j][k]; t2[k] = (1.0f - A.campos[k]) / d[j][k]; }
+            const float tmin = fmaxf(fminf(t1[0], t2[0]), fmaxf(fminf(t1[1], t2[1]), fminf(t1[2], t2[2])));
+            const float tmax = fminf(fmaxf(t1[0], t2[0]), fminf(fmaxf(t1[1], t2[1]), fmaxf(t1[2], t2[2])));
+            t0[j] = fmaxf((tmin < tmax) ? tmin : 0.0f, 0.0f);
+            cum[j] = 0.0;          // torch.cumsum accumulates float32 in double on the CPU path we are pinned to
+            T[j] = 1.0f; rc[j][0] = rc[j][1] = rc[j][2] = 0.0f;
+        }
         for (int base = 0; base < S; base += 64) {
             const int i = base + lane;
             const bool in = i < S;
-            const float seg = in ? dt + dtj * (A.U[(size_t)ray * S + i] - 0.5f) : 0.0f;
-            // inclusive prefix sum over the chunk, sequential in the sample index
-            double mycum = 0.0, prev = 0.0;
-            for (int j = 0; j < 64; ++j) {
-                const double before = cum;
-                cum += (double)__shfl(seg, j);
-                if (lane == j) { mycum = cum; prev = before; }
-            }
-            const float e0 = t0 + (float)prev, e1 = t0 + (float)mycum;
-            const float mid = (e0 + e1) / 2.0f;
-            float p[3];
-            bool valid = in;
+            float seg[NS], p[NS][3], sigma[NS], col[NS][3];
+            bool valid[NS];
+            unsigned long long vm[NS];
+            int nv[NS], rank[NS], total = 0;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                p[k] = A.campos[k] + d[k] * mid;
-                valid = valid && (p[k] > -1.0f) && (p[k] < 1.0f);
-            }
-            const unsigned long long vm = __ballot(valid);
-            const int nv = __popcll(vm);
-            st_samples += nv;
-            st_pass += (nv + 15) / 16;
-            const int rank = __popcll(vm & ((1ull << lane) - 1ull));
-            float sigma = 0.0f, col[3] = {0.0f, 0.0f, 0.0f};
-            for (int g0 = 0; g0 < nv; g0 += 16) {
-                // lane (s, kq) evaluates the (g0+s)-th in-cube sample of the chunk: find its owner lane
-                const int want = g0 + (lane & 15);
-                unsigned long long m = vm;
-                int owner = 0;
-                {   // select the want-th set bit of vm (want < nv, else reuse the first)
-                    const int w2 = want < nv ? want : g0;
-                    for (int b = 0; b < w2; ++b) m &= m - 1;
-                    owner = __ffsll((long long)m) - 1;
+            for (int j = 0; j < NS; ++j) {
+                seg[j] = in ? dt + dtj * (A.U[rayi[j] * S + i] - 0.5f) : 0.0f;
+                // inclusive prefix sum over the chunk, sequential in the sample index
+                double mycum = 0.0, prev = 0.0;
+                for (int q = 0; q < 64; ++q) {
+                    const double before = cum[j];
+                    cum[j] += (double)__shfl(seg[j], q);
+                    if (lane == q) { mycum = cum[j]; prev = before; }
                 }
-                float q[3];
+                const float e0 = t0[j] + (float)prev, e1 = t0[j] + (float)mycum;
+                const float mid = (e0 + e1) / 2.0f;
+                valid[j] = in && rlive[j];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) q[k] = __shfl(p[k], owner);
-                float sg, cc[3];
-                uv_networks(A, act, lane, q, d, sg, cc);
-                // owners pull their result from lane slot (kq = 0 copy)
-                const int slot = rank - g0;
-                const bool mine = valid && slot >= 0 && slot < 16;
-                const float psg = __shfl(sg, slot & 15), p0 = __shfl(cc[0], slot & 15), p1 = __shfl(cc[1], slot & 15),
-                            p2 = __shfl(cc[2], slot & 15);
-                if (mine) { sigma = psg; col[0] = p0; col[1] = p1; col[2] = p2; }
+                for (int k = 0; k < 3; ++k) {
+                    p[j][k] = A.campos[k] + d[j][k] * mid;
+                    valid[j] = valid[j] && (p[j][k] > -1.0f) && (p[j][k] < 1.0f);
+                }
+                vm[j] = __ballot(valid[j]);
+                nv[j] = __popcll(vm[j]);
+                rank[j] = __popcll(vm[j] & ((1ull << lane) - 1ull)) + total;     // index in the combined list
+                total += nv[j];
+                sigma[j] = 0.0f; col[j][0] = col[j][1] = col[j][2] = 0.0f;
             }
-            if (A.dbg_sigma && in) {
-                A.dbg_sigma[(size_t)ray * S + i] = sigma;
+            st_samples += total;
+            st_pass += (total + 15) / 16;
+            for (int g0 = 0; g0 < total; g0 += 16 * NS) {
+                // lane (s, kq) of tile ts evaluates entry g0 + 16 ts + s of the combined list: find its ray and owner lane
+                float q[NS][3], vq[NS][3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) A.dbg_col[((size_t)ray * S + i) * 3 + k] = col[k];
+                for (int ts = 0; ts < NS; ++ts) {
+                    int want = g0 + 16 * ts + (lane & 15);
+                    if (want >= total) want = g0;                        // padding: reuse the first entry of the pass
+                    int jr = 0, off = 0;
+#pragma unroll
+                    for (int j = 0; j + 1 < NS; ++j)
+                        if (want >= off + nv[j]) { off += nv[j]; jr = j + 1; }
+                    unsigned long long m = vm[0];
+#pragma unroll
+                    for (int j = 1; j < NS; ++j) m = jr == j ? vm[j] : m;
+                    for (int b = 0; b < want - off; ++b) m &= m - 1;     // select the (want - off)-th set bit
+                    const int owner = __ffsll((long long)m) - 1;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        float pv = __shfl(p[0][k], owner), dv = d[0][k];
+#pragma unroll
+                        for (int j = 1; j < NS; ++j) {
+                            const float pj = __shfl(p[j][k], owner);
+                            pv = jr == j ? pj : pv;
+                            dv = jr == j ? d[j][k] : dv;
+                        }
+                        q[ts][k] = pv; vq[ts][k] = dv;
+                    }
+                }
+                float sg[NS], cc[NS][3];
+                uv_networks<NS>(A, act, lane, q, vq, sg, cc);
+                // owners pull their result from lane slot (kq = 0 copy) of their tile
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    const int rel = rank[j] - g0;
+                    const bool mine = valid[j] && rel >= 0 && rel < 16 * NS;
+                    const int slot = rel & 15, tsel = (rel >> 4) & (NS - 1);
+                    float psg = __shfl(sg[0], slot), p0 = __shfl(cc[0][0], slot), p1 = __shfl(cc[0][1], slot), p2 = __shfl(cc[0][2], slot);
+#pragma unroll
+                    for (int ts = 1; ts < NS; ++ts) {
+                        const float a = __shfl(sg[ts], slot), b0 = __shfl(cc[ts][0], slot), b1 = __shfl(cc[ts][1], slot), b2 = __shfl(cc[ts][2], slot);
+                        if (tsel == ts) { psg = a; p0 = b0; p1 = b1; p2 = b2; }
+                    }
+                    if (mine) { sigma[j] = psg; col[j][0] = p0; col[j][1] = p1; col[j][2] = p2; }
+                }
             }
-            // ray_march (renderer.py:222-233): sequential in the sample index
-            const float op = 1.0f - expf(-(sigma * (valid ? 1.0f : 0.0f)) * seg);
-            for (int j = 0; j < 64; ++j) {
-                if (base + j >= S) break;
-                const float o = __shfl(op, j);
-                const float w = o * T;
-                T = T * ((1.0f - o) + 1e-10f);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) rc[k] += __shfl(col[k], j) * w;
+            for (int j = 0; j < NS; ++j) {
+                if (A.dbg_sigma && in && rlive[j]) {
+                    A.dbg_sigma[rayi[j] * S + i] = sigma[j];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) A.dbg_col[(rayi[j] * S + i) * 3 + k] = col[j][k];
+                }
+                // ray_march (renderer.py:222-233): sequential in the sample index
+                const float op = 1.0f - expf(-(sigma[j] * (valid[j] ? 1.0f : 0.0f)) * seg[j]);
+                for (int q = 0; q < 64; ++q) {
+                    if (base + q >= S) break;
+                    const float o = __shfl(op, q);
+                    const float w = o * T[j];
+                    T[j] = T[j] * ((1.0f - o) + 1e-10f);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) rc[j][k] += __shfl(col[j][k], q) * w;
+                }
             }
         }
         if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                float c = rc[k];
-                if (A.has_bg) c += A.bg[k] * T;
-                c = powf(c * 1.0f + 1e-5f, (float)(1.0 / 2.2));          // simple_tone_map (renderer.py:7-8)
-                A.color[(size_t)ray * 3 + k] = fminf(fmaxf(c, 0.0f), 1.0f);
+            for (int j = 0; j < NS; ++j) {
+                if (!rlive[j]) continue;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float c = rc[j][k];
+                    if (A.has_bg) c += A.bg[k] * T[j];
+                    c = powf(c * 1.0f + 1e-5f, (float)(1.0 / 2.2));          // simple_tone_map (renderer.py:7-8)
+                    A.color[rayi[j] * 3 + k] = fminf(fmaxf(c, 0.0f), 1.0f);
+                }
+                A.trans[rayi[j]] = T[j];
             }
-            A.trans[ray] = T;
         }
     }
     if (A.stats && lane == 0) {
