@@ -204,26 +204,52 @@ template <int NT_OUT, int NS>
 __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4, int lane, const float *act, f32x4 out[NS][NT_OUT])
 {
     load_bias<NT_OUT, NS>(bias, lane >> 4, out);
-    KStepA<NT_OUT, NS> k0, k1, k2, k3;
-    kload<NT_OUT, NS>(w, act, 0, lane, k0);
-    kload<NT_OUT, NS>(w, act, 1, lane, k1);
+    if constexpr (NS == 1) {
+        KStepA<NT_OUT, NS> k0, k1, k2, k3;
+        kload<NT_OUT, NS>(w, act, 0, lane, k0);
+        kload<NT_OUT, NS>(w, act, 1, lane, k1);
 #pragma unroll 1
-    for (int t = 0; t < KT4; t += 4) {
-        // sched_barrier(0) pins the order: without it hipcc sinks every load next to its first use and waits
-        // vmcnt(0) before each group of four MFMAs
-        kload<NT_OUT, NS>(w, act, t + 2, lane, k2);
-        kload<NT_OUT, NS>(w, act, t + 3, lane, k3);
-        __builtin_amdgcn_sched_barrier(0);
-        kmma<NT_OUT, NS>(k0, out);
-        kmma<NT_OUT, NS>(k1, out);
-        __builtin_amdgcn_sched_barrier(0);
-        const int tn = t + 4 < KT4 ? t + 4 : t;          // last iteration: harmless reload instead of a branch
-        kload<NT_OUT, NS>(w, act, tn, lane, k0);
-        kload<NT_OUT, NS>(w, act, tn + 1, lane, k1);
-        __builtin_amdgcn_sched_barrier(0);
-        kmma<NT_OUT, NS>(k2, out);
-        kmma<NT_OUT, NS>(k3, out);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < KT4; t += 4) {
+            // sched_barrier(0) pins the order: without it hipcc sinks every load next to its first use and waits
+            // vmcnt(0) before each group of four MFMAs
+            kload<NT_OUT, NS>(w, act, t + 2, lane, k2);
+            kload<NT_OUT, NS>(w, act, t + 3, lane, k3);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma<NT_OUT, NS>(k0, out);
+            kmma<NT_OUT, NS>(k1, out);
+            __builtin_amdgcn_sched_barrier(0);
+            const int tn = t + 4 < KT4 ? t + 4 : t;          // last iteration: harmless reload instead of a branch
+            kload<NT_OUT, NS>(w, act, tn, lane, k0);
+            kload<NT_OUT, NS>(w, act, tn + 1, lane, k1);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma<NT_OUT, NS>(k2, out);
+            kmma<NT_OUT, NS>(k3, out);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // one wave per SIMD: nobody else covers the L2 / Infinity-Cache latency, so FOUR k-steps of weights are in flight
+        // behind four k-steps of MFMAs (4 x 32 x NS MFMAs = 4096 matrix-pipe cycles of cover at NS = 2)
+        KStepA<NT_OUT, NS> a0, a1, a2, a3, b0, b1, b2, b3;
+        kload<NT_OUT, NS>(w, act, 0, lane, a0); kload<NT_OUT, NS>(w, act, 1, lane, a1);
+        kload<NT_OUT, NS>(w, act, 2, lane, a2); kload<NT_OUT, NS>(w, act, 3, lane, a3);
+#pragma unroll 1
+        for (int t = 0; t < KT4; t += 8) {
+            const bool has_b = t + 4 < KT4;
+            const int tb = has_b ? t + 4 : t;                    // harmless reload when the layer ends on the first half
+            kload<NT_OUT, NS>(w, act, tb, lane, b0); kload<NT_OUT, NS>(w, act, tb + 1, lane, b1);
+            kload<NT_OUT, NS>(w, act, tb + 2, lane, b2); kload<NT_OUT, NS>(w, act, tb + 3, lane, b3);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma<NT_OUT, NS>(a0, out); kmma<NT_OUT, NS>(a1, out); kmma<NT_OUT, NS>(a2, out); kmma<NT_OUT, NS>(a3, out);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_b) {
+                const int ta = t + 8 < KT4 ? t + 8 : t;
+                kload<NT_OUT, NS>(w, act, ta, lane, a0); kload<NT_OUT, NS>(w, act, ta + 1, lane, a1);
+                kload<NT_OUT, NS>(w, act, ta + 2, lane, a2); kload<NT_OUT, NS>(w, act, ta + 3, lane, a3);
+                __builtin_amdgcn_sched_barrier(0);
+                kmma<NT_OUT, NS>(b0, out); kmma<NT_OUT, NS>(b1, out); kmma<NT_OUT, NS>(b2, out); kmma<NT_OUT, NS>(b3, out);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 }
 
