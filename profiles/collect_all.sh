@@ -5,9 +5,9 @@
 #   3. PMC passes (own runs, kernel-trace only alongside) for the faithful and the fully baked variant
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-python bench.py 2>gpurun_out/bench_stderr.log | grep '^{' > gpurun_out/r01_bench.json
+timeout 600 python bench.py 2>gpurun_out/bench_stderr.log | grep '^{' > gpurun_out/r01_bench.json
 rm -rf gpurun_out/kt && mkdir -p gpurun_out/kt
-rocprofv3 --kernel-trace --stats -d gpurun_out/kt -o kt -- python bench.py --extras 0 --cpu-seconds 0 2>/dev/null | grep '^{' > gpurun_out/r01_bench_headline_under_rocprof.json
+timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/kt -o kt -- python bench.py --extras 0 --cpu-seconds 0 2>/dev/null | grep '^{' > gpurun_out/r01_bench_headline_under_rocprof.json
 python profiles/summarize_rocpd.py $(find gpurun_out/kt -name "*.db" | head -1) > gpurun_out/r01_kernel_stats_headline.txt
 bash profiles/collect_pmc.sh faithful > /dev/null
 bash profiles/collect_pmc.sh baked --bake-density 1 --bake-color 1 > /dev/null

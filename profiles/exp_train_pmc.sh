@@ -5,7 +5,7 @@ OUT=gpurun_out/pmc_train; rm -rf $OUT; mkdir -p $OUT
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU" "TA_TA_BUSY_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  CPU=0 STEPS=3 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -o p$i -- python profiles/exp_train_step.py > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  CPU=0 STEPS=3 timeout 180 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -o p$i -- python profiles/exp_train_step.py > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
 python - <<'PY'
 import csv, glob, collections
