@@ -3,7 +3,7 @@
 // What the reference does per iteration (TriPlane/main.py:264-299): field(rays, is_train=True) (FieldBase.py:251-312),
 // rgb MSE + 8e-5 * density_L1 (Field.py:149-152), autograd, torch.optim.Adam over the 8 groups of get_optparam_groups
 // (Field.py:34-46), lr decay.  Here the step is a short sequence of kernels over HBM-resident buffers (288 GB: the
-// per-sample activations of a 4096-ray batch are simply kept, 2.8 KB per active sample):
+// per-sample activations of a 4096-ray batch are simply kept, 1.7 KB per active sample):
 //
 //   train_density_kernel       every (step, ray) pair in parallel: sample_ray + normalize + compute_gauge + the 48-feature
 //                              density fetch -> xs = Linear(48,1) - 10 (pre-softplus), -inf where the sample is invalid

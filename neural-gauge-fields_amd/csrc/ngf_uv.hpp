@@ -5,8 +5,9 @@
 //   ray_march            renderer.py:176-247    simple_tone_map     renderer.py:7-8
 //
 // 1.33 M MAC per sample, no data to speak of (5.4 MB of weights): the path is bound by the fp32 matrix pipe.
-// One wave renders one ray: lane i owns sample i of a 64-sample chunk (segment jitter, prefix sum, position,
-// in-cube test).  In-cube samples are compacted and pushed through the three MLPs 16 at a time on
+// One wave renders rays two at a time (NS = 2): lane i owns sample i of a 64-sample chunk of each (segment jitter, prefix sum,
+// position, in-cube test).  The in-cube samples of both rays are compacted into one list and pushed through the three MLPs 32 at
+// a time on
 // v_mfma_f32_16x16x4_f32 with FOUR lanes per sample (lane (s, kq)); the product is evaluated transposed (rows =
 // units, columns = samples) so a lane's accumulators are 64 of the 256 activations of its own sample and are the
 // B operand of the next layer without any data movement.  Weights are pre-permuted at create time into
