@@ -217,8 +217,11 @@ def main():
     achieved = bytes_launch / (k_ms * 1e-3) / 1e9
     # Executed matrix work of the launch: passes x MFMAs per 16-sample pass x 2*16*16*4 flop (v_mfma_f32_16x16x4_f32);
     # agrees with rocprofv3's SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 (profiles/r01_pmc_*.txt).
-    mfma_per_pass = 80 if args.bake_color else 224
-    mfma_flops = st[2] * mfma_per_pass * 2048.0 if model == "triplane" else None
+    # (144 feature + 64 layer-2 MFMAs per pass, or 64 with the baked colour planes; the 16 view-input MFMAs are spent once per
+    # 8-ray tile since the per-ray view fold)
+    mfma_per_pass = 64 if args.bake_color else 208
+    tile_w = 8 if n_local >= 8 * 256 * 12 else 4
+    mfma_flops = (st[2] * mfma_per_pass + ((n_local + tile_w - 1) // tile_w) * 16) * 2048.0 if model == "triplane" else None
     pmc = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_baked.json" if args.bake_color else "r01_pmc_faithful.json")))

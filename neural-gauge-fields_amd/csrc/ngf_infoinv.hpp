@@ -59,6 +59,7 @@ struct InfoInvPolicy {
     static constexpr int WAVES = kInfoInvWaves;
     static constexpr bool PROFILE = false;
     static constexpr bool VLDS = true;
+    static constexpr bool VIEW_FOLD = false;
     static constexpr int NSTEP = 1;
     static constexpr int BATCH = kBatch;
     static constexpr int RING = 128;

@@ -314,12 +314,19 @@ struct TriPlanePolicy {
         return valid ? sg : 0.0f;
     }
     // vf: the owner ray's 16 cached view inputs (VLDS) or nullptr; od: the owner ray's direction
-    __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
-                                                 const float od[3], int lane, float c[3], unsigned long long *tk = nullptr)
+    static constexpr bool VIEW_FOLD = VLDS;                      // small split tiles: b1 + W1[:, view].view once per ray per tile
+    __device__ static __forceinline__ void fold_view(const float *smem, const float *vfeat, float *pre, int n_rays, int lane)
     {
-        const f32x4 v = VLDS ? *reinterpret_cast<const f32x4 *>(vf + (lane >> 4) * 4) : view_entries16(od, lane >> 4);
-        if constexpr (BAKE_C) mlp_pass16_baked(A, smem, rec, v, lane, c);
-        else mlp_pass16<48>(A, smem, rec, v, lane, c, tk);
+        if constexpr (BAKE_C) view_fold16<MlpLayout16Baked::W1V / 64, MlpLayout16Baked::B1, 4>(per_pass16(smem), vfeat, pre, n_rays, lane);
+        else view_fold16<MlpLayout16<48>::W1 / 64 + 3 * MlpLayout16<48>::QCH, MlpLayout16<48>::B1, MlpLayout16<48>::KT>(per_pass16(smem), vfeat, pre, n_rays, lane);
+    }
+    __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
+                                                 const float od[3], int lane, float c[3], unsigned long long *tk = nullptr, const float *pre = nullptr)
+    {
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (!pre) v = VLDS ? *reinterpret_cast<const f32x4 *>(vf + (lane >> 4) * 4) : view_entries16(od, lane >> 4);
+        if constexpr (BAKE_C) mlp_pass16_baked(A, smem, rec, v, lane, c, pre);
+        else mlp_pass16<48>(A, smem, rec, v, lane, c, tk, pre);
     }
 };
 
@@ -382,6 +389,16 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
             f32x4 *dst = reinterpret_cast<f32x4 *>(vfeat + rl * kViewFeat);      // split march: K lanes store the same values
 #pragma unroll
             for (int q = 0; q < 4; ++q) dst[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        }
+        // tiles of <= 8 rays: fold the view part of layer 1 into one 64-float vector per ray (behind the 8 x 16 view inputs)
+        bool view_fold = false;
+        if constexpr (SPLIT && P::VIEW_FOLD) {
+            view_fold = A.tile_w <= 8;
+            if (view_fold) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                P::fold_view(smem, vfeat, vfeat + 8 * kViewFeat, A.tile_w, lane);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
         }
         float T = 1.0f, acc = 0.0f, dep = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
         int i = 0, head = 0, count = 0;
@@ -492,9 +509,10 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 float od[3] = {0.0f, 0.0f, 0.0f};
                 if constexpr (!P::VLDS) { od[0] = __shfl(d[0], owner); od[1] = __shfl(d[1], owner); od[2] = __shfl(d[2], owner); }
                 float c[3];
+                [[maybe_unused]] const float *pre = view_fold ? vfeat + 8 * kViewFeat + owner * 64 : nullptr;
                 if constexpr (P::PROFILE) {
                     unsigned long long tk[5] = {0, 0, 0, 0, 0};
-                    P::shade(A, smem, rec, vfeat + owner * kViewFeat, od, lane, c, tk);
+                    P::shade(A, smem, rec, vfeat + owner * kViewFeat, od, lane, c, tk, pre);
                     prof[1] += tk[0] - t_sec;      // ring read, address setup, gather 0 + view MFMAs issued
                     prof[2] += tk[1] - tk[0];      // wait for plane 0 + interpolate
                     prof[3] += tk[2] - tk[1];      // layer-1 MFMAs (planes 1, 2 gathered behind them)
@@ -502,7 +520,8 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     prof[6] += tk[3] - tk[4];      // layer 3 (VALU dot, 2 cross-lane adds, sigmoid)
                     t_sec = tk[3];
                 } else {
-                    P::shade(A, smem, rec, vfeat + owner * kViewFeat, od, lane, c);
+                    if constexpr (P::VIEW_FOLD) P::shade(A, smem, rec, vfeat + owner * kViewFeat, od, lane, c, nullptr, pre);
+                    else P::shade(A, smem, rec, vfeat + owner * kViewFeat, od, lane, c);
                 }
                 // result list, structure-of-arrays: res[0..B) owner lane ids, then weighted r, g, b
                 if (lane < BATCH) {

@@ -165,9 +165,32 @@ __device__ __forceinline__ void layer1_plane16(const float *blob, int lane, cons
 // re-issued for plane p+1 at once, and plane p's 48 MFMAs run while that gather is in flight.
 #define NGF_TICK(i) do { if (tk) tk[i] = __builtin_readcyclecounter(); } while (0)
 
+// Fold (ii) of SURVEY section 7: the view-direction part of layer 1 is constant per ray.  For small tiles the kernel evaluates
+// b1 + W1[:, view] . view ONCE per ray per tile (view_fold16: the same 16 MFMAs a pass would spend on it) into an LDS table in
+// accumulator order; a pass then starts from its sample's ray vector `pre` (4 broadcast ds_read_b128) instead of the bias and
+// skips those 16 MFMAs and their operand reads.  Same products, same order: bit-identical.
+template <int OW1V, int OB1, int KSTRIDE>     // OW1V: first view k-step; KSTRIDE: k-steps per unit tile in the image
+__device__ __forceinline__ void view_fold16(const float *blob, const float *vfeat, float *pre, int n_rays, int lane)
+{
+    const int kq = lane >> 4, s = lane & 15;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(vfeat + (s < n_rays ? s : 0) * kViewFeat + kq * 4);
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(blob + OB1 + kq * 16 + mt * 4);
+    const float *w1 = blob + OW1V * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = NGF_MFMA16(w1[(mt * KSTRIDE + j) * 64], v[j], acc[mt]);
+    if (s < n_rays) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4 *>(pre + s * 64 + kq * 16 + mt * 4) = acc[mt];
+    }
+}
+
 template <int APP>
 __device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v,
-                                           int lane, float rgb[3], unsigned long long *tk = nullptr)
+                                           int lane, float rgb[3], unsigned long long *tk = nullptr, const float *pre = nullptr)
 {
     using L = MlpLayout16<APP>;
     blob = per_pass16(blob);
@@ -177,9 +200,13 @@ __device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blo
     gather16_issue<APP, 0>(A, rec, kq, g);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[4];
+    if (pre) {      // per-ray b1 + W1[:, view] . view from the tile's table
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(blob + L::B1 + kq * 16 + mt * 4);
-    {   // view-direction inputs: lane-quarter kq supplies entries kq*4 .. kq*4+3 (v)
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(pre + kq * 16 + mt * 4);
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(blob + L::B1 + kq * 16 + mt * 4);
+        // view-direction inputs: lane-quarter kq supplies entries kq*4 .. kq*4+3 (v)
         const float *w1 = blob + L::W1 + lane;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -251,7 +278,7 @@ __device__ __forceinline__ void baked16_consume(const BakedHalf &g, float sum[16
 // pre-activations are summed in plain VGPRs first and only then become the MFMA accumulator of the 16 view-input
 // MFMAs (updating MFMA accumulators with VALU adds in between made hipcc spill heavily).
 __device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v,
-                                                 int lane, float rgb[3])
+                                                 int lane, float rgb[3], const float *pre = nullptr)
 {
     using L = MlpLayout16Baked;
     blob = per_pass16(blob);
@@ -262,8 +289,11 @@ __device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const floa
     baked16_issue<1>(A, rec, kq, gb);
     __builtin_amdgcn_sched_barrier(0);
     float sum[16];
+    {
+        const float *b0 = pre ? pre + kq * 16 : blob + L::B1 + kq * 16;      // per-ray view fold, or the bias
 #pragma unroll
-    for (int k = 0; k < 16; ++k) sum[k] = blob[L::B1 + kq * 16 + k];
+        for (int k = 0; k < 16; ++k) sum[k] = b0[k];
+    }
     __builtin_amdgcn_sched_barrier(0);
     baked16_consume<0>(ga, sum);
     __builtin_amdgcn_sched_barrier(0);
@@ -288,7 +318,7 @@ __device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const floa
     f32x4 acc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{sum[4 * mt], sum[4 * mt + 1], sum[4 * mt + 2], sum[4 * mt + 3]};
-    {
+    if (!pre) {
         const float *w1 = blob + L::W1V + lane;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
