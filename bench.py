@@ -224,7 +224,8 @@ def main():
     mfma_flops = (st[2] * mfma_per_pass + ((n_local + tile_w - 1) // tile_w) * 16) * 2048.0 if model == "triplane" else None
     pmc = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_baked.json" if args.bake_color else "r01_pmc_faithful.json")))
+        pmc_name = "r01_pmc_infoinv.json" if model == "infoinv" else ("r01_pmc_baked.json" if args.bake_color else "r01_pmc_faithful.json")
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
     except Exception:
         pass
     pmc_txt = "no PMC summary under profiles/" if pmc is None else (
@@ -245,6 +246,13 @@ def main():
                     "flops_counted": "executed fp32 MFMA flops of the colour MLP (layer 1 pre-composed with `basis`): the binding "
                                      "resource" + busy_txt,
                     "flops_per_launch": mfma_flops}
+    elif pmc is not None and args.preset == "R1" and world == 1:
+        # InfoInv: the march runs its density MLP on the matrix pipe too, so the executed flops are not a function of the pass count
+        # alone; take them from the PMC run of this very command (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512, profiles/r01_pmc_infoinv.txt)
+        tf = pmc["mfma_flops_per_dispatch"] / (k_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                    "traffic": pmc.get("hbm_traffic_bytes_per_launch"), "flops_per_launch": pmc["mfma_flops_per_dispatch"],
+                    "flops_counted": "executed fp32 MFMA flops from rocprofv3 --pmc (profiles/r01_pmc_infoinv.txt)" + busy_txt}
     else:
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None}
     roofline.update({"kernel": "ngf::render_kernel", "kernel_ms": k_ms, "active_samples_per_ray": s_active,
