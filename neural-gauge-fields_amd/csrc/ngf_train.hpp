@@ -141,9 +141,12 @@ __global__ void __launch_bounds__(256) train_density_kernel(const TrainArgs T)
     const RenderArgs &A = T.R;
     const int64_t total = (int64_t)A.S * A.n;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const int i = (int)(idx / A.n);
-        const int64_t r = idx % A.n;
+    for (int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < total; wi += stride) {
+        // a wave takes 64 CONSECUTIVE steps of one ray: its gathers share texels (two steps per texel) instead of touching 64
+        // unrelated cells of 64 random training rays; the dense buffers stay step-major for the per-ray sweeps
+        const int64_t r = wi / A.S;
+        const int i = (int)(wi - r * A.S);
+        const int64_t idx = (int64_t)i * A.n + r;
         float xn[3], z, dist, tt[6];
         const bool valid = sample_geometry(A, r, i, xn, z, dist);
         if (!valid) {                               // outside the box / in free space of the alpha mask: sigma = 0, no fetches
@@ -772,9 +775,12 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     // wave-uniform trip count: the scatter below exchanges values between lanes
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < total; base += stride) {
-        const int64_t idx0 = base + lane;
-        const bool inr = idx0 < total;
-        const int64_t idx = inr ? idx0 : total - 1;
+        // ray-major work order like the forward kernel: the scatter of a wave lands on the few cache lines along one ray
+        const int64_t wi0 = base + lane;
+        const bool inr = wi0 < total;
+        const int64_t wi = inr ? wi0 : total - 1;
+        const int64_t rr = wi / A.S;
+        const int64_t idx = (int64_t)(wi - rr * A.S) * A.n + rr;
         float dx = inr ? T.dx[idx] : 0.0f;
         const bool active = inr && (T.w[idx] > A.thr);
         const bool work = (dx != 0.0f) | active;
