@@ -51,3 +51,24 @@ def test_uv_no_background_and_short_chunks():
     out = m(torch.from_numpy(g["campos"])[None], torch.from_numpy(g["raydir"][:7])[None], None, jitter_u=torch.from_numpy(U)[None])
     assert np.abs(out["color"][0].cpu().numpy() - o_color).max() < 5e-4
     assert np.abs(out["transmittance"][0].cpu().numpy() - o_trans).max() < 2e-5
+
+
+def test_two_rays_per_wave_is_bit_identical(monkeypatch):
+    """The default kernel renders two rays per wave (every weight load feeds two MFMAs); a sample's arithmetic does not
+    depend on its tile, so the one-ray-per-wave kernel (NGF_UV_TILES=1) gives the same bits -- also for an odd ray count
+    (the last wave's second ray is a dummy) and a single ray."""
+    import ngf_amd  # noqa: F401
+    from ngf_amd import synth, uvmapping
+    net = uvmapping.NeuTex(primitive_type="sphere", sample_num=64)
+    net.load_params(synth.uvmapping_params(31, "sphere"))
+    campos, dirs = synth.dtu_rays(600, 800)
+    for n in (1, 37, 64):
+        pick = (synth.hash_uniform(8, n, (n,)) * np.float32(dirs.shape[0])).astype(np.int64)
+        rd = torch.from_numpy(dirs[pick])[None].cuda()
+        cp = torch.from_numpy(campos)[None].cuda()
+        U = torch.from_numpy(synth.hash_uniform(8, 100 + n, (1, n, 64))).cuda()
+        two = net(cp, rd, None, jitter_u=U)
+        monkeypatch.setenv("NGF_UV_TILES", "1")
+        one = net(cp, rd, None, jitter_u=U)
+        monkeypatch.delenv("NGF_UV_TILES")
+        assert torch.equal(two["color"], one["color"]) and torch.equal(two["transmittance"], one["transmittance"]), n
