@@ -444,10 +444,36 @@ def capture_uv_edit(name="uv_edit", seed=61, n=160):
     print(f"{name}: " + ", ".join(f"{k} {v.shape}" for k, v in out.items() if k.endswith("mode3")))
 
 
+def capture_ref_checkpoint(name="ref_ckpt_triplane", seed=71):
+    """A checkpoint WRITTEN BY THE REFERENCE (Base.save, FieldBase.py:94-109) for a small model with an alpha mask, plus the
+    reference's own render of a few rays with it: the drop-in must load the file as is (main.py:34-38) and reproduce the pixels."""
+    F = _import_ref("TriPlane")
+    aabb = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
+    grid = [12, 10, 9]
+    plane_hw = ((10, 12), (9, 10), (9, 12))
+    gauge_hw = (6, 7)
+    params = synth.triplane_params(seed, plane_hw, gauge_hw, preset="R1", gauge_std=0.04)
+    with contextlib.redirect_stdout(io.StringIO()):
+        field = F.TriPlane(aabb, grid, "cpu", near_far=[2.0, 6.0], alphaMask_thres=1e-4, distance_scale=25,
+                           rayMarch_weight_thres=1e-4, step_ratio=0.5, gauge_start=0)
+    _load_params(field, params)
+    dhw = (7, 8, 9)
+    vol, _ = synth.alpha_mask_bits(seed, dhw)
+    field.alphaMask = F.AlphaGridMask("cpu", torch.tensor([[-1.45, -1.4, -1.5], [1.4, 1.5, 1.3]]), torch.from_numpy(vol.astype(np.float32)))
+    path = os.path.join(HERE, name + ".th")
+    field.save(path)
+    rays = _rays_for_case(seed, 64, 32)
+    with torch.no_grad():
+        out = field(torch.from_numpy(rays), white_bg=True, is_train=False, N_samples=40, iteration=30001)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=seed, rays=rays, rgb_map=out["rgb_map"].numpy(), depth_map=out["depth_map"].numpy(),
+                        plane_hw=np.array(plane_hw), gauge_hw=np.array(gauge_hw), mask_dhw=np.array(dhw))
+    print(f"{name}: {os.path.getsize(path)} bytes, mean rgb {float(out['rgb_map'].mean()):.4f}")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1:       # regenerate one fixture without touching the others
-        {"evalout": capture_evalout, "train": capture_train, "uv_edit": capture_uv_edit}[sys.argv[1]]()
+        {"evalout": capture_evalout, "train": capture_train, "uv_edit": capture_uv_edit, "ref_ckpt": capture_ref_checkpoint}[sys.argv[1]]()
         sys.exit(0)
     capture_ops()
     capture_triplane("triplane_r1_gauge", seed=11, preset="R1", gauge_on=True, gauge_std=0.05, with_mask=False, S=48)
@@ -463,3 +489,4 @@ if __name__ == "__main__":
     capture_evalout()
     capture_train()
     capture_uv_edit()
+    capture_ref_checkpoint()

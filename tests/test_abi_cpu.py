@@ -85,3 +85,26 @@ def test_cpu_device_fails_loudly():
     f = triplane.TriPlane(aabb, [16] * 3, "cpu", step_ratio=0.5)
     with pytest.raises(RuntimeError, match="GPU only"):
         f(torch.zeros(4, 6), N_samples=4)
+
+
+def test_loads_a_checkpoint_written_by_the_reference():
+    """tests/golden/ref_ckpt_triplane.th was written by the reference's Base.save (make_golden.py capture_ref_checkpoint); the
+    drop-in builds from its kwargs and loads it exactly like TriPlane/main.py:34-38 does."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck = torch.load(os.path.join(root, "tests", "golden", "ref_ckpt_triplane.th"), map_location="cpu", weights_only=False)
+    kw = dict(ck["kwargs"])
+    kw.update({"device": "cpu"})
+    f = triplane.TriPlane(**kw)
+    f.load(ck)
+    g = np.load(os.path.join(root, "tests", "golden", "ref_ckpt_triplane.npz"))
+    from ngf_amd import synth
+    params = synth.triplane_params(int(g["seed"]), tuple(tuple(int(v) for v in hw) for hw in g["plane_hw"]), tuple(int(v) for v in g["gauge_hw"]),
+                                   preset="R1", gauge_std=0.04)
+    sd = f.state_dict()
+    assert set(sd) == set(params)
+    for k, v in params.items():
+        assert np.array_equal(sd[k].numpy(), v), k
+    vol, _ = synth.alpha_mask_bits(int(g["seed"]), tuple(int(v) for v in g["mask_dhw"]))
+    assert np.array_equal(f.alphaMask.alpha_volume[0, 0].numpy(), vol.astype(np.float32))
+    assert abs(float(f.stepSize) - 0.5 * float(np.mean((np.float32(3.0) / (np.array([12, 10, 9], np.float32) - 1))))) < 1e-6

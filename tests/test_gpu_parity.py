@@ -302,3 +302,19 @@ def test_alpha_mask_build_and_ray_filter():
     # the rebuilt mask is used by the next render and by a checkpoint round trip
     out = f(rays.cuda(), N_samples=32, iteration=30001)
     assert bool(torch.isfinite(out["rgb_map"]).all())
+
+
+def test_renders_a_checkpoint_written_by_the_reference():
+    """The reference's own checkpoint file, loaded as is, renders the reference's own pixels."""
+    import os
+    from ngf_amd import triplane
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck = torch.load(os.path.join(ROOT, "tests", "golden", "ref_ckpt_triplane.th"), map_location="cpu", weights_only=False)
+    kw = dict(ck["kwargs"])
+    kw.update({"device": "cuda"})
+    f = triplane.TriPlane(**kw)
+    f.load(ck)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_ckpt_triplane.npz"))
+    out = f(torch.from_numpy(g["rays"]).cuda(), white_bg=True, is_train=False, N_samples=40, iteration=30001)
+    np.testing.assert_allclose(out["rgb_map"].cpu().numpy(), g["rgb_map"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["depth_map"].cpu().numpy(), g["depth_map"], rtol=1e-4, atol=1e-5)
