@@ -395,10 +395,10 @@ static int launch_render(K kernel, K kernel_split, const ngf_field *f, RenderArg
     // consecutive steps (bit-identical results).  Small tiles shorten the critical path of a tile and even out the
     // tiles-per-wave quantisation, which bounds small launches (one rank's shard of a frame, the reference's 4096-ray
     // chunks) and still buys 5 % on a full frame.  Measured in profiles/r01_split_march.txt: tile_w = 8 is best from
-    // 40 000 rays to the full frame, tile_w = 4 for a 4000-ray chunk (0.31 ms vs 0.53 ms).  NGF_TILE_W / NGF_SPLIT override for experiments.
+    // 160 000 rays to the full frame, tile_w = 4 below (80 000 rays: 1.43-1.49 vs 1.51-1.53 ms; 4000 rays: 0.29 vs 0.51 ms).  NGF_TILE_W / NGF_SPLIT override for experiments.
     const int waves = threads / kWave;
     int tw = 64;
-    if (kernel_split) tw = A.n < 8 * (int64_t)f->num_cus * waves ? 4 : wide_tile;      // below one 8-ray tile per resident wave: 4-ray tiles
+    if (kernel_split) tw = A.n < 40 * (int64_t)f->num_cus * waves ? 4 : wide_tile;     // up to ~120 k rays (5 tiles of 8 per resident wave) 4-ray tiles balance better
     if (const char *e = getenv("NGF_TILE_W")) tw = atoi(e);
     if (tw != 64 && tw != 32 && tw != 16 && tw != 8 && tw != 4) return fail(NGF_E_ARG, "NGF_TILE_W must be 64, 32, 16, 8 or 4");
     bool split = tw < 64 && kernel_split;
