@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Build the HIP library (hipcc cross-compiles gfx950 without a GPU) and the C oracle when their .so files are missing, so
+    that a fresh checkout can run `pytest` directly; normally __graft_entry__.build() has done it already."""
+    import ngf_amd  # noqa: F401
+    from ngf_amd import _lib
+    from oracle import oracle
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
+    if not os.path.exists(os.path.join(ROOT, "oracle", "libngf_oracle.so")):
+        oracle.build()
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
