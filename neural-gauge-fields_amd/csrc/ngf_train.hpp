@@ -804,6 +804,22 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
             dt[2 * p] = dx * (b.wy0 * (v10 - v00) + b.wy1 * (v11 - v01)) * b.sx;
             dt[2 * p + 1] = dx * (b.wx0 * (v01 - v00) + b.wx1 * (v11 - v10)) * b.sy;
         }
+        // consecutive lanes are consecutive steps of one ray, half a texel apart: merge the contributions of lanes that hit the
+        // SAME cell inside aligned pairs, then quads, before anything goes to L2 (a merged lane's values become 0 and are skipped)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int d = 1; d <= 2; d <<= 1) {
+                const int oi = __shfl_xor(didx[p], d);
+                const bool take = ((lane & d) == 0) & (oi == didx[p]) & ((lane & (d - 1)) == 0);      // receiver: lower lane of the pair / quad
+                const bool give = ((lane & d) != 0) & (oi == didx[p]) & ((lane & (d - 1)) == 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float ov = __shfl_xor(dw[p][k], d);
+                    dw[p][k] = take ? dw[p][k] + ov : (give ? 0.0f : dw[p][k]);
+                }
+            }
+        }
         // density-gradient images: the two taps of a row are consecutive floats -> lane pairs write them together
         // (32 samples x 2 floats per instruction: half as many cache lines per atomic instruction)
 #pragma unroll
@@ -838,7 +854,22 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
             for (int p = 0; p < 3; ++p) {
                 const Tex &tx = A.gau[p];
                 Bil b = bil_setup(u[p], v[p], tx);
-                const float wt[4] = {b.w00, b.w10, b.w01, b.w11};
+                // the 8 contributions of this sample's cell: gv[tap][channel] = tap weight * gradient; same-cell lanes merged as above
+                float gv[4][2] = {{b.w00 * dg[p][0], b.w00 * dg[p][1]}, {b.w10 * dg[p][0], b.w10 * dg[p][1]},
+                                  {b.w01 * dg[p][0], b.w01 * dg[p][1]}, {b.w11 * dg[p][0], b.w11 * dg[p][1]}};
+#pragma unroll
+                for (int d = 1; d <= 2; d <<= 1) {
+                    const int oi = __shfl_xor(b.idx, d);
+                    const bool take = ((lane & d) == 0) & (oi == b.idx) & ((lane & (d - 1)) == 0);
+                    const bool give = ((lane & d) != 0) & (oi == b.idx) & ((lane & (d - 1)) == 0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const float ov = __shfl_xor(gv[k][c], d);
+                            gv[k][c] = take ? gv[k][c] + ov : (give ? 0.0f : gv[k][c]);
+                        }
+                }
                 // a row of the cell is 4 consecutive floats (2 texels x 2 channels): 16 samples x 4 floats per instruction
 #pragma unroll
                 for (int row = 0; row < 2; ++row) {
@@ -846,9 +877,9 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
                     for (int sq = 0; sq < 4; ++sq) {
                         const int src = sq * 16 + (lane >> 2), e = lane & 3;
                         const int ii = __shfl(b.idx, src);
-                        const float wa = __shfl(wt[2 * row], src), wb = __shfl(wt[2 * row + 1], src);
-                        const float d0 = __shfl(dg[p][0], src), d1 = __shfl(dg[p][1], src);
-                        const float val = (e < 2 ? wa : wb) * ((e & 1) ? d1 : d0);
+                        const float v0 = __shfl(gv[2 * row][0], src), v1 = __shfl(gv[2 * row][1], src);
+                        const float v2 = __shfl(gv[2 * row + 1][0], src), v3 = __shfl(gv[2 * row + 1][1], src);
+                        const float val = e == 0 ? v0 : (e == 1 ? v1 : (e == 2 ? v2 : v3));
                         if (val != 0.0f) atomicAdd(T.g_gau[p] + ((size_t)ii + (size_t)row * tx.stride) * 2 + e, val);
                     }
                 }
