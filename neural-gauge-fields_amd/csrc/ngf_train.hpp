@@ -671,19 +671,34 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const
         // feature gradients -> packed colour planes: the 48 channels of one tap are CONSECUTIVE floats, so the wave scatters
         // (sample, plane) by (sample, plane): 4 taps x 48 channels = 3 instructions of 64 lanes over 12 cache lines, instead of
         // every lane hitting its own line
-        for (int sp = 0; sp < 48; ++sp) {
-            const float *tp = tap + sp * 5;
-            const int smp = sp / 3, p = sp - 3 * smp;
-            const int idx = __float_as_int(tp[0]);
+        // (the list is in (ray, step) order: consecutive samples of a pass are half a texel apart, and runs of samples in the SAME
+        // cell are summed in registers first and scattered once)
+#pragma unroll 1
+        for (int p = 0; p < 3; ++p) {
             const Tex &tx = A.app[p];
+            int s0 = 0;
+            while (s0 < 16) {
+                const int idx = __float_as_int(tap[(s0 * 3 + p) * 5]);
+                float acc3[3] = {0.0f, 0.0f, 0.0f};
+                int s1 = s0;
+                do {
+                    const float *tp = tap + (s1 * 3 + p) * 5;
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int e = u * 64 + lane;                 // 0..191 = tap * 48 + channel
-                const int tp_i = e / 48, c = e - 48 * tp_i;
-                const float wt = tp[1 + tp_i];
-                const size_t off = ((size_t)idx + (tp_i & 1) + (tp_i >> 1) * (size_t)tx.stride) * 48 + c;
-                const float g = DFt[smp * kDfStride + p * 48 + c];
-                if (wt != 0.0f) atomicAdd(T.g_app[p] + off, wt * g);
+                    for (int u = 0; u < 3; ++u) {
+                        const int e = u * 64 + lane;                 // 0..191 = tap * 48 + channel
+                        const int tp_i = e / 48, c = e - 48 * tp_i;
+                        acc3[u] = fmaf(tp[1 + tp_i], DFt[s1 * kDfStride + p * 48 + c], acc3[u]);
+                    }
+                    ++s1;
+                } while (s1 < 16 && __float_as_int(tap[(s1 * 3 + p) * 5]) == idx);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int e = u * 64 + lane;
+                    const int tp_i = e / 48, c = e - 48 * tp_i;
+                    const size_t off = ((size_t)idx + (tp_i & 1) + (tp_i >> 1) * (size_t)tx.stride) * 48 + c;
+                    if (acc3[u] != 0.0f) atomicAdd(T.g_app[p] + off, acc3[u]);
+                }
+                s0 = s1;
             }
         }
         if (live && q == 0) {
