@@ -868,9 +868,9 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
     hipLaunchKernelGGL(train_scan_kernel, dim3(ray_blocks), dim3(64), 0, st, T, 1);
 
     const size_t lds_f = (size_t)(((kFwdImage + 3) & ~3) + kTrainWaves * kFwdTileFloats) * sizeof(float),
-                 lds_b = (size_t)(((kBwdImage + 3) & ~3) + kTrainWaves * kBwdTileFloats) * sizeof(float);
+                 lds_b = (size_t)(((kBwdImage + 3) & ~3) + kTrainWavesBwd * kBwdTileFloats) * sizeof(float);
     static_assert((((kFwdImage + 3) & ~3) + kTrainWaves * kFwdTileFloats) * 4 <= 160 * 1024, "colour forward LDS");
-    static_assert((((kBwdImage + 3) & ~3) + kTrainWaves * kBwdTileFloats) * 4 <= 160 * 1024, "colour backward LDS");
+    static_assert((((kBwdImage + 3) & ~3) + kTrainWavesBwd * kBwdTileFloats) * 4 <= 160 * 1024, "colour backward LDS");
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(train_color_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(train_color_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     const bool single = n_active <= t->chunk;
@@ -890,7 +890,7 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
             T.store = 1;
             hipLaunchKernelGGL(train_color_fwd_kernel, dim3(tr_grid(t, passes, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_f, st, T);
         }
-        hipLaunchKernelGGL(train_color_bwd_kernel, dim3(tr_grid(t, passes, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_b, st, T);
+        hipLaunchKernelGGL(train_color_bwd_kernel, dim3(tr_grid(t, passes, kTrainWavesBwd, 1)), dim3(kTrainWavesBwd * 64), lds_b, st, T);
         const int rows = T.chunk_n;
         int splits = rows / 512;
         if (splits < 1) splits = 1;

@@ -35,7 +35,8 @@
 
 namespace ngf {
 
-constexpr int kTrainWaves = 4;                 // waves per workgroup in the MFMA kernels
+constexpr int kTrainWaves = 4;                 // waves per workgroup in the colour forward kernel
+constexpr int kTrainWavesBwd = 6;              // ... and in the colour backward kernel (its tiles alias, see kBwdTileFloats)
 constexpr int kFeat = 144;                     // colour features (3 planes x 48)
 constexpr int kIn1 = 159, kIn1Pad = 160;       // [g(144), view(15)] (+1 zero pad)
 constexpr int kLd1 = 164, kLd2 = 68;           // LDS row strides == 4 (mod 32): lane (row n, k = 4j+q) -> bank 4n+q, two lanes per bank
@@ -374,7 +375,9 @@ __device__ __forceinline__ void list_sample_coords(const RenderArgs &A, int64_t 
 
 constexpr int kFwdTileFloats = (kIn1Pad + 64 + 64) * 16;                  // [F; view], H1, H2
 constexpr int kDfStride = kFeat + 1;                                       // DF is kept sample-major (bank-conflict-free rows)
-constexpr int kBwdTileFloats = (64 + 64 + 64) * 16 + 16 * kDfStride + 16 * 16;   // H1, H2 (then D1), D2, DF^T, tap table
+// backward tiles per wave: [H1 | D2 | pad] is overwritten by DF^T once d1 exists and d2 / d1 have been written out; [H2, then D1]; tap table
+constexpr int kBwdTileFloats = 16 * kDfStride + 64 * 16 + 16 * 16;
+static_assert(16 * kDfStride >= 2 * 64 * 16, "DF^T must cover the H1 and D2 tiles it aliases");
 
 // ---- per-step weight images -------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) train_fold_kernel(const TrainArgs T, float *fwd, float *bwd)
@@ -582,7 +585,7 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
 }
 
 // ---- 5. colour backward over the active list --------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const TrainArgs T)
+__global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(const TrainArgs T)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RenderArgs &A = T.R;
@@ -591,11 +594,11 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const
     const float *img = smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
-    float *H1t = smem + ((kBwdImage + 3) & ~3) + wave * kBwdTileFloats, *H2t = H1t + 64 * 16, *D2t = H2t + 64 * 16, *DFt = D2t + 64 * 16,
-          *tap = DFt + 16 * kDfStride;       // tap[s][p] = {texel index, w00, w10, w01, w11}
+    float *H1t = smem + ((kBwdImage + 3) & ~3) + wave * kBwdTileFloats, *D2t = H1t + 64 * 16, *DFt = H1t, *H2t = H1t + 16 * kDfStride,
+          *tap = H2t + 64 * 16;              // tap[s][p] = {texel index, w00, w10, w01, w11}
     float *D1t = H2t;                        // h2 is dead once d2 exists
     const int passes = (T.chunk_n + 15) / 16;
-    for (int pass = blockIdx.x * kTrainWaves + wave; pass < passes; pass += gridDim.x * kTrainWaves) {
+    for (int pass = blockIdx.x * kTrainWavesBwd + wave; pass < passes; pass += gridDim.x * kTrainWavesBwd) {
         const int local = pass * 16 + n;
         const bool live = local < T.chunk_n;
         const int64_t row = live ? local : 0;
@@ -624,9 +627,7 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         dense16<false, 2, 64, 64, 64>(img + kBwdW2T, kLd2, 64, nullptr, D2t, D1t, H1t, lane);              // d1 = (W2^T d2) * [h1 > 0]
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        dense16<false, 0, kFeat, 64, 64, kDfStride>(img + kBwdW1T, kLd2, kFeat, nullptr, D1t, DFt, nullptr, lane);   // df = W1'^T d1
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // rows for the weight-gradient GEMMs
+        // rows for the weight-gradient GEMMs (d2 leaves LDS here: its tile and h1's are about to become DF^T)
         if (live && q == 0) {
             float *d = T.D3 + row * 16;
             d[0] = d3[0]; d[1] = d3[1]; d[2] = d3[2];
@@ -635,6 +636,9 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_bwd_kernel(const
         }
         tile_to_rows(D2t, 64, T.D2, 64, row, live, lane);
         tile_to_rows(D1t, 64, T.D1, 64, row, live, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        dense16<false, 0, kFeat, 64, 64, kDfStride>(img + kBwdW1T, kLd2, kFeat, nullptr, D1t, DFt, nullptr, lane);   // df = W1'^T d1
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // d loss / d t through the bilinear cell (lane (q, n): channels 12q..12q+11 of every plane of sample n) and the tap table
         float t[6], xn[3];
         list_sample_coords(A, r, i, t, xn);
