@@ -220,7 +220,7 @@ def main():
     # (144 feature + 64 layer-2 MFMAs per pass, or 64 with the baked colour planes; the 16 view-input MFMAs are spent once per
     # 8-ray tile since the per-ray view fold)
     mfma_per_pass = 64 if args.bake_color else 208
-    tile_w = 8 if n_local >= 40 * 256 * 12 else 4          # launch_render's choice (csrc/ngf_hip.hip)
+    tile_w = 8 if n_local >= 40 * 256 * 12 else 4          # launch_render's choice (csrc/ngf_field.hip)
     mfma_flops = (st[2] * mfma_per_pass + ((n_local + tile_w - 1) // tile_w) * 16) * 2048.0 if model == "triplane" else None
     pmc = None
     try:

@@ -48,7 +48,7 @@ class UvDesc(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile libngf_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    args = ["make", "-C", _CSRC, "libngf_hip.so"] + (["-B"] if force else [])
+    args = ["make", "-j4", "-C", _CSRC, "libngf_hip.so"] + (["-B"] if force else [])
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
     return SO_PATH
 

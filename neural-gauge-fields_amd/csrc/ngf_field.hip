@@ -1,24 +1,9 @@
-// ngf_hip.hip -- C ABI (include/ngf.h) + host side of the gfx950 ray-march library.
-//
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC ngf_hip.hip -o libngf_hip.so
-// (see Makefile).  No torch, no CPU fallback: every entry point runs HIP kernels or fails.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <cstdlib>
-#include <new>
-#include <vector>
-
-#include "../../include/ngf.h"
+// ngf_field.hip -- C ABI (include/ngf.h), TriPlane / InfoInv part: field handle, render / march / decode / alpha-mask / ray
+// entry points and the training step (they share the plane packing kernels).  No torch, no CPU fallback: every entry point
+// runs HIP kernels or fails.  Build: see Makefile (hipcc --offload-arch=gfx950 -O3 -ffp-contract=off).
+#include "ngf_host.hpp"
 #include "ngf_infoinv.hpp"
 #include "ngf_render.hpp"
-#include "ngf_uv.hpp"
-#include "ngf_eval.hpp"
 #include "ngf_train.hpp"
 
 using namespace ngf;
@@ -26,7 +11,7 @@ using namespace ngf;
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *fmt, ...)
+int ngf::fail(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -34,12 +19,6 @@ static int fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
-
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess) return fail(NGF_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));    \
-    } while (0)
 
 struct ngf_field {
     int32_t model = 0, flags = 0, plane_c = 0, dens_dim = 0, app = 0;
@@ -52,7 +31,6 @@ struct ngf_field {
     int64_t bytes = 0;
     int num_cus = 256;
 };
-static constexpr int kCounters = 256;
 
 // ---- packing kernels -----------------------------------------------------------------------------
 // NCHW [C,H,W] channels [c0,c0+nc) -> zero-bordered channel-last [(H+2)][(W+2)][nc]
@@ -224,13 +202,6 @@ static void build_rgb_image16(int F, bool bake, const std::vector<float> &basis,
     img[oB3 + 3] = 0.0f;
 }
 
-static int d2h(std::vector<float> &dst, const float *src, size_t n, hipStream_t st)
-{
-    dst.resize(n);
-    if (!src) return fail(NGF_E_ARG, "missing weight tensor");
-    HIP_TRY(hipMemcpyAsync(dst.data(), src, n * sizeof(float), hipMemcpyDeviceToHost, st));
-    return NGF_OK;
-}
 
 static int alloc_f(float **p, size_t n, ngf_field *f)
 {
@@ -592,111 +563,6 @@ extern "C" int ngf_generate_rays(int32_t H, int32_t W, float focal, const float 
     return NGF_OK;
 }
 
-// ================================ eval output stage ========================================================
-static int eval_grid(int64_t n)
-{
-    int64_t g = (n + kEvalThreads - 1) / kEvalThreads;
-    if (g > kEvalMaxBlocks) g = kEvalMaxBlocks;
-    return g < 1 ? 1 : (int)g;
-}
-
-extern "C" int ngf_eval_frame_u8(const float *rgb, int64_t n_values, uint8_t *out, void *hip_stream)
-{
-    if (n_values < 0 || (n_values > 0 && (!rgb || !out))) return fail(NGF_E_ARG, "ngf_eval_frame_u8: bad argument");
-    if (n_values == 0) return NGF_OK;
-    hipLaunchKernelGGL(frame_u8_kernel, dim3(eval_grid(n_values)), dim3(kEvalThreads), 0, (hipStream_t)hip_stream, rgb, n_values, out);
-    HIP_TRY(hipGetLastError());
-    return NGF_OK;
-}
-
-extern "C" int64_t ngf_eval_workspace_bytes(int32_t H, int32_t W, int32_t filter_size)
-{
-    // reductions: 2 floats or 1 double per block; SSIM: five float64 moment images after the vertical blur
-    int64_t b = (int64_t)kEvalMaxBlocks * 2 * sizeof(double);
-    if (H > 0 && W > 0 && filter_size > 0 && filter_size <= H) b += 5 * (int64_t)(H - filter_size + 1) * W * 3 * (int64_t)sizeof(double);
-    return b;
-}
-
-extern "C" int ngf_eval_depth_range(const float *depth, int64_t n, float *range, void *workspace, void *hip_stream)
-{
-    if (!depth || !range || !workspace || n <= 0) return fail(NGF_E_ARG, "ngf_eval_depth_range: bad argument");
-    const int g = eval_grid(n);
-    hipStream_t st = (hipStream_t)hip_stream;
-    hipLaunchKernelGGL(depth_range_partial_kernel, dim3(g), dim3(kEvalThreads), 0, st, depth, n, (float *)workspace);
-    hipLaunchKernelGGL(depth_range_final_kernel, dim3(1), dim3(kEvalThreads), 0, st, (const float *)workspace, g, range);
-    HIP_TRY(hipGetLastError());
-    return NGF_OK;
-}
-
-extern "C" int ngf_eval_depth_colormap(const float *depth, int64_t n, const float *range, const uint8_t *lut, uint8_t *out, void *hip_stream)
-{
-    if (n < 0 || (n > 0 && (!depth || !range || !lut || !out))) return fail(NGF_E_ARG, "ngf_eval_depth_colormap: bad argument");
-    if (n == 0) return NGF_OK;
-    hipLaunchKernelGGL(depth_colormap_kernel, dim3(eval_grid(n)), dim3(kEvalThreads), 0, (hipStream_t)hip_stream, depth, n, range, lut, out);
-    HIP_TRY(hipGetLastError());
-    return NGF_OK;
-}
-
-extern "C" int ngf_eval_mse(const float *a, const float *b, int64_t n, double *out, void *workspace, void *hip_stream)
-{
-    if (!a || !b || !out || !workspace || n <= 0) return fail(NGF_E_ARG, "ngf_eval_mse: bad argument");
-    const int g = eval_grid(n);
-    hipStream_t st = (hipStream_t)hip_stream;
-    hipLaunchKernelGGL(mse_partial_kernel, dim3(g), dim3(kEvalThreads), 0, st, a, b, n, (double *)workspace);
-    hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(kEvalThreads), 0, st, (const double *)workspace, g, (double)n, out);
-    HIP_TRY(hipGetLastError());
-    return NGF_OK;
-}
-
-extern "C" int ngf_eval_ssim(const float *img0, const float *img1, int32_t H, int32_t W, double max_val, int32_t filter_size,
-                             double filter_sigma, double k1, double k2, double *mean_out, double *map_out, void *workspace, void *hip_stream)
-{
-    if (!img0 || !img1 || !mean_out || !workspace) return fail(NGF_E_ARG, "ngf_eval_ssim: null argument");
-    if (filter_size < 1 || filter_size > kSsimMaxTaps) return fail(NGF_E_UNSUPPORTED, "ngf_eval_ssim: filter_size must be in 1..%d", kSsimMaxTaps);
-    if (H < filter_size || W < filter_size) return fail(NGF_E_ARG, "ngf_eval_ssim: image %dx%d smaller than the %d-tap filter", H, W, filter_size);
-    SsimArgs a;
-    // the reference's 1-D Gaussian (utils.py:121-125), float64
-    const int hw = filter_size / 2;
-    const double shift = (2 * hw - filter_size + 1) / 2.0;
-    double sum = 0.0;
-    for (int i = 0; i < filter_size; ++i) {
-        const double t = ((double)(i - hw) + shift) / filter_sigma;
-        a.filt[i] = exp(-0.5 * (t * t));
-        sum += a.filt[i];
-    }
-    for (int i = 0; i < filter_size; ++i) a.filt[i] /= sum;
-    a.taps = filter_size; a.H = H; a.W = W; a.Ho = H - filter_size + 1; a.Wo = W - filter_size + 1;
-    a.c1 = (k1 * max_val) * (k1 * max_val);
-    a.c2 = (k2 * max_val) * (k2 * max_val);
-    hipStream_t st = (hipStream_t)hip_stream;
-    double *partial = (double *)workspace;
-    double *tmp = partial + 2 * kEvalMaxBlocks;
-    const int64_t n_v = (int64_t)a.Ho * W * 3, n_o = (int64_t)a.Ho * a.Wo * 3;
-    const int g = eval_grid(n_o);
-    hipLaunchKernelGGL(ssim_vertical_kernel, dim3(eval_grid(n_v)), dim3(kEvalThreads), 0, st, a, img0, img1, tmp);
-    hipLaunchKernelGGL(ssim_horizontal_kernel, dim3(g), dim3(kEvalThreads), 0, st, a, (const double *)tmp, map_out, partial);
-    hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(kEvalThreads), 0, st, (const double *)partial, g, (double)n_o, mean_out);
-    HIP_TRY(hipGetLastError());
-    return NGF_OK;
-}
-
-extern "C" int ngf_pack_mask_bits(const float *volume, int64_t n, uint8_t *bits, void *hip_stream)
-{
-    if (!volume || !bits || n <= 0) return fail(NGF_E_ARG, "ngf_pack_mask_bits: bad argument");
-    hipLaunchKernelGGL(pack_mask_bits_kernel, dim3(eval_grid((n + 7) / 8)), dim3(kEvalThreads), 0, (hipStream_t)hip_stream, volume, n, bits);
-    HIP_TRY(hipGetLastError());
-    return NGF_OK;
-}
-
-extern "C" int ngf_resize_bilinear(const float *src, int32_t C, int32_t Hi, int32_t Wi, float *dst, int32_t Ho, int32_t Wo, void *hip_stream)
-{
-    if (!src || !dst || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return fail(NGF_E_ARG, "ngf_resize_bilinear: bad argument");
-    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(eval_grid((int64_t)C * Ho * Wo)), dim3(kEvalThreads), 0, (hipStream_t)hip_stream, src, C, Hi, Wi, dst,
-                       Ho, Wo);
-    HIP_TRY(hipGetLastError());
-    return NGF_OK;
-}
-
 // ================================ training step ============================================================
 enum { TP_PLANE = 0, TP_GAUGE = 3, TP_DENS_W = 6, TP_DENS_B = 7, TP_BASIS = 8, TP_W1 = 9, TP_B1 = 10, TP_W2 = 11, TP_B2 = 12, TP_W3 = 13,
        TP_B3 = 14, TP_COUNT = 15 };
@@ -964,223 +830,3 @@ extern "C" int ngf_train_adam(ngf_trainer *t, int32_t which, int32_t step_count,
     return NGF_OK;
 }
 
-// ================================ UV-Mapping (NeuTex) ===================================================================
-struct ngf_uv {
-    float *w = nullptr;
-    float *tex = nullptr;          // owned copy of the edit texture (ngf_uv_set_texture)
-    unsigned int *counters = nullptr;
-    mutable std::atomic<unsigned> next_counter{0};
-    UvArgs proto;
-    int num_cus = 256;
-};
-
-extern "C" int ngf_uv_destroy(ngf_uv *m)
-{
-    if (!m) return NGF_OK;
-    if (m->w) (void)hipFree(m->w);
-    if (m->tex) (void)hipFree(m->tex);
-    if (m->counters) (void)hipFree(m->counters);
-    delete m;
-    return NGF_OK;
-}
-
-namespace {
-struct UvPacker {
-    std::vector<float> buf;
-    static int hidden(int t, int kq) { return (t >> 2) * 16 + 4 * kq + (t & 3); }
-    int align() { while (buf.size() & 3) buf.push_back(0.0f); return (int)buf.size(); }
-    // imap(t, kq) -> input index (or -1); KT k-steps; NT unit tiles (multiple of 4)
-    template <typename F>
-    int dense(const std::vector<float> &W, int out_f, int in_f, int KT, int NT, F imap)
-    {
-        const int off = align();
-        buf.resize(off + (size_t)KT * NT * 64, 0.0f);
-        for (int t = 0; t < KT; ++t)
-            for (int g = 0; g < NT / 4; ++g)
-                for (int l = 0; l < 64; ++l)
-                    for (int e = 0; e < 4; ++e) {
-                        const int o = (4 * g + e) * 16 + (l & 15), i = imap(t, l >> 4);
-                        buf[off + (((size_t)t * (NT / 4) + g) * 64 + l) * 4 + e] = (o < out_f && i >= 0 && i < in_f) ? W[(size_t)o * in_f + i] : 0.0f;
-                    }
-        return off;
-    }
-    template <typename F>
-    int out_layer(const std::vector<float> &W, int out_f, int in_f, int KT, F imap)
-    {
-        const int off = align();
-        buf.resize(off + (size_t)KT * 64, 0.0f);
-        for (int t = 0; t < KT; ++t)
-            for (int l = 0; l < 64; ++l) {
-                const int o = l & 15, i = imap(t, l >> 4);
-                buf[off + (size_t)t * 64 + l] = (o < out_f && i >= 0 && i < in_f) ? W[(size_t)o * in_f + i] : 0.0f;
-            }
-        return off;
-    }
-    int bias(const std::vector<float> &b, int out_f, int NT)
-    {
-        const int off = align();
-        buf.resize(off + (size_t)NT * 16, 0.0f);
-        for (int kq = 0; kq < 4; ++kq)
-            for (int mt = 0; mt < NT; ++mt)
-                for (int r = 0; r < 4; ++r) {
-                    const int o = mt * 16 + 4 * kq + r;
-                    buf[off + kq * (NT * 4) + mt * 4 + r] = o < out_f ? b[o] : 0.0f;
-                }
-        return off;
-    }
-    int bias4(const std::vector<float> &b, int out_f)
-    {
-        const int off = align();
-        for (int e = 0; e < 4; ++e) buf.push_back(e < out_f ? b[e] : 0.0f);
-        return off;
-    }
-};
-}  // namespace
-
-extern "C" int ngf_uv_create(const ngf_uv_desc *d, ngf_uv **out, void *hip_stream)
-{
-    if (!d || !out) return fail(NGF_E_ARG, "ngf_uv_create: null argument");
-    *out = nullptr;
-    hipStream_t st = (hipStream_t)hip_stream;
-    const int ud = d->sphere ? 3 : 2;
-    const int in_uv = ud + 20 * ud;
-    static const int kOut[NGF_UV_LAYERS] = {256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 1, 64, 128, 128, 128, 0,
-                                            256, 256, 256, 256, 256, 256, 3, 256, 256, 256, 256, 3};
-    static const int kIn[NGF_UV_LAYERS] = {63, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 63, 64, 128, 128, 128,
-                                           0, 256, 256, 256, 256, 256, 256, 295, 256, 256, 256, 256};
-    std::vector<std::vector<float>> W(NGF_UV_LAYERS), B(NGF_UV_LAYERS);
-    for (int l = 0; l < NGF_UV_LAYERS; ++l) {
-        const int o = l == 16 ? ud : kOut[l], i = l == 17 ? in_uv : kIn[l];
-        if (!d->w[l] || !d->b[l]) return fail(NGF_E_ARG, "ngf_uv_create: layer %d missing", l);
-        int rc;
-        if ((rc = d2h(W[l], d->w[l], (size_t)o * i, st)) || (rc = d2h(B[l], d->b[l], o, st))) return rc;
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    ngf_uv *m = new (std::nothrow) ngf_uv();
-    if (!m) return fail(NGF_E_HIP, "out of host memory");
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) m->num_cus = prop.multiProcessorCount;
-    UvArgs &A = m->proto;
-    memset(&A, 0, sizeof(A));
-    A.sphere = d->sphere ? 1 : 0;
-    UvPacker P;
-    auto nat = [](int t, int kq) { return 4 * t + kq; };                      // positional-encoding inputs: natural order
-    auto hid = [](int t, int kq) { return UvPacker::hidden(t, kq); };         // previous layer's accumulator order
-    // geometry
-    A.geo_w0 = P.dense(W[0], 256, 63, 16, 16, nat);  A.geo_b0 = P.bias(B[0], 256, 16);
-    for (int l = 0; l < 10; ++l) {
-        const int o = P.dense(W[1 + l], 256, 256, 64, 16, hid);
-        if (l == 0) A.geo_wh = o;
-    }
-    for (int l = 0; l < 10; ++l) {
-        const int o = P.bias(B[1 + l], 256, 16);
-        if (l == 0) A.geo_bh = o;
-    }
-    A.geo_wo = P.out_layer(W[11], 1, 256, 64, hid);  A.geo_bo = P.bias4(B[11], 1);
-    // gauge
-    A.ga_w0 = P.dense(W[12], 64, 63, 16, 4, nat);    A.ga_b0 = P.bias(B[12], 64, 4);
-    A.ga_w1 = P.dense(W[13], 128, 64, 16, 8, hid);   A.ga_b1 = P.bias(B[13], 128, 8);
-    A.ga_w2 = P.dense(W[14], 128, 128, 32, 8, hid);  A.ga_b2 = P.bias(B[14], 128, 8);
-    A.ga_w3 = P.dense(W[15], 128, 128, 32, 8, hid);  A.ga_b3 = P.bias(B[15], 128, 8);
-    A.ga_wo = P.out_layer(W[16], ud, 128, 32, hid);  A.ga_bo = P.bias4(B[16], ud);
-    // texture
-    A.t1_w0 = P.dense(W[17], 256, in_uv, d->sphere ? 16 : 12, 16, nat);  A.t1_b0 = P.bias(B[17], 256, 16);
-    for (int l = 0; l < 5; ++l) {
-        const int o = P.dense(W[18 + l], 256, 256, 64, 16, hid);
-        if (l == 0) A.t1_wh = o;
-    }
-    for (int l = 0; l < 5; ++l) {
-        const int o = P.bias(B[18 + l], 256, 16);
-        if (l == 0) A.t1_bh = o;
-    }
-    A.c1_w = P.out_layer(W[23], 3, 256, 64, hid);    A.c1_b = P.bias4(B[23], 3);
-    A.t2_w0 = P.dense(W[24], 256, 295, 76, 16, [](int t, int kq) { return t < 64 ? UvPacker::hidden(t, kq) : 256 + 4 * (t - 64) + kq; });
-    A.t2_b0 = P.bias(B[24], 256, 16);
-    for (int l = 0; l < 3; ++l) {
-        const int o = P.dense(W[25 + l], 256, 256, 64, 16, hid);
-        if (l == 0) A.t2_wh = o;
-    }
-    for (int l = 0; l < 3; ++l) {
-        const int o = P.bias(B[25 + l], 256, 16);
-        if (l == 0) A.t2_bh = o;
-    }
-    A.t2_wo = P.out_layer(W[28], 3, 256, 64, hid);   A.t2_bo = P.bias4(B[28], 3);
-    P.align();
-    auto bail = [&](int code) { ngf_uv_destroy(m); return code; };
-    if (hipMalloc((void **)&m->w, P.buf.size() * sizeof(float)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(uv weights) failed"));
-    if (hipMemcpyAsync(m->w, P.buf.data(), P.buf.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-        return bail(fail(NGF_E_HIP, "uploading the packed UV weights failed"));
-    if (hipMalloc((void **)&m->counters, kCounters * sizeof(unsigned)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(counters) failed"));
-    A.w = m->w;
-    *out = m;
-    return NGF_OK;
-}
-
-extern "C" int ngf_uv_set_texture(ngf_uv *m, const float *tex, int32_t faces, int32_t H, int32_t W, int32_t C, int32_t mode, void *hip_stream)
-{
-    if (!m) return fail(NGF_E_ARG, "ngf_uv_set_texture: null model");
-    if (m->tex) { (void)hipFree(m->tex); m->tex = nullptr; }
-    m->proto.tex = nullptr;
-    if (!tex) return NGF_OK;                       // cubemap_ = None: back to the plain texture branch
-    const bool sphere = m->proto.sphere != 0;
-    if (faces != (sphere ? 6 : 1) || H < 1 || W < 1 || C < 3 || C > 4 || (sphere && H != W) || mode < 0 || mode > 4)
-        return fail(NGF_E_ARG, "ngf_uv_set_texture: expected %s, 3-4 channels, mode 0..4 (got faces=%d %dx%dx%d mode %d)",
-                    sphere ? "a [6,R,R,C] cube map" : "a [H,W,C] square", faces, H, W, C, mode);
-    const size_t n = (size_t)faces * H * W * C;
-    HIP_TRY(hipMalloc((void **)&m->tex, n * sizeof(float)));
-    HIP_TRY(hipMemcpyAsync(m->tex, tex, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
-    m->proto.tex = m->tex; m->proto.tex_h = H; m->proto.tex_w = W; m->proto.tex_c = C; m->proto.tex_mode = mode;
-    return NGF_OK;
-}
-
-extern "C" int ngf_uv_texture_edit(const ngf_uv *m, const float *uv, const float *orig, int64_t n, float *out, void *hip_stream)
-{
-    if (!m || !uv || !orig || !out || n < 0) return fail(NGF_E_ARG, "ngf_uv_texture_edit: bad argument");
-    if (!m->proto.tex) return fail(NGF_E_ARG, "ngf_uv_texture_edit: no texture set (ngf_uv_set_texture)");
-    if (n == 0) return NGF_OK;
-    int64_t g = (n + 255) / 256;
-    if (g > 4096) g = 4096;
-    const UvArgs &A = m->proto;
-    hipLaunchKernelGGL(uv_texture_edit_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)hip_stream, A.tex, A.tex_h, A.tex_w, A.tex_c, A.tex_mode, A.sphere,
-                       uv, orig, n, out);
-    HIP_TRY(hipGetLastError());
-    return NGF_OK;
-}
-
-extern "C" int ngf_uv_render(const ngf_uv *m, const float *campos_host, const float *raydir, const float *bg_host, const float *jitter_u,
-                             int64_t n_rays, int32_t n_samples, float *color, float *transmittance, float *dbg_sigma, float *dbg_col,
-                             uint64_t *stats, void *hip_stream)
-{
-    if (!m || !campos_host || !raydir || !jitter_u || !color || !transmittance) return fail(NGF_E_ARG, "ngf_uv_render: null argument");
-    if (n_rays < 0 || n_samples <= 0) return fail(NGF_E_ARG, "ngf_uv_render: n_rays=%lld n_samples=%d", (long long)n_rays, n_samples);
-    if ((dbg_sigma == nullptr) != (dbg_col == nullptr)) return fail(NGF_E_ARG, "ngf_uv_render: dbg_sigma and dbg_col go together");
-    if (n_rays == 0) return NGF_OK;
-    hipStream_t st = (hipStream_t)hip_stream;
-    UvArgs A = m->proto;
-    A.raydir = raydir; A.U = jitter_u; A.color = color; A.trans = transmittance; A.dbg_sigma = dbg_sigma; A.dbg_col = dbg_col;
-    A.R = n_rays; A.S = n_samples; A.stats = (unsigned long long *)stats;
-    for (int k = 0; k < 3; ++k) { A.campos[k] = campos_host[k]; A.bg[k] = bg_host ? bg_host[k] : 0.0f; }
-    A.has_bg = bg_host ? 1 : 0;
-    const unsigned slot = m->next_counter.fetch_add(1) % kCounters;
-    A.ray_counter = m->counters + slot;
-    HIP_TRY(hipMemsetAsync(A.ray_counter, 0, sizeof(unsigned), st));
-    int64_t grid = (n_rays + 7) / 8;
-    if (grid > (int64_t)m->num_cus) grid = m->num_cus;
-    const size_t lds = (size_t)8 * kUvWaveLds * sizeof(float);
-    // two rays per wave (every weight load feeds two MFMAs, 4 waves per CU) unless NGF_UV_TILES=1 (one ray per wave, 8 waves)
-    int tiles = 2;
-    if (const char *e = getenv("NGF_UV_TILES")) tiles = atoi(e);
-    if (tiles == 2) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(uv_render_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(uv_render_kernel<2>, dim3((unsigned)grid), dim3(256), lds, st, A);
-    } else if (tiles == 1) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(uv_render_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(uv_render_kernel<1>, dim3((unsigned)grid), dim3(512), lds, st, A);
-    } else {
-        return fail(NGF_E_ARG, "NGF_UV_TILES must be 1 or 2");
-    }
-    HIP_TRY(hipGetLastError());
-    return NGF_OK;
-}
