@@ -116,3 +116,27 @@ def test_evaluation_path_renders_poses(tmp_path):
     diff = (evalout.to_uint8(ref).reshape(H, W, 3).int() - frames[0].int()).abs()
     assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 0.01          # device-built rays differ in the last ulp
     assert not torch.equal(frames[0], frames[1])
+
+
+def test_evaluation_mirror_on_a_tiny_dataset(tmp_path):
+    """evalout.evaluation = TriPlane/main.py:73-138 without LPIPS / MP4: per test view renderer + device output stage, PSNR list,
+    PNGs and mean.txt.  Ground truth = the field's own render (+ a constant offset), so the PSNR is known in closed form."""
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import load_case, field_for_case
+    g, params, step, mask = load_case("triplane_r1_gauge")
+    f = field_for_case(g, params, mask)
+    H = W = 20
+    views = [torch.from_numpy(synth.lookat_rays(H, W, c2w=synth.lookat_pose(azim_deg=a))) for a in (20.0, 80.0, 200.0, 290.0)]
+    with torch.no_grad():
+        gts = [(f(v.cuda(), N_samples=40, white_bg=True, iteration=30001)["rgb_map"].clamp(0, 1) * 0.5 + 0.25).cpu() for v in views]
+    ds = types.SimpleNamespace(near_far=[2.0, 6.0], img_wh=(W, H), all_rays=torch.stack(views), all_rgbs=torch.stack(gts))
+    psnrs = evalout.evaluation(ds, f, None, savePath=str(tmp_path), N_vis=2, prtx="t_", N_samples=40, white_bg=True)
+    assert len(psnrs) == 2 and all(np.isfinite(psnrs))                     # N_vis=2 of 4 views -> views 0 and 2
+    for k, idx in enumerate((0, 2)):
+        rgb = f(views[idx].cuda(), N_samples=40, white_bg=True, iteration=30001)["rgb_map"].clamp(0, 1).cpu()
+        want = -10.0 * np.log(torch.mean((rgb - gts[idx]) ** 2).item()) / np.log(10.0)
+        assert abs(psnrs[k] - want) < 1e-4
+    assert (tmp_path / "t_000.png").exists() and (tmp_path / "rgbd" / "t_001.png").exists()
+    vals = np.loadtxt(tmp_path / "t_mean.txt")
+    assert vals.shape == (2,) and abs(vals[0] - np.mean(psnrs)) < 1e-6 and 0.0 < vals[1] <= 1.0
