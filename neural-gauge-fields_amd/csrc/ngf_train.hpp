@@ -35,7 +35,7 @@
 
 namespace ngf {
 
-constexpr int kTrainWaves = 4;                 // waves per workgroup in the colour forward kernel
+constexpr int kTrainWaves = 6;                 // waves per workgroup in the colour forward kernel (H2 overwrites the dead feature tile)
 constexpr int kTrainWavesBwd = 6;              // ... and in the colour backward kernel (its tiles alias, see kBwdTileFloats)
 constexpr int kFeat = 144;                     // colour features (3 planes x 48)
 constexpr int kIn1 = 159, kIn1Pad = 160;       // [g(144), view(15)] (+1 zero pad)
@@ -373,7 +373,7 @@ __device__ __forceinline__ void list_sample_coords(const RenderArgs &A, int64_t 
     triplane_gauge(A, xn, A.mode, t);
 }
 
-constexpr int kFwdTileFloats = (kIn1Pad + 64 + 64) * 16;                  // [F; view], H1, H2
+constexpr int kFwdTileFloats = (kIn1Pad + 64) * 16;                       // [F; view] (H2 goes there once layer 1 is done and F is stored), H1
 constexpr int kDfStride = kFeat + 1;                                       // DF is kept sample-major (bank-conflict-free rows)
 // backward tiles per wave: [H1 | D2 | pad] is overwritten by DF^T once d1 exists and d2 / d1 have been written out; [H2, then D1]; tap table
 constexpr int kBwdTileFloats = 16 * kDfStride + 64 * 16 + 16 * 16;
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
     const float *img = smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
-    float *Ft = smem + ((kFwdImage + 3) & ~3) + wave * kFwdTileFloats, *H1t = Ft + kIn1Pad * 16, *H2t = H1t + 64 * 16;
+    float *Ft = smem + ((kFwdImage + 3) & ~3) + wave * kFwdTileFloats, *H1t = Ft + kIn1Pad * 16, *H2t = Ft;
     const int passes = (T.chunk_n + 15) / 16;
     for (int pass = blockIdx.x * kTrainWaves + wave; pass < passes; pass += gridDim.x * kTrainWaves) {
         const int local = pass * 16 + n;
@@ -476,6 +476,12 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         dense16<false, 1, 64, kIn1Pad, kIn1Pad>(img + kFwdW1, kLd1, 64, img + kFwdB1, Ft, H1t, nullptr, lane);      // relu(W1' f + W1v view + b1)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (T.store) {          // the feature tile leaves LDS now: layer 2 writes its output over it
+            const int64_t row = live ? local : 0;
+            tile_to_rows(Ft, kFeat, T.F, kFeat, row, live, lane);
+            tile_to_rows(Ft + kFeat * 16, 16, T.V, 16, row, live, lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
         dense16<false, 1, 64, 64, 64>(img + kFwdW2, kLd2, 64, img + kFwdB2, H1t, H2t, nullptr, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // layer 3 + sigmoid on the VALU: lane (q, n) sums its 16 hidden units, then the four quarters meet
@@ -496,8 +502,6 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
         }
         if (T.store) {
             const int64_t row = live ? local : 0;
-            tile_to_rows(Ft, kFeat, T.F, kFeat, row, live, lane);
-            tile_to_rows(Ft + kFeat * 16, 16, T.V, 16, row, live, lane);
             tile_to_rows(H1t, 64, T.H1, 64, row, live, lane);
             tile_to_rows(H2t, 64, T.H2, 64, row, live, lane);
         }
