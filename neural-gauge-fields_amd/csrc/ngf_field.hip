@@ -758,14 +758,13 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         }
         hipLaunchKernelGGL(train_color_bwd_kernel, dim3(tr_grid(t, passes, kTrainWavesBwd, 1)), dim3(kTrainWavesBwd * 64), lds_b, st, T);
         const int rows = T.chunk_n;
-        int splits = rows / 512;
-        if (splits < 1) splits = 1;
-        if (splits > 256) splits = 256;
-        hipLaunchKernelGGL(xty_kernel, dim3(1 * 4 * splits), dim3(64), 0, st, (const float *)T.D3, 16, (const float *)T.H2, 64, rows, 1, 4, 3, 64, t->g_dense[TP_W3], 64, splits);
-        hipLaunchKernelGGL(xty_kernel, dim3(4 * 4 * splits), dim3(64), 0, st, (const float *)T.D2, 64, (const float *)T.H1, 64, rows, 4, 4, 64, 64, t->g_dense[TP_W2], 64, splits);
+        int xg = (rows + 31) / 32;                      // 32-sample chunks; at most two workgroups per CU walk them
+        if (xg > 2 * t->num_cus) xg = 2 * t->num_cus;
+        hipLaunchKernelGGL((xty_block_kernel<1, 4>), dim3(xg), dim3(256), 0, st, (const float *)T.D3, 16, (const float *)T.H2, 64, rows, 3, 64, t->g_dense[TP_W3], 64);
+        hipLaunchKernelGGL((xty_block_kernel<4, 4>), dim3(xg), dim3(256), 0, st, (const float *)T.D2, 64, (const float *)T.H1, 64, rows, 64, 64, t->g_dense[TP_W2], 64);
         // the 15 view columns of layer 1 directly, the 144 feature columns through M = Delta1^T F (train_unfold_kernel)
-        hipLaunchKernelGGL(xty_kernel, dim3(4 * 1 * splits), dim3(64), 0, st, (const float *)T.D1, 64, (const float *)T.V, 16, rows, 4, 1, 64, 15, t->g_dense[TP_W1] + 144, 159, splits);
-        hipLaunchKernelGGL(xty_kernel, dim3(4 * 9 * splits), dim3(64), 0, st, (const float *)T.D1, 64, (const float *)T.F, 144, rows, 4, 9, 64, 144, T.M, 144, splits);
+        hipLaunchKernelGGL((xty_block_kernel<4, 1>), dim3(xg), dim3(256), 0, st, (const float *)T.D1, 64, (const float *)T.V, 16, rows, 64, 15, t->g_dense[TP_W1] + 144, 159);
+        hipLaunchKernelGGL((xty_block_kernel<4, 9>), dim3(xg), dim3(256), 0, st, (const float *)T.D1, 64, (const float *)T.F, 144, rows, 64, 144, T.M, 144);
         hipLaunchKernelGGL(colsum_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const float *)T.D3, 16, rows, 3, t->g_dense[TP_B3]);
         hipLaunchKernelGGL(colsum_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const float *)T.D2, 64, rows, 64, t->g_dense[TP_B2]);
         hipLaunchKernelGGL(colsum_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const float *)T.D1, 64, rows, 64, t->g_dense[TP_B1]);
