@@ -22,7 +22,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -40,7 +39,7 @@ def alg_bytes_per_ray(s_active: float, model: str) -> float:
 
 
 def build_field(model, preset, device, bake, bake_color=False):
-    from helpers import big_case, field_for_case
+    from ngf_amd.cases import big_case, field_for_case
     g, params, step = big_case(model, preset)
     f = field_for_case(g, params, None, device=device, bake=bake, bake_color=bake_color)
     f.handle()

@@ -134,6 +134,13 @@ int ngf_field_ray_filter(const ngf_field *f, const float *rays, int64_t n, int32
 int ngf_generate_rays(int32_t H, int32_t W, float focal, const float *c2w_host, int32_t row0, int32_t rows,
                       float *rays, void *hip_stream);
 
+/* Replaces: get_rays_dir on the full-image ('no_crop') pixel grid of DtuDataset.__getitem__ (UV-Mapping/data/dtu.py:27-37,
+ * 160-168): raydir [rows*W,3] for image rows [row0,row0+rows).  HOST pointers: focal[2], princpt[2] (in_camFocal /
+ * in_camPrincpt of the view) and rot[9] = extrinsics[view][0:3,0:3] row-major (dtu.py:133; applied transposed and
+ * normalised with the reference's + 1e-5, all float32 like the reference's numpy arithmetic). */
+int ngf_generate_rays_dtu(int32_t H, int32_t W, const float *focal_host, const float *princpt_host, const float *rot_host,
+                          int32_t row0, int32_t rows, float *raydir, void *hip_stream);
+
 /* ---- eval output stage: what `evaluation` (TriPlane/main.py:73-138) does to every
  * rendered frame on the host, here on the device so that a frame leaves HBM as 8-bit images and scalars.
  * `workspace` is caller-owned device scratch of at least ngf_eval_workspace_bytes(H, W, filter_size) bytes
@@ -244,6 +251,14 @@ int ngf_uv_texture_edit(const ngf_uv *m, const float *uv, const float *orig, int
 int ngf_uv_render(const ngf_uv *m, const float *campos_host, const float *raydir, const float *bg_host,
                   const float *jitter_u, int64_t n_rays, int32_t n_samples, float *color, float *transmittance,
                   float *dbg_sigma, float *dbg_col, uint64_t *stats, void *hip_stream);
+
+/* Experiment / test knobs of the launch code (tile shapes, kernel variants, A/B ablations used by the bit-identity tests and the
+ * scripts under profiles/).  Process-wide; value -1 restores the library default.  The library never reads the environment:
+ * this explicit call is the only way to change what a launch does.  Names: "tile_w" (64/32/16/8/4), "split" (0/1), "waves",
+ * "nstep", "profile", "ablate" (bit mask, see ngf_device.hpp), "uv_tiles" (1/2), "kernel" (0 = fused march+shade waves, 1 =
+ * specialised march / shade waves), "stage" (1 = LDS-staged density strips). */
+int ngf_debug_set(const char *name, int32_t value);
+int32_t ngf_debug_get(const char *name);
 
 const char *ngf_last_error(void);
 int ngf_abi_version(void);

@@ -6,4 +6,4 @@ Sub-modules: ``triplane`` / ``infoinv`` / ``uvmapping`` (drop-in field modules o
 generation), ``dist`` (ray-sharded multi-GPU render), ``synth`` (seeded inputs), ``_lib`` (ctypes binding of
 libngf_hip.so).
 """
-__all__ = ["triplane", "infoinv", "uvmapping", "fieldbase", "geometry", "opt", "rays", "dist", "synth"]
+__all__ = ["triplane", "infoinv", "uvmapping", "fieldbase", "geometry", "opt", "rays", "dist", "synth", "cases"]

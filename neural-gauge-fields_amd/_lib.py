@@ -16,11 +16,11 @@ F_BAKE_DENSITY = 1
 F_BAKE_COLOR = 2
 
 SYMBOLS = ["ngf_field_create", "ngf_field_destroy", "ngf_field_render", "ngf_field_decode_rgb", "ngf_field_march",
-           "ngf_generate_rays", "ngf_last_error", "ngf_abi_version", "ngf_field_bytes", "ngf_sizeof_field_desc",
+           "ngf_generate_rays", "ngf_generate_rays_dtu", "ngf_last_error", "ngf_abi_version", "ngf_field_bytes", "ngf_sizeof_field_desc",
            "ngf_uv_create", "ngf_uv_destroy", "ngf_uv_render", "ngf_field_alpha", "ngf_field_ray_filter",
            "ngf_eval_workspace_bytes", "ngf_eval_frame_u8", "ngf_eval_depth_range", "ngf_eval_depth_colormap", "ngf_eval_mse",
            "ngf_eval_ssim", "ngf_trainer_create", "ngf_trainer_destroy", "ngf_trainer_bytes", "ngf_sizeof_train_desc", "ngf_train_backward",
-           "ngf_train_get_grad", "ngf_train_adam", "ngf_resize_bilinear", "ngf_uv_set_texture", "ngf_uv_texture_edit", "ngf_field_alpha_mask_build", "ngf_pack_mask_bits"]
+           "ngf_train_get_grad", "ngf_train_adam", "ngf_resize_bilinear", "ngf_uv_set_texture", "ngf_uv_texture_edit", "ngf_field_alpha_mask_build", "ngf_pack_mask_bits", "ngf_debug_set", "ngf_debug_get"]
 
 
 class FieldDesc(C.Structure):
@@ -73,6 +73,8 @@ def lib():
                                       C.c_void_p, C.c_void_p]
         L.ngf_generate_rays.argtypes = [C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                         C.c_void_p]
+        L.ngf_generate_rays_dtu.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                            C.c_void_p]
         L.ngf_field_alpha.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
         L.ngf_field_alpha_mask_build.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                                  C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -93,6 +95,9 @@ def lib():
         L.ngf_eval_mse.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ngf_eval_ssim.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_double, C.c_double,
                                     C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ngf_debug_set.argtypes = [C.c_char_p, C.c_int32]
+        L.ngf_debug_get.argtypes = [C.c_char_p]
+        L.ngf_debug_get.restype = C.c_int32
         if L.ngf_abi_version() != 1 or L.ngf_sizeof_field_desc() != C.sizeof(FieldDesc):
             raise RuntimeError("libngf_hip.so ABI mismatch (version or ngf_field_desc layout)")
         _LIB = L
@@ -102,3 +107,35 @@ def lib():
 def check(rc: int):
     if rc != 0:
         raise RuntimeError("libngf_hip: " + (lib().ngf_last_error() or b"?").decode())
+
+
+class knobs:
+    """Context manager over ngf_debug_set: ``with _lib.knobs(tile_w=8, split=1): ...`` -- experiment / test knobs of the launch
+    code, restored to their previous values on exit.  (The library does not read environment variables.)"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+        self.old = {}
+
+    def __enter__(self):
+        L = lib()
+        for k, v in self.kw.items():
+            self.old[k] = L.ngf_debug_get(k.encode())
+            check(L.ngf_debug_set(k.encode(), int(v)))
+        return self
+
+    def __exit__(self, *exc):
+        L = lib()
+        for k, v in self.old.items():
+            L.ngf_debug_set(k.encode(), int(v))
+        return False
+
+
+def knobs_from_env():
+    """Opt-in for the experiment scripts under profiles/: map NGF_TILE_W / NGF_SPLIT / NGF_WAVES / NGF_NSTEP / NGF_PROFILE /
+    NGF_ABLATE / NGF_UV_TILES / NGF_KERNEL / NGF_STAGE of the environment to ngf_debug_set calls (unset -> library default).
+    Nothing in the product path calls this."""
+    L = lib()
+    for k in ("tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage"):
+        v = os.environ.get("NGF_" + k.upper())
+        check(L.ngf_debug_set(k.encode(), int(v) if v not in (None, "") else -1))

@@ -20,6 +20,28 @@ int ngf::fail(int code, const char *fmt, ...)
     return code;
 }
 
+static std::atomic<int> g_knob[ngf::KNOB_COUNT];
+static const char *const g_knob_name[ngf::KNOB_COUNT] = {"tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage"};
+static bool g_knob_init = [] { for (auto &k : g_knob) k.store(-1); return true; }();
+
+int ngf::knob(int id) { return g_knob[id].load(std::memory_order_relaxed); }
+
+extern "C" int ngf_debug_set(const char *name, int32_t value)
+{
+    if (!name) return fail(NGF_E_ARG, "ngf_debug_set: null name");
+    for (int k = 0; k < ngf::KNOB_COUNT; ++k)
+        if (!strcmp(name, g_knob_name[k])) { g_knob[k].store(value); return NGF_OK; }
+    return fail(NGF_E_ARG, "ngf_debug_set: unknown knob '%s'", name);
+}
+
+extern "C" int32_t ngf_debug_get(const char *name)
+{
+    if (name)
+        for (int k = 0; k < ngf::KNOB_COUNT; ++k)
+            if (!strcmp(name, g_knob_name[k])) return g_knob[k].load();
+    return -1;
+}
+
 struct ngf_field {
     int32_t model = 0, flags = 0, plane_c = 0, dens_dim = 0, app = 0;
     float *tex[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // dens[3], app[3], gau[3]
@@ -95,6 +117,22 @@ __global__ void generate_rays_kernel(int H, int W, float focal, float r00, float
         r[3] = (dx * r00 + dy * r01) + dz * r02;
         r[4] = (dx * r10 + dy * r11) + dz * r12;
         r[5] = (dx * r20 + dy * r21) + dz * r22;
+    }
+}
+
+// get_rays_dir on the 'no_crop' pixel grid (UV-Mapping/data/dtu.py:27-37, 160-168): integer pixel coordinates, float32 focal /
+// principal point / rotation as the shipped in_cam*.npy hold them; dirs = rot^T (x, y, 1) summed in row order, / (norm + 1e-5)
+__global__ void generate_rays_dtu_kernel(int W, float fx, float fy, float cx, float cy, float r00, float r01, float r02, float r10,
+                                         float r11, float r12, float r20, float r21, float r22, int row0, int rows, float *__restrict__ raydir)
+{
+    const int64_t total = (int64_t)rows * W;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(q % W), row = row0 + (int)(q / W);
+        const float x = ((float)col - cx) / fx, y = ((float)row - cy) / fy;
+        float dx = (r00 * x + r10 * y) + r20, dy = (r01 * x + r11 * y) + r21, dz = (r02 * x + r12 * y) + r22;
+        const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz) + 1e-5f;
+        float *r = raydir + q * 3;
+        r[0] = dx / nrm; r[1] = dy / nrm; r[2] = dz / nrm;
     }
 }
 
@@ -349,7 +387,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
             A.mask.inv[k] = 1.0f / (d->mask_aabb[3 + k] - d->mask_aabb[k]) * 2;   // invgridSize (FieldBase.py:29)
         }
     }
-    if (hipMalloc((void **)&f->counters, (kCounters + 8) * sizeof(unsigned)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(counters) failed"));      // + 6 ints for the mask build's index bounds
+    if (hipMalloc((void **)&f->counters, kCounters * sizeof(unsigned)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(counters) failed"));
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "packing failed: %s", hipGetErrorString(hipGetLastError())));
     *out = f;
     return NGF_OK;
@@ -366,14 +404,14 @@ static int launch_render(K kernel, K kernel_split, const ngf_field *f, RenderArg
     // consecutive steps (bit-identical results).  Small tiles shorten the critical path of a tile and even out the
     // tiles-per-wave quantisation, which bounds small launches (one rank's shard of a frame, the reference's 4096-ray
     // chunks) and still buys 5 % on a full frame.  Measured in profiles/r01_split_march.txt: tile_w = 8 is best from
-    // 160 000 rays to the full frame, tile_w = 4 below (80 000 rays: 1.43-1.49 vs 1.51-1.53 ms; 4000 rays: 0.29 vs 0.51 ms).  NGF_TILE_W / NGF_SPLIT override for experiments.
+    // 160 000 rays to the full frame, tile_w = 4 below (80 000 rays: 1.43-1.49 vs 1.51-1.53 ms; 4000 rays: 0.29 vs 0.51 ms).  ngf_debug_set("tile_w" / "split") override for experiments.
     const int waves = threads / kWave;
     int tw = 64;
     if (kernel_split) tw = A.n < 40 * (int64_t)f->num_cus * waves ? 4 : wide_tile;     // up to ~120 k rays (5 tiles of 8 per resident wave) 4-ray tiles balance better
-    if (const char *e = getenv("NGF_TILE_W")) tw = atoi(e);
-    if (tw != 64 && tw != 32 && tw != 16 && tw != 8 && tw != 4) return fail(NGF_E_ARG, "NGF_TILE_W must be 64, 32, 16, 8 or 4");
+    if (knob(KNOB_TILE_W) >= 0) tw = knob(KNOB_TILE_W);
+    if (tw != 64 && tw != 32 && tw != 16 && tw != 8 && tw != 4) return fail(NGF_E_ARG, "knob tile_w must be 64, 32, 16, 8 or 4");
     bool split = tw < 64 && kernel_split;
-    if (const char *e = getenv("NGF_SPLIT")) split = atoi(e) != 0 && kernel_split;
+    if (knob(KNOB_SPLIT) >= 0) split = knob(KNOB_SPLIT) != 0 && kernel_split;
     A.tile_w = tw;
     A.tile_shift = tw == 64 ? 6 : tw == 32 ? 5 : tw == 16 ? 4 : tw == 8 ? 3 : 2;
     K k = split ? kernel_split : kernel;
@@ -402,20 +440,20 @@ static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
     // tuning knobs (measurements in profiles/): waves per CU and march steps in flight per lane
     int w = 12, ns = 1;                   // measured best (profiles/r01_sweep.txt)
-    if (const char *e = getenv("NGF_WAVES")) w = atoi(e);
-    if (const char *e = getenv("NGF_NSTEP")) ns = atoi(e);
+    if (knob(KNOB_WAVES) >= 0) w = knob(KNOB_WAVES);
+    if (knob(KNOB_NSTEP) >= 0) ns = knob(KNOB_NSTEP);
     if (ns == 2) {
         if (w == 8) return launch_policy<TriPlanePolicy<BD, BC, 8, 2>>(f, A, st);
-        return fail(NGF_E_ARG, "NGF_NSTEP=2 is built for NGF_WAVES=8 only");
+        return fail(NGF_E_ARG, "knob nstep = 2 is built for waves = 8 only");
     }
-    if (getenv("NGF_PROFILE")) {      // stats[4..9] += section cycles (profiles/exp_sections.py); stats must hold 10 counters
+    if (knob(KNOB_PROFILE) > 0) {      // stats[4..9] += section cycles (profiles/exp_sections.py); stats must hold 10 counters
         if constexpr (!BC) return launch_policy<TriPlanePolicy<BD, false, 12, 1, true>>(f, A, st);
     }
     switch (w) {
     case 8: return launch_policy<TriPlanePolicy<BD, BC, 8, 1>>(f, A, st);
     case 12: return launch_policy<TriPlanePolicy<BD, BC, 12, 1>>(f, A, st);
     case 16: return launch_policy<TriPlanePolicy<BD, BC, 16, 1>>(f, A, st);
-    default: return fail(NGF_E_ARG, "NGF_WAVES must be 8, 12 or 16");
+    default: return fail(NGF_E_ARG, "knob waves must be 8, 12 or 16");
     }
 }
 
@@ -436,7 +474,7 @@ extern "C" int ngf_field_render(const ngf_field *f, const float *rays, int64_t n
     RenderArgs A = f->proto;
     A.rays = rays; A.jitter = jitter; A.rgb = rgb; A.depth = depth; A.n = n; A.S = n_samples;
     A.white_bg = white_bg ? 1 : 0; A.mode = mode ? 1 : 0; A.stats = (unsigned long long *)stats;
-    if (const char *e = getenv("NGF_ABLATE")) A.ablate = atoi(e);     // profiling only: results are wrong when set
+    if (knob(KNOB_ABLATE) > 0) A.ablate = knob(KNOB_ABLATE);          // ngf_debug_set("ablate", bits): A/B timing and bit-identity tests only
     return render_common(f, A, (hipStream_t)hip_stream);
 }
 
@@ -521,17 +559,19 @@ extern "C" int ngf_field_alpha_mask_build(const ngf_field *f, int32_t mode, cons
     const int64_t n = (int64_t)gx * gy * gz;
     int rc = launch_alpha(f, nullptr, L, n, mode, length, alpha_zyx, st);
     if (rc) return rc;
-    // bounds: 6 ints in front of the caller's count word would need another buffer; the handle's counter block has room
-    int *bounds = reinterpret_cast<int *>(f->counters + kCounters);
-    const int init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1};
-    HIP_TRY(hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, st));
+    // index bounds of the occupied voxels: per-call scratch on the call's stream (concurrent builds on one handle do not share it)
+    int *bounds = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&bounds, 6 * sizeof(int), st));
+    hipLaunchKernelGGL(mask_bounds_init_kernel, dim3(1), dim3(64), 0, st, bounds);
     HIP_TRY(hipMemsetAsync(count, 0, sizeof(uint64_t), st));
     int64_t grid = (n + 255) / 256;
     if (grid > 16 * (int64_t)f->num_cus) grid = 16 * (int64_t)f->num_cus;
     hipLaunchKernelGGL(mask_pool_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const float *)alpha_zyx, gx, gy, gz, thres, volume_zyx, bounds,
                        (unsigned long long *)count);
     hipLaunchKernelGGL(mask_aabb_kernel, dim3(1), dim3(64), 0, st, f->proto, L, (const int *)bounds, new_aabb);
-    HIP_TRY(hipGetLastError());
+    const hipError_t launch_err = hipGetLastError();
+    (void)hipFreeAsync(bounds, st);
+    HIP_TRY(launch_err);
     return NGF_OK;
 }
 
@@ -559,6 +599,21 @@ extern "C" int ngf_generate_rays(int32_t H, int32_t W, float focal, const float 
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(generate_rays_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, H, W, focal, c[0], c[1], c[2], c[4],
                        c[5], c[6], c[8], c[9], c[10], c[3], c[7], c[11], row0, rows, rays);
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+extern "C" int ngf_generate_rays_dtu(int32_t H, int32_t W, const float *focal, const float *princpt, const float *rot, int32_t row0,
+                                     int32_t rows, float *raydir, void *hip_stream)
+{
+    if (!focal || !princpt || !rot || !raydir || H <= 0 || W <= 0 || rows < 0 || row0 < 0 || row0 + rows > H)
+        return fail(NGF_E_ARG, "ngf_generate_rays_dtu: bad argument");
+    if (rows == 0) return NGF_OK;
+    const int64_t total = (int64_t)rows * W;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(generate_rays_dtu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, W, focal[0], focal[1], princpt[0],
+                       princpt[1], rot[0], rot[1], rot[2], rot[3], rot[4], rot[5], rot[6], rot[7], rot[8], row0, rows, raydir);
     HIP_TRY(hipGetLastError());
     return NGF_OK;
 }

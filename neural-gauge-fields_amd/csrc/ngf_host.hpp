@@ -22,6 +22,11 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
 static constexpr int kCounters = 256;      // launches in flight per handle (tile / ray queue heads)
 
+// Experiment / test knobs (ngf_debug_set, include/ngf.h).  Process-wide, set ONLY through the explicit ABI call -- never read
+// from the environment, so a stray variable in a user's shell cannot change what a launch computes.  -1 = library default.
+enum Knob { KNOB_TILE_W = 0, KNOB_SPLIT, KNOB_WAVES, KNOB_NSTEP, KNOB_PROFILE, KNOB_ABLATE, KNOB_UV_TILES, KNOB_KERNEL, KNOB_STAGE, KNOB_COUNT };
+int knob(int id);                          // current value (ngf_field.hip)
+
 }  // namespace ngf
 
 #define HIP_TRY(expr)                                                                                        \

@@ -665,6 +665,12 @@ __global__ void __launch_bounds__(256) mask_pool_kernel(const float *__restrict_
     if (cnt) atomicAdd(count, cnt);
 }
 
+__global__ void mask_bounds_init_kernel(int *bounds)
+{
+    if (threadIdx.x < 3) bounds[threadIdx.x] = 0x7fffffff;
+    else if (threadIdx.x < 6) bounds[threadIdx.x] = -1;
+}
+
 // valid_xyz.amin(0) / amax(0) (FieldBase.py:204-208): coordinates are monotone in their lattice index, so the box of the occupied
 // voxels is the lattice point of the index bounds (taken per axis with min/max to stay correct for a flipped aabb)
 __global__ void mask_aabb_kernel(const RenderArgs A, const Lattice L, const int *bounds, float *new_aabb)

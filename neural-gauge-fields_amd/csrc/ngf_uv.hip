@@ -209,9 +209,9 @@ extern "C" int ngf_uv_render(const ngf_uv *m, const float *campos_host, const fl
     int64_t grid = (n_rays + 7) / 8;
     if (grid > (int64_t)m->num_cus) grid = m->num_cus;
     const size_t lds = (size_t)8 * kUvWaveLds * sizeof(float);
-    // two rays per wave (every weight load feeds two MFMAs, 4 waves per CU) unless NGF_UV_TILES=1 (one ray per wave, 8 waves)
+    // two rays per wave (every weight load feeds two MFMAs, 4 waves per CU) unless ngf_debug_set("uv_tiles", 1) (one ray per wave, 8 waves)
     int tiles = 2;
-    if (const char *e = getenv("NGF_UV_TILES")) tiles = atoi(e);
+    if (knob(KNOB_UV_TILES) >= 0) tiles = knob(KNOB_UV_TILES);
     if (tiles == 2) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(uv_render_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(uv_render_kernel<2>, dim3((unsigned)grid), dim3(256), lds, st, A);
@@ -219,7 +219,7 @@ extern "C" int ngf_uv_render(const ngf_uv *m, const float *campos_host, const fl
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(uv_render_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(uv_render_kernel<1>, dim3((unsigned)grid), dim3(512), lds, st, A);
     } else {
-        return fail(NGF_E_ARG, "NGF_UV_TILES must be 1 or 2");
+        return fail(NGF_E_ARG, "knob uv_tiles must be 1 or 2");
     }
     HIP_TRY(hipGetLastError());
     return NGF_OK;

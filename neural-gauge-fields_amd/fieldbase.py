@@ -120,9 +120,19 @@ class Base(torch.nn.Module):
     # --- the HIP handle ----------------------------------------------------------------------------
     def _param_key(self):
         ps = [(n, p.data_ptr(), p._version, tuple(p.shape)) for n, p in self.named_parameters()]
+        if getattr(self, 'check_params', False):
+            ps.append(tuple(float(p.detach().double().sum()) + float(p.detach().double().abs().sum()) for p in self.parameters()))
         m = None if self.alphaMask is None else (self.alphaMask.alpha_volume.data_ptr(), self.alphaMask.alpha_volume._version)
         return (tuple(ps), m, float(self.stepSize), tuple(self.aabb.reshape(-1).tolist()), self.bake_density, self.bake_color,
                 tuple(self.near_far), float(self.distance_scale), float(self.rayMarch_weight_thres))
+
+    def invalidate(self):
+        """Force the packed device image to be rebuilt at the next call.  The handle is rebuilt automatically when a parameter
+        tensor is replaced or modified through autograd-tracked in-place ops (optimizer.step(), load_state_dict, up_sampling,
+        shrink: they bump ``Parameter._version``).  Writes that bypass the version counter -- ``param.data.mul_(...)``, raw
+        pointer writes from another library -- are invisible to it: call ``invalidate()`` after them, or set
+        ``field.check_params = True`` (debug: the key then carries a device-side checksum of every parameter, one sync per call)."""
+        self._handle_key = None
 
     def _fill_desc(self, d: _lib.FieldDesc, keep: list):
         raise NotImplementedError
@@ -227,39 +237,49 @@ class Base(torch.nn.Module):
         return {'rgb_map': rgb, 'depth_map': depth}
 
     # --- model management on top of the march's device code ---------------------------------
-    ALPHA_MODE = 0        # compute_alpha runs with the gauge OFF in TriPlane (iteration=-1, FieldBase.py:154)
+    def _alpha_mode(self, **kw) -> int:
+        """Kernel mode of compute_alpha: TriPlane runs it with the gauge OFF (iteration=-1, FieldBase.py:154); the InfoInv tree
+        passes infoinv=True/False down to compute_density (InfoInv/models/FieldBase.py:140-156)."""
+        if kw:
+            raise TypeError(f"unexpected keyword arguments {sorted(kw)}")
+        return 0
 
     @torch.no_grad()
-    def compute_alpha(self, xyz_locs, length=1):
-        """FieldBase.py:140-159: alpha = 1 - exp(-sigma * length) at world-space points [..., 3]."""
+    def compute_alpha(self, xyz_locs, length=1, **kw):
+        """FieldBase.py:140-159 (InfoInv: compute_alpha(xyz_locs, length=1, infoinv=True)): alpha = 1 - exp(-sigma * length) at
+        world-space points [..., 3]."""
+        mode = self._alpha_mode(**kw)
         dev = torch.device(self.device)
         pts = xyz_locs.to(device=dev, dtype=torch.float32).reshape(-1, 3).contiguous()
         out = torch.empty((pts.shape[0],), device=dev, dtype=torch.float32)
         if pts.shape[0]:
             with torch.cuda.device(dev):
-                _lib.check(_lib.lib().ngf_field_alpha(self.handle(), pts.data_ptr(), pts.shape[0], int(self.ALPHA_MODE),
+                _lib.check(_lib.lib().ngf_field_alpha(self.handle(), pts.data_ptr(), pts.shape[0], int(mode),
                                                       C.c_float(float(length)), out.data_ptr(),
                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return out.view(xyz_locs.shape[:-1])
 
     @torch.no_grad()
-    def getDenseAlpha(self, gridSize=None):
-        """FieldBase.py:161-178: alpha on the [gx,gy,gz] lattice of the aabb (one launch instead of gx slices)."""
+    def getDenseAlpha(self, gridSize=None, **kw):
+        """FieldBase.py:161-178 (InfoInv: getDenseAlpha(gridSize=None, infoinv=True)): alpha on the [gx,gy,gz] lattice of the
+        aabb (one launch instead of gx slices)."""
         gridSize = self.gridSize.tolist() if gridSize is None else [int(g) for g in gridSize]
         dev = torch.device(self.device)
         samples = torch.stack(torch.meshgrid(torch.linspace(0, 1, gridSize[0]), torch.linspace(0, 1, gridSize[1]),
                                              torch.linspace(0, 1, gridSize[2]), indexing='ij'), -1).to(dev)
         aabb = self.aabb.to(dev)
         dense_xyz = aabb[0] * (1 - samples) + aabb[1] * samples
-        alpha = self.compute_alpha(dense_xyz.view(-1, 3), float(self.stepSize)).view(gridSize)
+        alpha = self.compute_alpha(dense_xyz.view(-1, 3), float(self.stepSize), **kw).view(gridSize)
         return alpha, dense_xyz
 
     @torch.no_grad()
-    def updateAlphaMask(self, gridSize=(200, 200, 200)):
-        """FieldBase.py:180-216 (with getDenseAlpha :161-178 inside): dense alpha on the lattice, clamp, 3x3x3 max-pool,
+    def updateAlphaMask(self, gridSize=(200, 200, 200), **kw):
+        """FieldBase.py:180-216 (InfoInv: updateAlphaMask(gridSize, infoinv=True), InfoInv/models/FieldBase.py:180-193, called as
+        field.updateAlphaMask(tuple(reso_mask), infoinv=infoinv) by InfoInv/main.py:325) with getDenseAlpha :161-178 inside: dense alpha on the lattice, clamp, 3x3x3 max-pool,
         threshold, new AlphaGridMask, and the aabb of the occupied lattice points -- one C-ABI call
         (ngf_field_alpha_mask_build); only the three torch.linspace vectors are made on the host, like the reference makes
         its lattice, so the points are bit-identical to dense_xyz."""
+        mode = self._alpha_mode(**kw)
         gx, gy, gz = (int(g) for g in gridSize)
         dev = torch.device(self.device)
         lin = [torch.linspace(0, 1, g).to(dev) for g in (gx, gy, gz)]
@@ -269,7 +289,7 @@ class Base(torch.nn.Module):
         count = torch.zeros((1,), device=dev, dtype=torch.int64)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().ngf_field_alpha_mask_build(
-                self.handle(), int(self.ALPHA_MODE), lin[0].data_ptr(), lin[1].data_ptr(), lin[2].data_ptr(), gx, gy, gz,
+                self.handle(), int(mode), lin[0].data_ptr(), lin[1].data_ptr(), lin[2].data_ptr(), gx, gy, gz,
                 C.c_float(float(self.stepSize)), C.c_float(float(self.alphaMask_thres)), alpha.data_ptr(), vol.data_ptr(),
                 new_aabb.data_ptr(), count.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         if int(count.item()) == 0:            # the reference fails here too (amin of an empty tensor); it also prints this total

@@ -37,7 +37,9 @@ class TriPlane(Base):
         d.dens_w2, d.dens_b2 = dp(m[2].weight), dp(m[2].bias)
         d.dens_w3, d.dens_b3 = dp(m[4].weight), dp(m[4].bias)
 
-    ALPHA_MODE = 1        # compute_alpha(..., infoinv=True) by default (InfoInv/models/FieldBase.py:140)
+    def _alpha_mode(self, infoinv=True) -> int:
+        """compute_alpha / getDenseAlpha / updateAlphaMask(..., infoinv=True) of InfoInv/models/FieldBase.py:140,161,180."""
+        return int(bool(infoinv))
 
     def forward(self, rays_chunk, white_bg=True, is_train=False, N_samples=-1, infoinv=True, collect_stats=False, out=None):
         """InfoInv/models/FieldBase.py:228."""

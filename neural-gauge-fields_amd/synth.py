@@ -157,7 +157,8 @@ def lookat_rays(H=800, W=800, c2w=None, camera_angle_x=0.6911112070083618, rows=
     if c2w is None:
         c2w = lookat_pose()
     c2w = np.asarray(c2w, np.float32)
-    focal = np.float32(0.5 * 800 / math.tan(0.5 * camera_angle_x)) * np.float32(W / 800.0)
+    # blender.py:46-47 computes the focal length in double; torch rounds it to float32 once when it divides the pixel grid by it
+    focal = np.float32(0.5 * 800 / math.tan(0.5 * camera_angle_x) * (W / 800))
     r0, r1 = (0, H) if rows is None else rows
     i = (np.arange(W, dtype=np.float32) + np.float32(0.5))[None, :].repeat(r1 - r0, 0)
     j = (np.arange(r0, r1, dtype=np.float32) + np.float32(0.5))[:, None].repeat(W, 1)
@@ -249,3 +250,30 @@ def dtu_rays(H=600, W=800, campos=(1.7514, 0.0961, -4.7220), focal=(1446.17, 144
     d = ((i - center[0]) / focal[0])[..., None] * right + ((j - center[1]) / focal[1])[..., None] * down + fwd
     d /= np.linalg.norm(d, axis=-1, keepdims=True)
     return c.astype(np.float32), np.ascontiguousarray(d.reshape(-1, 3).astype(np.float32))
+
+
+# Camera 0 of the DTU scan the reference ships (UV-Mapping/data/DTU/scan83/trainData/in_camFocal.npy, in_camPrincpt.npy,
+# in_camExtrinsics.npy[0][:3,:3], in_camOrgs.npy[0]; float32 values, also stored in tests/golden/rays_dtu.npz): the view of
+# BASELINE config 4's bench leg.  The extrinsic block is a scaled rotation (|row| ~ 135.9), as shipped.
+DTU_VIEW0 = {
+    "focal": (1446.165283203125, 1441.587646484375),
+    "princpt": (411.6026611328125, 309.53546142578125),
+    "rot": ((131.82720947265625, 1.0162771940231323, 32.87162780761719),
+            (-2.003077507019043, 135.79864501953125, 3.834646224975586),
+            (-32.82627487182617, -4.205236434936523, 131.7753448486328)),
+    "campos": (1.7514456510543823, 0.09612564742565155, -4.722002983093262),
+}
+
+
+def dtu_rays_dir(H, W, focal, princpt, rot, rows=None):
+    """Restatement of get_rays_dir on the 'no_crop' pixel grid (UV-Mapping/data/dtu.py:27-37,160-168), float32 like the
+    reference (float32 pixel coordinates, focal, principal point and rotation): raydir [rows*W, 3]."""
+    f, c, r = np.asarray(focal, np.float32), np.asarray(princpt, np.float32), np.asarray(rot, np.float32)
+    r0, r1 = (0, H) if rows is None else rows
+    px = np.arange(W, dtype=np.float32)[None, :].repeat(r1 - r0, 0)
+    py = np.arange(r0, r1, dtype=np.float32)[:, None].repeat(W, 1)
+    x, y = (px - c[0]) / f[0], (py - c[1]) / f[1]
+    d = np.stack([(r[0, j] * x + r[1, j] * y) + r[2, j] for j in range(3)], -1)         # sum_i rot[i][j] * dirs[i], i = 0, 1, 2 in order
+    n = np.sqrt((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2])
+    d = d / (n + np.float32(1e-5))[..., None]
+    return np.ascontiguousarray(d.reshape(-1, 3), dtype=np.float32)

@@ -103,6 +103,7 @@ class Trainer:
             self.lr = list(state_from.lr)
         self._loss = torch.zeros((1,), dtype=torch.float64, device=self.dev)
         self.last_active = 0
+        self._gauge_on = True          # set by backward(); optimizer_step() before any backward() updates nothing but must not raise
         self._build()
 
     def _build(self):
@@ -207,7 +208,7 @@ class Trainer:
                 self.steps[k] += 1
                 _lib.check(self.L.ngf_train_adam(self._h, k, self.steps[k], float(self.lr[k]), float(self.betas[0]), float(self.betas[1]),
                                                  float(self.eps), float(self.l1), st))
-        self.field._handle_key = None      # parameters changed behind torch's back: the eval image is re-packed on the next render
+        self.field.invalidate()      # parameters changed behind torch's back: the eval image is re-packed on the next render
         self.lr = [x * self.lr_factor for x in self.lr]
 
     def step(self, rays_train, rgb_train, iteration, N_samples=-1, white_bg=True, jitter=None, coin=None):

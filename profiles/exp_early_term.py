@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from helpers import big_case, field_for_case
-from ngf_amd import synth
+from ngf_amd import _lib, synth
 
 rays = torch.from_numpy(synth.lookat_rays(800, 800)).cuda()
 for model, preset, bake in (("triplane", "R1", 0), ("triplane", "R2", 0), ("triplane", "R0", 0), ("triplane", "R1", 3), ("infoinv", "R1", 0)):
@@ -17,6 +17,7 @@ for model, preset, bake in (("triplane", "R1", 0), ("triplane", "R2", 0), ("trip
     for mode in ("32", ""):
         if mode: os.environ["NGF_ABLATE"] = mode
         else: os.environ.pop("NGF_ABLATE", None)
+        _lib.knobs_from_env()          # the library itself never reads the environment (ngf_debug_set)
         for _ in range(2): out = f(rays, N_samples=192, collect_stats=True, **kw)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
         for a, b in ev:

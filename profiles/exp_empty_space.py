@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from helpers import big_case, field_for_case
-from ngf_amd import synth, triplane
+from ngf_amd import _lib, synth, triplane
 
 rays = torch.from_numpy(synth.lookat_rays(800, 800)).cuda()
 g, params, step = big_case("triplane", "R1")
@@ -23,6 +23,7 @@ for S in (192, -1):
     for mode in ("96", "32", ""):
         if mode: os.environ["NGF_ABLATE"] = mode
         else: os.environ.pop("NGF_ABLATE", None)
+        _lib.knobs_from_env()          # the library itself never reads the environment (ngf_debug_set)
         for _ in range(2): out = f(rays, N_samples=S, iteration=30001)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
         for a, b in ev:

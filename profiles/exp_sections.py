@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from helpers import big_case, field_for_case
-from ngf_amd import synth
+from ngf_amd import _lib, synth
+_lib.knobs_from_env()          # NGF_PROFILE above -> ngf_debug_set("profile", 1)
 names = ["march steps", "shade: ring read + setup + gather0/view MFMA issue", "shade: wait plane 0 + interpolate",
          "shade: layer-1 MFMAs (160)", "shade: layer 2 (64 MFMAs)", "shade: result list + collect",
          "shade: layer 3 (VALU dot + 2 cross-lane adds + sigmoid)"]

@@ -9,7 +9,8 @@ sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
 import numpy as np, torch
 from helpers import big_case, field_for_case
 import ngf_amd
-from ngf_amd import synth
+from ngf_amd import _lib, synth
+_lib.knobs_from_env()
 g, params, step = big_case("triplane", "R1")
 bd = bool(int(os.environ.get("BD", "0")))
 f = field_for_case(g, params, None, device="cuda", bake=bd)

@@ -9,7 +9,8 @@ import os, sys
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
 import numpy as np, torch
 from helpers import big_case, field_for_case
-from ngf_amd import synth
+from ngf_amd import _lib, synth
+_lib.knobs_from_env()
 g, params, step = big_case("triplane", "R1")
 f = field_for_case(g, params, None, device="cuda", bake=int(os.environ.get("BAKE", "0")))
 out = {}

@@ -201,6 +201,37 @@ def capture_alpha_mask(name="triplane_alpha_mask", seed=41):
           f"(bbox only {kept_bbox.shape[0]})")
 
 
+def capture_infoinv_alpha(name="infoinv_alpha_mask", seed=43):
+    """InfoInv tree: compute_alpha / getDenseAlpha / updateAlphaMask with infoinv=True and infoinv=False
+    (InfoInv/models/FieldBase.py:140-193; main.py:325 passes the flag through) on a small lattice."""
+    F = _import_ref("InfoInv")
+    aabb = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
+    grid = [22, 22, 22]
+    plane_hw = ((16, 18), (14, 16), (14, 18))
+    params = synth.infoinv_params(seed, plane_hw, preset="R1")
+    mgrid = (12, 11, 10)
+    pts = (synth.hash_uniform(seed, 710, (150, 3)) * np.float32(3.4) - np.float32(1.7)).astype(np.float32)
+    out = {}
+    for flag in (True, False):
+        with contextlib.redirect_stdout(io.StringIO()):
+            field = F.TriPlane(aabb, grid, "cpu", near_far=[2.0, 6.0], alphaMask_thres=0.06, distance_scale=25,
+                               rayMarch_weight_thres=1e-4, step_ratio=0.5)
+        _load_params(field, params)
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            a_pts = field.compute_alpha(torch.from_numpy(pts), 0.37, infoinv=flag)
+            dense_alpha, _ = field.getDenseAlpha(mgrid, infoinv=flag)
+            field.updateAlphaMask(mgrid, infoinv=flag)
+        tag = "on" if flag else "off"
+        out.update({f"alpha_pts_{tag}": a_pts.numpy(), f"dense_alpha_{tag}": dense_alpha.numpy(),
+                    f"mask_volume_{tag}": field.alphaMask.alpha_volume[0, 0].numpy().copy()})
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), model="infoinv", seed=seed, preset="R1", aabb=aabb.numpy(), grid=np.array(grid),
+                        plane_hw=np.array(plane_hw), near_far=np.array([2.0, 6.0], np.float32), step_ratio=np.float32(0.5),
+                        distance_scale=np.float32(25), thr=np.float32(1e-4), alphaMask_thres=np.float32(0.06), mgrid=np.array(mgrid), pts=pts,
+                        **out, **_checksums(params))
+    print(f"{name}: occupancy on {out['mask_volume_on'].mean():.3f} off {out['mask_volume_off'].mean():.3f}, "
+          f"max |alpha on - off| {np.abs(out['dense_alpha_on'] - out['dense_alpha_off']).max():.3f}")
+
+
 def capture_uv(name, seed, primitive_type, R=96, S=64):
     """UV-Mapping colour path through the reference's own sub-modules, composed as NeuTex.forward does
     (model.py:30-50); NeuTex.forward itself is CUDA-hardwired (gauge_fields.py:129,154) and cannot run here.
@@ -300,6 +331,71 @@ def capture_evalout():
                         ssim5=np.float64(ssim5), mse=np.float64(loss.item()), psnr=np.float64(psnr), depth=depth, depth_idx_nearfar=d_nf,
                         depth_finite=finite, depth_idx_auto=d_auto, depth_auto_range=np.asarray(mm_auto, np.float64), rgb=rgb, rgb8=rgb8)
     print(f"evalout: ssim {ssim:.6f} ssim5 {ssim5:.6f} psnr {psnr:.4f} depth idx mean {d_nf.mean():.2f} auto range {mm_auto}")
+
+
+def _ref_functions(relpath, names, ns):
+    """Execute the named top-level function definitions of a reference source file (which does not import here) from
+    its syntax tree, in namespace ``ns``.  Nothing of the reference's text is stored: only the functions' outputs."""
+    import ast
+    tree = ast.parse(open(os.path.join(REF, relpath)).read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(keep) == len(names), (relpath, names)
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "reference:" + relpath, "exec"), ns)
+    return ns
+
+
+def capture_rays():
+    """Ray generation FROM THE REFERENCE's own functions.
+
+    rays_blender.npz: get_ray_directions + get_rays (TriPlane/dataLoader/ray_utils.py:24-42,66-87) executed from the
+    module's syntax tree (the module imports kornia, absent here), with the Blender loader's call pattern
+    (blender.py:46-53,84-85): focal from camera_angle_x, directions / torch.norm(directions, dim=-1, keepdim=True),
+    rays = cat(rays_o, rays_d).  kornia.create_meshgrid is supplied the way kornia defines it:
+    create_meshgrid(H, W, normalized_coordinates=False) = [1,H,W,2] with [...,0] = x = linspace(0, W-1, W) along
+    columns and [...,1] = y = linspace(0, H-1, H) along rows.
+    rays_dtu.npz: get_rays_dir (UV-Mapping/data/dtu.py:27-37) on the 'no_crop' pixel grid of DtuDataset.__getitem__
+    (dtu.py:160-169: integer pixel coordinates, float32) with the cameras the reference ships
+    (UV-Mapping/data/DTU/scan83/trainData/in_cam*.npy, views 0 and 33).
+    Fixtures keep whole image rows (what ngf_generate_rays* produces) of a few rows only."""
+    def create_meshgrid(H, W, normalized_coordinates=False):
+        assert not normalized_coordinates
+        xs = torch.linspace(0, W - 1, W)
+        ys = torch.linspace(0, H - 1, H)
+        return torch.stack(torch.meshgrid([xs, ys], indexing="ij"), dim=-1).permute(1, 0, 2).unsqueeze(0)
+
+    ns = _ref_functions("TriPlane/dataLoader/ray_utils.py", ("get_ray_directions", "get_rays"), {"torch": torch, "np": np, "create_meshgrid": create_meshgrid})
+    out = {}
+    cases = (("a", 800, 800, 0.6911112070083618, synth.lookat_pose(), (0, 1, 2, 399, 400, 401, 798, 799)),
+             ("b", 37, 53, 0.9, synth.lookat_pose(3.2, -20.0, 250.0), tuple(range(37))))
+    for tag, H, W, angle, c2w, rows in cases:
+        focal = 0.5 * 800 / np.tan(0.5 * angle)            # blender.py:46 (np.float64 scalar, like the loader's)
+        focal *= W / 800                                   # blender.py:47
+        directions = ns["get_ray_directions"](H, W, [focal, focal])                    # blender.py:51
+        directions = directions / torch.norm(directions, dim=-1, keepdim=True)         # blender.py:52
+        rays_o, rays_d = ns["get_rays"](directions, torch.FloatTensor(c2w))            # blender.py:68,84
+        rays = torch.cat([rays_o, rays_d], 1).reshape(H, W, 6).numpy()                 # blender.py:85
+        out.update({f"{tag}_H": H, f"{tag}_W": W, f"{tag}_focal": np.float64(focal), f"{tag}_c2w": np.asarray(c2w, np.float32),
+                    f"{tag}_rows": np.array(rows), f"{tag}_rays": np.ascontiguousarray(rays[list(rows)])})
+    np.savez_compressed(os.path.join(HERE, "rays_blender.npz"), **out)
+    print("rays_blender:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.endswith("rays")})
+
+    ns = _ref_functions("UV-Mapping/data/dtu.py", ("get_rays_dir",), {"np": np})
+    cam = os.path.join(REF, "UV-Mapping", "data", "DTU", "scan83", "trainData")
+    focal_all, princpt_all = np.load(os.path.join(cam, "in_camFocal.npy")), np.load(os.path.join(cam, "in_camPrincpt.npy"))
+    ext_all, org_all = np.load(os.path.join(cam, "in_camExtrinsics.npy")), np.load(os.path.join(cam, "in_camOrgs.npy"))
+    H, W = 600, 800
+    out = {"H": H, "W": W}
+    for view, rows in ((0, (0, 1, 299, 300, 598, 599)), (33, (100, 101, 455))):
+        px, py = np.meshgrid(np.arange(W).astype(np.float32), np.arange(H).astype(np.float32))     # dtu.py:160-163
+        pixelcoords = np.stack((px, py), axis=-1).astype(np.float32)                                 # dtu.py:165
+        camrot = ext_all[view][0:3, 0:3]                                                             # dtu.py:133
+        raydir = ns["get_rays_dir"](pixelcoords, H, W, focal_all[view], camrot, princpt_all[view])   # dtu.py:166-168
+        assert raydir.dtype == np.float32
+        out.update({f"v{view}_focal": focal_all[view], f"v{view}_princpt": princpt_all[view], f"v{view}_rot": camrot,
+                    f"v{view}_campos": org_all[view].astype(np.float32),                             # dtu.py:136 (.float())
+                    f"v{view}_rows": np.array(rows), f"v{view}_raydir": np.ascontiguousarray(raydir[list(rows)])})
+    np.savez_compressed(os.path.join(HERE, "rays_dtu.npz"), **out)
+    print("rays_dtu:", {k: v.shape for k, v in out.items() if k.endswith("raydir")})
 
 
 def capture_train(name="train_r1", seed=51, S=40, steps=2):
@@ -473,7 +569,7 @@ def capture_ref_checkpoint(name="ref_ckpt_triplane", seed=71):
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1:       # regenerate one fixture without touching the others
-        {"evalout": capture_evalout, "train": capture_train, "uv_edit": capture_uv_edit, "ref_ckpt": capture_ref_checkpoint}[sys.argv[1]]()
+        {"evalout": capture_evalout, "train": capture_train, "uv_edit": capture_uv_edit, "ref_ckpt": capture_ref_checkpoint, "rays": capture_rays, "infoinv_alpha": capture_infoinv_alpha}[sys.argv[1]]()
         sys.exit(0)
     capture_ops()
     capture_triplane("triplane_r1_gauge", seed=11, preset="R1", gauge_on=True, gauge_std=0.05, with_mask=False, S=48)
@@ -484,9 +580,11 @@ if __name__ == "__main__":
     capture_infoinv("infoinv_r1_on", seed=21, preset="R1", infoinv=True, S=40)
     capture_infoinv("infoinv_r1_off", seed=22, preset="R1", infoinv=False, S=40)
     capture_alpha_mask()
+    capture_infoinv_alpha()
     capture_uv("uv_sphere", seed=31, primitive_type="sphere")
     capture_uv("uv_square", seed=32, primitive_type="square")
     capture_evalout()
     capture_train()
     capture_uv_edit()
     capture_ref_checkpoint()
+    capture_rays()

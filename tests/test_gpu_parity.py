@@ -3,10 +3,12 @@ vectors captured from the reference.  Tolerance (BASELINE.json north_star): 1e-4
 written below as rtol=1e-4 with atol=1e-5 on pixel values in [0,1]; we also assert the much tighter
 bound the implementation actually achieves so regressions show up.
 """
+import os
+
 import numpy as np
 import pytest
 
-from helpers import big_case, field_for_case, load_case, oracle_for_case, psnr
+from helpers import GOLDEN, big_case, field_for_case, load_case, oracle_for_case, psnr
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
@@ -120,7 +122,7 @@ def test_deterministic_and_chunk_independent():
 
 
 @pytest.mark.parametrize("name", ["triplane_r1_gauge", "triplane_r1_mask", "infoinv_r1_on"])
-def test_split_march_is_bit_identical(name, monkeypatch):
+def test_split_march_is_bit_identical(name):
     """The split march (tile_w rays x 64/tile_w lanes per ray on consecutive steps, csrc/ngf_render.hpp render_kernel<P, true>)
     chains transmittance / acc / depth from lane to lane in step order, so every tile shape gives the pixels of the
     one-ray-per-lane march bit for bit.  S = 45 is not a multiple of any lanes-per-ray count; the batch is ragged."""
@@ -128,23 +130,23 @@ def test_split_march_is_bit_identical(name, monkeypatch):
     f = field_for_case(g, params, mask)
     rays = torch.from_numpy(g["rays"]).cuda()[:203]
     kw = {"infoinv": True} if name.startswith("infoinv") else {"iteration": 30001}
-    monkeypatch.setenv("NGF_TILE_W", "64"); monkeypatch.setenv("NGF_SPLIT", "0")
-    ref = f(rays, N_samples=45, **kw)
-    for tw in ("32", "16", "8", "4"):
-        monkeypatch.setenv("NGF_TILE_W", tw); monkeypatch.setenv("NGF_SPLIT", "1")
-        got = f(rays, N_samples=45, **kw)
+    from ngf_amd._lib import knobs
+    with knobs(tile_w=64, split=0, kernel=0):
+        ref = f(rays, N_samples=45, **kw)
+    for tw in (32, 16, 8, 4):
+        with knobs(tile_w=tw, split=1, kernel=0):
+            got = f(rays, N_samples=45, **kw)
         assert torch.equal(ref["rgb_map"], got["rgb_map"]), tw
         assert torch.equal(ref["depth_map"], got["depth_map"]), tw
-    monkeypatch.delenv("NGF_TILE_W"); monkeypatch.delenv("NGF_SPLIT")
     got = f(rays, N_samples=45, **kw)          # the default choice
     assert torch.equal(ref["rgb_map"], got["rgb_map"]) and torch.equal(ref["depth_map"], got["depth_map"])
 
 
 @pytest.mark.parametrize("name,bias", [("triplane_r1_gauge", None), ("triplane_r1_gauge", 25.0), ("triplane_r1_mask", 14.0), ("infoinv_r1_on", None)])
-def test_early_termination_is_bit_identical(name, bias, monkeypatch):
+def test_early_termination_is_bit_identical(name, bias):
     """The march stops a tile once, for all its rays, T is below half an ulp of acc and of depth / z_max (and below the
     colour threshold): no later sample can change an output bit; iterations in which no lane has a valid sample are skipped
-    before their gathers.  Checked against the full march (NGF_ABLATE=96 switches both off) on the
+    before their gathers.  Checked against the full march (knob ablate = 96 switches both off) on the
     golden scenes, on opaque variants of them (a surface right at the box entry: termination after a few steps) and
     against the oracle, with and without a white background, S = 160."""
     g, params, step, mask = load_case(name)
@@ -155,11 +157,11 @@ def test_early_termination_is_bit_identical(name, bias, monkeypatch):
     orc = oracle_for_case(g, params, step, mask)
     rays = torch.from_numpy(g["rays"]).cuda()
     kw = {"infoinv": True} if name.startswith("infoinv") else {"iteration": 30001}
+    from ngf_amd._lib import knobs
     for white in (True, False):
-        monkeypatch.setenv("NGF_ABLATE", "96")               # 32: no early termination, 64: no empty-iteration skip
-        full = f(rays, N_samples=160, white_bg=white, collect_stats=True, **kw)
+        with knobs(ablate=96):                               # 32: no early termination, 64: no empty-iteration skip
+            full = f(rays, N_samples=160, white_bg=white, collect_stats=True, **kw)
         n_full = int(f.last_stats[0])
-        monkeypatch.delenv("NGF_ABLATE")
         early = f(rays, N_samples=160, white_bg=white, collect_stats=True, **kw)
         n_early = int(f.last_stats[0])
         assert torch.equal(full["rgb_map"], early["rgb_map"]) and torch.equal(full["depth_map"], early["depth_map"])
@@ -199,25 +201,51 @@ def test_headline_geometry_chunk(model, preset):
             print(f"   bake_density={bd} bake_color={bc}: max abs err {eb:.2e}")
 
 
-def test_generate_rays_matches_loader_restatement():
-    """ngf_generate_rays vs the numpy restatement of get_ray_directions/get_rays (synth.lookat_rays)."""
+def test_generate_rays_matches_reference():
+    """ngf_generate_rays vs rays produced by the reference's own get_ray_directions / get_rays with the Blender loader's
+    call pattern (tests/golden/rays_blender.npz, make_golden.capture_rays): origins bit-exact, directions to matmul rounding."""
     from ngf_amd import rays as nrays
-    from ngf_amd import synth
-    c2w = synth.lookat_pose()
-    want = synth.lookat_rays(800, 800, c2w, rows=(390, 410))
-    got = nrays.generate_rays(800, 800, nrays.blender_focal(800), c2w, rows=(390, 410)).cpu().numpy()
-    assert got.shape == want.shape
-    assert np.array_equal(got[:, :3], want[:, :3])
-    assert np.abs(got[:, 3:] - want[:, 3:]).max() < 3e-7          # matmul rounding order only
-    # and the renders of both ray sets agree
+    fx = np.load(os.path.join(GOLDEN, "rays_blender.npz"))
+    for tag in ("a", "b"):
+        H, W, c2w = int(fx[tag + "_H"]), int(fx[tag + "_W"]), fx[tag + "_c2w"]
+        focal = float(np.float32(fx[tag + "_focal"]))               # torch rounds the loader's double focal to float32 once
+        whole = nrays.generate_rays(H, W, focal, c2w).cpu().numpy().reshape(H, W, 6)
+        for k, r in enumerate(fx[tag + "_rows"]):
+            want = fx[tag + "_rays"][k]
+            got = nrays.generate_rays(H, W, focal, c2w, rows=(int(r), int(r) + 1)).cpu().numpy()
+            assert np.array_equal(got, whole[int(r)])               # row blocks = rows of the whole frame (sharded render)
+            assert np.array_equal(got[:, :3], want[:, :3])
+            assert np.abs(got[:, 3:] - want[:, 3:]).max() <= 3e-7
+    assert nrays.blender_focal(800) == float(np.float32(fx["a_focal"]))
+    # and the renders of the reference's rays and the device's rays agree
     g, params, step = big_case("triplane", "R1")
     f = field_for_case(g, params, None)
-    a = f(torch.from_numpy(want[:4096]).cuda(), N_samples=96, iteration=30001)["rgb_map"]
-    b = f(torch.from_numpy(got[:4096]).cuda(), N_samples=96, iteration=30001)["rgb_map"]
+    want = fx["a_rays"][3:6].reshape(-1, 6)
+    got = nrays.generate_rays(800, 800, nrays.blender_focal(800), fx["a_c2w"], rows=(399, 402))
+    a = f(torch.from_numpy(want).cuda(), N_samples=96, iteration=30001)["rgb_map"]
+    b = f(got, N_samples=96, iteration=30001)["rgb_map"]
     # a 1-ulp change of a direction can move a sample across the box face or a texel edge (SURVEY.md section 7,
     # hazard 1), so single pixels may differ by ~1e-3; everything else agrees to rounding
     diff = (a - b).abs()
     assert float(diff.max()) < 5e-3 and float((diff > 1e-5).float().mean()) < 1e-2
+
+
+def test_generate_rays_dtu_matches_reference():
+    """ngf_generate_rays_dtu vs the reference's own get_rays_dir on the shipped DTU cameras (tests/golden/rays_dtu.npz)."""
+    from ngf_amd import rays as nrays
+    from ngf_amd import synth
+    fx = np.load(os.path.join(GOLDEN, "rays_dtu.npz"))
+    H, W = int(fx["H"]), int(fx["W"])
+    for v in (0, 33):
+        cam = (fx[f"v{v}_focal"], fx[f"v{v}_princpt"], fx[f"v{v}_rot"])
+        for k, r in enumerate(fx[f"v{v}_rows"]):
+            got = nrays.generate_rays_dtu(H, W, *cam, rows=(int(r), int(r) + 1)).cpu().numpy()
+            want = fx[f"v{v}_raydir"][k]
+            assert np.abs(got - want).max() <= 3e-7
+            assert np.mean(got != want) < 0.01                      # same float32 operation order: expected bit-exact
+    v0 = synth.DTU_VIEW0
+    assert np.array_equal(np.float32(v0["focal"]), fx["v0_focal"]) and np.array_equal(np.float32(v0["rot"]), fx["v0_rot"])
+    assert np.array_equal(np.float32(v0["princpt"]), fx["v0_princpt"]) and np.array_equal(np.float32(v0["campos"]), fx["v0_campos"])
 
 
 def test_bench_rccl_path_single_gpu(tmp_path):
@@ -302,6 +330,36 @@ def test_alpha_mask_build_and_ray_filter():
     # the rebuilt mask is used by the next render and by a checkpoint round trip
     out = f(rays.cuda(), N_samples=32, iteration=30001)
     assert bool(torch.isfinite(out["rgb_map"]).all())
+
+
+def test_infoinv_alpha_api_takes_the_infoinv_flag():
+    """InfoInv tree: compute_alpha / getDenseAlpha / updateAlphaMask(..., infoinv=True|False) (InfoInv/models/FieldBase.py:140-193;
+    InfoInv/main.py:325 calls field.updateAlphaMask(tuple(reso_mask), infoinv=infoinv)) against the reference's own outputs in
+    BOTH modes -- with infoinv=False the occupancy mask must come from the un-modulated densities."""
+    g, params, step, _ = load_case("infoinv_alpha_mask")
+    mgrid = tuple(int(v) for v in g["mgrid"])
+    pts = torch.from_numpy(g["pts"]).cuda()
+    for flag, tag in ((True, "on"), (False, "off")):
+        f = field_for_case(g, params, None)
+        f.alphaMask_thres = float(g["alphaMask_thres"])
+        a = f.compute_alpha(pts, 0.37, infoinv=flag)
+        np.testing.assert_allclose(a.cpu().numpy(), g["alpha_pts_" + tag], rtol=2e-4, atol=2e-7)
+        alpha, _ = f.getDenseAlpha(mgrid, infoinv=flag)
+        np.testing.assert_allclose(alpha.cpu().numpy(), g["dense_alpha_" + tag], rtol=2e-4, atol=2e-7)
+        f.updateAlphaMask(mgrid, infoinv=flag)
+        vol = f.alphaMask.alpha_volume[0, 0].cpu().numpy()
+        pooled = torch.nn.functional.max_pool3d(torch.from_numpy(g["dense_alpha_" + tag]).clamp(0, 1).transpose(0, 2)[None, None], 3, 1, 1)[0, 0].numpy()
+        near_thr = np.abs(pooled - float(g["alphaMask_thres"])) < 1e-6
+        assert np.array_equal(vol[~near_thr], g["mask_volume_" + tag][~near_thr])
+        assert 0.02 < vol.mean() < 0.98
+    assert np.abs(g["dense_alpha_on"] - g["dense_alpha_off"]).max() > 1e-2            # the two modes really differ
+    # default = infoinv=True, like the reference's signatures
+    f = field_for_case(g, params, None)
+    assert torch.equal(f.compute_alpha(pts, 0.37), f.compute_alpha(pts, 0.37, infoinv=True))
+    # the TriPlane tree has no such keyword (TriPlane/models/FieldBase.py:140)
+    gt, pt, _, _ = load_case("triplane_r1_gauge")
+    with pytest.raises(TypeError):
+        field_for_case(gt, pt, None).compute_alpha(pts, 1.0, infoinv=True)
 
 
 def test_renders_a_checkpoint_written_by_the_reference():

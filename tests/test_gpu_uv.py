@@ -53,12 +53,12 @@ def test_uv_no_background_and_short_chunks():
     assert np.abs(out["transmittance"][0].cpu().numpy() - o_trans).max() < 2e-5
 
 
-def test_two_rays_per_wave_is_bit_identical(monkeypatch):
+def test_two_rays_per_wave_is_bit_identical():
     """The default kernel renders two rays per wave (every weight load feeds two MFMAs); a sample's arithmetic does not
-    depend on its tile, so the one-ray-per-wave kernel (NGF_UV_TILES=1) gives the same bits -- also for an odd ray count
+    depend on its tile, so the one-ray-per-wave kernel (knob uv_tiles = 1) gives the same bits -- also for an odd ray count
     (the last wave's second ray is a dummy) and a single ray."""
     import ngf_amd  # noqa: F401
-    from ngf_amd import synth, uvmapping
+    from ngf_amd import _lib, synth, uvmapping
     net = uvmapping.NeuTex(primitive_type="sphere", sample_num=64)
     net.load_params(synth.uvmapping_params(31, "sphere"))
     campos, dirs = synth.dtu_rays(600, 800)
@@ -68,7 +68,6 @@ def test_two_rays_per_wave_is_bit_identical(monkeypatch):
         cp = torch.from_numpy(campos)[None].cuda()
         U = torch.from_numpy(synth.hash_uniform(8, 100 + n, (1, n, 64))).cuda()
         two = net(cp, rd, None, jitter_u=U)
-        monkeypatch.setenv("NGF_UV_TILES", "1")
-        one = net(cp, rd, None, jitter_u=U)
-        monkeypatch.delenv("NGF_UV_TILES")
+        with _lib.knobs(uv_tiles=1):
+            one = net(cp, rd, None, jitter_u=U)
         assert torch.equal(two["color"], one["color"]) and torch.equal(two["transmittance"], one["transmittance"]), n

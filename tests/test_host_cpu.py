@@ -136,3 +136,22 @@ def test_shard_bounds_cover_everything():
             spans = [ndist.shard_bounds(n, w, r)[:2] for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+def test_ray_restatements_match_reference_fixtures():
+    """The numpy restatements of the loaders' ray generation (synth.lookat_rays, synth.dtu_rays_dir: what the sharded bench and
+    the CPU-side checks feed on) against rays produced by the reference's own functions (make_golden.capture_rays)."""
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fx = np.load(os.path.join(here, "rays_blender.npz"))
+    for tag, angle in (("a", 0.6911112070083618), ("b", 0.9)):
+        H, W, c2w = int(fx[tag + "_H"]), int(fx[tag + "_W"]), fx[tag + "_c2w"]
+        for k, r in enumerate(fx[tag + "_rows"]):
+            mine = synth.lookat_rays(H, W, c2w, camera_angle_x=angle, rows=(int(r), int(r) + 1))
+            assert np.array_equal(mine[:, :3], fx[tag + "_rays"][k][:, :3])
+            assert np.abs(mine[:, 3:] - fx[tag + "_rays"][k][:, 3:]).max() <= 3e-7        # matmul rounding order
+    fd = np.load(os.path.join(here, "rays_dtu.npz"))
+    for v in (0, 33):
+        for k, r in enumerate(fd[f"v{v}_rows"]):
+            mine = synth.dtu_rays_dir(600, 800, fd[f"v{v}_focal"], fd[f"v{v}_princpt"], fd[f"v{v}_rot"], rows=(int(r), int(r) + 1))
+            assert np.array_equal(mine, fd[f"v{v}_raydir"][k])

@@ -63,3 +63,21 @@ def test_samplers_match_aten(golden_dir):
                                C.c_int64(q.shape[0]), out3.ctypes.data_as(C.c_void_p))
     assert np.array_equal(out3 > 0, g["out3"] > 0)       # the path only uses the sign (FieldBase.py:264)
     assert np.max(np.abs(out3 - g["out3"])) <= 5e-7
+
+
+def test_infoinv_compute_alpha_both_modes():
+    """compute_alpha(xyz, length, infoinv=True|False) of the InfoInv tree (InfoInv/models/FieldBase.py:140-156) through the C
+    restatement's density, against the reference's own outputs (tests/golden/infoinv_alpha_mask.npz)."""
+    from helpers import load_case, oracle_for_case
+    g, params, step, _ = load_case("infoinv_alpha_mask")
+    pts = g["pts"]
+    inside = np.all((pts >= g["aabb"][0]) & (pts <= g["aabb"][1]), axis=1)
+    xn = (pts - g["aabb"][0]) * (np.float32(2.0) / (g["aabb"][1] - g["aabb"][0])) - np.float32(1.0)
+    coords = np.stack([xn[:, 0], xn[:, 1], xn[:, 1], xn[:, 2], xn[:, 0], xn[:, 2]], 1).astype(np.float32)
+    for flag, tag in ((1, "on"), (0, "off")):
+        g["infoinv"] = np.array(flag)
+        orc = oracle_for_case(g, params, step, None)
+        alpha = 1.0 - np.exp(-orc.density_at(coords) * np.float32(0.37))
+        # outside the box the reference still evaluates the planes (grid_sample zero padding): compare everywhere
+        np.testing.assert_allclose(alpha, g["alpha_pts_" + tag], rtol=2e-5, atol=2e-7)
+    assert inside.any() and (~inside).any()
