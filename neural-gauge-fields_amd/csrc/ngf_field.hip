@@ -4,6 +4,7 @@
 #include "ngf_host.hpp"
 #include "ngf_infoinv.hpp"
 #include "ngf_render.hpp"
+#include "ngf_render_pc.hpp"
 #include "ngf_train.hpp"
 
 using namespace ngf;
@@ -435,9 +436,61 @@ static int launch_policy(const ngf_field *f, RenderArgs &A, hipStream_t st)
     else return launch_render(render_kernel<P, false>, (decltype(&render_kernel<P, false>))nullptr, f, A, P::WAVES * kWave, lds, st, wide);
 }
 
+// Specialised march / shade waves (ngf_render_pc.hpp): NM march waves + NS shade waves per CU.
+template <typename P, int NM, int NS, int TW>
+static int launch_pc(const ngf_field *f, RenderArgs &A, hipStream_t st)
+{
+    const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + PcLds<NM>::TOTAL) * sizeof(float);
+    if (lds > 160 * 1024) return fail(NGF_E_ARG, "the specialised kernel needs %zu bytes of LDS (> 160 KiB)", lds);
+    const unsigned slot = f->next_counter.fetch_add(1) % kCounters;
+    A.tile_counter = f->counters + slot;
+    HIP_TRY(hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned), st));
+    A.tile_w = TW;
+    A.tile_shift = TW == 8 ? 3 : 2;
+    auto k = render_pc_kernel<P, NM, NS, TW>;
+    static bool attr_set = false;             // per instantiation
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int64_t tiles = (A.n + TW - 1) / TW;
+    int64_t grid = (tiles + NM - 1) / NM;
+    if (grid > f->num_cus) grid = f->num_cus;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3((NM + NS) * kWave), lds, st, A);
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
 template <bool BD, bool BC>
 static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
+    // default: the fused kernel (every wave marches and shades).  ngf_debug_set("kernel", 1) selects the specialised march / shade
+    // waves of ngf_render_pc.hpp: bit-identical, but SLOWER on gfx950 (R1 frame 10.7-12.7 ms vs 10.0 ms, profiles/r02_pc_kernel.txt),
+    // because fp32 MFMA and fp32 VALU execute on the same SIMD datapath and never overlap -- not across waves, not within a wave
+    // (profiles/micro/mfma_valu_overlap.hip: 8.7 ms + 3.1 ms run together in 11.6 ms) -- so there is nothing for the split to overlap.
+    int kernel = knob(KNOB_KERNEL) >= 0 ? knob(KNOB_KERNEL) : 0;
+    if (A.dbg_weight || A.skip_rgb || knob(KNOB_NSTEP) > 1 || (knob(KNOB_PROFILE) > 0 && knob(KNOB_KERNEL) != 1)) kernel = 0;
+    if (knob(KNOB_TILE_W) > 8 || knob(KNOB_SPLIT) == 0) kernel = 0;
+    if (kernel == 1 && knob(KNOB_PROFILE) > 0) {      // section cycles: stats[4..12] (profiles/exp_sections_pc.py); stats must hold 13 counters
+        if constexpr (!BC) {
+            using PP = TriPlanePolicy<BD, false, 12, 1, true>;
+            return knob(KNOB_WAVES) == 88 ? launch_pc<PP, 8, 8, 8>(f, A, st) : launch_pc<PP, 12, 4, 8>(f, A, st);
+        }
+    }
+    if (kernel == 1) {
+        using P = TriPlanePolicy<BD, BC, 12, 1>;
+        int tw = A.n < 40 * (int64_t)f->num_cus * 12 ? 4 : 8;
+        if (knob(KNOB_TILE_W) == 4 || knob(KNOB_TILE_W) == 8) tw = knob(KNOB_TILE_W);
+        const int w = knob(KNOB_WAVES) >= 0 ? knob(KNOB_WAVES) : 124;         // experiment: march waves * 10 + shade waves
+        switch (w) {
+        case 124: return tw == 8 ? launch_pc<P, 12, 4, 8>(f, A, st) : launch_pc<P, 12, 4, 4>(f, A, st);
+        case 88: return tw == 8 ? launch_pc<P, 8, 8, 8>(f, A, st) : launch_pc<P, 8, 8, 4>(f, A, st);
+        case 84: return tw == 8 ? launch_pc<P, 8, 4, 8>(f, A, st) : launch_pc<P, 8, 4, 4>(f, A, st);
+        case 128: return launch_pc<P, 12, 4, 8>(f, A, st);
+        default: return fail(NGF_E_ARG, "specialised kernel: knob waves must be 124, 88 or 84");
+        }
+    }
     // tuning knobs (measurements in profiles/): waves per CU and march steps in flight per lane
     int w = 12, ns = 1;                   // measured best (profiles/r01_sweep.txt)
     if (knob(KNOB_WAVES) >= 0) w = knob(KNOB_WAVES);

@@ -320,6 +320,12 @@ struct TriPlanePolicy {
         if constexpr (BAKE_C) view_fold16<MlpLayout16Baked::W1V / 64, MlpLayout16Baked::B1, 4>(per_pass16(smem), vfeat, pre, n_rays, lane);
         else view_fold16<MlpLayout16<48>::W1 / 64 + 3 * MlpLayout16<48>::QCH, MlpLayout16<48>::B1, MlpLayout16<48>::KT>(per_pass16(smem), vfeat, pre, n_rays, lane);
     }
+    // the same from view inputs held in registers (lane (s, kq): entries kq*4 .. kq*4+3 of ray s) -- ngf_render_pc.hpp
+    __device__ static __forceinline__ void fold_view_regs(const float *smem, const f32x4 v, float *pre, int n_rays, int lane)
+    {
+        if constexpr (BAKE_C) view_fold16_regs<MlpLayout16Baked::W1V / 64, MlpLayout16Baked::B1, 4>(per_pass16(smem), v, pre, n_rays, lane);
+        else view_fold16_regs<MlpLayout16<48>::W1 / 64 + 3 * MlpLayout16<48>::QCH, MlpLayout16<48>::B1, MlpLayout16<48>::KT>(per_pass16(smem), v, pre, n_rays, lane);
+    }
     __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
                                                  const float od[3], int lane, float c[3], unsigned long long *tk = nullptr, const float *pre = nullptr)
     {

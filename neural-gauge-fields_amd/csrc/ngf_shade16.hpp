@@ -170,10 +170,9 @@ __device__ __forceinline__ void layer1_plane16(const float *blob, int lane, cons
 // accumulator order; a pass then starts from its sample's ray vector `pre` (4 broadcast ds_read_b128) instead of the bias and
 // skips those 16 MFMAs and their operand reads.  Same products, same order: bit-identical.
 template <int OW1V, int OB1, int KSTRIDE>     // OW1V: first view k-step; KSTRIDE: k-steps per unit tile in the image
-__device__ __forceinline__ void view_fold16(const float *blob, const float *vfeat, float *pre, int n_rays, int lane)
+__device__ __forceinline__ void view_fold16_regs(const float *blob, const f32x4 v, float *pre, int n_rays, int lane)
 {
     const int kq = lane >> 4, s = lane & 15;
-    const f32x4 v = *reinterpret_cast<const f32x4 *>(vfeat + (s < n_rays ? s : 0) * kViewFeat + kq * 4);
     f32x4 acc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(blob + OB1 + kq * 16 + mt * 4);
@@ -186,6 +185,15 @@ __device__ __forceinline__ void view_fold16(const float *blob, const float *vfea
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4 *>(pre + s * 64 + kq * 16 + mt * 4) = acc[mt];
     }
+}
+
+// the same with the view inputs of ray s read from the tile's LDS table (lane (s, kq) takes entries kq*4 .. kq*4+3)
+template <int OW1V, int OB1, int KSTRIDE>
+__device__ __forceinline__ void view_fold16(const float *blob, const float *vfeat, float *pre, int n_rays, int lane)
+{
+    const int kq = lane >> 4, s = lane & 15;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(vfeat + (s < n_rays ? s : 0) * kViewFeat + kq * 4);
+    view_fold16_regs<OW1V, OB1, KSTRIDE>(blob, v, pre, n_rays, lane);
 }
 
 template <int APP>

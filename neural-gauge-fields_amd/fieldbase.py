@@ -226,7 +226,7 @@ class Base(torch.nn.Module):
             white_bg = False
         else:
             white_bg = True
-        stats = torch.zeros(12, dtype=torch.int64, device=dev) if collect_stats else None   # [4:] = section cycles under NGF_PROFILE
+        stats = torch.zeros(16, dtype=torch.int64, device=dev) if collect_stats else None   # [4:] = section cycles under the profile knob
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
             _lib.check(_lib.lib().ngf_field_render(

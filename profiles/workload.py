@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""One named GPU workload, run a few times -- what profiles/collect.sh puts under rocprofv3.  Product-side imports only.
+
+    python profiles/workload.py <name> [reps]
+names: triplane_R0 | triplane_R1 | triplane_R2 | triplane_R1_bd (bake density) | triplane_R1_bdc (both bakes) | infoinv_R1
+       (800x800 frame, S = 192, BASELINE configs 2 / 3) | uv_sphere (BASELINE config 4: 76 800 DTU-camera rays x 64 samples)
+       | train_R1 (4096-ray training iteration)
+Optional knobs through the environment of THIS script (mapped to ngf_debug_set): NGF_KERNEL, NGF_TILE_W, NGF_STAGE, ..."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import ngf_amd  # noqa: F401
+from ngf_amd import _lib, cases, rays as nrays, synth
+
+name = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+_lib.knobs_from_env()
+dev = "cuda"
+
+
+def timed(fn, n):
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+
+if name.startswith(("triplane", "infoinv")):
+    parts = name.split("_")
+    model, preset, bake = parts[0], parts[1], (parts[2] if len(parts) > 2 else "")
+    g, params, step = cases.big_case(model, preset)
+    f = cases.field_for_case(g, params, None, device=dev, bake="d" in bake, bake_color="c" in bake)
+    rays = nrays.generate_rays(800, 800, nrays.blender_focal(800), synth.lookat_pose())
+    kw = {"iteration": 30001} if model == "triplane" else {"infoinv": True}
+    run = lambda: f(rays, N_samples=192, white_bg=True, **kw)
+    run(); run()
+    ms = timed(run, reps)
+    f(rays, N_samples=192, white_bg=True, collect_stats=True, **kw)
+    st = f.last_stats.cpu().numpy().astype(np.float64)
+    print(f"{name}: {ms:.3f} ms/frame = {640000 / ms / 1e3:.2f} Mray/s; evaluated {st[0] / 640000:.1f} active {st[1] / 640000:.2f} samples/ray, {st[2]:.0f} passes")
+elif name == "uv_sphere":
+    from ngf_amd import uvmapping
+    net = uvmapping.NeuTex(primitive_type="sphere", sample_num=64, device=dev)
+    net.load_params(synth.uvmapping_params(5, "sphere"))
+    v = synth.DTU_VIEW0
+    dirs = nrays.generate_rays_dtu(600, 800, v["focal"], v["princpt"], v["rot"], rows=(252, 348))[None]
+    cam = torch.tensor(v["campos"], dtype=torch.float32)[None]
+    U = torch.rand((1, dirs.shape[1], 64), device=dev)
+    run = lambda: net(cam, dirs, None, jitter_u=U)
+    run()
+    ms = timed(run, max(2, reps // 2))
+    net(cam, dirs, None, jitter_u=U, collect_stats=True)
+    us = net.last_stats.cpu().numpy().astype(np.float64)
+    fl = us[1] * 16 * 2 * 1334592.0
+    print(f"uv_sphere: {ms:.2f} ms = {dirs.shape[1] / ms / 1e3:.3f} Mray/s; in-cube {us[0] / dirs.shape[1]:.1f} samples/ray, executed {fl / (ms * 1e-3) / 1e12:.1f} TFLOP/s")
+elif name.startswith("train"):
+    from ngf_amd import train
+    preset = name.split("_")[1]
+    g, params, step = cases.big_case("triplane", preset)
+    f = cases.field_for_case(g, params, None, device=dev)
+    S = int(f.nSamples)
+    frame = synth.lookat_rays(800, 800)
+    pick = (synth.hash_uniform(9, 1, (4096,)) * np.float32(frame.shape[0])).astype(np.int64)
+    rays = torch.from_numpy(frame[pick]).to(dev)
+    tgt = torch.from_numpy(synth.hash_uniform(9, 2, (4096, 3))).to(dev)
+    tr = train.Trainer(f, batch_size=4096, max_samples=S)
+    it = [0]
+
+    def run():
+        tr.step(rays, tgt, it[0], N_samples=S); it[0] += 1
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    print(f"{name}: S={S}, {tr.last_active} active samples, {ms:.3f} ms/iteration")
+else:
+    raise SystemExit("unknown workload " + name)

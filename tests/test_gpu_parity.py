@@ -142,6 +142,51 @@ def test_split_march_is_bit_identical(name):
     assert torch.equal(ref["rgb_map"], got["rgb_map"]) and torch.equal(ref["depth_map"], got["depth_map"])
 
 
+@pytest.mark.parametrize("bake", [0, 1, 2, 3])
+@pytest.mark.parametrize("name", TRIPLANE)
+def test_specialised_kernel_is_bit_identical(name, bake):
+    """The default TriPlane kernel splits the waves of a CU into march waves and shade waves (csrc/ngf_render_pc.hpp: LDS record
+    queues, ray-major lanes with a DPP chain, per-ray colour sums in record order).  Every ray sees the arithmetic of the fused
+    kernel in the same order, so the pixels are the fused kernel's bit for bit -- for both tile widths, ragged batches and
+    S = 45 (not a multiple of any lanes-per-ray count)."""
+    from ngf_amd._lib import knobs
+    g, params, step, mask = load_case(name)
+    f = field_for_case(g, params, mask, bake=bool(bake & 1), bake_color=bool(bake & 2))
+    kw = _mode(g)
+    for n in (1, 7, 203, len(g["rays"])):
+        rays = torch.from_numpy(g["rays"]).cuda()[:n]
+        for white in (True, False):
+            for tw in (8, 4):
+                # reference: the fused kernel, one ray per lane; with baked colour planes the small-tile kernels start a sample's
+                # layer-1 sum from the per-ray view term (the unsplit one adds it last), so there the reference is the fused
+                # kernel at the same tile width
+                with knobs(kernel=0, tile_w=tw if bake & 2 else 64, split=1 if bake & 2 else 0):
+                    ref = f(rays, N_samples=45, white_bg=white, collect_stats=True, **kw)
+                st_ref = f.last_stats.clone()
+                with knobs(kernel=1, tile_w=tw):
+                    got = f(rays, N_samples=45, white_bg=white, collect_stats=True, **kw)
+                assert torch.equal(ref["rgb_map"], got["rgb_map"]), (n, white, tw)
+                assert torch.equal(ref["depth_map"], got["depth_map"]), (n, white, tw)
+                assert int(st_ref[1]) == int(f.last_stats[1]) and int(f.last_stats[3]) == n      # active samples, rays (the evaluated count depends on the tile shape: early termination is per tile)
+
+
+def test_specialised_kernel_full_frame_bit_identical():
+    """The same on the headline frame (640 000 rays, S = 192, R1 and the MLP-stress preset R2) and on an 80 000-ray shard."""
+    from ngf_amd._lib import knobs
+    from ngf_amd import rays as nrays, synth
+    rays = nrays.generate_rays(800, 800, nrays.blender_focal(800), synth.lookat_pose())
+    for preset in ("R1", "R2", "R0"):
+        g, params, step = big_case("triplane", preset)
+        f = field_for_case(g, params, None)
+        for sub in (rays, rays[:80000]):
+            with knobs(kernel=0):
+                ref = f(sub, N_samples=192, iteration=30001)
+            with knobs(kernel=1):
+                got = f(sub, N_samples=192, iteration=30001)
+            assert torch.equal(ref["rgb_map"], got["rgb_map"]) and torch.equal(ref["depth_map"], got["depth_map"]), preset
+        f.release()
+
+
 @pytest.mark.parametrize("name,bias", [("triplane_r1_gauge", None), ("triplane_r1_gauge", 25.0), ("triplane_r1_mask", 14.0), ("infoinv_r1_on", None)])
 def test_early_termination_is_bit_identical(name, bias):
     """The march stops a tile once, for all its rays, T is below half an ulp of acc and of depth / z_max (and below the
