@@ -27,6 +27,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32 matrix peak = fp32 vector peak (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)
+L2_PEAK_TBS = 34.5          # MI355X_MICROARCH.md: aggregate L2 bandwidth
 H = W = 800
 S = 192
 
@@ -36,6 +38,54 @@ def alg_bytes_per_ray(s_active: float, model: str) -> float:
     if model == "triplane":
         return 24 + 16 + S * 864.0 + s_active * 2304.0
     return 24 + 16 + S * 1152.0 + s_active * 3456.0
+
+
+def so_sha16():
+    import hashlib
+    from ngf_amd import _lib
+    return hashlib.sha256(open(_lib.SO_PATH, "rb").read()).hexdigest()[:16]
+
+
+def load_pmc(tag):
+    """profiles/r02_<tag>_pmc.json (profiles/collect.sh + summarize_pmc.py, committed) or None; `stale` = collected with another build."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", f"r02_{tag}_pmc.json")))
+    except Exception:
+        return None
+    d["file"] = f"profiles/r02_{tag}_pmc.json"
+    d["stale"] = d.get("so_sha16") != so_sha16()
+    return d
+
+
+def physical_roofs(pmc, k_ms, share=1.0):
+    """Physically bounded utilisation figures of the launch, every one <= 1 by construction.  Busy fractions are counter ratios
+    of the rocprofv3 run of this workload; rates divide the counters' bytes by THIS run's measured kernel time."""
+    if pmc is None:
+        return {"note": "no rocprofv3 --pmc summary of this workload under profiles/"}
+    t = k_ms * 1e-3
+    out = {"source": pmc["file"], "pmc_stale": pmc["stale"], "kernel_ms_under_pmc": pmc.get("kernel_ms_under_pmc")}
+    if "mfma_busy_frac" in pmc and "valu_busy_frac" in pmc:
+        out["simd_vector_datapath"] = {
+            "mfma_busy_frac": pmc["mfma_busy_frac"], "valu_busy_frac": pmc["valu_busy_frac"],
+            "frac": pmc["mfma_busy_frac"] + pmc["valu_busy_frac"],
+            "note": "fp32 MFMA and fp32 VALU execute on the same SIMD datapath on gfx950 and never overlap (profiles/micro/"
+                    "mfma_valu_overlap.hip, profiles/r02_micro_mfma_valu_overlap.txt: 8.75 ms + 3.07 ms run together in 11.63 ms), so "
+                    "their busy cycles add; this sum is the binding roof of the kernel"}
+    if "ta_busy_frac" in pmc:
+        out["texture_addresser_busy_frac"] = pmc["ta_busy_frac"]
+    if "lds_busy_frac" in pmc:
+        out["lds_busy_frac"] = pmc["lds_busy_frac"]
+    if "l2_read_bytes_per_launch" in pmc:
+        l2 = pmc["l2_read_bytes_per_launch"] * share / t / 1e12
+        out["l2"] = {"read_TBps": l2, "peak_TBps": L2_PEAK_TBS, "frac": l2 / L2_PEAK_TBS, "hit_frac": pmc.get("l2_hit_frac"), "l1_hit_frac": pmc.get("l1_hit_frac")}
+    if "hbm_traffic_bytes_per_launch" in pmc:
+        hb = pmc["hbm_traffic_bytes_per_launch"] * share / t / 1e9
+        out["hbm_fabric"] = {"GBps": hb, "peak_GBps": HBM_PEAK_GBS, "frac": hb / HBM_PEAK_GBS,
+                             "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; includes Infinity-Cache hits"}
+    for k in ("sq_wait_inst_any_frac", "sq_wait_any_frac", "sq_active_inst_any_frac", "vgpr", "scratch_bytes_per_lane", "lds_bytes"):
+        if k in pmc:
+            out[k] = pmc[k]
+    return out
 
 
 def build_field(model, preset, device, bake, bake_color=False):
@@ -143,6 +193,7 @@ def main():
     ap.add_argument("--bake-color", type=int, default=0, help="1 = NGF_F_BAKE_COLOR (pre-composed layer-1 colour planes)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="N=1 only: also time the other presets / variants (untimed region)")
+    ap.add_argument("--knobs", default="", help="experiments only: comma-separated ngf_debug_set knobs, e.g. waves=12,tile_w=8,kernel=1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,6 +215,11 @@ def main():
     from ngf_amd import dist as ndist
     from ngf_amd import synth
 
+    if args.knobs:
+        from ngf_amd import _lib
+        for kv in args.knobs.split(","):
+            k_, v_ = kv.split("=")
+            _lib.check(_lib.lib().ngf_debug_set(k_.strip().encode(), int(v_)))
     model = args.model
     kw = {"iteration": 30001} if model == "triplane" else {"infoinv": True}
     f, g, params, step = build_field(model, args.preset, device, bool(args.bake_density), bool(args.bake_color))
@@ -221,43 +277,34 @@ def main():
     mfma_per_pass = 64 if args.bake_color else 208
     tile_w = 8 if n_local >= 40 * 256 * 12 else 4          # launch_render's choice (csrc/ngf_field.hip)
     mfma_flops = (st[2] * mfma_per_pass + ((n_local + tile_w - 1) // tile_w) * 16) * 2048.0 if model == "triplane" else None
-    pmc = None
-    try:
-        pmc_name = "r01_pmc_infoinv.json" if model == "infoinv" else ("r01_pmc_baked.json" if args.bake_color else "r01_pmc_faithful.json")
-        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
-    except Exception:
-        pass
-    pmc_txt = "no PMC summary under profiles/" if pmc is None else (
-        f"PMC: {pmc['hbm_traffic_bytes_per_launch'] / 1e9:.2f} GB of fabric traffic per launch, L2 hit {100 * pmc['l2_hit_frac']:.0f} %, "
-        f"L1 hit {100 * pmc['l1_hit_frac']:.0f} %")
-    busy_txt = "" if pmc is None else (f" per PMC (MFMA pipe {100 * pmc['mfma_busy_frac']:.0f} % busy, TA {100 * pmc['ta_busy_frac']:.0f} %, "
-                                        f"fabric traffic {pmc['hbm_traffic_bytes_per_launch'] / (pmc['kernel_ms_under_pmc'] * 1e-3) / 8e12 * 100:.0f} % of the HBM peak)")
-    alg = {"unit": "GB/s", "achieved": achieved, "peak": HBM_PEAK_GBS, "frac": achieved / HBM_PEAK_GBS,
-           "bytes_per_launch": bytes_launch,
-           "note": "SURVEY 8 D3 accounting: every bilinear tap counted once, no cache credit.  The 52 MB texture set is L2 / "
-                   f"Infinity-Cache resident ({pmc_txt}), so this exceeds "
-                   "the HBM peak by construction and HBM is not the binding resource."}
+    # rocprofv3 --pmc summary of THIS workload (profiles/collect.sh -> profiles/r02_<workload>_pmc.json); flagged stale when the
+    # library it was collected with is not the one loaded now
+    tag = f"{model}_{args.preset}" + ("_bd" if args.bake_density and not args.bake_color else "") + ("_bdc" if args.bake_color else "")
+    pmc = load_pmc(tag)
+    if mfma_flops is None and pmc is not None:
+        # InfoInv runs its density MLP on the matrix pipe inside the march, so the executed flops are not a function of the pass
+        # count alone: take SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 of the PMC run of this very workload
+        mfma_flops = pmc.get("mfma_flops_per_dispatch")
+    alg = {"tag": "model, not a bound (SURVEY 8 D3 accounting: every bilinear tap counted once, no cache credit; the 52 MB texture set is "
+                  "L1/L2/Infinity-Cache resident, so this exceeds the HBM peak by construction)",
+           "unit": "GB/s", "achieved": achieved, "peak": HBM_PEAK_GBS, "frac_of_hbm_peak": achieved / HBM_PEAK_GBS, "bytes_per_launch": bytes_launch,
+           "flops_per_launch": (S * 550.0 + s_active * 71400.0) * n_local if model == "triplane" else None}
     if mfma_flops is not None:
         tf = mfma_flops / (k_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
-                    "traffic": None if pmc is None or model != "triplane" or args.preset != "R1" else pmc.get("hbm_traffic_bytes_per_launch") * n_local / n_total,
-                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE of the full-frame launch (profiles/r01_pmc_*.txt), scaled to this rank's share of the rays",
-                    "flops_counted": "executed fp32 MFMA flops of the colour MLP (layer 1 pre-composed with `basis`): the binding "
-                                     "resource" + busy_txt,
-                    "flops_per_launch": mfma_flops}
-    elif pmc is not None and args.preset == "R1" and world == 1:
-        # InfoInv: the march runs its density MLP on the matrix pipe too, so the executed flops are not a function of the pass count
-        # alone; take them from the PMC run of this very command (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512, profiles/r01_pmc_infoinv.txt)
-        tf = pmc["mfma_flops_per_dispatch"] / (k_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
-                    "traffic": pmc.get("hbm_traffic_bytes_per_launch"), "flops_per_launch": pmc["mfma_flops_per_dispatch"],
-                    "flops_counted": "executed fp32 MFMA flops from rocprofv3 --pmc (profiles/r01_pmc_infoinv.txt)" + busy_txt}
+        roofline = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                    "traffic": None if pmc is None else pmc.get("hbm_traffic_bytes_per_launch", 0.0) * n_local / n_total,
+                    "flops_per_launch": mfma_flops,
+                    "flops_counted": "EXECUTED fp32 MFMA flops (v_mfma_f32_16x16x4_f32: passes x MFMAs x 2048; equals rocprofv3 "
+                                     "SQ_INSTS_VALU_MFMA_MOPS_F32 x 512), layer 1 pre-composed with `basis`, per-ray view fold"}
     else:
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None}
+        # no matrix work counted (e.g. InfoInv without a PMC summary): the physical HBM-side figure, or nothing -- never the model bytes
+        hb = None if pmc is None or "hbm_traffic_bytes_per_launch" not in pmc else pmc["hbm_traffic_bytes_per_launch"] * n_local / n_total
+        roofline = {"bound": "hbm", "achieved": None if hb is None else hb / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": None if hb is None else hb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": hb}
+    roofline["physical"] = physical_roofs(pmc, k_ms, n_local / n_total)
     roofline.update({"kernel": "ngf::render_kernel", "kernel_ms": k_ms, "active_samples_per_ray": s_active,
                      "evaluated_samples_per_ray": st[0] / n_local,      # in-box samples the march evaluated (exact early termination skips the rest)
-                      "mlp_passes": st[2], "algorithmic_hbm": alg,
-                     "algorithmic_flops_per_launch": (S * 550.0 + s_active * 71400.0) * n_local if model == "triplane" else None})
+                      "mlp_passes": st[2], "algorithmic_d3": alg})
 
     result = {
         "metric": "Mray/sec (800x800 lego-style frame, 192 samples/ray)", "value": value, "unit": "Mray/s", "n_gpus": world,
@@ -269,6 +316,8 @@ def main():
                    "bake_density": int(args.bake_density), "bake_color": int(args.bake_color)},
         "roofline": roofline,
     }
+    if args.knobs:
+        result["config"]["knobs"] = args.knobs
 
     if dist_on:
         # untimed: the gathered, re-ordered frame of the last step against a direct render of the whole frame on this rank
@@ -309,30 +358,42 @@ def main():
                     sx = fx.last_stats.cpu().numpy().astype(np.float64)
                     sa = sx[1] / n_total
                     tag = {0: "", 1: "_bake_density", 2: "_bake_color", 3: "_bake_density_color"}[bake]
+                    ptag = f"{mdl}_{preset}" + {0: "", 1: "_bd", 2: "_bc", 3: "_bdc"}[bake]
+                    px = load_pmc(ptag)
+                    if mdl == "triplane":
+                        fl = (sx[2] * (64 if bake & 2 else 208) + (n_total // 8) * 16) * 2048.0
+                    else:
+                        fl = None if px is None else px.get("mfma_flops_per_dispatch")
                     extras[f"{mdl}_{preset}{tag}"] = {
                         "Mray/s": n_total / ms / 1e3, "kernel_ms": ms, "active_samples_per_ray": sa,
-                        "alg_GBps": alg_bytes_per_ray(sa, mdl) * n_total / (ms * 1e-3) / 1e9}
+                        "executed_mfma_TFLOPs": None if fl is None else fl / (ms * 1e-3) / 1e12,
+                        "mfma_frac_of_157.3": None if fl is None else fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                        "physical": physical_roofs(px, ms),
+                        "algorithmic_d3_GBps (model, not a bound)": alg_bytes_per_ray(sa, mdl) * n_total / (ms * 1e-3) / 1e9}
                     fx.release()
                 except Exception as ex:  # an extra must never take the headline number down with it
                     extras[f"{mdl}_{preset}"] = {"error": repr(ex)}
             try:    # BASELINE config 4: UV-Mapping (NeuTex) colour path, DTU-like 800x600 view, 64 samples/ray, sphere gauge
                 from ngf_amd import uvmapping
+                from ngf_amd import rays as nrays
                 up = synth.uvmapping_params(5, "sphere")
                 net = uvmapping.NeuTex(primitive_type="sphere", sample_num=64, device=device)
                 net.load_params(up)
-                cam, dirs = synth.dtu_rays(600, 800, rows=(252, 348))                 # 96 rows through the object: 76 800 rays
-                cam_t, dirs_t = torch.from_numpy(cam)[None], torch.from_numpy(dirs)[None].to(device)
-                Uj = torch.rand((1, dirs.shape[0], 64), device=device)
+                v0 = synth.DTU_VIEW0              # camera 0 of the DTU scan the reference ships; rays made on the device (ngf_generate_rays_dtu)
+                dirs_t = nrays.generate_rays_dtu(600, 800, v0["focal"], v0["princpt"], v0["rot"], rows=(252, 348), device=device)[None]   # 96 rows through the object: 76 800 rays
+                cam_t = torch.tensor(v0["campos"], dtype=torch.float32)[None]
+                n_uv = dirs_t.shape[1]
+                Uj = torch.rand((1, n_uv, 64), device=device)
                 net(cam_t, dirs_t, None, jitter_u=Uj)
                 ms = kernel_ms(lambda: net(cam_t, dirs_t, None, jitter_u=Uj), 3, device)
                 net(cam_t, dirs_t, None, jitter_u=Uj, collect_stats=True)
                 us = net.last_stats.cpu().numpy().astype(np.float64)
                 flops = us[1] * 16 * 2 * 1334592.0                                    # executed: passes x 16 samples x 2 x MAC/sample
                 extras["uvmapping_sphere"] = {
-                    "Mray/s": dirs.shape[0] / ms / 1e3, "kernel_ms": ms, "rays": int(dirs.shape[0]),
-                    "in_cube_samples_per_ray": us[0] / dirs.shape[0], "executed_TFLOPs": flops / (ms * 1e-3) / 1e12,
-                    "mfma_frac_of_157.3": flops / (ms * 1e-3) / 157.3e12,
-                    "algorithmic_TFLOPs_all_64_samples": dirs.shape[0] * 64 * 2 * 1334592.0 / (ms * 1e-3) / 1e12}
+                    "Mray/s": n_uv / ms / 1e3, "kernel_ms": ms, "rays": int(n_uv),
+                    "in_cube_samples_per_ray": us[0] / n_uv, "executed_TFLOPs": flops / (ms * 1e-3) / 1e12,
+                    "mfma_frac_of_157.3": flops / (ms * 1e-3) / 157.3e12, "physical": physical_roofs(load_pmc("uv_sphere"), ms),
+                    "algorithmic_TFLOPs_all_64_samples (model)": n_uv * 64 * 2 * 1334592.0 / (ms * 1e-3) / 1e12}
                 net.release()
             except Exception as ex:
                 extras["uvmapping_sphere"] = {"error": repr(ex)}

@@ -5,9 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for bd, bc in ((0, 0), (1, 0), (1, 1)):
     for w in ("8", "12", "16"):
         for tw in ("4", "8", "16"):
-            env = dict(os.environ, NGF_WAVES=w, NGF_TILE_W=tw)
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--extras", "0", "--cpu-seconds", "0",
-                                "--bake-density", str(bd), "--bake-color", str(bc)], env=env, capture_output=True, text=True)
+                                "--bake-density", str(bd), "--bake-color", str(bc), "--knobs", f"waves={w},tile_w={tw}"], capture_output=True, text=True)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if not line:
                 print(f"bake {bd}{bc} waves {w} tile_w {tw}: failed {r.stderr[-200:]}")

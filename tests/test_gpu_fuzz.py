@@ -65,9 +65,22 @@ def test_random_configuration_matches_oracle(k):
     rgb, depth = out["rgb_map"].cpu().numpy(), out["depth_map"].cpu().numpy()
     bad_rgb = np.abs(rgb - o_rgb) > (1e-5 + 1e-4 * np.abs(o_rgb))
     bad_depth = np.abs(depth - o_depth) > (1e-5 + 1e-4 * np.abs(o_depth))
-    # a weight within an ulp of the 1e-4 threshold (or a sample on the box face) may flip: at most one pixel in 200, by < 2e-3
-    assert bad_rgb.mean() <= 0.005 and bad_depth.mean() <= 0.005, (k, float(bad_rgb.mean()), float(bad_depth.mean()))
-    assert float(np.abs(rgb - o_rgb).max()) < 2e-3 and float(np.abs(depth - o_depth).max()) < 2e-3
+    # depth_map has no threshold in it (sum of ALL weights x z, FieldBase.py:305-306) and the sample positions / masks are
+    # bit-exact, so nothing may be forgiven there
+    assert not bad_depth.any(), (k, int(bad_depth.sum()), float(np.abs(depth - o_depth).max()))
+    # rgb_map: the only legitimate source of an out-of-tolerance pixel is a sample whose weight sits at the colour threshold
+    # (weight > 1e-4, FieldBase.py:289) and is classified differently by the two expf implementations.  Every such pixel must
+    # be explained by the oracle's own per-sample weights of that ray: n_near samples within rounding distance of the threshold
+    # (the transmittance is a product of up to S factors of 1 ulp each), and a difference of at most n_near flipped samples.
+    thr = float(g["thr"])
+    rel = (S + 8) * 2.0 ** -23
+    for r in np.unique(np.nonzero(bad_rgb)[0]):
+        _, _, dbg = orc.render(rays[r:r + 1], S, white_bg=white, debug_rays=1)
+        w = dbg["weight"][0].astype(np.float64)
+        n_near = int(np.sum(np.abs(w - thr) <= rel * thr))
+        worst = float(np.abs(rgb[r] - o_rgb[r]).max())
+        assert n_near >= 1, f"case {k} ray {r}: |rgb - oracle| = {worst:.3e} with no weight within {rel:.1e} (relative) of the threshold"
+        assert worst <= n_near * 1.05 * thr + 1e-5, f"case {k} ray {r}: {worst:.3e} is more than {n_near} threshold flips can move a pixel"
     # determinism and batch independence
     again = f(torch.from_numpy(rays).cuda(), N_samples=S, white_bg=white, **kw)
     assert torch.equal(out["rgb_map"], again["rgb_map"]) and torch.equal(out["depth_map"], again["depth_map"])

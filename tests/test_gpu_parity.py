@@ -293,6 +293,35 @@ def test_generate_rays_dtu_matches_reference():
     assert np.array_equal(np.float32(v0["princpt"]), fx["v0_princpt"]) and np.array_equal(np.float32(v0["campos"]), fx["v0_campos"])
 
 
+def test_eight_rank_data_path_on_one_gpu():
+    """BASELINE config 5 (800x800 frame sharded 8-way) without a second GPU: the 8 ranks' row sets (10-row blocks dealt round
+    robin, ngf_amd.dist.interleaved_rows) are generated on the device and rendered ONE AFTER THE OTHER into the send buffers of
+    ngf_amd.dist (shard_buffers: [3*per | per] float32, what all_gather_into_tensor concatenates rank-major), then put back in
+    image order by dist.deinterleave: bit-identical to the single-launch frame.  Covers the 80 000-ray / tile_w = 4 launch shape
+    every rank runs on the 8-GPU node, the packing of the exchange buffer and the reorder."""
+    from ngf_amd import dist as ndist
+    from ngf_amd import rays as nrays, synth
+    H = W = 800
+    world, block = 8, 10
+    per = H * W // world
+    g, params, step = big_case("triplane", "R1")
+    f = field_for_case(g, params, None)
+    focal, c2w = nrays.blender_focal(W), synth.lookat_pose()
+    whole = f(nrays.generate_rays(H, W, focal, c2w), N_samples=192, white_bg=True, iteration=30001)
+    recv = torch.empty((world, 4 * per), device="cuda")                     # rank-major, as the all-gather lays it out
+    for rank in range(world):
+        rows = ndist.interleaved_rows(H, world, rank, block)
+        rays = torch.cat([nrays.generate_rays(H, W, focal, c2w, rows=r) for r in rows], 0)
+        assert rays.shape[0] == per
+        send, rgb_view, depth_view = ndist.shard_buffers(per, "cuda")
+        f(rays, N_samples=192, white_bg=True, iteration=30001, out=(rgb_view, depth_view))
+        recv[rank] = send
+    rgb = recv[:, : 3 * per].reshape(world * per, 3)
+    depth = recv[:, 3 * per:].reshape(world * per)
+    rgb, depth = ndist.deinterleave(rgb, depth, H, W, world, block)
+    assert torch.equal(rgb, whole["rgb_map"]) and torch.equal(depth, whole["depth_map"])
+
+
 def test_bench_rccl_path_single_gpu(tmp_path):
     """The N>1 path of bench.py (nccl init, barrier, all_gather of composited pixels) on ONE GPU."""
     import json
