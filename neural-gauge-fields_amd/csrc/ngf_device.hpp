@@ -67,6 +67,7 @@ struct RenderArgs {
 // ---- bilinear cell: ATen grid_sampler_2d, align_corners=True, padding_mode='zeros' -------------
 struct Bil {
     int32_t idx;                 // padded texel index of the (x0,y0) tap; +1, +stride, +stride+1 are the others
+    int32_t cx, cy;              // the same tap as padded (column, row); only the LDS-staged variant reads them
     float w00, w10, w01, w11;    // (1-fx)(1-fy), fx(1-fy), (1-fx)fy, fx*fy ; all 0 when the cell is out of range
 };
 
@@ -84,7 +85,9 @@ __device__ __forceinline__ Bil bil_setup(float u, float v, const Tex &t)
     float cx = fminf(fmaxf(fx, -1.0f), t.fw);
     float cy = fminf(fmaxf(fy, -1.0f), t.fh);
     Bil b;
-    b.idx = ((int)cy + 1) * t.stride + ((int)cx + 1);
+    b.cx = (int)cx + 1;
+    b.cy = (int)cy + 1;
+    b.idx = b.cy * t.stride + b.cx;
     b.w00 = in ? wx0 * wy0 : 0.0f;
     b.w10 = in ? wx1 * wy0 : 0.0f;
     b.w01 = in ? wx0 * wy1 : 0.0f;

@@ -5,6 +5,7 @@
 #include "ngf_infoinv.hpp"
 #include "ngf_render.hpp"
 #include "ngf_render_pc.hpp"
+#include "ngf_stage.hpp"
 #include "ngf_train.hpp"
 
 using namespace ngf;
@@ -498,6 +499,13 @@ static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
     if (ns == 2) {
         if (w == 8) return launch_policy<TriPlanePolicy<BD, BC, 8, 2>>(f, A, st);
         return fail(NGF_E_ARG, "knob nstep = 2 is built for waves = 8 only");
+    }
+    if (knob(KNOB_STAGE) > 0 && !A.dbg_weight && !A.skip_rgb) {      // LDS-staged texture strips (ngf_stage.hpp), faithful layout only; stats[13] += staged iterations
+        if constexpr (!BD && !BC) {
+            if (w == 8) return launch_policy<TriPlaneStagedPolicy<8>>(f, A, st);
+            if (w == 12) return launch_policy<TriPlaneStagedPolicy<12>>(f, A, st);
+            return fail(NGF_E_ARG, "knob stage: waves must be 8 (gauge + density strips) or 12 (gauge strips)");
+        }
     }
     if (knob(KNOB_PROFILE) > 0) {      // stats[4..9] += section cycles (profiles/exp_sections.py); stats must hold 10 counters
         if constexpr (!BC) return launch_policy<TriPlanePolicy<BD, false, 12, 1, true>>(f, A, st);

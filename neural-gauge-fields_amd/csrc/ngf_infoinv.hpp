@@ -60,6 +60,8 @@ struct InfoInvPolicy {
     static constexpr bool PROFILE = false;
     static constexpr bool VLDS = true;
     static constexpr bool VIEW_FOLD = false;
+    static constexpr bool STAGED = false;
+    static constexpr int STAGE_FLOATS = 0;
     static constexpr int NSTEP = 1;
     static constexpr int BATCH = kBatch;
     static constexpr int RING = 128;

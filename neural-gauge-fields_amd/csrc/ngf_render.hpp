@@ -28,7 +28,7 @@
 namespace ngf {
 
 // LDS carve (floats): [blob | per wave: ring of RING records, result list, view inputs of the 64 rays]
-template <typename P> constexpr int wave_lds_floats() { return P::RING * kRecFloats + P::BATCH * 4 + (P::VLDS ? kWave * kViewFeat : 0); }
+template <typename P> constexpr int wave_lds_floats() { return P::RING * kRecFloats + P::BATCH * 4 + (P::VLDS ? kWave * kViewFeat : 0) + P::STAGE_FLOATS; }
 
 // The 16 view-direction inputs of rgb_decoder layer 1 (networks.py:27-29, 205-216):
 //   u[F..F+14] = [d(3), sin(d_x), sin(2 d_x), sin(d_y), sin(2 d_y), sin(d_z), sin(2 d_z), cos(same 6)], u[F+15] = 0 (pad)
@@ -296,6 +296,8 @@ template <bool BAKE_D, bool BAKE_C, int WAVES_, int NSTEP_, bool PROFILE_ = fals
 struct TriPlanePolicy {
     static constexpr bool PROFILE = PROFILE_;
     static constexpr bool INFOINV = false;
+    static constexpr bool STAGED = false;                       // ngf_stage.hpp: LDS-staged texture strips
+    static constexpr int STAGE_FLOATS = 0;
     static constexpr int WAVES = WAVES_;
     static constexpr int NSTEP = NSTEP_;
     static constexpr int BATCH = kBatch16;
@@ -360,6 +362,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int S = A.S;
     unsigned long long st_valid = 0, st_active = 0, st_pass = 0, st_rays = 0;
+    [[maybe_unused]] unsigned long long st_staged = 0;          // STAGED: march iterations served from LDS strips (stats[13])
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // PROFILE only: cycles per section, summed over the wave's life
 
     for (;;) {
@@ -438,7 +441,12 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                         // mask): sigma = alpha = w = 0 for all of them, T / acc / depth keep their values -> skip the whole step
                         if (!A.dbg_weight && !(A.ablate & 64) && !__any(valid)) { empty_step = true; break; }
                     }
-                    sigma[u] = P::sigma(A, smem, valid, x, lane, t[u]);
+                    if constexpr (SPLIT && P::STAGED) {
+                        float *dscr = P::STAGE_FLOATS > 0 ? vfeat + kWave * kViewFeat : nullptr;
+                        sigma[u] = P::sigma_staged(A, vfeat, dscr, valid, x, lane, t[u], A.stats ? &st_staged : nullptr);
+                    } else {
+                        sigma[u] = P::sigma(A, smem, valid, x, lane, t[u]);
+                    }
                     st_valid += __popcll(__ballot(valid));
                 }
                 if (empty_step) {
@@ -585,6 +593,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         if constexpr (P::PROFILE) {
             for (int k = 0; k < 7; ++k) atomicAdd(A.stats + 4 + k, prof[k]);
         }
+        if constexpr (P::STAGED) atomicAdd(A.stats + 13, st_staged);
     }
 }
 

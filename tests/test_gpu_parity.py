@@ -142,6 +142,25 @@ def test_split_march_is_bit_identical(name):
     assert torch.equal(ref["rgb_map"], got["rgb_map"]) and torch.equal(ref["depth_map"], got["depth_map"])
 
 
+@pytest.mark.parametrize("name", ["triplane_r1_gauge", "triplane_r2_nogauge", "triplane_r1_mask"])
+def test_lds_staged_strips_are_bit_identical(name):
+    """The LDS-staged texture variant (csrc/ngf_stage.hpp, knob stage = 1): gauge strips (gauge on) / density strips (gauge off,
+    8 waves per CU) are loaded once per tile iteration into LDS and tapped from there; the arithmetic on the fetched values is
+    unchanged, so the pixels are the gather kernel's bit for bit, whether an iteration's rectangle fits the strip or falls back."""
+    from ngf_amd._lib import knobs
+    g, params, step, mask = load_case(name)
+    f = field_for_case(g, params, mask)
+    rays = torch.from_numpy(g["rays"]).cuda()
+    for it in (30001, -1):                   # gauge on / off
+        for white in (True, False):
+            ref = f(rays, N_samples=45, white_bg=white, iteration=it)
+            for waves in (12, 8):
+                for tw in (8, 4):
+                    with knobs(stage=1, waves=waves, tile_w=tw, kernel=0):
+                        got = f(rays, N_samples=45, white_bg=white, iteration=it, collect_stats=True)
+                    assert torch.equal(ref["rgb_map"], got["rgb_map"]) and torch.equal(ref["depth_map"], got["depth_map"]), (it, white, waves, tw)
+
+
 @pytest.mark.parametrize("bake", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", TRIPLANE)
 def test_specialised_kernel_is_bit_identical(name, bake):
