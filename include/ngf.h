@@ -196,7 +196,7 @@ typedef struct ngf_train_desc {
     float mask_aabb[6];
     int64_t max_rays;              /* largest batch (args.batch_size) */
     int32_t max_samples;           /* largest N_samples */
-    int64_t chunk_samples;         /* active samples whose activations are kept at once; 0 = 262144 */
+    int64_t chunk_samples;         /* active samples whose activation rows (1.7 KB each) are kept at once; 0 = the whole batch (up to 9 Mi samples) */
 } ngf_train_desc;
 typedef struct ngf_trainer ngf_trainer;
 int ngf_trainer_create(const ngf_train_desc *desc, ngf_trainer **out, void *hip_stream);
@@ -207,10 +207,14 @@ int32_t ngf_sizeof_train_desc(void);
  * trainer's buffers (zeroed first).  jitter [n] = the per-ray U[0,1) of sample_ray (FieldBase.py:129-130; NULL = 0),
  * white_bg = `white_bg or coin` of FieldBase.py:299, gauge_on = (iteration >= gauge_start).  *rgb_loss (DEVICE double)
  * receives the SUM of squared residuals (divide by 3n); *n_active_host (HOST, nullable) the active-sample count.
- * Synchronises the stream once (the colour kernels' launch geometry depends on the active count). */
+ * Asynchronous on the stream when n_active_host is NULL and one chunk holds every sample of the batch (chunk_samples = 0: the
+ * default): the colour kernels then read the active count on the device.  Passing n_active_host, or a chunk smaller than
+ * n * n_samples, costs one stream synchronisation per call.  ngf_train_get_active copies the count of the last backward of an
+ * n-ray batch into a DEVICE int32 without synchronising. */
 int ngf_train_backward(ngf_trainer *t, const float *rays, const float *rgb_train, const float *jitter, int64_t n,
                        int32_t n_samples, int32_t white_bg, int32_t gauge_on, double *rgb_loss, int64_t *n_active_host,
                        void *hip_stream);
+int ngf_train_get_active(ngf_trainer *t, int64_t n, int32_t *out_device, void *hip_stream);
 /* the gradient of parameter `which` in its reference layout -> out (device) */
 int ngf_train_get_grad(ngf_trainer *t, int32_t which, float *out, void *hip_stream);
 /* torch.optim.Adam's update of parameter `which` from the gradient held by the trainer; step_count >= 1 is that

@@ -782,8 +782,11 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
         }
     }
     const size_t cap = (size_t)d->max_rays * d->max_samples;
-    t->chunk = d->chunk_samples > 0 ? d->chunk_samples : 262144;
+    // activation rows kept at once: by default the whole batch (1.7 KB per sample -- 6.2 GB for 4096 rays x 884 samples; the MI355X
+    // has 288 GB), which also lets the step run without a host round trip; at most ~16 GB unless the caller asks otherwise
+    t->chunk = d->chunk_samples > 0 ? d->chunk_samples : (int64_t)std::min<size_t>(cap, (size_t)9 << 20);
     if ((size_t)t->chunk > cap) t->chunk = (int64_t)((cap + 15) & ~(size_t)15);
+    if (d->chunk_samples <= 0 && (size_t)t->chunk >= cap) t->chunk = (int64_t)((cap + 15) & ~(size_t)15);
     const size_t ch = (size_t)t->chunk;
     if ((rc = tr_alloc(t, &T.xs, cap)) || (rc = tr_alloc(t, &T.w, cap)) || (rc = tr_alloc(t, &T.dx, cap)) || (rc = tr_alloc(t, &T.c, cap * 3)) ||
         (rc = tr_alloc(t, &T.dt, cap * 6)) || (rc = tr_alloc(t, &T.G, (size_t)d->max_rays * 3)) || (rc = tr_alloc(t, &T.count, (size_t)d->max_rays)) ||
@@ -843,30 +846,43 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
     const int ray_blocks = (int)((n + 3) / 4);        // sixteen lanes per ray
     hipLaunchKernelGGL(train_scan_kernel, dim3(ray_blocks), dim3(64), 0, st, T, 0);
     hipLaunchKernelGGL(train_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)T.count, n, T.offset);
+    // The colour kernels walk the active list.  When one chunk of activation rows holds every sample of the batch (the default:
+    // HBM is sized for it) they read the active count from the device and run with fixed grids -- the stream never waits for the
+    // host.  With a smaller chunk (chunk_samples of the descriptor) the count comes to the host to cut the list into chunks.
+    const bool no_sync = t->chunk >= pairs && !n_active_host;
     int32_t n_active = 0;
-    HIP_TRY(hipMemcpyAsync(&n_active, T.offset + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));          // the launch geometry of the colour kernels depends on the active count
-    if (n_active_host) *n_active_host = n_active;
+    if (!no_sync) {
+        HIP_TRY(hipMemcpyAsync(&n_active, T.offset + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (n_active_host) *n_active_host = n_active;
+    }
     hipLaunchKernelGGL(train_scan_kernel, dim3(ray_blocks), dim3(64), 0, st, T, 1);
 
     const size_t lds_f = (size_t)(((kFwdImage + 3) & ~3) + kTrainWaves * kFwdTileFloats) * sizeof(float),
                  lds_b = (size_t)(((kBwdImage + 3) & ~3) + kTrainWavesBwd * kBwdTileFloats) * sizeof(float);
     static_assert((((kFwdImage + 3) & ~3) + kTrainWaves * kFwdTileFloats) * 4 <= 160 * 1024, "colour forward LDS");
     static_assert((((kBwdImage + 3) & ~3) + kTrainWavesBwd * kBwdTileFloats) * 4 <= 160 * 1024, "colour backward LDS");
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(train_color_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(train_color_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-    const bool single = n_active <= t->chunk;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(train_color_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(train_color_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+        attr_set = true;
+    }
+    const int32_t *cnt = no_sync ? T.offset + n : nullptr;
+    T.n_active_dev = cnt;
+    const int64_t list_len = no_sync ? pairs : n_active;          // upper bound of the list length the loops below are sized for
+    const bool single = list_len <= t->chunk;
     // colour forward over the whole list (activations kept when the list fits one chunk)
-    for (int64_t base = 0; base < n_active; base += t->chunk) {
+    for (int64_t base = 0; base < list_len; base += t->chunk) {
         T.chunk_base = (int32_t)base;
-        T.chunk_n = (int32_t)std::min<int64_t>(t->chunk, n_active - base);
+        T.chunk_n = (int32_t)std::min<int64_t>(t->chunk, list_len - base);
         T.store = single ? 1 : 0;
         hipLaunchKernelGGL(train_color_fwd_kernel, dim3(tr_grid(t, (T.chunk_n + 15) / 16, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_f, st, T);
     }
     hipLaunchKernelGGL(train_composite_bwd_kernel, dim3(ray_blocks), dim3(64), 0, st, T);
-    for (int64_t base = 0; base < n_active; base += t->chunk) {
+    for (int64_t base = 0; base < list_len; base += t->chunk) {
         T.chunk_base = (int32_t)base;
-        T.chunk_n = (int32_t)std::min<int64_t>(t->chunk, n_active - base);
+        T.chunk_n = (int32_t)std::min<int64_t>(t->chunk, list_len - base);
         const int passes = (T.chunk_n + 15) / 16;
         if (!single) {
             T.store = 1;
@@ -876,14 +892,16 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         const int rows = T.chunk_n;
         int xg = (rows + 31) / 32;                      // 32-sample chunks; at most two workgroups per CU walk them
         if (xg > 2 * t->num_cus) xg = 2 * t->num_cus;
-        hipLaunchKernelGGL((xty_block_kernel<1, 4>), dim3(xg), dim3(256), 0, st, (const float *)T.D3, 16, (const float *)T.H2, 64, rows, 3, 64, t->g_dense[TP_W3], 64);
-        hipLaunchKernelGGL((xty_block_kernel<4, 4>), dim3(xg), dim3(256), 0, st, (const float *)T.D2, 64, (const float *)T.H1, 64, rows, 64, 64, t->g_dense[TP_W2], 64);
+        int cg = (rows + 255) / 256;
+        if (cg > 4 * t->num_cus) cg = 4 * t->num_cus;
+        hipLaunchKernelGGL((xty_block_kernel<1, 4>), dim3(xg), dim3(256), 0, st, (const float *)T.D3, 16, (const float *)T.H2, 64, rows, 3, 64, t->g_dense[TP_W3], 64, cnt);
+        hipLaunchKernelGGL((xty_block_kernel<4, 4>), dim3(xg), dim3(256), 0, st, (const float *)T.D2, 64, (const float *)T.H1, 64, rows, 64, 64, t->g_dense[TP_W2], 64, cnt);
         // the 15 view columns of layer 1 directly, the 144 feature columns through M = Delta1^T F (train_unfold_kernel)
-        hipLaunchKernelGGL((xty_block_kernel<4, 1>), dim3(xg), dim3(256), 0, st, (const float *)T.D1, 64, (const float *)T.V, 16, rows, 64, 15, t->g_dense[TP_W1] + 144, 159);
-        hipLaunchKernelGGL((xty_block_kernel<4, 9>), dim3(xg), dim3(256), 0, st, (const float *)T.D1, 64, (const float *)T.F, 144, rows, 64, 144, T.M, 144);
-        hipLaunchKernelGGL(colsum_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const float *)T.D3, 16, rows, 3, t->g_dense[TP_B3]);
-        hipLaunchKernelGGL(colsum_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const float *)T.D2, 64, rows, 64, t->g_dense[TP_B2]);
-        hipLaunchKernelGGL(colsum_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const float *)T.D1, 64, rows, 64, t->g_dense[TP_B1]);
+        hipLaunchKernelGGL((xty_block_kernel<4, 1>), dim3(xg), dim3(256), 0, st, (const float *)T.D1, 64, (const float *)T.V, 16, rows, 64, 15, t->g_dense[TP_W1] + 144, 159, cnt);
+        hipLaunchKernelGGL((xty_block_kernel<4, 9>), dim3(xg), dim3(256), 0, st, (const float *)T.D1, 64, (const float *)T.F, 144, rows, 64, 144, T.M, 144, cnt);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cg), dim3(256), 0, st, (const float *)T.D3, 16, rows, 3, t->g_dense[TP_B3], cnt);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cg), dim3(256), 0, st, (const float *)T.D2, 64, rows, 64, t->g_dense[TP_B2], cnt);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cg), dim3(256), 0, st, (const float *)T.D1, 64, rows, 64, t->g_dense[TP_B1], cnt);
     }
     hipLaunchKernelGGL(train_unfold_kernel, dim3(96), dim3(256), 0, st, T, t->g_dense[TP_W1], t->g_dense[TP_BASIS]);
     hipLaunchKernelGGL(train_density_bwd_kernel, dim3(tr_grid(t, pairs, 256)), dim3(256), 0, st, T);
@@ -894,6 +912,13 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
     }
     HIP_TRY(hipMemcpyAsync(rgb_loss, T.loss, sizeof(double), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+extern "C" int ngf_train_get_active(ngf_trainer *t, int64_t n, int32_t *out, void *hip_stream)
+{
+    if (!t || !out || n <= 0 || n > t->d.max_rays) return fail(NGF_E_ARG, "ngf_train_get_active: bad argument");
+    HIP_TRY(hipMemcpyAsync(out, t->proto.offset + n, sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
     return NGF_OK;
 }
 

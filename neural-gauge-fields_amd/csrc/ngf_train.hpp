@@ -70,12 +70,21 @@ struct TrainArgs {
     float *M;                                       // [64,144] = Delta1^T F, accumulated over the chunks
     double *loss;            // [2]: sum of squared residuals, (unused)
     int32_t chunk_base, chunk_n;      // the slice of the active list this launch works on
+    const int32_t *n_active_dev;      // non-NULL: the active count lives on the device (offset[n]); chunk_n is then only the capacity and
+                                      // the kernels clip it themselves -- no host round trip between the scan and the colour kernels
     int32_t store;           // colour forward: also write F, V, H1, H2 rows of the chunk
     float inv_count;         // 1 / (3 n): the mean of the MSE
 };
 
 // ---- geometry of sample (ray r, step i): Base.sample_ray + normalize_coord + compute_gauge --------------------------------
 // returns valid; xn = normalised position (compute_gauge and the gauge gradient start from it)
+__device__ __forceinline__ int chunk_rows(const TrainArgs &T)
+{
+    if (!T.n_active_dev) return T.chunk_n;
+    const int left = *T.n_active_dev - T.chunk_base;
+    return left < 0 ? 0 : (left < T.chunk_n ? left : T.chunk_n);
+}
+
 __device__ __forceinline__ bool sample_geometry(const RenderArgs &A, int64_t r, int i, float xn[3], float &z, float &dist)
 {
     float o[3], d[3];
@@ -443,10 +452,11 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     float *Ft = smem + ((kFwdImage + 3) & ~3) + wave * kFwdTileFloats, *H1t = Ft + kIn1Pad * 16, *H2t = Ft;
-    const int passes = (T.chunk_n + 15) / 16;
+    const int chunk_n = chunk_rows(T);
+    const int passes = (chunk_n + 15) / 16;
     for (int pass = blockIdx.x * kTrainWaves + wave; pass < passes; pass += gridDim.x * kTrainWaves) {
         const int local = pass * 16 + n;
-        const bool live = local < T.chunk_n;
+        const bool live = local < chunk_n;
         const int64_t slot = T.chunk_base + (live ? local : 0);
         const int64_t r = T.list[2 * slot];
         const int i = T.list[2 * slot + 1];
@@ -601,10 +611,11 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(co
     float *H1t = smem + ((kBwdImage + 3) & ~3) + wave * kBwdTileFloats, *D2t = H1t + 64 * 16, *DFt = H1t, *H2t = H1t + 16 * kDfStride,
           *tap = H2t + 64 * 16;              // tap[s][p] = {texel index, w00, w10, w01, w11}
     float *D1t = H2t;                        // h2 is dead once d2 exists
-    const int passes = (T.chunk_n + 15) / 16;
+    const int chunk_n = chunk_rows(T);
+    const int passes = (chunk_n + 15) / 16;
     for (int pass = blockIdx.x * kTrainWavesBwd + wave; pass < passes; pass += gridDim.x * kTrainWavesBwd) {
         const int local = pass * 16 + n;
-        const bool live = local < T.chunk_n;
+        const bool live = local < chunk_n;
         const int64_t row = live ? local : 0;
         const int64_t slot = T.chunk_base + row;
         const int64_t r = T.list[2 * slot];
@@ -725,8 +736,9 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(co
 // [Mvalid][ldo]) at the end.
 template <int MT, int NT>
 __global__ void __launch_bounds__(256) xty_block_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ Y, int ldy, int rows,
-                                                        int Mvalid, int Nvalid, float *out, int ldo)
+                                                        int Mvalid, int Nvalid, float *out, int ldo, const int32_t *rows_dev)
 {
+    if (rows_dev) rows = min(rows, *rows_dev);              // the row count lives on the device (no host sync on the active count)
     constexpr int CH = 32;                                              // samples per chunk = 8 MFMA k-steps
     constexpr int LX = 16 * MT + ((MT & 1) ? 0 : 16), LY = 16 * NT + ((NT & 1) ? 0 : 16);   // row strides == 16 (mod 32): 2 lanes per bank
     constexpr int TILES = MT * NT, PER_WAVE = (TILES + 3) / 4;
@@ -779,15 +791,18 @@ __global__ void __launch_bounds__(256) xty_block_kernel(const float *__restrict_
     }
 }
 
-// bias gradients: column sums of a row-major [rows, ld] matrix (cols <= 64); one block per 256 rows
-__global__ void __launch_bounds__(256) colsum_kernel(const float *__restrict__ X, int ld, int rows, int cols, float *out)
+// bias gradients: column sums of a row-major [rows, ld] matrix (cols <= 64); blocks walk 256-row slabs
+__global__ void __launch_bounds__(256) colsum_kernel(const float *__restrict__ X, int ld, int rows, int cols, float *out, const int32_t *rows_dev)
 {
+    if (rows_dev) rows = min(rows, *rows_dev);
     __shared__ float sh[4][64];
     const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int r0 = blockIdx.x * 256, r1 = min(rows, r0 + 256);
     float s = 0.0f;
     if (c < cols)
-        for (int r = r0 + part; r < r1; r += 4) s += X[(size_t)r * ld + c];
+        for (int r0 = blockIdx.x * 256; r0 < rows; r0 += gridDim.x * 256) {
+            const int r1 = min(rows, r0 + 256);
+            for (int r = r0 + part; r < r1; r += 4) s += X[(size_t)r * ld + c];
+        }
     sh[part][c] = s;
     __syncthreads();
     if (part == 0 && c < cols) atomicAdd(out + c, (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]));

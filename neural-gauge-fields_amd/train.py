@@ -50,6 +50,7 @@ def _bind(L):
     L.ngf_train_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                      C.POINTER(C.c_int64), C.c_void_p]
     L.ngf_train_get_grad.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.ngf_train_get_active.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.ngf_train_adam.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
     if L.ngf_sizeof_train_desc() != C.sizeof(TrainDesc):
         raise RuntimeError("libngf_hip.so ABI mismatch (ngf_train_desc layout)")
@@ -102,7 +103,7 @@ class Trainer:
                     self.steps[k] = state_from.steps[k]
             self.lr = list(state_from.lr)
         self._loss = torch.zeros((1,), dtype=torch.float64, device=self.dev)
-        self.last_active = 0
+        self._active = torch.zeros((1,), dtype=torch.int32, device=self.dev)
         self._gauge_on = True          # set by backward(); optimizer_step() before any backward() updates nothing but must not raise
         self._build()
 
@@ -158,6 +159,11 @@ class Trainer:
     def scratch_bytes(self) -> int:
         return int(self.L.ngf_trainer_bytes(self._h))
 
+    @property
+    def last_active(self) -> int:
+        """Active (weight > thr) samples of the last backward; reading it synchronises with the device."""
+        return int(self._active.item())
+
     # ---------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def backward(self, rays_train, rgb_train, N_samples=-1, white_bg=True, iteration=0, jitter=None, coin=None):
@@ -178,11 +184,13 @@ class Trainer:
             c = float(torch.rand((1,))) if coin is None else float(coin)   # FieldBase.py:299
             white_bg = c < 0.5
         gauge_on = int(iteration >= self.field.gauge_start)
-        na = C.c_int64(0)
+        # no host pointer for the active count: the call stays asynchronous (the colour kernels read the count on the device);
+        # ``last_active`` fetches it lazily from a device int
         with torch.cuda.device(self.dev):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             _lib.check(self.L.ngf_train_backward(self._h, rays.data_ptr(), tgt.data_ptr(), jitter.data_ptr(), n, S, int(bool(white_bg)), gauge_on,
-                                                 self._loss.data_ptr(), C.byref(na), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        self.last_active = int(na.value)
+                                                 self._loss.data_ptr(), None, st))
+            _lib.check(self.L.ngf_train_get_active(self._h, n, self._active.data_ptr(), st))
         self._gauge_on = gauge_on
         return self._loss[0] / (3.0 * n)
 
