@@ -88,10 +88,10 @@ def physical_roofs(pmc, k_ms, share=1.0):
     return out
 
 
-def build_field(model, preset, device, bake, bake_color=False):
+def build_field(model, preset, device, bake, bake_color=False, no_fold=False):
     from ngf_amd.cases import big_case, field_for_case
     g, params, step = big_case(model, preset)
-    f = field_for_case(g, params, None, device=device, bake=bake, bake_color=bake_color)
+    f = field_for_case(g, params, None, device=device, bake=bake, bake_color=bake_color, no_fold=no_fold)
     f.handle()
     return f, g, params, step
 
@@ -347,21 +347,22 @@ def main():
             result["speedup_vs_cpu_port"] = value / cb["value"]
         if args.extras:
             extras = {}
-            for mdl, preset, bake in (("triplane", "R0", 0), ("triplane", "R2", 0), ("triplane", args.preset, 1), ("triplane", args.preset, 3),
-                                      ("triplane", "R0", 1), ("triplane", "R2", 3), ("infoinv", "R1", 0)):
+            # bake bit 2 = NGF_F_NO_FOLD: level 0 (un-composed `basis` stage, view inputs per sample) -- what the default's folds buy
+            for mdl, preset, bake in (("triplane", "R0", 0), ("triplane", "R2", 0), ("triplane", args.preset, 4), ("triplane", args.preset, 1),
+                                      ("triplane", args.preset, 3), ("triplane", "R0", 1), ("triplane", "R2", 3), ("infoinv", "R1", 0)):
                 try:
-                    fx, _, _, _ = build_field(mdl, preset, device, bool(bake & 1), bool(bake & 2))
+                    fx, _, _, _ = build_field(mdl, preset, device, bool(bake & 1), bool(bake & 2), bool(bake & 4))
                     kx = {"iteration": 30001} if mdl == "triplane" else {"infoinv": True}
                     ms = kernel_ms(lambda: fx(rays, N_samples=S, white_bg=True, **kx), 5, device)      # includes 1st-call warm-up
                     ms = kernel_ms(lambda: fx(rays, N_samples=S, white_bg=True, **kx), 10, device)
                     fx(rays, N_samples=S, collect_stats=True, **kx)
                     sx = fx.last_stats.cpu().numpy().astype(np.float64)
                     sa = sx[1] / n_total
-                    tag = {0: "", 1: "_bake_density", 2: "_bake_color", 3: "_bake_density_color"}[bake]
-                    ptag = f"{mdl}_{preset}" + {0: "", 1: "_bd", 2: "_bc", 3: "_bdc"}[bake]
+                    tag = {0: "", 1: "_bake_density", 2: "_bake_color", 3: "_bake_density_color", 4: "_no_fold_level0"}[bake]
+                    ptag = f"{mdl}_{preset}" + {0: "", 1: "_bd", 2: "_bc", 3: "_bdc", 4: "_nofold"}[bake]
                     px = load_pmc(ptag)
                     if mdl == "triplane":
-                        fl = (sx[2] * (64 if bake & 2 else 208) + (n_total // 8) * 16) * 2048.0
+                        fl = (sx[2] * (64 if bake & 2 else 208) + (n_total // 8) * 16) * 2048.0 if bake != 4 else sx[2] * 548 * 2048.0
                     else:
                         fl = None if px is None else px.get("mfma_flops_per_dispatch")
                     extras[f"{mdl}_{preset}{tag}"] = {

@@ -37,6 +37,10 @@ enum {
     NGF_F_BAKE_DENSITY = 1, /* TriPlane: pre-compose density_decoder Linear(48,1) with the 16 density
                               channels of each plane (exact algebra: a Linear commutes with bilinear
                               interpolation); the march then gathers 1 instead of 16 channels per tap */
+    NGF_F_NO_FOLD = 4,      /* level 0 of the optimisation ladder: rgb_decoder exactly as written (networks.py:25-30) -- `basis` is its own
+                              144 x 144 matrix stage and the view inputs enter layer 1 per sample.  Without this flag layer 1 is
+                              pre-composed with `basis` (W1' = W1[:, :F] . basis, fp64 accumulate) and, for small tiles, its
+                              view-direction part is evaluated once per ray.  For measuring what the pre-compositions buy. */
     NGF_F_BAKE_COLOR = 2    /* pre-compose rgb_decoder layer 1 (W1[:, :F] . basis, no activation in between:
                               networks.py:17,26-30) with the colour channels of each plane: colour planes
                               become 64-channel layer-1 pre-activation planes, the shade pass keeps only the

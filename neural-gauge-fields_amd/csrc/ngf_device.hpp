@@ -58,6 +58,7 @@ struct RenderArgs {
     Tex app[3];            // colour texels (48 | 72 channels)
     Tex gau[3];            // 2-ch gauge offsets (TriPlane)
     MaskVol mask;
+    const float *basis_pack;  // NGF_F_NO_FOLD: rgb_decoder.basis packed for the basis MFMA stage (ngf_shade16.hpp), else NULL
     const float *blob;     // packed MLP image (copied into LDS by every workgroup)
     int32_t blob_floats;
     float wd[48];          // TriPlane faithful density_decoder.weight

@@ -48,6 +48,7 @@ struct ngf_field {
     int32_t model = 0, flags = 0, plane_c = 0, dens_dim = 0, app = 0;
     float *tex[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // dens[3], app[3], gau[3]
     float *blob = nullptr;
+    float *basis_pack = nullptr;
     uint8_t *mask = nullptr;
     unsigned int *counters = nullptr;
     mutable std::atomic<unsigned> next_counter{0};
@@ -185,6 +186,49 @@ static void build_rgb_image(int F, const std::vector<float> &basis, const std::v
 // 16-wide (v_mfma_f32_16x16x4_f32) image of rgb_decoder for TriPlane (ngf_shade16.hpp).  Lane (s, kq): hidden
 // unit of accumulator (mt, r) is n = mt*16 + 4*kq + r.  With bake = true the plane part of layer 1 goes to the
 // texture baker instead: wp[p][n][c] = W1'[n][p*APPc + c] (natural unit order: channel n of a baked texel = unit n).
+// NGF_F_NO_FOLD: layer 1 un-composed, inputs in the accumulator order of the basis stage; basis packed for streaming
+static void build_rgb_image16_nofold(int F, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
+                                     const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3, const std::vector<float> &b3,
+                                     float *img, std::vector<float> &bpack)
+{
+    using L = MlpLayout16NoFold;
+    const int IN = F + 15, APPc = F / 3, QCH = APPc / 4;
+    auto hidden = [](int mt, int r, int kq) { return mt * 16 + 4 * kq + r; };
+    // layer 1: k-step t < 36 takes g unit (t/4)*16 + 4kq + (t&3); t >= 36 view entry kq*4 + (t-36) (entry 15 = zero pad)
+    for (int mt = 0; mt < 4; ++mt)
+        for (int t = 0; t < L::KT; ++t)
+            for (int l = 0; l < 64; ++l) {
+                const int kq = l >> 4, n = mt * 16 + (l & 15);
+                float wv = 0.0f;
+                if (t < 36) wv = w1[(size_t)n * IN + hidden(t >> 2, t & 3, kq)];
+                else if (kq * 4 + (t - 36) < 15) wv = w1[(size_t)n * IN + F + kq * 4 + (t - 36)];
+                img[L::W1 + ((size_t)mt * L::KT + t) * 64 + l] = wv;
+            }
+    for (int mt = 0; mt < 4; ++mt)
+        for (int t = 0; t < 16; ++t)
+            for (int l = 0; l < 64; ++l)
+                img[L::W2 + ((size_t)mt * 16 + t) * 64 + l] = w2[(size_t)(mt * 16 + (l & 15)) * 64 + hidden(t >> 2, t & 3, l >> 4)];
+    for (int kq = 0; kq < 4; ++kq)
+        for (int k = 0; k < 16; ++k) {
+            const int n = hidden(k >> 2, k & 3, kq);
+            img[L::B1 + kq * 16 + k] = b1[n];
+            img[L::B2 + kq * 16 + k] = b2[n];
+            for (int c = 0; c < 3; ++c) img[L::W3 + c * 64 + kq * 16 + k] = w3[(size_t)c * 64 + n];
+        }
+    for (int c = 0; c < 3; ++c) img[L::B3 + c] = b3[c];
+    img[L::B3 + 3] = 0.0f;
+    // basis stage: k-step t = P*12 + j takes colour channel P*48 + 16*(j/4) + 4kq + (j&3) (the gather order of mlp_pass16);
+    // output unit tile mt (9 tiles), group g = mt/4, element e = mt%4
+    bpack.assign(kBasisPackFloats, 0.0f);
+    for (int t = 0; t < 36; ++t)
+        for (int mt = 0; mt < 9; ++mt)
+            for (int l = 0; l < 64; ++l) {
+                const int kq = l >> 4, j = t % QCH;
+                const int ch = (t / QCH) * APPc + 16 * (j / 4) + 4 * kq + (j & 3);
+                bpack[(((size_t)t * 3 + mt / 4) * 64 + l) * 4 + (mt & 3)] = basis[(size_t)(mt * 16 + (l & 15)) * F + ch];
+            }
+}
+
 static void build_rgb_image16(int F, bool bake, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
                               const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3,
                               const std::vector<float> &b3, float *img, std::vector<float> &wp)
@@ -262,6 +306,7 @@ extern "C" int ngf_field_destroy(ngf_field *f)
     for (float *t : f->tex)
         if (t) (void)hipFree(t);
     if (f->blob) (void)hipFree(f->blob);
+    if (f->basis_pack) (void)hipFree(f->basis_pack);
     if (f->mask) (void)hipFree(f->mask);
     if (f->counters) (void)hipFree(f->counters);
     delete f;
@@ -298,6 +343,8 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
 
     const bool bake = tri && (d->flags & NGF_F_BAKE_DENSITY);
     const bool bake_c = tri && (d->flags & NGF_F_BAKE_COLOR);
+    const bool no_fold = tri && (d->flags & NGF_F_NO_FOLD);
+    if (no_fold && (bake || bake_c)) return bail(fail(NGF_E_ARG, "NGF_F_NO_FOLD is the un-composed formulation: it excludes the NGF_F_BAKE_* flags"));
 
     // MLP weights: to the host once, pre-compose, permute, back to HBM as one LDS image
     std::vector<float> basis, w1, b1, w2, b2, w3, b3;
@@ -316,10 +363,12 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     }
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "hipStreamSynchronize failed in ngf_field_create"));
 
-    const int rgb_floats = tri ? (bake_c ? MlpLayout16Baked::TOTAL : MlpLayout16<48>::TOTAL) : MlpLayout<72>::TOTAL;
+    const int rgb_floats = tri ? (no_fold ? MlpLayout16NoFold::TOTAL : (bake_c ? MlpLayout16Baked::TOTAL : MlpLayout16<48>::TOTAL)) : MlpLayout<72>::TOTAL;
     const int dens_floats = tri ? 0 : InfoInvDensLayout::TOTAL;
     std::vector<float> img((size_t)rgb_floats + dens_floats, 0.0f), wp;
-    if (tri) build_rgb_image16(F, bake_c, basis, w1, b1, w2, b2, w3, b3, img.data(), wp);
+    std::vector<float> bpack;
+    if (no_fold) build_rgb_image16_nofold(F, basis, w1, b1, w2, b2, w3, b3, img.data(), bpack);
+    else if (tri) build_rgb_image16(F, bake_c, basis, w1, b1, w2, b2, w3, b3, img.data(), wp);
     else build_rgb_image(F, basis, w1, b1, w2, b2, w3, b3, img.data());
     if (!tri) build_infoinv_density_image(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
     if ((rc = alloc_f(&f->blob, img.size(), f))) return bail(rc);
@@ -335,6 +384,12 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     }
     A.blob = f->blob;
     A.blob_floats = (int)img.size();
+    if (no_fold) {
+        if ((rc = alloc_f(&f->basis_pack, bpack.size(), f))) return bail(rc);
+        if (hipMemcpyAsync(f->basis_pack, bpack.data(), bpack.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess)
+            return bail(fail(NGF_E_HIP, "uploading the packed basis matrix failed"));
+        A.basis_pack = f->basis_pack;
+    }
     if (tri) {
         for (int i = 0; i < 48; ++i) A.wd[i] = dw1[i];
         A.bd = db1[0];
@@ -521,6 +576,7 @@ static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
 static int render_common(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
     if (f->model == NGF_MODEL_INFOINV) return launch_policy<InfoInvPolicy>(f, A, st);
+    if (f->flags & NGF_F_NO_FOLD) return launch_policy<TriPlaneNoFoldPolicy>(f, A, st);
     const bool bd = f->flags & NGF_F_BAKE_DENSITY, bc = f->flags & NGF_F_BAKE_COLOR;
     if (bd) return bc ? launch_triplane<true, true>(f, A, st) : launch_triplane<true, false>(f, A, st);
     return bc ? launch_triplane<false, true>(f, A, st) : launch_triplane<false, false>(f, A, st);
@@ -574,6 +630,7 @@ extern "C" int ngf_field_decode_rgb(const ngf_field *f, const float *coords, con
     };
     int rc;
     if (f->model == NGF_MODEL_INFOINV) rc = go(decode_rgb_kernel<InfoInvPolicy>);
+    else if (f->flags & NGF_F_NO_FOLD) rc = go(decode_rgb_kernel<TriPlaneNoFoldPolicy>);
     else if (f->flags & NGF_F_BAKE_COLOR) rc = go(decode_rgb_kernel<TriPlanePolicy<false, true, 8, 1>>);
     else rc = go(decode_rgb_kernel<TriPlanePolicy<false, false, 8, 1>>);
     if (rc) return rc;

@@ -338,6 +338,17 @@ struct TriPlanePolicy {
     }
 };
 
+// NGF_F_NO_FOLD (level 0): un-composed rgb_decoder, view inputs per sample; 8 waves per CU (the basis stage keeps 36 more accumulators)
+struct TriPlaneNoFoldPolicy : TriPlanePolicy<false, false, 8, 1> {
+    static constexpr bool VIEW_FOLD = false;
+    __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
+                                                 const float od[3], int lane, float c[3], unsigned long long * = nullptr, const float * = nullptr)
+    {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(vf + (lane >> 4) * 4);
+        mlp_pass16_nofold(A, smem, rec, v, lane, c);
+    }
+};
+
 // ---- the fused kernel ---------------------------------------------------------------------------
 // SPLIT = false: one ray per lane, tile_w (<= 64) rays per tile.  SPLIT = true (small launches: one rank's shard of a frame,
 // the reference's 4096-ray chunks): a tile holds tile_w = 64 >> k rays and every ray is marched by K = 64 / tile_w lanes that

@@ -247,6 +247,127 @@ __device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blo
     NGF_TICK(3);                       // layers 2-3 done
 }
 
+
+// ---- NGF_F_NO_FOLD: level 0 of SURVEY section 7 -- rgb_decoder exactly as written (networks.py:25-30) -----------------------------
+//   g = basis(feat)                144 x 144, no bias / activation: its own MFMA stage (324 MFMAs per pass)
+//   in = [g, view, PE(view)]       the view inputs enter per sample (no per-ray fold)
+//   Linear(159 -> 64) + ReLU ...   layer 1 on the un-composed W1 (160 MFMAs), then layers 2 and 3 as usual
+// The basis matrix (83 KB) does not fit LDS next to the layers: it is streamed from L2 as [k-step][3 tile groups][lane][4] (one
+// 16-byte load feeds four MFMAs).  The 144 outputs land in accumulator order (unit mt*16 + 4*kq + r of the lane's own sample),
+// which is the B operand order of the next layer, so layer 1 consumes them in place.
+struct MlpLayout16NoFold {                 // LDS image (floats): layer 1 on [g(144) | view(16)] in accumulator order, then as MlpLayout16
+    static constexpr int KT = 40;
+    static constexpr int W1 = 0;                  // [4 mt][40][64]
+    static constexpr int W2 = W1 + 4 * KT * 64;
+    static constexpr int B1 = W2 + 4 * 16 * 64;
+    static constexpr int B2 = B1 + 64;
+    static constexpr int W3 = B2 + 64;
+    static constexpr int B3 = W3 + 192;
+    static constexpr int TOTAL = B3 + 4;
+};
+constexpr int kBasisPackFloats = 36 * 3 * 64 * 4;      // [36 k-steps][3 groups of 4 unit tiles (9 used)][64 lanes][4]
+
+struct BasisPair { f32x4 a[2][3]; };              // A operands of two k-steps (9 unit tiles in 3 groups of 4)
+
+template <int T0>
+__device__ __forceinline__ void basis_load(const float *__restrict__ bpack, int lane, BasisPair &w)
+{
+    const f32x4 *wp = reinterpret_cast<const f32x4 *>(bpack) + (size_t)T0 * 3 * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int gq = 0; gq < 3; ++gq) w.a[u][gq] = wp[(u * 3 + gq) * 64];
+}
+
+__device__ __forceinline__ void basis_mma(const BasisPair &w, float f0, float f1, f32x4 g[9])
+{
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float f = u ? f1 : f0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            g[e] = NGF_MFMA16(w.a[u][0][e], f, g[e]);
+            g[4 + e] = NGF_MFMA16(w.a[u][1][e], f, g[4 + e]);
+        }
+        g[8] = NGF_MFMA16(w.a[u][2][0], f, g[8]);
+    }
+}
+
+// the 12 k-steps of plane P: two k-steps of weights are in flight behind the 18 MFMAs of the previous two (sched_barrier pins
+// the order; left alone hipcc hoists all 36 sixteen-byte loads of a plane and spills)
+template <int P>
+__device__ __forceinline__ void basis_plane16(const float *__restrict__ bpack, int lane, const float feat[12], f32x4 g[9])
+{
+    BasisPair w0, w1;
+    basis_load<P * 12>(bpack, lane, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    basis_load<P * 12 + 2>(bpack, lane, w1);
+    __builtin_amdgcn_sched_barrier(0);
+    basis_mma(w0, feat[0], feat[1], g);
+    __builtin_amdgcn_sched_barrier(0);
+    basis_load<P * 12 + 4>(bpack, lane, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    basis_mma(w1, feat[2], feat[3], g);
+    __builtin_amdgcn_sched_barrier(0);
+    basis_load<P * 12 + 6>(bpack, lane, w1);
+    __builtin_amdgcn_sched_barrier(0);
+    basis_mma(w0, feat[4], feat[5], g);
+    __builtin_amdgcn_sched_barrier(0);
+    basis_load<P * 12 + 8>(bpack, lane, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    basis_mma(w1, feat[6], feat[7], g);
+    __builtin_amdgcn_sched_barrier(0);
+    basis_load<P * 12 + 10>(bpack, lane, w1);
+    __builtin_amdgcn_sched_barrier(0);
+    basis_mma(w0, feat[8], feat[9], g);
+    __builtin_amdgcn_sched_barrier(0);
+    basis_mma(w1, feat[10], feat[11], g);
+}
+
+__device__ __forceinline__ void mlp_pass16_nofold(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v, int lane,
+                                                  float rgb[3])
+{
+    using L = MlpLayout16NoFold;
+    blob = per_pass16(blob);
+    const int kq = lane >> 4;
+    Gather16<48> gth;
+    float feat[12];
+    f32x4 g[9];
+#pragma unroll
+    for (int mt = 0; mt < 9; ++mt) g[mt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    gather16_issue<48, 0>(A, rec, kq, gth);
+    __builtin_amdgcn_sched_barrier(0);
+    mix16<48>(gth, feat);
+    __builtin_amdgcn_sched_barrier(0);
+    gather16_issue<48, 1>(A, rec, kq, gth);
+    __builtin_amdgcn_sched_barrier(0);
+    basis_plane16<0>(A.basis_pack, lane, feat, g);
+    __builtin_amdgcn_sched_barrier(0);
+    mix16<48>(gth, feat);
+    __builtin_amdgcn_sched_barrier(0);
+    gather16_issue<48, 2>(A, rec, kq, gth);
+    __builtin_amdgcn_sched_barrier(0);
+    basis_plane16<1>(A.basis_pack, lane, feat, g);
+    __builtin_amdgcn_sched_barrier(0);
+    mix16<48>(gth, feat);
+    __builtin_amdgcn_sched_barrier(0);
+    basis_plane16<2>(A.basis_pack, lane, feat, g);
+    __builtin_amdgcn_sched_barrier(0);
+    // layer 1: k-step (mt_in, r) takes g[mt_in][r]; the last four k-steps take the lane's four view inputs
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(blob + L::B1 + kq * 16 + mt * 4);
+    const float *w1 = blob + L::W1 + lane;
+#pragma unroll
+    for (int t = 0; t < 40; ++t) {
+        const float x = t < 36 ? g[t >> 2][t & 3] : v[t & 3];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = NGF_MFMA16(w1[(mt * L::KT + t) * 64], x, acc[mt]);
+        if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // keeps the LDS operand reads next to their MFMAs (register pressure)
+    }
+    mlp_tail16(blob, L::W2, L::B2, L::W3, L::B3, lane, acc, rgb);
+}
+
 // ---- NGF_F_BAKE_COLOR: 64-channel layer-1 pre-activation planes, channel = hidden unit mt*16 + 4*kq + r ----------------------
 struct BakedHalf {                // half a plane: 4 taps x 2 float4 = accumulator tiles 2h, 2h+1
     f32x4 raw[4][2];

@@ -51,7 +51,7 @@ class Base(torch.nn.Module):
 
     def __init__(self, aabb, gridSize, device, alphaMask=None, near_far=[2.0, 6.0], alphaMask_thres=0.001,
                  distance_scale=25, rayMarch_weight_thres=0.0001, step_ratio=2.0, gauge_start=0, bake_density=False,
-                 bake_color=False):
+                 bake_color=False, no_fold=False):
         super().__init__()
         self.aabb = aabb if torch.is_tensor(aabb) else torch.tensor(aabb, dtype=torch.float32)
         self.alphaMask = alphaMask
@@ -63,6 +63,7 @@ class Base(torch.nn.Module):
         self.step_ratio = step_ratio
         self.bake_density = bool(bake_density)      # NGF_F_BAKE_DENSITY (TriPlane)
         self.bake_color = bool(bake_color)          # NGF_F_BAKE_COLOR (TriPlane)
+        self.no_fold = bool(no_fold)                # NGF_F_NO_FOLD (TriPlane): rgb_decoder exactly as written, for measurements
         self._handle = None
         self._handle_key = None
         self.last_stats = None
@@ -123,7 +124,7 @@ class Base(torch.nn.Module):
         if getattr(self, 'check_params', False):
             ps.append(tuple(float(p.detach().double().sum()) + float(p.detach().double().abs().sum()) for p in self.parameters()))
         m = None if self.alphaMask is None else (self.alphaMask.alpha_volume.data_ptr(), self.alphaMask.alpha_volume._version)
-        return (tuple(ps), m, float(self.stepSize), tuple(self.aabb.reshape(-1).tolist()), self.bake_density, self.bake_color,
+        return (tuple(ps), m, float(self.stepSize), tuple(self.aabb.reshape(-1).tolist()), self.bake_density, self.bake_color, self.no_fold,
                 tuple(self.near_far), float(self.distance_scale), float(self.rayMarch_weight_thres))
 
     def invalidate(self):
@@ -163,7 +164,8 @@ class Base(torch.nn.Module):
         d.model, d.plane_c, d.dens_dim = self.MODEL, self.PLANE_C, self.DENS_DIM
         d.flags = 0
         if self.MODEL == _lib.MODEL_TRIPLANE:
-            d.flags = (_lib.F_BAKE_DENSITY if self.bake_density else 0) | (_lib.F_BAKE_COLOR if self.bake_color else 0)
+            d.flags = ((_lib.F_BAKE_DENSITY if self.bake_density else 0) | (_lib.F_BAKE_COLOR if self.bake_color else 0) |
+                       (_lib.F_NO_FOLD if self.no_fold else 0))
 
         def dp(t):
             t = t.detach().to(device=dev, dtype=torch.float32).contiguous()

@@ -143,6 +143,38 @@ def test_split_march_is_bit_identical(name):
 
 
 @pytest.mark.parametrize("name", ["triplane_r1_gauge", "triplane_r2_nogauge", "triplane_r1_mask"])
+def test_no_fold_level0_matches_reference(name):
+    """NGF_F_NO_FOLD: rgb_decoder exactly as written (networks.py:25-30) -- `basis` as its own 144x144 matrix stage, view inputs
+    per sample -- against the oracle, the reference's golden pixels, and the default (pre-composed layer 1, per-ray view fold)
+    path, which may differ from it by rounding only."""
+    g, params, step, mask = load_case(name)
+    orc = oracle_for_case(g, params, step, mask)
+    f0 = field_for_case(g, params, mask, no_fold=True)
+    f1 = field_for_case(g, params, mask)
+    rays = torch.from_numpy(g["rays"]).cuda()
+    S = int(g["S"])
+    white = bool(int(g["white_bg"]))
+    kw = _mode(g)
+    a = f0(rays, N_samples=S, white_bg=white, **kw)
+    b = f1(rays, N_samples=S, white_bg=white, **kw)
+    o_rgb, o_depth = orc.render(g["rays"], S, white_bg=white)
+    _close(a["rgb_map"].cpu().numpy(), o_rgb, "no-fold rgb vs oracle")
+    _close(a["rgb_map"].cpu().numpy(), g["rgb_map"], "no-fold rgb vs reference golden")
+    assert torch.equal(a["depth_map"], b["depth_map"])                                   # the march is the same code
+    assert float((a["rgb_map"] - b["rgb_map"]).abs().max()) < 1e-5                       # folds (i) + (ii): rounding only
+    # the colour stage alone
+    from ngf_amd import synth
+    n = 203
+    coords = (synth.hash_uniform(77, 1, (n, 6)) * np.float32(2.2) - np.float32(1.1)).astype(np.float32)
+    dirs = synth.hash_normal(77, 2, (n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    got = f0.decode_rgb(torch.from_numpy(coords), torch.from_numpy(dirs), mode=1).cpu().numpy()
+    assert np.abs(got - orc.color_at(coords, dirs)).max() < 5e-6
+    with pytest.raises(RuntimeError):
+        field_for_case(g, params, mask, no_fold=True, bake=True).handle()
+
+
+@pytest.mark.parametrize("name", ["triplane_r1_gauge", "triplane_r2_nogauge", "triplane_r1_mask"])
 def test_lds_staged_strips_are_bit_identical(name):
     """The LDS-staged texture variant (csrc/ngf_stage.hpp, knob stage = 1): gauge strips (gauge on) / density strips (gauge off,
     8 waves per CU) are loaded once per tile iteration into LDS and tapped from there; the arithmetic on the fetched values is
