@@ -41,6 +41,10 @@ enum {
                               144 x 144 matrix stage and the view inputs enter layer 1 per sample.  Without this flag layer 1 is
                               pre-composed with `basis` (W1' = W1[:, :F] . basis, fp64 accumulate) and, for small tiles, its
                               view-direction part is evaluated once per ray.  For measuring what the pre-compositions buy. */
+    NGF_F_SPLIT_BF16 = 8,   /* colour-MLP products on v_mfma_f32_16x16x32_bf16 with every fp32 operand split into three bf16 terms and
+                              fp32 accumulation: fp32-level error (dropped cross terms < 2^-24 of a product) at ~0.4 x the matrix
+                              cycles of the fp32 MFMA path, which on gfx950 runs on the vector datapath.  Not bit-identical to the
+                              default (different summation tree); opt-in, see DESIGN.md. */
     NGF_F_BAKE_COLOR = 2    /* pre-compose rgb_decoder layer 1 (W1[:, :F] . basis, no activation in between:
                               networks.py:17,26-30) with the colour channels of each plane: colour planes
                               become 64-channel layer-1 pre-activation planes, the shade pass keeps only the

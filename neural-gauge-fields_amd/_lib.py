@@ -15,6 +15,7 @@ MODEL_TRIPLANE, MODEL_INFOINV = 0, 1
 F_BAKE_DENSITY = 1
 F_BAKE_COLOR = 2
 F_NO_FOLD = 4
+F_SPLIT_BF16 = 8
 
 SYMBOLS = ["ngf_field_create", "ngf_field_destroy", "ngf_field_render", "ngf_field_decode_rgb", "ngf_field_march",
            "ngf_generate_rays", "ngf_generate_rays_dtu", "ngf_last_error", "ngf_abi_version", "ngf_field_bytes", "ngf_sizeof_field_desc",

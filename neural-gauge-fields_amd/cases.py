@@ -21,7 +21,7 @@ def big_case(model="triplane", preset="R1", res=256, seed=3):
     return g, params, step
 
 
-def field_for_case(g, params, mask, device="cuda", bake=False, bake_color=False, no_fold=False):
+def field_for_case(g, params, mask, device="cuda", bake=False, bake_color=False, no_fold=False, split_bf16=False):
     """Build the ngf_amd field (HIP path) for a case dict (a golden fixture or big_case) and a parameter dict."""
     import torch
     from . import infoinv, triplane
@@ -30,7 +30,7 @@ def field_for_case(g, params, mask, device="cuda", bake=False, bake_color=False,
               rayMarch_weight_thres=float(g["thr"]), step_ratio=float(g["step_ratio"]))
     grid = [int(v) for v in g["grid"]]
     if str(g["model"]) == "triplane":
-        f = triplane.TriPlane(aabb, grid, device, gauge_start=0, bake_density=bake, bake_color=bake_color, no_fold=no_fold, **kw)
+        f = triplane.TriPlane(aabb, grid, device, gauge_start=0, bake_density=bake, bake_color=bake_color, no_fold=no_fold, split_bf16=split_bf16, **kw)
     else:
         f = infoinv.TriPlane(aabb, grid, device, **kw)
     f.load_params(params)

@@ -186,6 +186,83 @@ static void build_rgb_image(int F, const std::vector<float> &basis, const std::v
 // 16-wide (v_mfma_f32_16x16x4_f32) image of rgb_decoder for TriPlane (ngf_shade16.hpp).  Lane (s, kq): hidden
 // unit of accumulator (mt, r) is n = mt*16 + 4*kq + r.  With bake = true the plane part of layer 1 goes to the
 // texture baker instead: wp[p][n][c] = W1'[n][p*APPc + c] (natural unit order: channel n of a baked texel = unit n).
+// NGF_F_SPLIT_BF16: bf16 round-to-nearest-even and the 3-term split of a weight
+static uint16_t f2bf(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static float bf2f(uint16_t h)
+{
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static void split3(float x, uint16_t out[3])
+{
+    out[0] = f2bf(x);
+    const float r1 = x - bf2f(out[0]);
+    out[1] = f2bf(r1);
+    const float r2 = r1 - bf2f(out[1]);
+    out[2] = f2bf(r2);
+}
+
+// LDS image of ngf_shade_bf16.hpp: A fragments [mt][k-block][part][lane][8 bf16]; lane (i, kq), element e of k-block kb holds the
+// weight of output unit mt*16 + i for the (kb*8 + e)-th input that lane quarter kq supplies
+static void build_rgb_image_bf16(int F, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
+                                 const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3, const std::vector<float> &b3,
+                                 float *img)
+{
+    using L = MlpLayoutBf16;
+    const int IN = F + 15, APPc = F / 3;
+    std::vector<double> w1f((size_t)64 * (F + 16), 0.0);       // W1' = [W1[:, :F] . basis | W1[:, F:F+15] | 0]
+    for (int n = 0; n < 64; ++n) {
+        for (int k = 0; k < F; ++k) {
+            double s = 0.0;
+            for (int j = 0; j < F; ++j) s += (double)w1[(size_t)n * IN + j] * (double)basis[(size_t)j * F + k];
+            w1f[(size_t)n * (F + 16) + k] = s;
+        }
+        for (int k = 0; k < 15; ++k) w1f[(size_t)n * (F + 16) + F + k] = w1[(size_t)n * IN + F + k];
+    }
+    auto hidden = [](int mt, int r, int kq) { return mt * 16 + 4 * kq + r; };
+    uint16_t *h16 = reinterpret_cast<uint16_t *>(img);
+    auto put = [&](int base_floats, int nkb, int mt, int kb, int l, int e, float wv) {
+        uint16_t p3[3];
+        split3(wv, p3);
+        for (int part = 0; part < 3; ++part)
+            h16[((size_t)base_floats + ((((size_t)mt * nkb + kb) * 3 + part) * 64 + l) * 4) * 2 + e] = p3[part];
+    };
+    for (int mt = 0; mt < 4; ++mt)
+        for (int kb = 0; kb < L::KB1; ++kb)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int kq = l >> 4, n = mt * 16 + (l & 15), j = kb * 8 + e;
+                    int col;
+                    if (j < 36) { const int P = j / 12, jj = j % 12; col = P * APPc + 16 * (jj / 4) + 4 * kq + (jj & 3); }
+                    else col = F + kq * 4 + (j - 36);                                   // view entry (entry 15 = zero pad column)
+                    put(L::W1, L::KB1, mt, kb, l, e, (float)w1f[(size_t)n * (F + 16) + col]);
+                }
+    for (int mt = 0; mt < 4; ++mt)
+        for (int kb = 0; kb < L::KB2; ++kb)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int kq = l >> 4, n = mt * 16 + (l & 15), j = kb * 8 + e;
+                    put(L::W2, L::KB2, mt, kb, l, e, w2[(size_t)n * 64 + hidden(j >> 2, j & 3, kq)]);
+                }
+    for (int kq = 0; kq < 4; ++kq)
+        for (int k = 0; k < 16; ++k) {
+            const int n = hidden(k >> 2, k & 3, kq);
+            img[L::B1 + kq * 16 + k] = b1[n];
+            img[L::B2 + kq * 16 + k] = b2[n];
+            for (int c = 0; c < 3; ++c) img[L::W3 + c * 64 + kq * 16 + k] = w3[(size_t)c * 64 + n];
+        }
+    for (int c = 0; c < 3; ++c) img[L::B3 + c] = b3[c];
+    img[L::B3 + 3] = 0.0f;
+}
+
 // NGF_F_NO_FOLD: layer 1 un-composed, inputs in the accumulator order of the basis stage; basis packed for streaming
 static void build_rgb_image16_nofold(int F, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
                                      const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3, const std::vector<float> &b3,
@@ -344,7 +421,9 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     const bool bake = tri && (d->flags & NGF_F_BAKE_DENSITY);
     const bool bake_c = tri && (d->flags & NGF_F_BAKE_COLOR);
     const bool no_fold = tri && (d->flags & NGF_F_NO_FOLD);
+    const bool split_bf16 = tri && (d->flags & NGF_F_SPLIT_BF16);
     if (no_fold && (bake || bake_c)) return bail(fail(NGF_E_ARG, "NGF_F_NO_FOLD is the un-composed formulation: it excludes the NGF_F_BAKE_* flags"));
+    if (split_bf16 && (bake_c || no_fold)) return bail(fail(NGF_E_ARG, "NGF_F_SPLIT_BF16 applies to the pre-composed layer-1 formulation (no NGF_F_BAKE_COLOR / NGF_F_NO_FOLD)"));
 
     // MLP weights: to the host once, pre-compose, permute, back to HBM as one LDS image
     std::vector<float> basis, w1, b1, w2, b2, w3, b3;
@@ -363,11 +442,12 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     }
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "hipStreamSynchronize failed in ngf_field_create"));
 
-    const int rgb_floats = tri ? (no_fold ? MlpLayout16NoFold::TOTAL : (bake_c ? MlpLayout16Baked::TOTAL : MlpLayout16<48>::TOTAL)) : MlpLayout<72>::TOTAL;
+    const int rgb_floats = tri ? (split_bf16 ? MlpLayoutBf16::TOTAL : no_fold ? MlpLayout16NoFold::TOTAL : (bake_c ? MlpLayout16Baked::TOTAL : MlpLayout16<48>::TOTAL)) : MlpLayout<72>::TOTAL;
     const int dens_floats = tri ? 0 : InfoInvDensLayout::TOTAL;
     std::vector<float> img((size_t)rgb_floats + dens_floats, 0.0f), wp;
     std::vector<float> bpack;
-    if (no_fold) build_rgb_image16_nofold(F, basis, w1, b1, w2, b2, w3, b3, img.data(), bpack);
+    if (split_bf16) build_rgb_image_bf16(F, basis, w1, b1, w2, b2, w3, b3, img.data());
+    else if (no_fold) build_rgb_image16_nofold(F, basis, w1, b1, w2, b2, w3, b3, img.data(), bpack);
     else if (tri) build_rgb_image16(F, bake_c, basis, w1, b1, w2, b2, w3, b3, img.data(), wp);
     else build_rgb_image(F, basis, w1, b1, w2, b2, w3, b3, img.data());
     if (!tri) build_infoinv_density_image(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
@@ -577,6 +657,14 @@ static int render_common(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
     if (f->model == NGF_MODEL_INFOINV) return launch_policy<InfoInvPolicy>(f, A, st);
     if (f->flags & NGF_F_NO_FOLD) return launch_policy<TriPlaneNoFoldPolicy>(f, A, st);
+    if (f->flags & NGF_F_SPLIT_BF16) {
+        if (knob(KNOB_TILE_W) > 8 || knob(KNOB_SPLIT) == 0) return fail(NGF_E_ARG, "NGF_F_SPLIT_BF16 renders with split tiles of 4 or 8 rays");
+        // 8 waves per CU: the pass keeps 48 registers of A fragments next to the gather buffer -- at the 168 registers that 12 waves
+        // leave it spills 84 and runs 12.8 ms instead of 8.4 ms (profiles/r02_split_bf16.txt)
+        if (knob(KNOB_WAVES) == 12)
+            return (f->flags & NGF_F_BAKE_DENSITY) ? launch_policy<TriPlaneBf16Policy<true, 12>>(f, A, st) : launch_policy<TriPlaneBf16Policy<false, 12>>(f, A, st);
+        return (f->flags & NGF_F_BAKE_DENSITY) ? launch_policy<TriPlaneBf16Policy<true, 8>>(f, A, st) : launch_policy<TriPlaneBf16Policy<false, 8>>(f, A, st);
+    }
     const bool bd = f->flags & NGF_F_BAKE_DENSITY, bc = f->flags & NGF_F_BAKE_COLOR;
     if (bd) return bc ? launch_triplane<true, true>(f, A, st) : launch_triplane<true, false>(f, A, st);
     return bc ? launch_triplane<false, true>(f, A, st) : launch_triplane<false, false>(f, A, st);
@@ -631,6 +719,7 @@ extern "C" int ngf_field_decode_rgb(const ngf_field *f, const float *coords, con
     int rc;
     if (f->model == NGF_MODEL_INFOINV) rc = go(decode_rgb_kernel<InfoInvPolicy>);
     else if (f->flags & NGF_F_NO_FOLD) rc = go(decode_rgb_kernel<TriPlaneNoFoldPolicy>);
+    else if (f->flags & NGF_F_SPLIT_BF16) rc = go(decode_rgb_kernel<TriPlaneBf16Policy<false, 8>>);
     else if (f->flags & NGF_F_BAKE_COLOR) rc = go(decode_rgb_kernel<TriPlanePolicy<false, true, 8, 1>>);
     else rc = go(decode_rgb_kernel<TriPlanePolicy<false, false, 8, 1>>);
     if (rc) return rc;

@@ -62,6 +62,7 @@ struct InfoInvPolicy {
     static constexpr bool VIEW_FOLD = false;
     static constexpr bool STAGED = false;
     static constexpr int STAGE_FLOATS = 0;
+    static constexpr int VFEAT_FLOATS = kWave * kViewFeat;
     static constexpr int NSTEP = 1;
     static constexpr int BATCH = kBatch;
     static constexpr int RING = 128;

@@ -24,11 +24,12 @@
 #pragma once
 #include "ngf_device.hpp"
 #include "ngf_shade16.hpp"
+#include "ngf_shade_bf16.hpp"
 
 namespace ngf {
 
 // LDS carve (floats): [blob | per wave: ring of RING records, result list, view inputs of the 64 rays]
-template <typename P> constexpr int wave_lds_floats() { return P::RING * kRecFloats + P::BATCH * 4 + (P::VLDS ? kWave * kViewFeat : 0) + P::STAGE_FLOATS; }
+template <typename P> constexpr int wave_lds_floats() { return P::RING * kRecFloats + P::BATCH * 4 + P::VFEAT_FLOATS + P::STAGE_FLOATS; }
 
 // The 16 view-direction inputs of rgb_decoder layer 1 (networks.py:27-29, 205-216):
 //   u[F..F+14] = [d(3), sin(d_x), sin(2 d_x), sin(d_y), sin(2 d_y), sin(d_z), sin(2 d_z), cos(same 6)], u[F+15] = 0 (pad)
@@ -302,6 +303,7 @@ struct TriPlanePolicy {
     static constexpr int NSTEP = NSTEP_;
     static constexpr int BATCH = kBatch16;
     static constexpr bool VLDS = WAVES_ <= 12;                  // per-ray view inputs cached in LDS (4 KB / wave) or recomputed per pass
+    static constexpr int VFEAT_FLOATS = VLDS ? kWave * kViewFeat : 0;       // view inputs of up to 64 rays (+ the per-ray fold table of small tiles)
     static constexpr int RING = NSTEP_ == 1 ? 128 : 256;        // >= BATCH-1 + 64*NSTEP records
     __device__ static __forceinline__ float sigma(const RenderArgs &A, const float *, bool valid, const float x[3], int, float t[6])
     {
@@ -335,6 +337,20 @@ struct TriPlanePolicy {
         if (!pre) v = VLDS ? *reinterpret_cast<const f32x4 *>(vf + (lane >> 4) * 4) : view_entries16(od, lane >> 4);
         if constexpr (BAKE_C) mlp_pass16_baked(A, smem, rec, v, lane, c, pre);
         else mlp_pass16<48>(A, smem, rec, v, lane, c, tk, pre);
+    }
+};
+
+// NGF_F_SPLIT_BF16: the colour MLP on the bf16 matrix pipe with 3-term split operands (ngf_shade_bf16.hpp).  Split tiles of <= 8 rays
+// only (the wave keeps the view inputs of 8 rays); 8 waves per CU (the pass needs ~200 registers).
+template <bool BAKE_D, int WAVES_ = 8>
+struct TriPlaneBf16Policy : TriPlanePolicy<BAKE_D, false, WAVES_, 1> {
+    static constexpr bool VIEW_FOLD = false;
+    static constexpr int VFEAT_FLOATS = 8 * kViewFeat;
+    __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
+                                                 const float od[3], int lane, float c[3], unsigned long long * = nullptr, const float * = nullptr)
+    {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(vf + (lane >> 4) * 4);
+        mlp_pass16_bf16(A, smem, rec, v, lane, c);
     }
 };
 

@@ -83,6 +83,11 @@ __device__ __forceinline__ f32x4 view_entries16(const float d[3], int kq)
 
 #define NGF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// ReLU in ONE instruction.  fmaxf(x, 0.0f) compiles to v_max_f32 x, x, x (quieting a possible signalling NaN) + v_max_f32 0, x; the
+// inputs here are MFMA accumulators (never signalling NaNs), so the first instruction is dead weight: 32 of them per pass.
+// v_med3_f32(x, 0, +inf) = max(x, 0) for every non-NaN x: bit-identical results.
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+
 // layers 2 and 3; acc[mt][r] = layer-1 pre-activation of hidden unit mt*16 + 4*kq + r
 __device__ __forceinline__ void mlp_tail16(const float *blob, int oW2, int oB2, int oW3, int oB3, int lane, const f32x4 acc[4],
                                            float rgb[3], unsigned long long *tk = nullptr)
@@ -94,7 +99,7 @@ __device__ __forceinline__ void mlp_tail16(const float *blob, int oW2, int oB2, 
     const float *w2 = blob + oW2 + lane;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-        const float h = fmaxf(acc[t >> 2][t & 3], 0.0f);
+        const float h = relu1(acc[t >> 2][t & 3]);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) c[mt] = NGF_MFMA16(w2[(mt * 16 + t) * 64], h, c[mt]);
     }
@@ -104,7 +109,7 @@ __device__ __forceinline__ void mlp_tail16(const float *blob, int oW2, int oB2, 
     for (int ch = 0; ch < 3; ++ch) {
         float s = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s = fmaf(w3[ch * 64 + k], fmaxf(c[k >> 2][k & 3], 0.0f), s);
+        for (int k = 0; k < 16; ++k) s = fmaf(w3[ch * 64 + k], relu1(c[k >> 2][k & 3]), s);
         s = s + __shfl_xor(s, 16);
         s = s + __shfl_xor(s, 32);
         s = s + blob[oB3 + ch];

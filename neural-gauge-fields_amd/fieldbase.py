@@ -51,7 +51,7 @@ class Base(torch.nn.Module):
 
     def __init__(self, aabb, gridSize, device, alphaMask=None, near_far=[2.0, 6.0], alphaMask_thres=0.001,
                  distance_scale=25, rayMarch_weight_thres=0.0001, step_ratio=2.0, gauge_start=0, bake_density=False,
-                 bake_color=False, no_fold=False):
+                 bake_color=False, no_fold=False, split_bf16=False):
         super().__init__()
         self.aabb = aabb if torch.is_tensor(aabb) else torch.tensor(aabb, dtype=torch.float32)
         self.alphaMask = alphaMask
@@ -64,6 +64,7 @@ class Base(torch.nn.Module):
         self.bake_density = bool(bake_density)      # NGF_F_BAKE_DENSITY (TriPlane)
         self.bake_color = bool(bake_color)          # NGF_F_BAKE_COLOR (TriPlane)
         self.no_fold = bool(no_fold)                # NGF_F_NO_FOLD (TriPlane): rgb_decoder exactly as written, for measurements
+        self.split_bf16 = bool(split_bf16)          # NGF_F_SPLIT_BF16 (TriPlane): colour MLP on bf16 MFMA with 3-term split operands
         self._handle = None
         self._handle_key = None
         self.last_stats = None
@@ -124,7 +125,7 @@ class Base(torch.nn.Module):
         if getattr(self, 'check_params', False):
             ps.append(tuple(float(p.detach().double().sum()) + float(p.detach().double().abs().sum()) for p in self.parameters()))
         m = None if self.alphaMask is None else (self.alphaMask.alpha_volume.data_ptr(), self.alphaMask.alpha_volume._version)
-        return (tuple(ps), m, float(self.stepSize), tuple(self.aabb.reshape(-1).tolist()), self.bake_density, self.bake_color, self.no_fold,
+        return (tuple(ps), m, float(self.stepSize), tuple(self.aabb.reshape(-1).tolist()), self.bake_density, self.bake_color, self.no_fold, self.split_bf16,
                 tuple(self.near_far), float(self.distance_scale), float(self.rayMarch_weight_thres))
 
     def invalidate(self):
@@ -165,7 +166,7 @@ class Base(torch.nn.Module):
         d.flags = 0
         if self.MODEL == _lib.MODEL_TRIPLANE:
             d.flags = ((_lib.F_BAKE_DENSITY if self.bake_density else 0) | (_lib.F_BAKE_COLOR if self.bake_color else 0) |
-                       (_lib.F_NO_FOLD if self.no_fold else 0))
+                       (_lib.F_NO_FOLD if self.no_fold else 0) | (_lib.F_SPLIT_BF16 if self.split_bf16 else 0))
 
         def dp(t):
             t = t.detach().to(device=dev, dtype=torch.float32).contiguous()

@@ -2,7 +2,7 @@
 """One named GPU workload, run a few times -- what profiles/collect.sh puts under rocprofv3.  Product-side imports only.
 
     python profiles/workload.py <name> [reps]
-names: triplane_R0 | triplane_R1 | triplane_R2 | triplane_R1_bd (bake density) | triplane_R1_bdc (both bakes) | infoinv_R1
+names: triplane_R0 | triplane_R1 | triplane_R2 | triplane_R1_bd (bake density) | triplane_R1_bdc (both bakes) | triplane_R1_nofold | infoinv_R1
        (800x800 frame, S = 192, BASELINE configs 2 / 3) | uv_sphere (BASELINE config 4: 76 800 DTU-camera rays x 64 samples)
        | train_R1 (4096-ray training iteration)
 Optional knobs through the environment of THIS script (mapped to ngf_debug_set): NGF_KERNEL, NGF_TILE_W, NGF_STAGE, ..."""
@@ -34,7 +34,10 @@ if name.startswith(("triplane", "infoinv")):
     parts = name.split("_")
     model, preset, bake = parts[0], parts[1], (parts[2] if len(parts) > 2 else "")
     g, params, step = cases.big_case(model, preset)
-    f = cases.field_for_case(g, params, None, device=dev, bake="d" in bake, bake_color="c" in bake)
+    nofold, split = bake == "nofold", bake.startswith("split")          # "split" | "splitd" (with baked density)
+    plain = not (nofold or split)
+    f = cases.field_for_case(g, params, None, device=dev, bake=(plain and "d" in bake) or bake == "splitd", bake_color=plain and "c" in bake,
+                             no_fold=nofold, split_bf16=split)
     rays = nrays.generate_rays(800, 800, nrays.blender_focal(800), synth.lookat_pose())
     kw = {"iteration": 30001} if model == "triplane" else {"infoinv": True}
     run = lambda: f(rays, N_samples=192, white_bg=True, **kw)

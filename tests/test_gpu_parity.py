@@ -142,6 +142,41 @@ def test_split_march_is_bit_identical(name):
     assert torch.equal(ref["rgb_map"], got["rgb_map"]) and torch.equal(ref["depth_map"], got["depth_map"])
 
 
+@pytest.mark.parametrize("bake_density", [False, True])
+@pytest.mark.parametrize("name", ["triplane_r1_gauge", "triplane_r2_nogauge", "triplane_r1_mask"])
+def test_split_bf16_colour_mlp_keeps_fp32_accuracy(name, bake_density):
+    """NGF_F_SPLIT_BF16 (opt-in): the colour MLP's products on the bf16 matrix pipe with 3-term split operands and fp32 accumulation
+    (csrc/ngf_shade_bf16.hpp).  Same tolerance against the oracle and the reference's golden pixels as the fp32-MFMA path, and
+    within fp32 rounding noise of that path (the dropped cross terms are < 2^-24 of a product)."""
+    g, params, step, mask = load_case(name)
+    orc = oracle_for_case(g, params, step, mask)
+    fs = field_for_case(g, params, mask, bake=bake_density, split_bf16=True)
+    fd = field_for_case(g, params, mask, bake=bake_density)
+    rays = torch.from_numpy(g["rays"]).cuda()
+    S = int(g["S"])
+    white = bool(int(g["white_bg"]))
+    kw = _mode(g)
+    a = fs(rays, N_samples=S, white_bg=white, **kw)
+    b = fd(rays, N_samples=S, white_bg=white, **kw)
+    o_rgb, o_depth = orc.render(g["rays"], S, white_bg=white)
+    ea = _close(a["rgb_map"].cpu().numpy(), o_rgb, "split-bf16 rgb vs oracle")
+    _close(a["rgb_map"].cpu().numpy(), g["rgb_map"], "split-bf16 rgb vs reference golden")
+    assert ea < 5e-6
+    assert torch.equal(a["depth_map"], b["depth_map"])                                   # the march is the same code
+    assert float((a["rgb_map"] - b["rgb_map"]).abs().max()) < 2e-6
+    for n in (1, 7, 65):                                                                 # ragged launches
+        c = fs(rays[:n], N_samples=S, white_bg=white, **kw)
+        assert torch.equal(c["rgb_map"], a["rgb_map"][:n])
+    # the colour stage alone, per sample
+    from ngf_amd import synth
+    n = 203
+    coords = (synth.hash_uniform(78, 1, (n, 6)) * np.float32(2.2) - np.float32(1.1)).astype(np.float32)
+    dirs = synth.hash_normal(78, 2, (n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    got = fs.decode_rgb(torch.from_numpy(coords), torch.from_numpy(dirs), mode=1).cpu().numpy()
+    assert np.abs(got - orc.color_at(coords, dirs)).max() < 5e-6
+
+
 @pytest.mark.parametrize("name", ["triplane_r1_gauge", "triplane_r2_nogauge", "triplane_r1_mask"])
 def test_no_fold_level0_matches_reference(name):
     """NGF_F_NO_FOLD: rgb_decoder exactly as written (networks.py:25-30) -- `basis` as its own 144x144 matrix stage, view inputs
