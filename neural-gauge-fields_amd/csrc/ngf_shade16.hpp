@@ -83,10 +83,11 @@ __device__ __forceinline__ f32x4 view_entries16(const float d[3], int kq)
 
 #define NGF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// ReLU in ONE instruction.  fmaxf(x, 0.0f) compiles to v_max_f32 x, x, x (quieting a possible signalling NaN) + v_max_f32 0, x; the
-// inputs here are MFMA accumulators (never signalling NaNs), so the first instruction is dead weight: 32 of them per pass.
-// v_med3_f32(x, 0, +inf) = max(x, 0) for every non-NaN x: bit-identical results.
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+// ReLU in ONE instruction.  fmaxf(x, 0.0f) compiles to v_max_f32 x, x, x (quieting a possible signalling NaN) + v_max_f32 0, x -- and
+// LLVM folds v_med3_f32(x, 0, inf) back into the same pair.  The sign-magnitude order of IEEE floats makes the INTEGER maximum of the
+// bit pattern with 0 the same function for every non-NaN x (negative floats, -0 included, are negative integers -> +0): one
+// v_max_i32, bit-identical results, 32 instructions fewer per pass.
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
 // layers 2 and 3; acc[mt][r] = layer-1 pre-activation of hidden unit mt*16 + 4*kq + r
 __device__ __forceinline__ void mlp_tail16(const float *blob, int oW2, int oB2, int oW3, int oB3, int lane, const f32x4 acc[4],
