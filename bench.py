@@ -88,10 +88,10 @@ def physical_roofs(pmc, k_ms, share=1.0):
     return out
 
 
-def build_field(model, preset, device, bake, bake_color=False, no_fold=False):
+def build_field(model, preset, device, bake=False, bake_color=False, no_fold=False, split_bf16=False):
     from ngf_amd.cases import big_case, field_for_case
     g, params, step = big_case(model, preset)
-    f = field_for_case(g, params, None, device=device, bake=bake, bake_color=bake_color, no_fold=no_fold)
+    f = field_for_case(g, params, None, device=device, bake=bake, bake_color=bake_color, no_fold=no_fold, split_bf16=split_bf16)
     f.handle()
     return f, g, params, step
 
@@ -347,30 +347,44 @@ def main():
             result["speedup_vs_cpu_port"] = value / cb["value"]
         if args.extras:
             extras = {}
-            # bake bit 2 = NGF_F_NO_FOLD: level 0 (un-composed `basis` stage, view inputs per sample) -- what the default's folds buy
-            for mdl, preset, bake in (("triplane", "R0", 0), ("triplane", "R2", 0), ("triplane", args.preset, 4), ("triplane", args.preset, 1),
-                                      ("triplane", args.preset, 3), ("triplane", "R0", 1), ("triplane", "R2", 3), ("infoinv", "R1", 0)):
+            # the other presets and the opt-in formulations: (model, preset, field flags, result tag, PMC tag)
+            variants = (("triplane", "R0", {}, "", ""), ("triplane", "R2", {}, "", ""),
+                        ("triplane", args.preset, {"no_fold": True}, "_no_fold_level0", "_nofold"),        # rgb_decoder as written: what the folds buy
+                        ("triplane", args.preset, {"split_bf16": True}, "_split_bf16", "_split"),           # colour MLP on bf16 MFMA, 3-term split operands
+                        ("triplane", "R2", {"split_bf16": True}, "_split_bf16", "_split"),
+                        ("triplane", args.preset, {"bake": True}, "_bake_density", "_bd"),
+                        ("triplane", args.preset, {"bake": True, "split_bf16": True}, "_bake_density_split_bf16", "_splitd"),
+                        ("triplane", args.preset, {"bake": True, "bake_color": True}, "_bake_density_color", "_bdc"),
+                        ("triplane", "R0", {"bake": True}, "_bake_density", "_bd"),
+                        ("triplane", "R2", {"bake": True, "bake_color": True}, "_bake_density_color", "_bdc"),
+                        ("infoinv", "R1", {}, "", ""))
+            for mdl, preset, flags, tag, ptag_sfx in variants:
                 try:
-                    fx, _, _, _ = build_field(mdl, preset, device, bool(bake & 1), bool(bake & 2), bool(bake & 4))
+                    fx, _, _, _ = build_field(mdl, preset, device, **flags)
                     kx = {"iteration": 30001} if mdl == "triplane" else {"infoinv": True}
                     ms = kernel_ms(lambda: fx(rays, N_samples=S, white_bg=True, **kx), 5, device)      # includes 1st-call warm-up
                     ms = kernel_ms(lambda: fx(rays, N_samples=S, white_bg=True, **kx), 10, device)
                     fx(rays, N_samples=S, collect_stats=True, **kx)
                     sx = fx.last_stats.cpu().numpy().astype(np.float64)
                     sa = sx[1] / n_total
-                    tag = {0: "", 1: "_bake_density", 2: "_bake_color", 3: "_bake_density_color", 4: "_no_fold_level0"}[bake]
-                    ptag = f"{mdl}_{preset}" + {0: "", 1: "_bd", 2: "_bc", 3: "_bdc", 4: "_nofold"}[bake]
-                    px = load_pmc(ptag)
-                    if mdl == "triplane":
-                        fl = (sx[2] * (64 if bake & 2 else 208) + (n_total // 8) * 16) * 2048.0 if bake != 4 else sx[2] * 548 * 2048.0
+                    px = load_pmc(f"{mdl}_{preset}{ptag_sfx}")
+                    entry = {"Mray/s": n_total / ms / 1e3, "kernel_ms": ms, "active_samples_per_ray": sa}
+                    if flags.get("split_bf16"):
+                        bf = sx[2] * 168 * 2 * 16 * 16 * 32                    # executed bf16 MFMA flops: 168 v_mfma_f32_16x16x32_bf16 per pass
+                        entry.update({"executed_bf16_mfma_TFLOPs": bf / (ms * 1e-3) / 1e12, "bf16_mfma_frac_of_2500": bf / (ms * 1e-3) / 1e12 / 2500.0,
+                                      "note": "six bf16 products per fp32 product (3-term split, fp32 accumulate): fp32-level error, "
+                                              "max |rgb - fp32 path| < 2e-6 (tests/test_gpu_parity.py::test_split_bf16_colour_mlp_keeps_fp32_accuracy)"})
                     else:
-                        fl = None if px is None else px.get("mfma_flops_per_dispatch")
-                    extras[f"{mdl}_{preset}{tag}"] = {
-                        "Mray/s": n_total / ms / 1e3, "kernel_ms": ms, "active_samples_per_ray": sa,
-                        "executed_mfma_TFLOPs": None if fl is None else fl / (ms * 1e-3) / 1e12,
-                        "mfma_frac_of_157.3": None if fl is None else fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
-                        "physical": physical_roofs(px, ms),
-                        "algorithmic_d3_GBps (model, not a bound)": alg_bytes_per_ray(sa, mdl) * n_total / (ms * 1e-3) / 1e9}
+                        if mdl == "triplane":
+                            per_pass = 548 if flags.get("no_fold") else (64 if flags.get("bake_color") else 208)
+                            fl = sx[2] * per_pass * 2048.0 + (0 if flags.get("no_fold") else (n_total // 8) * 16 * 2048.0)
+                        else:
+                            fl = None if px is None else px.get("mfma_flops_per_dispatch")
+                        entry.update({"executed_mfma_TFLOPs": None if fl is None else fl / (ms * 1e-3) / 1e12,
+                                      "mfma_frac_of_157.3": None if fl is None else fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF})
+                    entry["physical"] = physical_roofs(px, ms)
+                    entry["algorithmic_d3_GBps (model, not a bound)"] = alg_bytes_per_ray(sa, mdl) * n_total / (ms * 1e-3) / 1e9
+                    extras[f"{mdl}_{preset}{tag}"] = entry
                     fx.release()
                 except Exception as ex:  # an extra must never take the headline number down with it
                     extras[f"{mdl}_{preset}"] = {"error": repr(ex)}

@@ -100,6 +100,13 @@ if "SQ_INSTS_VALU_MFMA_MOPS_F32" in m:
     out["mfma_flops_per_dispatch"] = m["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512
     print(f"MFMA f32 flops/dispatch = {out['mfma_flops_per_dispatch']:.4g} -> {out['mfma_flops_per_dispatch'] / (ms * 1e-3) / 1e12:.1f} TFLOP/s "
           f"= {100 * out['mfma_flops_per_dispatch'] / (ms * 1e-3) / 157.3e12:.1f} % of the 157.3 TFLOP/s fp32 matrix peak (at the PMC-run duration)")
+if m.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0) > 0:
+    out["mfma_bf16_flops_per_dispatch"] = m["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512
+    print(f"MFMA bf16 flops/dispatch = {out['mfma_bf16_flops_per_dispatch']:.4g} -> {out['mfma_bf16_flops_per_dispatch'] / (ms * 1e-3) / 1e12:.1f} TFLOP/s "
+          f"= {100 * out['mfma_bf16_flops_per_dispatch'] / (ms * 1e-3) / 2500e12:.1f} % of the ~2500 TFLOP/s dense bf16 matrix peak")
+if "SQ_VALU_MFMA_COEXEC_CYCLES" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+    out["mfma_valu_coexec_frac_of_mfma_busy"] = m["SQ_VALU_MFMA_COEXEC_CYCLES"] / max(m["SQ_VALU_MFMA_BUSY_CYCLES"], 1.0)
+    print(f"VALU / MFMA co-execution = {100 * out['mfma_valu_coexec_frac_of_mfma_busy']:.1f} % of the MFMA-busy cycles (SQ_VALU_MFMA_COEXEC_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES)")
 if "SQ_INSTS_VMEM_RD" in m:
     out["vmem_read_insts_per_launch"] = m["SQ_INSTS_VMEM_RD"]
 so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neural-gauge-fields_amd", "csrc", "libngf_hip.so")
