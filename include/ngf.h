@@ -240,8 +240,11 @@ int ngf_train_adam(ngf_trainer *t, int32_t which, int32_t step_count, float lr, 
  *   [24..28] net_texture.block2.{0,2,4,6,8}            295-256, 3x 256-256, 256-3          (decoder.py:27-34)
  * sphere: primitive_type == 'sphere' (uv = normalize(q) in R^3) else 'square' (uv = tanh(q) in R^2). */
 #define NGF_UV_LAYERS 29
+enum { NGF_UV_F_SPLIT_BF16 = 1 };   /* ngf_uv_desc.flags: the eighteen 256 -> 256 layers and block2.0 (94 % of the MACs) as six bf16 MFMA
+                                       products per fp32 product (3-term split operands, fp32 accumulate): fp32-level error; opt-in */
 typedef struct ngf_uv_desc {
     int32_t sphere;
+    int32_t flags;                  /* NGF_UV_F_* (occupies what was alignment padding: the layout of the other members is unchanged) */
     const float *w[NGF_UV_LAYERS];
     const float *b[NGF_UV_LAYERS];
 } ngf_uv_desc;

@@ -45,7 +45,10 @@ UV_LAYERS = 29
 
 
 class UvDesc(C.Structure):
-    _fields_ = [("sphere", C.c_int32), ("w", C.c_void_p * UV_LAYERS), ("b", C.c_void_p * UV_LAYERS)]
+    _fields_ = [("sphere", C.c_int32), ("flags", C.c_int32), ("w", C.c_void_p * UV_LAYERS), ("b", C.c_void_p * UV_LAYERS)]
+
+
+UV_F_SPLIT_BF16 = 1
 
 
 def build(force: bool = False) -> str:

@@ -56,6 +56,45 @@ struct UvPacker {
             }
         return off;
     }
+    // split-bf16 image of a 256-unit layer: [KB][4 groups][3 parts][4 tiles][64 lanes][8 bf16]; imap(j, kq) = input index of the lane
+    // quarter's j-th input (j = 8 kb + e), as in dense()
+    static uint16_t f2bf(float x)
+    {
+        uint32_t u;
+        memcpy(&u, &x, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+        return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    static float bf2f(uint16_t h)
+    {
+        const uint32_t u = (uint32_t)h << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    }
+    template <typename F>
+    int dense_bf16(const std::vector<float> &W, int out_f, int in_f, int KB, F imap)
+    {
+        const int off = align();
+        buf.resize(off + (size_t)KB * 4 * 12 * 64 * 4, 0.0f);
+        uint16_t *h16 = reinterpret_cast<uint16_t *>(buf.data() + off);
+        for (int kb = 0; kb < KB; ++kb)
+            for (int g = 0; g < 4; ++g)
+                for (int e = 0; e < 4; ++e)
+                    for (int l = 0; l < 64; ++l)
+                        for (int ee = 0; ee < 8; ++ee) {
+                            const int o = (4 * g + e) * 16 + (l & 15), i = imap(kb * 8 + ee, l >> 4);
+                            const float wv = (o < out_f && i >= 0 && i < in_f) ? W[(size_t)o * in_f + i] : 0.0f;
+                            uint16_t p3[3];
+                            p3[0] = f2bf(wv);
+                            const float r1 = wv - bf2f(p3[0]);
+                            p3[1] = f2bf(r1);
+                            p3[2] = f2bf(r1 - bf2f(p3[1]));
+                            for (int part = 0; part < 3; ++part)
+                                h16[(((((size_t)kb * 4 + g) * 3 + part) * 4 + e) * 64 + l) * 8 + ee] = p3[part];
+                        }
+        return off;
+    }
     int bias(const std::vector<float> &b, int out_f, int NT)
     {
         const int off = align();
@@ -104,6 +143,7 @@ extern "C" int ngf_uv_create(const ngf_uv_desc *d, ngf_uv **out, void *hip_strea
     UvArgs &A = m->proto;
     memset(&A, 0, sizeof(A));
     A.sphere = d->sphere ? 1 : 0;
+    A.split_bf16 = (d->flags & NGF_UV_F_SPLIT_BF16) ? 1 : 0;
     UvPacker P;
     auto nat = [](int t, int kq) { return 4 * t + kq; };                      // positional-encoding inputs: natural order
     auto hid = [](int t, int kq) { return UvPacker::hidden(t, kq); };         // previous layer's accumulator order
@@ -146,6 +186,21 @@ extern "C" int ngf_uv_create(const ngf_uv_desc *d, ngf_uv **out, void *hip_strea
         if (l == 0) A.t2_bh = o;
     }
     A.t2_wo = P.out_layer(W[28], 3, 256, 64, hid);   A.t2_bo = P.bias4(B[28], 3);
+    if (A.split_bf16) {
+        for (int l = 0; l < 10; ++l) {
+            const int o = P.dense_bf16(W[1 + l], 256, 256, 8, hid);
+            if (l == 0) A.geo_qh = o;
+        }
+        for (int l = 0; l < 5; ++l) {
+            const int o = P.dense_bf16(W[18 + l], 256, 256, 8, hid);
+            if (l == 0) A.t1_qh = o;
+        }
+        A.t2_q0 = P.dense_bf16(W[24], 256, 295, 10, [](int t, int kq) { return t < 64 ? UvPacker::hidden(t, kq) : (t < 76 ? 256 + 4 * (t - 64) + kq : -1); });
+        for (int l = 0; l < 3; ++l) {
+            const int o = P.dense_bf16(W[25 + l], 256, 256, 8, hid);
+            if (l == 0) A.t2_qh = o;
+        }
+    }
     P.align();
     auto bail = [&](int code) { ngf_uv_destroy(m); return code; };
     if (hipMalloc((void **)&m->w, P.buf.size() * sizeof(float)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(uv weights) failed"));
@@ -212,12 +267,17 @@ extern "C" int ngf_uv_render(const ngf_uv *m, const float *campos_host, const fl
     // two rays per wave (every weight load feeds two MFMAs, 4 waves per CU) unless ngf_debug_set("uv_tiles", 1) (one ray per wave, 8 waves)
     int tiles = 2;
     if (knob(KNOB_UV_TILES) >= 0) tiles = knob(KNOB_UV_TILES);
-    if (tiles == 2) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(uv_render_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(uv_render_kernel<2>, dim3((unsigned)grid), dim3(256), lds, st, A);
+    if (tiles == 2 && A.split_bf16) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(uv_render_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((uv_render_kernel<2, true>), dim3((unsigned)grid), dim3(256), lds, st, A);
+    } else if (tiles == 2) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(uv_render_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((uv_render_kernel<2, false>), dim3((unsigned)grid), dim3(256), lds, st, A);
+    } else if (tiles == 1 && A.split_bf16) {
+        return fail(NGF_E_ARG, "NGF_UV_F_SPLIT_BF16 runs the two-rays-per-wave kernel only (knob uv_tiles must stay 2)");
     } else if (tiles == 1) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(uv_render_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(uv_render_kernel<1>, dim3((unsigned)grid), dim3(512), lds, st, A);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(uv_render_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((uv_render_kernel<1, false>), dim3((unsigned)grid), dim3(512), lds, st, A);
     } else {
         return fail(NGF_E_ARG, "knob uv_tiles must be 1 or 2");
     }

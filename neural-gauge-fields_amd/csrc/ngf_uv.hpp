@@ -36,6 +36,8 @@ struct UvArgs {
     // texture editing (decoder.py:79-121): cubemap_ [6,R,R,C] (sphere) or square [H,W,C], NULL = plain texture branch
     const float *tex;
     int32_t tex_h, tex_w, tex_c, tex_mode;
+    int32_t split_bf16;    // NGF_UV_F_SPLIT_BF16: the 256 -> 256 layers and block2.0 run as 3-term split bf16 products (dense_bf16)
+    int32_t pad2_;
     const float *w;        // packed weights / biases (offsets below, floats)
     // geometry
     int32_t geo_w0, geo_b0, geo_wh, geo_bh, geo_wo, geo_bo;       // wh/bh: 10 hidden layers, strides 65536 / 256
@@ -43,6 +45,8 @@ struct UvArgs {
     int32_t ga_w0, ga_b0, ga_w1, ga_b1, ga_w2, ga_b2, ga_w3, ga_b3, ga_wo, ga_bo;
     // texture
     int32_t t1_w0, t1_b0, t1_wh, t1_bh, c1_w, c1_b, t2_w0, t2_b0, t2_wh, t2_bh, t2_wo, t2_bo;
+    // split mode: bf16 images of the 256 -> 256 layers (stride kUvQLayer floats) and of block2.0 (10 k-blocks)
+    int32_t geo_qh, t1_qh, t2_q0, t2_qh;
 };
 
 __device__ __forceinline__ float act_fn(float x, float slope) { return fmaxf(x, 0.0f) + slope * fminf(x, 0.0f); }
@@ -145,6 +149,7 @@ __global__ void __launch_bounds__(256) uv_texture_edit_kernel(const float *tex, 
     }
 }
 
+constexpr int kUvQLayer = 8 * 4 * 12 * 64 * 4;      // floats of one 256 -> 256 layer's split-bf16 image: [8 k-blocks][4 groups][12 fragments][64 lanes][8 bf16]
 constexpr int kUvActSteps = 80;                    // k-steps of per-wave activation storage (74 used by block2.0)
 constexpr int kUvWaveLds = kUvActSteps * 64;       // floats per wave
 
@@ -254,6 +259,100 @@ __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4
     }
 }
 
+
+// ---- NGF_UV_F_SPLIT_BF16: a 256-unit dense layer on v_mfma_f32_16x16x32_bf16 with 3-term split operands -----------------------------
+// The technique of ngf_shade_bf16.hpp: every fp32 product becomes the six bf16 products of order <= 2 of (hi, mid, lo) splits, fp32
+// accumulate, fp32-level error.  A k-block is 8 of the lane's inputs (32 of the layer's): the B fragments are split from the fp32
+// activations in LDS once per k-block and serve all 16 unit tiles; the A fragments (weights, split on the host) stream from L2 as
+// [k-block][4 tile groups][3 parts][4 tiles][lane][8 bf16], in tile pairs, four pairs (96 registers) in flight.  A layer costs 768 x NS bf16 MFMAs (~17 cycles each) instead of 1024 x NS fp32 MFMAs (~33).
+typedef short uv_bf16x8 __attribute__((ext_vector_type(8)));
+struct UvSplit8 { uv_bf16x8 h, m, l; };
+__device__ __forceinline__ UvSplit8 uv_split8(const float x[8])
+{
+    UvSplit8 s;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hb = (__bf16)x[e];
+        const float r1 = x[e] - (float)hb;
+        const __bf16 mb = (__bf16)r1;
+        const float r2 = r1 - (float)mb;
+        const __bf16 lb = (__bf16)r2;
+        s.h[e] = __builtin_bit_cast(short, hb);
+        s.m[e] = __builtin_bit_cast(short, mb);
+        s.l[e] = __builtin_bit_cast(short, lb);
+    }
+    return s;
+}
+struct UvAPair { uv_bf16x8 a[3][2]; };            // [part hi / mid / lo][tile of the pair]: 24 registers
+// pair g2 (0..7) of k-block kb: tiles 2 g2, 2 g2 + 1
+__device__ __forceinline__ void uv_gload(const float *wq, int kb, int g2, int lane, UvAPair &G)
+{
+    const uv_bf16x8 *p = reinterpret_cast<const uv_bf16x8 *>(wq) + ((size_t)(kb * 4 + (g2 >> 1)) * 12 + (g2 & 1) * 2) * 64 + lane;
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) G.a[part][e] = p[(part * 4 + e) * 64];
+}
+#define NGF_UV_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// the six products for the two tiles of a pair, product-major so that consecutive MFMAs hit different accumulators
+template <int NS>
+__device__ __forceinline__ void uv_gmma(const UvAPair &G, const UvSplit8 x[NS], f32x4 out[NS][16], int base)
+{
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr) {
+        // smallest terms first: (A lo, B hi), (A hi, B lo), (A mid, B mid), (A mid, B hi), (A hi, B mid), (A hi, B hi)
+        const int pa = pr == 0 ? 2 : (pr == 2 || pr == 3 ? 1 : 0);
+        const int pb = pr == 1 ? 2 : (pr == 2 || pr == 4 ? 1 : 0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const uv_bf16x8 b = pb == 0 ? x[s].h : (pb == 1 ? x[s].m : x[s].l);
+                out[s][base + e] = NGF_UV_MFMA_BF16(G.a[pa][e], b, out[s][base + e]);
+            }
+    }
+}
+
+// KB k-blocks (8 inputs of every lane each; padded inputs have zero weights); act as in dense(): act[s][t][lane], t = the lane's input
+// index.  Four tile pairs (96 registers) are in flight: the pair consumed now was requested three pairs (72 x NS MFMAs) earlier.
+template <int NS>
+__device__ __forceinline__ void dense_bf16(const float *wq, const float *bias, int KB, int lane, const float *act, f32x4 out[NS][16])
+{
+    load_bias<16, NS>(bias, lane >> 4, out);
+    UvAPair A0, A1, A2, A3;
+    uv_gload(wq, 0, 0, lane, A0); uv_gload(wq, 0, 1, lane, A1); uv_gload(wq, 0, 2, lane, A2); uv_gload(wq, 0, 3, lane, A3);
+#pragma unroll 1
+    for (int kb = 0; kb < KB; ++kb) {
+        UvSplit8 x[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = act[s * kUvWaveLds + (kb * 8 + e) * 64 + lane];
+            x[s] = uv_split8(v);
+        }
+        const int kn = kb + 1 < KB ? kb + 1 : kb;                // last k-block: harmless reload instead of a branch
+        __builtin_amdgcn_sched_barrier(0);
+        uv_gmma<NS>(A0, x, out, 0);   __builtin_amdgcn_sched_barrier(0);  uv_gload(wq, kb, 4, lane, A0);  __builtin_amdgcn_sched_barrier(0);
+        uv_gmma<NS>(A1, x, out, 2);   __builtin_amdgcn_sched_barrier(0);  uv_gload(wq, kb, 5, lane, A1);  __builtin_amdgcn_sched_barrier(0);
+        uv_gmma<NS>(A2, x, out, 4);   __builtin_amdgcn_sched_barrier(0);  uv_gload(wq, kb, 6, lane, A2);  __builtin_amdgcn_sched_barrier(0);
+        uv_gmma<NS>(A3, x, out, 6);   __builtin_amdgcn_sched_barrier(0);  uv_gload(wq, kb, 7, lane, A3);  __builtin_amdgcn_sched_barrier(0);
+        uv_gmma<NS>(A0, x, out, 8);   __builtin_amdgcn_sched_barrier(0);  uv_gload(wq, kn, 0, lane, A0);  __builtin_amdgcn_sched_barrier(0);
+        uv_gmma<NS>(A1, x, out, 10);  __builtin_amdgcn_sched_barrier(0);  uv_gload(wq, kn, 1, lane, A1);  __builtin_amdgcn_sched_barrier(0);
+        uv_gmma<NS>(A2, x, out, 12);  __builtin_amdgcn_sched_barrier(0);  uv_gload(wq, kn, 2, lane, A2);  __builtin_amdgcn_sched_barrier(0);
+        uv_gmma<NS>(A3, x, out, 14);  __builtin_amdgcn_sched_barrier(0);  uv_gload(wq, kn, 3, lane, A3);  __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// a 256-unit layer on KT4 fp32 k-steps or (split mode) KT4 / 8 bf16 k-blocks; wq: the layer's packed bf16 weights (split mode)
+template <int NS, bool SPLIT>
+__device__ __forceinline__ void dense256(const UvArgs &A, const float *w, const float *wq, const float *bias, int KT4, int lane, const float *act,
+                                         f32x4 out[NS][16])
+{
+    if constexpr (SPLIT) dense_bf16<NS>(wq, bias, (KT4 + 7) / 8, lane, act, out);
+    else dense<16, NS>(w, bias, KT4, lane, act, out);
+}
+
 template <int NT, int NS>
 __device__ __forceinline__ void store_act(float *act, int lane, const f32x4 acc[NS][NT], float slope)
 {
@@ -316,7 +415,7 @@ __device__ __forceinline__ void store_pe(float *act, int t0, int KT, int lane, c
 // ---- the three networks for NS x 16 samples -----------------------------------------------------------------------------
 // p: position of the lane's sample in each tile, v: its ray direction.  Returns sigma and colour (identical in the 4 lanes of a
 // sample).
-template <int NS>
+template <int NS, bool SPLIT>
 __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lane, const float p[NS][3], const float v[NS][3], float sigma[NS],
                                             float col[NS][3])
 {
@@ -328,7 +427,7 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     store_act<16, NS>(act, lane, x, 0.0f);
 #pragma unroll 1
     for (int l = 0; l < 10; ++l) {
-        dense<16, NS>(W + A.geo_wh + (size_t)l * 65536, W + A.geo_bh + l * 256, 64, lane, act, x);
+        dense256<NS, SPLIT>(A, W + A.geo_wh + (size_t)l * 65536, W + A.geo_qh + (size_t)l * kUvQLayer, W + A.geo_bh + l * 256, 64, lane, act, x);
         store_act<16, NS>(act, lane, x, 0.0f);
     }
     {
@@ -374,7 +473,7 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     store_act<16, NS>(act, lane, x, 0.2f);
 #pragma unroll 1
     for (int l = 0; l < 5; ++l) {
-        dense<16, NS>(W + A.t1_wh + (size_t)l * 65536, W + A.t1_bh + l * 256, 64, lane, act, x);
+        dense256<NS, SPLIT>(A, W + A.t1_wh + (size_t)l * 65536, W + A.t1_qh + (size_t)l * kUvQLayer, W + A.t1_bh + l * 256, 64, lane, act, x);
         store_act<16, NS>(act, lane, x, 0.2f);
     }
     // act[0..63] = block1 output h; color1 and block2 both read it
@@ -382,11 +481,11 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     dense_out<NS>(W + A.c1_w, W + A.c1_b, 64, lane, act, c1);
     // block2: [h(256), v(3), PE6(v)(36)] -> 256 -> (3x) 256 -> 3
     store_pe<3, 6, NS>(act, 64, 12, lane, v);                 // 39 inputs + zero padding up to k-step 76
-    dense<16, NS>(W + A.t2_w0, W + A.t2_b0, 76, lane, act, x);
+    dense256<NS, SPLIT>(A, W + A.t2_w0, W + A.t2_q0, W + A.t2_b0, 76, lane, act, x);            // 76 k-steps -> 10 k-blocks in split mode (act rows 76..79 are zero)
     store_act<16, NS>(act, lane, x, 0.2f);
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
-        dense<16, NS>(W + A.t2_wh + (size_t)l * 65536, W + A.t2_bh + l * 256, 64, lane, act, x);
+        dense256<NS, SPLIT>(A, W + A.t2_wh + (size_t)l * 65536, W + A.t2_qh + (size_t)l * kUvQLayer, W + A.t2_bh + l * 256, 64, lane, act, x);
         store_act<16, NS>(act, lane, x, 0.2f);
     }
     dense_out<NS>(W + A.t2_wo, W + A.t2_bo, 64, lane, act, c2);
@@ -406,7 +505,7 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
 // One wave renders NS rays at a time: lane i owns sample i of a 64-sample chunk of each (segment jitter, prefix sum, position,
 // in-cube test); the in-cube samples of the NS rays form ONE list (ray 0's first) that is pushed through the networks NS x 16 at
 // a time.
-template <int NS>
+template <int NS, bool SPLIT = false>
 __global__ void __launch_bounds__(512 / NS) uv_render_kernel(const UvArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -502,7 +601,7 @@ __global__ void __launch_bounds__(512 / NS) uv_render_kernel(const UvArgs A)
                     }
                 }
                 float sg[NS], cc[NS][3];
-                uv_networks<NS>(A, act, lane, q, vq, sg, cc);
+                uv_networks<NS, SPLIT>(A, act, lane, q, vq, sg, cc);
                 // owners pull their result from lane slot (kq = 0 copy) of their tile
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {

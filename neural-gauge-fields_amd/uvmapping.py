@@ -73,9 +73,10 @@ class TextureMlpDecoder(nn.Module):
 
 
 class NeuTex(nn.Module):
-    def __init__(self, opt=None, primitive_type=None, sample_num=None, device='cuda'):
+    def __init__(self, opt=None, primitive_type=None, sample_num=None, device='cuda', split_bf16=False):
         super().__init__()
         self.opt = opt
+        self.split_bf16 = bool(split_bf16)          # NGF_UV_F_SPLIT_BF16: 256-unit layers as 3-term split bf16 MFMA products (opt-in)
         self.primitive_type = primitive_type or getattr(opt, 'primitive_type', 'square')
         self.sample_num = int(sample_num or getattr(opt, 'sample_num', 64))
         self.device = device
@@ -159,6 +160,7 @@ class NeuTex(nn.Module):
             raise RuntimeError("ngf_amd NeuTex renders on the GPU only (device='cuda'); there is no CPU path")
         d = _lib.UvDesc()
         d.sphere = int(self.primitive_type != 'square')
+        d.flags = _lib.UV_F_SPLIT_BF16 if self.split_bf16 else 0
         keep = []
         for i, lin in enumerate(self.layers()):
             w = lin.weight.detach().to(dev, torch.float32).contiguous()

@@ -71,3 +71,41 @@ def test_two_rays_per_wave_is_bit_identical():
         with _lib.knobs(uv_tiles=1):
             one = net(cp, rd, None, jitter_u=U)
         assert torch.equal(two["color"], one["color"]) and torch.equal(two["transmittance"], one["transmittance"]), n
+
+
+@pytest.mark.parametrize("name", ["uv_sphere", "uv_square"])
+def test_uv_split_bf16_keeps_the_fp32_tolerances(name):
+    """NGF_UV_F_SPLIT_BF16 (opt-in): the eighteen 256 -> 256 layers and block2.0 as six bf16 MFMA products per fp32 product
+    (3-term split operands, fp32 accumulate; csrc/ngf_uv.hpp dense_bf16).  The path is ill-conditioned by construction, so the
+    bar is the one the fp32-MFMA kernel is held to: the same tolerances against the oracle and the reference's golden pixels --
+    and the split kernel must sit as close to the oracle as the fp32 kernel does (its rounding noise is of the same size)."""
+    from ngf_amd import uvmapping
+    g, params = load_uv_case(name)
+    pt = str(g["primitive_type"])
+    orc = OracleUV(params, pt)
+    o_color, o_trans, dbg = orc.render(g["campos"], g["raydir"], g["U"], bg=g["bg"], debug=True)
+    args = (torch.from_numpy(g["campos"])[None], torch.from_numpy(g["raydir"])[None], torch.from_numpy(g["bg"])[None])
+    res = {}
+    for split in (False, True):
+        m = uvmapping.NeuTex(primitive_type=pt, sample_num=int(g["S"]), device="cuda", split_bf16=split)
+        m.load_params(params)
+        out = m(*args, jitter_u=torch.from_numpy(g["U"])[None], debug=True)
+        res[split] = (out["color"][0].cpu().numpy(), out["transmittance"][0].cpu().numpy(), out["sigma"][0].cpu().numpy(),
+                      out["point_color"][0].cpu().numpy())
+        m.release()
+    valid = dbg["valid"].astype(bool)
+    color, trans, sigma, pcol = res[True]
+    assert np.array_equal(sigma != 0, valid), "in-cube mask differs"
+    np.testing.assert_allclose(sigma[valid], dbg["sigma"][valid], rtol=5e-4, atol=1e-6)
+    assert np.abs(pcol[valid] - dbg["col"][valid]).max() < 5e-3
+    e = {s: (np.abs(res[s][1] - o_trans).max(), np.abs(res[s][0] - o_color).max(), np.abs(res[s][0] - g["color"]).max()) for s in (False, True)}
+    print(f"{name}: max|T-oracle| fp32 {e[False][0]:.2e} split {e[True][0]:.2e}; max|color-oracle| fp32 {e[False][1]:.2e} split {e[True][1]:.2e}; "
+          f"max|color-reference| fp32 {e[False][2]:.2e} split {e[True][2]:.2e}; max|color split - fp32| {np.abs(res[True][0] - res[False][0]).max():.2e}")
+    assert e[True][0] < 2e-5 and e[True][1] < 5e-4 and e[True][2] < 5e-4
+    assert e[True][1] < 3 * e[False][1] + 2e-5             # no worse than the fp32 kernel's own rounding noise (x3 slack)
+    with pytest.raises(RuntimeError):
+        from ngf_amd import _lib
+        m = uvmapping.NeuTex(primitive_type=pt, sample_num=int(g["S"]), device="cuda", split_bf16=True)
+        m.load_params(params)
+        with _lib.knobs(uv_tiles=1):
+            m(*args, jitter_u=torch.from_numpy(g["U"])[None])
