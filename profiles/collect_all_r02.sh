@@ -15,6 +15,7 @@ for wl in triplane_R1 triplane_R0 triplane_R2 triplane_R1_bd triplane_R1_bdc tri
   bash profiles/collect.sh r02_$wl $wl "ngf::render_kernel" > /dev/null 2>&1
 done
 bash profiles/collect.sh r02_uv_sphere uv_sphere "uv_render_kernel" > /dev/null 2>&1
+bash profiles/collect.sh r02_uv_sphere_split uv_sphere_split "uv_render_kernel" > /dev/null 2>&1
 NGF_STAGE=1 bash profiles/collect.sh r02_triplane_R0_staged triplane_R0 "ngf::render_kernel" > /dev/null 2>&1
 NGF_KERNEL=1 NGF_WAVES=88 bash profiles/collect.sh r02_triplane_R1_pc88 triplane_R1 "render_pc_kernel" > /dev/null 2>&1
 # training step: per-kernel times
