@@ -32,7 +32,7 @@ def field_for_case(g, params, mask, device="cuda", bake=False, bake_color=False,
     if str(g["model"]) == "triplane":
         f = triplane.TriPlane(aabb, grid, device, gauge_start=0, bake_density=bake, bake_color=bake_color, no_fold=no_fold, split_bf16=split_bf16, **kw)
     else:
-        f = infoinv.TriPlane(aabb, grid, device, **kw)
+        f = infoinv.TriPlane(aabb, grid, device, split_bf16=split_bf16, **kw)
     f.load_params(params)
     if mask is not None:
         bits, dhw, maabb = mask

@@ -263,6 +263,59 @@ static void build_rgb_image_bf16(int F, const std::vector<float> &basis, const s
     img[L::B3 + 3] = 0.0f;
 }
 
+// NGF_F_SPLIT_BF16 for InfoInv (ngf_infoinv.hpp mlp_pass_bf16_ii): LDS image (layer 2 fragments, biases, layer 3) and the streamed
+// layer-1 image [15 k-blocks][2 unit tiles][3 parts][64 lanes][8 bf16]; lane (i, hi), element e of k-block b holds the weight of
+// unit nt*32 + i for the lane half's (8 b + e)-th input: features (plane j/36, channel hi*36 + j%36), then its 8 view entries
+static void build_rgb_image_bf16_ii(int F, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
+                                    const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3, const std::vector<float> &b3,
+                                    float *img, std::vector<float> &w1pack)
+{
+    using L = MlpLayoutBf16II;
+    const int IN = F + 15, HALF = F / 6;
+    std::vector<double> w1f((size_t)64 * (F + 16), 0.0);
+    for (int n = 0; n < 64; ++n) {
+        for (int k = 0; k < F; ++k) {
+            double s = 0.0;
+            for (int j = 0; j < F; ++j) s += (double)w1[(size_t)n * IN + j] * (double)basis[(size_t)j * F + k];
+            w1f[(size_t)n * (F + 16) + k] = s;
+        }
+        for (int k = 0; k < 15; ++k) w1f[(size_t)n * (F + 16) + F + k] = w1[(size_t)n * IN + F + k];
+    }
+    auto unit = [](int k, int hi) { return (k >> 4) * 32 + ((k & 15) & 3) + 8 * ((k & 15) >> 2) + 4 * hi; };      // accumulator order of the 32x32 tile pair
+    w1pack.assign(kW1PackII, 0.0f);
+    uint16_t *p16 = reinterpret_cast<uint16_t *>(w1pack.data());
+    for (int b = 0; b < L::KB1; ++b)
+        for (int nt = 0; nt < 2; ++nt)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int hi = l >> 5, n = nt * 32 + (l & 31), j = 8 * b + e;
+                    float wv = 0.0f;
+                    if (j < 3 * HALF) wv = (float)w1f[(size_t)n * (F + 16) + (j / HALF) * (2 * HALF) + hi * HALF + (j % HALF)];
+                    else if (j < 3 * HALF + 8) wv = (float)w1f[(size_t)n * (F + 16) + F + hi * 8 + (j - 3 * HALF)];
+                    uint16_t p3[3];
+                    split3(wv, p3);
+                    for (int part = 0; part < 3; ++part) p16[((((size_t)b * 2 + nt) * 3 + part) * 64 + l) * 8 + e] = p3[part];
+                }
+    uint16_t *h16 = reinterpret_cast<uint16_t *>(img + L::W2);
+    for (int mt = 0; mt < 2; ++mt)
+        for (int q = 0; q < L::KB2; ++q)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    uint16_t p3[3];
+                    split3(w2[(size_t)(mt * 32 + (l & 31)) * 64 + unit(8 * q + e, l >> 5)], p3);
+                    for (int part = 0; part < 3; ++part) h16[((((size_t)mt * L::KB2 + q) * 3 + part) * 64 + l) * 8 + e] = p3[part];
+                }
+    for (int hi = 0; hi < 2; ++hi)
+        for (int k = 0; k < 32; ++k) {
+            const int n = unit(k, hi);
+            img[L::B1 + hi * 32 + k] = b1[n];
+            img[L::B2 + hi * 32 + k] = b2[n];
+            for (int c = 0; c < 3; ++c) img[L::W3 + c * 64 + hi * 32 + k] = w3[(size_t)c * 64 + n];
+        }
+    for (int c = 0; c < 3; ++c) img[L::B3 + c] = b3[c];
+    img[L::B3 + 3] = 0.0f;
+}
+
 // NGF_F_NO_FOLD: layer 1 un-composed, inputs in the accumulator order of the basis stage; basis packed for streaming
 static void build_rgb_image16_nofold(int F, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
                                      const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3, const std::vector<float> &b3,
@@ -422,6 +475,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     const bool bake_c = tri && (d->flags & NGF_F_BAKE_COLOR);
     const bool no_fold = tri && (d->flags & NGF_F_NO_FOLD);
     const bool split_bf16 = tri && (d->flags & NGF_F_SPLIT_BF16);
+    const bool split_ii = !tri && (d->flags & NGF_F_SPLIT_BF16);
     if (no_fold && (bake || bake_c)) return bail(fail(NGF_E_ARG, "NGF_F_NO_FOLD is the un-composed formulation: it excludes the NGF_F_BAKE_* flags"));
     if (split_bf16 && (bake_c || no_fold)) return bail(fail(NGF_E_ARG, "NGF_F_SPLIT_BF16 applies to the pre-composed layer-1 formulation (no NGF_F_BAKE_COLOR / NGF_F_NO_FOLD)"));
 
@@ -442,13 +496,14 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     }
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "hipStreamSynchronize failed in ngf_field_create"));
 
-    const int rgb_floats = tri ? (split_bf16 ? MlpLayoutBf16::TOTAL : no_fold ? MlpLayout16NoFold::TOTAL : (bake_c ? MlpLayout16Baked::TOTAL : MlpLayout16<48>::TOTAL)) : MlpLayout<72>::TOTAL;
+    const int rgb_floats = tri ? (split_bf16 ? MlpLayoutBf16::TOTAL : no_fold ? MlpLayout16NoFold::TOTAL : (bake_c ? MlpLayout16Baked::TOTAL : MlpLayout16<48>::TOTAL)) : (split_ii ? MlpLayoutBf16II::TOTAL : MlpLayout<72>::TOTAL);
     const int dens_floats = tri ? 0 : InfoInvDensLayout::TOTAL;
     std::vector<float> img((size_t)rgb_floats + dens_floats, 0.0f), wp;
     std::vector<float> bpack;
     if (split_bf16) build_rgb_image_bf16(F, basis, w1, b1, w2, b2, w3, b3, img.data());
     else if (no_fold) build_rgb_image16_nofold(F, basis, w1, b1, w2, b2, w3, b3, img.data(), bpack);
     else if (tri) build_rgb_image16(F, bake_c, basis, w1, b1, w2, b2, w3, b3, img.data(), wp);
+    else if (split_ii) build_rgb_image_bf16_ii(F, basis, w1, b1, w2, b2, w3, b3, img.data(), bpack);
     else build_rgb_image(F, basis, w1, b1, w2, b2, w3, b3, img.data());
     if (!tri) build_infoinv_density_image(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
     if ((rc = alloc_f(&f->blob, img.size(), f))) return bail(rc);
@@ -464,7 +519,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     }
     A.blob = f->blob;
     A.blob_floats = (int)img.size();
-    if (no_fold) {
+    if (no_fold || split_ii) {        // the matrix the shade streams from L2 (level-0 basis / InfoInv split layer 1)
         if ((rc = alloc_f(&f->basis_pack, bpack.size(), f))) return bail(rc);
         if (hipMemcpyAsync(f->basis_pack, bpack.data(), bpack.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess)
             return bail(fail(NGF_E_HIP, "uploading the packed basis matrix failed"));
@@ -655,7 +710,7 @@ static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
 
 static int render_common(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
-    if (f->model == NGF_MODEL_INFOINV) return launch_policy<InfoInvPolicy>(f, A, st);
+    if (f->model == NGF_MODEL_INFOINV) return (f->flags & NGF_F_SPLIT_BF16) ? launch_policy<InfoInvSplitPolicy>(f, A, st) : launch_policy<InfoInvPolicy>(f, A, st);
     if (f->flags & NGF_F_NO_FOLD) return launch_policy<TriPlaneNoFoldPolicy>(f, A, st);
     if (f->flags & NGF_F_SPLIT_BF16) {
         if (knob(KNOB_TILE_W) > 8 || knob(KNOB_SPLIT) == 0) return fail(NGF_E_ARG, "NGF_F_SPLIT_BF16 renders with split tiles of 4 or 8 rays");
@@ -717,7 +772,7 @@ extern "C" int ngf_field_decode_rgb(const ngf_field *f, const float *coords, con
         return NGF_OK;
     };
     int rc;
-    if (f->model == NGF_MODEL_INFOINV) rc = go(decode_rgb_kernel<InfoInvPolicy>);
+    if (f->model == NGF_MODEL_INFOINV) rc = (f->flags & NGF_F_SPLIT_BF16) ? go(decode_rgb_kernel<InfoInvSplitPolicy>) : go(decode_rgb_kernel<InfoInvPolicy>);
     else if (f->flags & NGF_F_NO_FOLD) rc = go(decode_rgb_kernel<TriPlaneNoFoldPolicy>);
     else if (f->flags & NGF_F_SPLIT_BF16) rc = go(decode_rgb_kernel<TriPlaneBf16Policy<false, 8>>);
     else if (f->flags & NGF_F_BAKE_COLOR) rc = go(decode_rgb_kernel<TriPlanePolicy<false, true, 8, 1>>);
@@ -735,9 +790,14 @@ static int launch_alpha(const ngf_field *f, const float *xyz, const Lattice &L, 
     if (grid > 8 * (int64_t)f->num_cus) grid = 8 * (int64_t)f->num_cus;
     if (f->model == NGF_MODEL_INFOINV) {
         const size_t lds = (size_t)((A.blob_floats + 3) & ~3) * sizeof(float);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(alpha_kernel<InfoInvPolicy>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (grid > (int64_t)f->num_cus) grid = f->num_cus;
-        hipLaunchKernelGGL(alpha_kernel<InfoInvPolicy>, dim3((unsigned)grid), dim3(256), lds, st, A, xyz, L, n, length, alpha);
+        if (f->flags & NGF_F_SPLIT_BF16) {        // same density MLP, other offset of its image in the LDS blob
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(alpha_kernel<InfoInvSplitPolicy>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(alpha_kernel<InfoInvSplitPolicy>, dim3((unsigned)grid), dim3(256), lds, st, A, xyz, L, n, length, alpha);
+        } else {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(alpha_kernel<InfoInvPolicy>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(alpha_kernel<InfoInvPolicy>, dim3((unsigned)grid), dim3(256), lds, st, A, xyz, L, n, length, alpha);
+        }
     } else if (f->flags & NGF_F_BAKE_DENSITY) {
         hipLaunchKernelGGL((alpha_kernel<TriPlanePolicy<true, false, 8, 1>>), dim3((unsigned)grid), dim3(256), 0, st, A, xyz, L, n, length, alpha);
     } else {

@@ -163,7 +163,7 @@ class Base(torch.nn.Module):
         d = _lib.FieldDesc()
         keep = []
         d.model, d.plane_c, d.dens_dim = self.MODEL, self.PLANE_C, self.DENS_DIM
-        d.flags = 0
+        d.flags = _lib.F_SPLIT_BF16 if self.split_bf16 else 0
         if self.MODEL == _lib.MODEL_TRIPLANE:
             d.flags = ((_lib.F_BAKE_DENSITY if self.bake_density else 0) | (_lib.F_BAKE_COLOR if self.bake_color else 0) |
                        (_lib.F_NO_FOLD if self.no_fold else 0) | (_lib.F_SPLIT_BF16 if self.split_bf16 else 0))

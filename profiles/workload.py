@@ -36,8 +36,8 @@ if name.startswith(("triplane", "infoinv")):
     g, params, step = cases.big_case(model, preset)
     nofold, split = bake == "nofold", bake.startswith("split")          # "split" | "splitd" (with baked density)
     plain = not (nofold or split)
-    f = cases.field_for_case(g, params, None, device=dev, bake=(plain and "d" in bake) or bake == "splitd", bake_color=plain and "c" in bake,
-                             no_fold=nofold, split_bf16=split)
+    f = cases.field_for_case(g, params, None, device=dev, bake=model == "triplane" and ((plain and "d" in bake) or bake == "splitd"),
+                             bake_color=model == "triplane" and plain and "c" in bake, no_fold=nofold, split_bf16=split)
     rays = nrays.generate_rays(800, 800, nrays.blender_focal(800), synth.lookat_pose())
     kw = {"iteration": 30001} if model == "triplane" else {"infoinv": True}
     run = lambda: f(rays, N_samples=192, white_bg=True, **kw)

@@ -142,6 +142,41 @@ def test_split_march_is_bit_identical(name):
     assert torch.equal(ref["rgb_map"], got["rgb_map"]) and torch.equal(ref["depth_map"], got["depth_map"])
 
 
+@pytest.mark.parametrize("name", INFOINV)
+def test_infoinv_split_bf16_keeps_fp32_accuracy(name):
+    """NGF_F_SPLIT_BF16 on the InfoInv tree: rgb_decoder (216 features + view -> 64 -> 64 -> 3) as 3-term split bf16 products on
+    v_mfma_f32_32x32x16_bf16, layer 1 streamed from L2 (csrc/ngf_infoinv.hpp mlp_pass_bf16_ii); the density MLP and the march are
+    the default's.  Same tolerances against oracle and reference goldens, within fp32 rounding noise of the fp32-MFMA path."""
+    g, params, step, mask = load_case(name)
+    orc = oracle_for_case(g, params, step, mask)
+    fs = field_for_case(g, params, mask, split_bf16=True)
+    fd = field_for_case(g, params, mask)
+    rays = torch.from_numpy(g["rays"]).cuda()
+    S = int(g["S"])
+    kw = _mode(g)
+    a = fs(rays, N_samples=S, white_bg=True, **kw)
+    b = fd(rays, N_samples=S, white_bg=True, **kw)
+    o_rgb, o_depth = orc.render(g["rays"], S, white_bg=True)
+    ea = _close(a["rgb_map"].cpu().numpy(), o_rgb, "split-bf16 rgb vs oracle")
+    _close(a["rgb_map"].cpu().numpy(), g["rgb_map"], "split-bf16 rgb vs reference golden")
+    assert ea < 5e-6
+    assert torch.equal(a["depth_map"], b["depth_map"])
+    assert float((a["rgb_map"] - b["rgb_map"]).abs().max()) < 2e-6
+    from ngf_amd import synth
+    n = 203
+    coords = (synth.hash_uniform(79, 1, (n, 6)) * np.float32(2.2) - np.float32(1.1)).astype(np.float32)
+    coords[:, 2] = coords[:, 1]; coords[:, 4] = coords[:, 0]; coords[:, 5] = coords[:, 3]        # InfoInv's identity split: (x,y),(y,z),(x,z)
+    dirs = synth.hash_normal(79, 2, (n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    mode = int(bool(int(g["infoinv"])))
+    got = fs.decode_rgb(torch.from_numpy(coords), torch.from_numpy(dirs), mode=mode).cpu().numpy()
+    ref = fd.decode_rgb(torch.from_numpy(coords), torch.from_numpy(dirs), mode=mode).cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-6
+    # the alpha-mask helpers run the (unchanged) density MLP from the other LDS image layout
+    pts = torch.from_numpy((synth.hash_uniform(79, 3, (64, 3)) * np.float32(3.0) - np.float32(1.5)).astype(np.float32)).cuda()
+    assert torch.equal(fs.compute_alpha(pts, 0.3), fd.compute_alpha(pts, 0.3))
+
+
 @pytest.mark.parametrize("bake_density", [False, True])
 @pytest.mark.parametrize("name", ["triplane_r1_gauge", "triplane_r2_nogauge", "triplane_r1_mask"])
 def test_split_bf16_colour_mlp_keeps_fp32_accuracy(name, bake_density):
