@@ -60,6 +60,11 @@ __device__ __forceinline__ void swap32(float &a, float &b)
 // density MLP: they stream from L2 as [k-block][2 unit tiles][3 parts][lane][8 bf16], requested one stage (a gather wait + 48
 // interpolations) before their MFMAs.  Layer 2 (4 k-blocks) keeps its fragments in LDS.  180 + 48 bf16 MFMAs of 8 passes replace
 // 232 + 64 fp32 MFMAs of 16 passes per 32 samples.
+// MEASURED (profiles/r02_infoinv_split.txt): correct (max |rgb - fp32 path| < 2e-6) but NOT faster -- 13.77 ms vs 13.56 ms per frame.
+// The two-lanes-per-sample pass already carries 32 accumulators + 36 PE factors + 48 gather registers per lane; the fragments and
+// splits push it past the 256 registers two waves per SIMD have (88 spills), and with one wave per SIMD (no spills) it is
+// 14.8 ms.  Kept as a tested variant behind the flag; the way forward is a four-lanes-per-sample pass (16 accumulators, 18 channels
+// per lane and plane), see DESIGN.md section 9.
 struct MlpLayoutBf16II {                      // LDS image (floats)
     static constexpr int KB1 = 15, KB2 = 4;
     static constexpr int W2 = 0;                              // [2 mt][4 kb][3 parts][64 lanes][4]
