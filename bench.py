@@ -357,7 +357,8 @@ def main():
                         ("triplane", args.preset, {"bake": True, "bake_color": True}, "_bake_density_color", "_bdc"),
                         ("triplane", "R0", {"bake": True}, "_bake_density", "_bd"),
                         ("triplane", "R2", {"bake": True, "bake_color": True}, "_bake_density_color", "_bdc"),
-                        ("infoinv", "R1", {}, "", ""))
+                        ("infoinv", "R1", {}, "", ""),
+                        ("infoinv", "R1", {"split_bf16": True}, "_split_bf16", "_split"))           # correct but not faster: register-bound (profiles/r02_infoinv_split.txt)
             for mdl, preset, flags, tag, ptag_sfx in variants:
                 try:
                     fx, _, _, _ = build_field(mdl, preset, device, **flags)
@@ -369,7 +370,9 @@ def main():
                     sa = sx[1] / n_total
                     px = load_pmc(f"{mdl}_{preset}{ptag_sfx}")
                     entry = {"Mray/s": n_total / ms / 1e3, "kernel_ms": ms, "active_samples_per_ray": sa}
-                    if flags.get("split_bf16"):
+                    if flags.get("split_bf16") and mdl == "infoinv":
+                        entry["note"] = "rgb_decoder as 3-term split bf16 products on v_mfma_f32_32x32x16_bf16; density MLP unchanged"
+                    elif flags.get("split_bf16"):
                         bf = sx[2] * 168 * 2 * 16 * 16 * 32                    # executed bf16 MFMA flops: 168 v_mfma_f32_16x16x32_bf16 per pass
                         entry.update({"executed_bf16_mfma_TFLOPs": bf / (ms * 1e-3) / 1e12, "bf16_mfma_frac_of_2500": bf / (ms * 1e-3) / 1e12 / 2500.0,
                                       "note": "six bf16 products per fp32 product (3-term split, fp32 accumulate): fp32-level error, "

@@ -11,7 +11,7 @@ rm -rf gpurun_out/kt && mkdir -p gpurun_out/kt
 timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/kt -o kt -- python bench.py --extras 0 --cpu-seconds 0 2>/dev/null | grep '^{' > gpurun_out/r02_bench_headline_under_rocprof.json
 python profiles/summarize_rocpd.py $(find gpurun_out/kt -name "*.db" | head -1) > gpurun_out/r02_kernel_stats_headline.txt
 rm -rf gpurun_out/kt
-for wl in triplane_R1 triplane_R0 triplane_R2 triplane_R1_bd triplane_R1_bdc triplane_R0_bd triplane_R2_bdc triplane_R1_nofold triplane_R1_split triplane_R2_split triplane_R1_splitd infoinv_R1; do
+for wl in triplane_R1 triplane_R0 triplane_R2 triplane_R1_bd triplane_R1_bdc triplane_R0_bd triplane_R2_bdc triplane_R1_nofold triplane_R1_split triplane_R2_split triplane_R1_splitd infoinv_R1 infoinv_R1_split; do
   bash profiles/collect.sh r02_$wl $wl "ngf::render_kernel" > /dev/null 2>&1
 done
 bash profiles/collect.sh r02_uv_sphere uv_sphere "uv_render_kernel" > /dev/null 2>&1
