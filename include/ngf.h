@@ -229,6 +229,13 @@ int ngf_train_get_grad(ngf_trainer *t, int32_t which, float *out, void *hip_stre
  * parameter's own step number; l1_weight (planes only) adds d/dp [l1_weight * mean(|p|)] to the gradient. */
 int ngf_train_adam(ngf_trainer *t, int32_t which, int32_t step_count, float lr, float beta1, float beta2, float eps,
                    float l1_weight, void *hip_stream);
+/* optimizer.step() for all 15 parameters: step_count[k] >= 1 updates parameter k with lr[k], step_count[k] <= 0 skips it (a
+ * parameter whose .grad is None).  The six plane updates are one launch each, the nine MLP parameters share one. */
+int ngf_train_adam_all(ngf_trainer *t, const int32_t step_count[NGF_TRAIN_PARAMS], const float lr[NGF_TRAIN_PARAMS], float beta1,
+                       float beta2, float eps, float l1_weight, void *hip_stream);
+/* The trainer keeps channel-last copies of the planes and gauge planes; ngf_train_adam keeps them current.  After writing to a
+ * plane's memory by any other means (checkpoint load, in-place edit) call this: the next backward re-packs all of them. */
+int ngf_train_params_changed(ngf_trainer *t);
 
 /* ---- UV-Mapping (NeuTex) colour path: UV-Mapping/model/model.py:27-59 ----------------------------------------
  * 29 nn.Linear layers in evaluation order, reference layouts (weight [out,in], bias [out], float32, device):

@@ -895,11 +895,15 @@ struct ngf_trainer {
     std::vector<void *> allocs;
     float *tex_d[3] = {}, *tex_a[3] = {}, *tex_g[3] = {};
     float *g_d[3] = {}, *g_a[3] = {}, *g_g[3] = {};
+    float *g_gb[3] = {};                     // gauge-plane gradients in the blocked layout the scatter writes (g_g: [texel][2])
     float *q_d[3] = {}, *d_d[3] = {};        // wd-projected density planes, scalar density-gradient images
     float *fwd_image = nullptr, *bwd_image = nullptr;      // LDS images of the colour MLP (train_fold_kernel)
     float *g_dense[TP_COUNT] = {};          // reference-layout gradient buffers of the MLP parameters (index TP_*)
     int64_t dense_n[TP_COUNT] = {};
     uint8_t *mask = nullptr;
+    bool tex_fresh[6] = {};                 // the packed copy of plane / gauge plane k holds the parameter's current values
+    char *zero_arena = nullptr;             // every buffer a step accumulates into (gradients, M, loss): one memset per step
+    size_t zero_bytes = 0;
     int64_t chunk = 0;
     int64_t bytes = 0;
     int num_cus = 256;
@@ -951,25 +955,52 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
     TrainArgs &T = t->proto;
     memset(&T, 0, sizeof(T));
     RenderArgs &A = T.R;
+    const int64_t dn[TP_COUNT] = {0, 0, 0, 0, 0, 0, 48, 1, 144 * 144, 64 * 159, 64, 64 * 64, 64, 3 * 64, 3};
+    // blocked gradient images (ngf_train.hpp, scatter_blocked): 16-float blocks of 4x4 texels (D_p) / 4x2 texels x 2 channels (gauge)
+    auto dblk = [&](int p) { return (size_t)((d->plane_w[p] + 2 + 3) / 4) * ((d->plane_h[p] + 2 + 3) / 4) * 16; };
+    auto gblk = [&](int p) { return (size_t)((d->gauge_w[p] + 2 + 3) / 4) * ((d->gauge_h[p] + 2 + 1) / 2) * 16; };
+    {   // the zero arena: [per plane: D_p, colour-plane gradient, gauge gradient] [MLP gradients] [M] [loss], 256-byte aligned pieces
+        size_t total = 0;
+        auto add = [&](size_t floats) { total += (floats * sizeof(float) + 255) & ~(size_t)255; };
+        for (int p = 0; p < 3; ++p) {
+            const size_t tex = (size_t)(d->plane_h[p] + 2) * (d->plane_w[p] + 2);
+            add(dblk(p)); add(tex * 48); add(gblk(p));
+        }
+        for (int k = TP_DENS_W; k < TP_COUNT; ++k) add((size_t)dn[k]);
+        add((size_t)64 * 144); add(4);
+        if ((rc = tr_alloc(t, &t->zero_arena, total))) return bail(rc);
+        t->zero_bytes = total;
+    }
+    size_t carved = 0;
+    auto carve = [&](size_t floats) {
+        float *q = reinterpret_cast<float *>(t->zero_arena + carved);
+        carved += (floats * sizeof(float) + 255) & ~(size_t)255;
+        return q;
+    };
     for (int p = 0; p < 3; ++p) {
         const int H = d->plane_h[p], W = d->plane_w[p], gh = d->gauge_h[p], gw = d->gauge_w[p];
         const size_t tex = (size_t)(H + 2) * (W + 2), gtex = (size_t)(gh + 2) * (gw + 2);
         if ((rc = tr_alloc(t, &t->tex_d[p], tex * 16)) || (rc = tr_alloc(t, &t->tex_a[p], tex * 48)) || (rc = tr_alloc(t, &t->tex_g[p], gtex * 2)) ||
-            (rc = tr_alloc(t, &t->q_d[p], tex)) || (rc = tr_alloc(t, &t->d_d[p], tex)) || (rc = tr_alloc(t, &t->g_d[p], tex * 16)) || (rc = tr_alloc(t, &t->g_a[p], tex * 48)) || (rc = tr_alloc(t, &t->g_g[p], gtex * 2)))
+            (rc = tr_alloc(t, &t->q_d[p], tex)) || (rc = tr_alloc(t, &t->g_d[p], tex * 16)) || (rc = tr_alloc(t, &t->g_g[p], gtex * 2)))
             return bail(rc);
+        t->d_d[p] = carve(dblk(p)); t->g_a[p] = carve(tex * 48); t->g_gb[p] = carve(gblk(p));
+        T.d_bw[p] = (W + 2 + 3) / 4; T.g_bw[p] = (gw + 2 + 3) / 4;
         A.dens[p] = Tex{t->tex_d[p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
         A.app[p] = Tex{t->tex_a[p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
         A.gau[p] = Tex{t->tex_g[p], gw, gh, gw + 2, (float)(gw - 1), (float)(gh - 1)};
-        T.g_dens[p] = t->g_d[p]; T.g_app[p] = t->g_a[p]; T.g_gau[p] = t->g_g[p];
+        T.g_dens[p] = t->g_d[p]; T.g_app[p] = t->g_a[p]; T.g_gau[p] = t->g_gb[p];
         T.q_dens[p] = t->q_d[p]; T.d_dens[p] = t->d_d[p];
     }
-    const int64_t dn[TP_COUNT] = {0, 0, 0, 0, 0, 0, 48, 1, 144 * 144, 64 * 159, 64, 64 * 64, 64, 3 * 64, 3};
     for (int k = TP_DENS_W; k < TP_COUNT; ++k) {
         t->dense_n[k] = dn[k];
-        if ((rc = tr_alloc(t, &t->g_dense[k], (size_t)dn[k]))) return bail(rc);
+        t->g_dense[k] = carve((size_t)dn[k]);
     }
+    T.M = carve((size_t)64 * 144);
+    T.loss = reinterpret_cast<double *>(carve(4));
+    if (carved != t->zero_bytes) return bail(fail(NGF_E_ARG, "trainer: zero arena layout mismatch"));
     T.wd = d->dens_w; T.bd = d->dens_b; T.basis = d->basis; T.w1 = d->w1; T.b1 = d->b1; T.w2 = d->w2; T.b2 = d->b2; T.w3 = d->w3; T.b3 = d->b3;
     T.g_wd = t->g_dense[TP_DENS_W]; T.g_bd = t->g_dense[TP_DENS_B];
+    T.g_b1 = t->g_dense[TP_B1]; T.g_b2 = t->g_dense[TP_B2]; T.g_b3 = t->g_dense[TP_B3];
     for (int k = 0; k < 3; ++k) {
         A.a0[k] = d->aabb[k];
         A.a1[k] = d->aabb[3 + k];
@@ -998,10 +1029,20 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
         (rc = tr_alloc(t, &T.dt, cap * 6)) || (rc = tr_alloc(t, &T.G, (size_t)d->max_rays * 3)) || (rc = tr_alloc(t, &T.count, (size_t)d->max_rays)) ||
         (rc = tr_alloc(t, &T.offset, (size_t)d->max_rays + 1)) || (rc = tr_alloc(t, &T.list, cap * 2)) || (rc = tr_alloc(t, &T.list_w, cap)) ||
         (rc = tr_alloc(t, &T.F, ch * 144)) || (rc = tr_alloc(t, &T.V, ch * 16)) || (rc = tr_alloc(t, &T.H1, ch * 64)) || (rc = tr_alloc(t, &T.H2, ch * 64)) ||
-        (rc = tr_alloc(t, &T.D3, ch * 16)) || (rc = tr_alloc(t, &T.D2, ch * 64)) || (rc = tr_alloc(t, &T.D1, ch * 64)) || (rc = tr_alloc(t, &T.M, (size_t)64 * 144)) ||
-        (rc = tr_alloc(t, &t->fwd_image, (size_t)kFwdImage)) || (rc = tr_alloc(t, &t->bwd_image, (size_t)kBwdImage)) ||
-        (rc = tr_alloc(t, &T.loss, (size_t)2)))
+        (rc = tr_alloc(t, &T.D3, ch * 16)) || (rc = tr_alloc(t, &T.D2, ch * 64)) || (rc = tr_alloc(t, &T.D1, ch * 64)) ||
+        (rc = tr_alloc(t, &t->fwd_image, (size_t)kFwdImage)) || (rc = tr_alloc(t, &t->bwd_image, (size_t)kBwdImage)))
         return bail(rc);
+    // the packed copies (their zero borders are written here and never again) and defined gradients before the first backward
+    for (int p = 0; p < 3; ++p) {
+        pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], d->plane_h[p], d->plane_w[p], 0, 16, t->tex_d[p]);
+        pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], d->plane_h[p], d->plane_w[p], 16, 48, t->tex_a[p]);
+        pack_plane_kernel<<<256, 256, 0, st>>>(d->gauge[p], d->gauge_h[p], d->gauge_w[p], 0, 2, t->tex_g[p]);
+        t->tex_fresh[p] = t->tex_fresh[3 + p] = true;
+        if (hipMemsetAsync(t->g_d[p], 0, (size_t)(d->plane_h[p] + 2) * (d->plane_w[p] + 2) * 16 * sizeof(float), st) != hipSuccess ||
+            hipMemsetAsync(t->g_g[p], 0, (size_t)(d->gauge_h[p] + 2) * (d->gauge_w[p] + 2) * 2 * sizeof(float), st) != hipSuccess)
+            return bail(fail(NGF_E_HIP, "trainer setup failed"));
+    }
+    if (hipMemsetAsync(t->zero_arena, 0, t->zero_bytes, st) != hipSuccess) return bail(fail(NGF_E_HIP, "trainer setup failed"));
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "trainer setup failed: %s", hipGetErrorString(hipGetLastError())));
     *out = t;
     return NGF_OK;
@@ -1029,21 +1070,24 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
     A.rays = rays; A.jitter = jitter; A.n = n; A.S = n_samples; A.white_bg = white_bg ? 1 : 0; A.mode = gauge_on ? 1 : 0;
     T.target = rgb_train;
     T.inv_count = 1.0f / (3.0f * (float)n);
-    // parameters -> packed textures (they changed since the last step); gradient buffers -> 0
+    A.ablate = knob(KNOB_ABLATE) > 0 ? knob(KNOB_ABLATE) : 0;      // timing experiments only (profiles/exp_train_ablate.sh)
+    // parameters -> packed textures where the trainer's copy is not current (ngf_train_adam writes the copy along with the parameter;
+    // ngf_train_params_changed marks every copy stale); gradient buffers -> 0
     for (int p = 0; p < 3; ++p) {
         const int H = d.plane_h[p], W = d.plane_w[p], gh = d.gauge_h[p], gw = d.gauge_w[p];
-        const size_t tex = (size_t)(H + 2) * (W + 2), gtex = (size_t)(gh + 2) * (gw + 2);
-        pack_plane_kernel<<<2048, 256, 0, st>>>(d.plane[p], H, W, 0, 16, t->tex_d[p]);
-        pack_plane_kernel<<<2048, 256, 0, st>>>(d.plane[p], H, W, 16, 48, t->tex_a[p]);
-        pack_plane_kernel<<<256, 256, 0, st>>>(d.gauge[p], gh, gw, 0, 2, t->tex_g[p]);
+        const size_t tex = (size_t)(H + 2) * (W + 2);
+        if (!t->tex_fresh[p]) {
+            pack_plane_kernel<<<2048, 256, 0, st>>>(d.plane[p], H, W, 0, 16, t->tex_d[p]);
+            pack_plane_kernel<<<2048, 256, 0, st>>>(d.plane[p], H, W, 16, 48, t->tex_a[p]);
+            t->tex_fresh[p] = true;
+        }
+        if (!t->tex_fresh[3 + p]) {
+            pack_plane_kernel<<<256, 256, 0, st>>>(d.gauge[p], gh, gw, 0, 2, t->tex_g[p]);
+            t->tex_fresh[3 + p] = true;
+        }
         hipLaunchKernelGGL(train_project_density_kernel, dim3(256), dim3(256), 0, st, (const float *)t->tex_d[p], d.dens_w + 16 * p, (int64_t)tex, t->q_d[p]);
-        HIP_TRY(hipMemsetAsync(t->d_d[p], 0, tex * sizeof(float), st));
-        HIP_TRY(hipMemsetAsync(t->g_a[p], 0, tex * 48 * sizeof(float), st));
-        HIP_TRY(hipMemsetAsync(t->g_g[p], 0, gtex * 2 * sizeof(float), st));
     }
-    for (int k = TP_DENS_W; k < TP_COUNT; ++k) HIP_TRY(hipMemsetAsync(t->g_dense[k], 0, (size_t)t->dense_n[k] * sizeof(float), st));
-    HIP_TRY(hipMemsetAsync(T.loss, 0, 2 * sizeof(double), st));
-    HIP_TRY(hipMemsetAsync(T.M, 0, (size_t)64 * 144 * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(t->zero_arena, 0, t->zero_bytes, st));
     T.fwd_image = t->fwd_image; T.bwd_image = t->bwd_image;
     hipLaunchKernelGGL(train_fold_kernel, dim3(48), dim3(256), 0, st, T, t->fwd_image, t->bwd_image);
 
@@ -1098,24 +1142,22 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         const int rows = T.chunk_n;
         int xg = (rows + 31) / 32;                      // 32-sample chunks; at most two workgroups per CU walk them
         if (xg > 2 * t->num_cus) xg = 2 * t->num_cus;
-        int cg = (rows + 255) / 256;
-        if (cg > 4 * t->num_cus) cg = 4 * t->num_cus;
         hipLaunchKernelGGL((xty_block_kernel<1, 4>), dim3(xg), dim3(256), 0, st, (const float *)T.D3, 16, (const float *)T.H2, 64, rows, 3, 64, t->g_dense[TP_W3], 64, cnt);
         hipLaunchKernelGGL((xty_block_kernel<4, 4>), dim3(xg), dim3(256), 0, st, (const float *)T.D2, 64, (const float *)T.H1, 64, rows, 64, 64, t->g_dense[TP_W2], 64, cnt);
         // the 15 view columns of layer 1 directly, the 144 feature columns through M = Delta1^T F (train_unfold_kernel)
         hipLaunchKernelGGL((xty_block_kernel<4, 1>), dim3(xg), dim3(256), 0, st, (const float *)T.D1, 64, (const float *)T.V, 16, rows, 64, 15, t->g_dense[TP_W1] + 144, 159, cnt);
         hipLaunchKernelGGL((xty_block_kernel<4, 9>), dim3(xg), dim3(256), 0, st, (const float *)T.D1, 64, (const float *)T.F, 144, rows, 64, 144, T.M, 144, cnt);
-        hipLaunchKernelGGL(colsum_kernel, dim3(cg), dim3(256), 0, st, (const float *)T.D3, 16, rows, 3, t->g_dense[TP_B3], cnt);
-        hipLaunchKernelGGL(colsum_kernel, dim3(cg), dim3(256), 0, st, (const float *)T.D2, 64, rows, 64, t->g_dense[TP_B2], cnt);
-        hipLaunchKernelGGL(colsum_kernel, dim3(cg), dim3(256), 0, st, (const float *)T.D1, 64, rows, 64, t->g_dense[TP_B1], cnt);
     }
     hipLaunchKernelGGL(train_unfold_kernel, dim3(96), dim3(256), 0, st, T, t->g_dense[TP_W1], t->g_dense[TP_BASIS]);
-    hipLaunchKernelGGL(train_density_bwd_kernel, dim3(tr_grid(t, pairs, 256)), dim3(256), 0, st, T);
+    hipLaunchKernelGGL(train_density_bwd_kernel, dim3(tr_grid(t, n * ((n_samples + 63) / 64), 4, 5)), dim3(256), 0, st, T);     // 33 KB of LDS: 4 workgroups per CU
+    UnblockArgs U;
     for (int p = 0; p < 3; ++p) {
         const int64_t tex = (int64_t)(d.plane_h[p] + 2) * (d.plane_w[p] + 2);
-        hipLaunchKernelGGL(train_density_finish_kernel, dim3(256), dim3(256), 0, st, (const float *)t->d_d[p], (const float *)t->tex_d[p], d.dens_w + 16 * p, tex,
-                           t->g_d[p], t->g_dense[TP_DENS_W] + 16 * p);
+        hipLaunchKernelGGL(train_density_finish_kernel, dim3(256), dim3(256), 0, st, (const float *)t->d_d[p], d.plane_w[p] + 2, T.d_bw[p], (const float *)t->tex_d[p],
+                           d.dens_w + 16 * p, tex, t->g_d[p], t->g_dense[TP_DENS_W] + 16 * p);
+        U.src[p] = t->g_gb[p]; U.dst[p] = t->g_g[p]; U.w2[p] = d.gauge_w[p] + 2; U.h2[p] = d.gauge_h[p] + 2; U.bw[p] = T.g_bw[p];
     }
+    hipLaunchKernelGGL(train_unblock_gauge_kernel, dim3(128, 3), dim3(256), 0, st, U);
     HIP_TRY(hipMemcpyAsync(rgb_loss, T.loss, sizeof(double), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipGetLastError());
     return NGF_OK;
@@ -1161,17 +1203,57 @@ extern "C" int ngf_train_adam(ngf_trainer *t, int32_t which, int32_t step_count,
     if (which < 3) {
         const int p = which, H = d.plane_h[p], W = d.plane_w[p];
         a.l1 = l1_weight / (float)((int64_t)64 * H * W);             // d/dp of l1_weight * mean(|p|)
-        hipLaunchKernelGGL(adam_plane_kernel, dim3(2048), dim3(256), 0, st, d.plane[p], d.exp_avg[which], d.exp_avg_sq[which], 64, H, W,
-                           (const float *)t->g_d[p], 16, (const float *)t->g_a[p], a);
+        if (!t->tex_fresh[p]) return fail(NGF_E_ARG, "ngf_train_adam: the planes changed (ngf_train_params_changed) and no backward has re-packed them");
+        hipLaunchKernelGGL((adam_plane_kernel<64, 16>), dim3(H * ((W + 63) / 64)), dim3(256), 0, st, d.plane[p], d.exp_avg[which], d.exp_avg_sq[which], H, W,
+                           (const float *)t->g_d[p], (const float *)t->g_a[p], t->tex_d[p], t->tex_a[p], a);
     } else if (which < 6) {
         const int p = which - 3;
-        hipLaunchKernelGGL(adam_plane_kernel, dim3(256), dim3(256), 0, st, d.gauge[p], d.exp_avg[which], d.exp_avg_sq[which], 2, d.gauge_h[p], d.gauge_w[p],
-                           (const float *)t->g_g[p], 2, (const float *)nullptr, a);
+        if (!t->tex_fresh[which]) return fail(NGF_E_ARG, "ngf_train_adam: the planes changed (ngf_train_params_changed) and no backward has re-packed them");
+        hipLaunchKernelGGL((adam_plane_kernel<2, 2>), dim3(d.gauge_h[p] * ((d.gauge_w[p] + 63) / 64)), dim3(256), 0, st, d.gauge[p], d.exp_avg[which],
+                           d.exp_avg_sq[which], d.gauge_h[p], d.gauge_w[p], (const float *)t->g_g[p], (const float *)nullptr, t->tex_g[p], (float *)nullptr, a);
     } else {
         float *params[TP_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d.dens_w, d.dens_b, d.basis, d.w1, d.b1, d.w2, d.b2, d.w3, d.b3};
         hipLaunchKernelGGL(adam_dense_kernel, dim3(64), dim3(256), 0, st, params[which], (const float *)t->g_dense[which], d.exp_avg[which],
                            d.exp_avg_sq[which], t->dense_n[which], a);
     }
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+extern "C" int ngf_train_params_changed(ngf_trainer *t)
+{
+    if (!t) return fail(NGF_E_ARG, "ngf_train_params_changed: null trainer");
+    for (bool &f : t->tex_fresh) f = false;
+    return NGF_OK;
+}
+
+extern "C" int ngf_train_adam_all(ngf_trainer *t, const int32_t *step_count, const float *lr, float beta1, float beta2, float eps, float l1_weight,
+                                  void *hip_stream)
+{
+    if (!t || !step_count || !lr) return fail(NGF_E_ARG, "ngf_train_adam_all: null argument");
+    const ngf_train_desc &d = t->d;
+    for (int k = 0; k < 6; ++k)
+        if (step_count[k] > 0) {
+            const int rc = ngf_train_adam(t, k, step_count[k], lr[k], beta1, beta2, eps, l1_weight, hip_stream);
+            if (rc != NGF_OK) return rc;
+        }
+    float *params[TP_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d.dens_w, d.dens_b, d.basis, d.w1, d.b1, d.w2, d.b2, d.w3, d.b3};
+    AdamDenseAll D;
+    int32_t at = 0;
+    for (int j = 0; j < kDenseParams; ++j) {
+        const int k = TP_DENS_W + j;
+        D.p[j] = params[k]; D.m[j] = d.exp_avg[k]; D.v[j] = d.exp_avg_sq[k]; D.g[j] = t->g_dense[k];
+        D.begin[j] = at;
+        AdamArgs &a = D.a[j];
+        a.lr = lr[k]; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.l1 = 0.0f; a.bc1 = 1.0f; a.bc2_sqrt = 1.0f;
+        if (step_count[k] > 0) {
+            a.bc1 = (float)(1.0 - pow((double)beta1, (double)step_count[k]));
+            a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step_count[k]));
+            at += (int32_t)t->dense_n[k];
+        }
+    }
+    D.begin[kDenseParams] = at;
+    if (at > 0) hipLaunchKernelGGL(adam_dense_all_kernel, dim3((at + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, D);
     HIP_TRY(hipGetLastError());
     return NGF_OK;
 }

@@ -32,6 +32,7 @@
 #pragma once
 #include "ngf_device.hpp"
 #include "ngf_render.hpp"
+#include "ngf_stage.hpp"          // wave_min
 
 namespace ngf {
 
@@ -52,12 +53,14 @@ struct TrainArgs {
     const float *wd, *bd;                       // density_decoder.weight [48], bias [1]
     const float *basis, *w1, *b1, *w2, *b2, *w3, *b3;
     float *g_wd, *g_bd;
+    float *g_b1, *g_b2, *g_b3;                  // bias gradients of the colour MLP (summed inside train_color_bwd_kernel)
     float *q_dens[3];        // wd-projected density planes (1 channel, packed): Q_p = sum_c wd[16p+c] plane_p[c]
-    float *d_dens[3];        // scalar density-gradient images: D_p[texel] = sum_samples w_tap * dx
-    // step-major dense per-sample buffers: index = step * n + ray
-    float *xs, *w, *dx;      // [S,n]
-    float *c;                // [S,n,3]
-    float *dt;               // [S,n,6]   d loss / d t from the colour path (active samples only)
+    float *d_dens[3];        // scalar density-gradient images: D_p[texel] = sum_samples w_tap * dx, in 4x4-texel blocks (d_bw per row)
+    int32_t d_bw[3], g_bw[3];                   // blocks per row of d_dens / g_gau (g_gau: 4x2-texel blocks of 2 channels)
+    // ray-major dense per-sample buffers: index = ray * S + step (a wave's 64 consecutive steps of one ray are 64 consecutive floats)
+    float *xs, *w, *dx;      // [n,S]
+    float *c;                // [n,S,3]
+    float *dt;               // [n,S,6]   d loss / d t from the colour path (active samples only)
     const float *target;     // [n,3]
     float *G;                // [n,3]   d loss / d rgb_map (before the clamp), 0 where clamped
     int32_t *count;          // [n]     active samples per ray
@@ -118,6 +121,7 @@ __device__ __forceinline__ bool sample_geometry(const RenderArgs &A, int64_t r, 
 // bilinear cell with what the backward needs: tap weights, the fractions and the d(pixel)/d(coord) scales
 struct BilG {
     int32_t idx;
+    int32_t cx, cy;                // padded (column, row) of the first tap
     float w00, w10, w01, w11;
     float wx0, wx1, wy0, wy1;      // 0 when the cell is out of range
     float sx, sy;                  // d px / d u = (W-1)/2, d py / d v = (H-1)/2
@@ -134,7 +138,8 @@ __device__ __forceinline__ BilG bilg_setup(float u, float v, const Tex &t)
     float cx = fminf(fmaxf(fx, -1.0f), t.fw);
     float cy = fminf(fmaxf(fy, -1.0f), t.fh);
     BilG b;
-    b.idx = ((int)cy + 1) * t.stride + ((int)cx + 1);
+    b.cx = (int)cx + 1; b.cy = (int)cy + 1;
+    b.idx = b.cy * t.stride + b.cx;
     b.wx0 = in ? wx0 : 0.0f; b.wx1 = in ? wx1 : 0.0f; b.wy0 = in ? wy0 : 0.0f; b.wy1 = in ? wy1 : 0.0f;
     b.w00 = in ? wx0 * wy0 : 0.0f;
     b.w10 = in ? wx1 * wy0 : 0.0f;
@@ -153,10 +158,10 @@ __global__ void __launch_bounds__(256) train_density_kernel(const TrainArgs T)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < total; wi += stride) {
         // a wave takes 64 CONSECUTIVE steps of one ray: its gathers share texels (two steps per texel) instead of touching 64
-        // unrelated cells of 64 random training rays; the dense buffers stay step-major for the per-ray sweeps
+        // unrelated cells of 64 random training rays, and its stores are one 256-byte run of the ray-major buffers
         const int64_t r = wi / A.S;
         const int i = (int)(wi - r * A.S);
-        const int64_t idx = (int64_t)i * A.n + r;
+        const int64_t idx = r * A.S + i;
         float xn[3], z, dist, tt[6];
         const bool valid = sample_geometry(A, r, i, xn, z, dist);
         if (!valid) {                               // outside the box / in free space of the alpha mask: sigma = 0, no fetches
@@ -164,27 +169,15 @@ __global__ void __launch_bounds__(256) train_density_kernel(const TrainArgs T)
             continue;
         }
         triplane_gauge(A, xn, A.mode, tt);          // compute_gauge (Field.py:53-75), identity split when the gauge is off
+        // density_decoder is linear: the four taps come from the wd-projected one-channel planes Q_p (train_project_density_kernel
+        // sums the 16 channels of a texel in the order the per-tap dot product here used to) -- 12 floats per sample, not 192
         float f = 0.0f;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const Tex &tx = A.dens[p];
             Bil b = bil_setup(tt[2 * p], tt[2 * p + 1], tx);
-            const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + (size_t)b.idx * 16);
-            const f32x4 *q01 = q00 + (size_t)tx.stride * 4;
-            float d00 = 0.0f, d10 = 0.0f, d01 = 0.0f, d11 = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v00 = q00[q], v10 = q00[4 + q], v01 = q01[q], v11 = q01[4 + q];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float w = T.wd[p * 16 + 4 * q + e];
-                    d00 = fmaf(w, v00[e], d00);
-                    d10 = fmaf(w, v10[e], d10);
-                    d01 = fmaf(w, v01[e], d01);
-                    d11 = fmaf(w, v11[e], d11);
-                }
-            }
-            f += bil_mix(b, d00, d10, d01, d11);
+            const float *q = T.q_dens[p] + b.idx;
+            f += bil_mix(b, q[0], q[1], q[tx.stride], q[tx.stride + 1]);
         }
         f = (f + T.bd[0]) + (-10.0f);
         T.xs[idx] = f;
@@ -235,7 +228,7 @@ __global__ void __launch_bounds__(64) train_scan_kernel(const TrainArgs T, int p
     for (int i0 = 0; i0 < A.S; i0 += 16) {
         const int i = i0 + seg;
         const bool inb = i < A.S;
-        const int64_t idx = (int64_t)(inb ? i : 0) * A.n + r;
+        const int64_t idx = r * A.S + (inb ? i : 0);
         const float z = tmin + A.step * ((float)i + jit);
         const float zn = tmin + A.step * ((float)(i + 1) + jit);
         const float dist = (i < A.S - 1) ? (zn - z) : 0.0f;
@@ -507,7 +500,7 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
             c[j] = 1.0f / (1.0f + expf(-s));
         }
         if (live && q == 0) {
-            float *dst = T.c + ((int64_t)i * A.n + r) * 3;
+            float *dst = T.c + ((int64_t)r * A.S + i) * 3;
             dst[0] = c[0]; dst[1] = c[1]; dst[2] = c[2];
         }
         if (T.store) {
@@ -533,7 +526,7 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
     const float bg = A.white_bg ? 1.0f : 0.0f;
     float acc = 0.0f, rgb[3] = {0.0f, 0.0f, 0.0f};
     for (int i = seg; i < A.S; i += 16) {
-        const int64_t idx = (int64_t)i * A.n + r;
+        const int64_t idx = r * A.S + i;
         const float w = T.w[idx];
         acc += w;
         if (w > A.thr) {
@@ -566,7 +559,7 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
     for (int i0 = ((A.S - 1) / 16) * 16; i0 >= 0; i0 -= 16) {
         const int i = i0 + seg;
         const bool inb = i < A.S;
-        const int64_t idx = (int64_t)(inb ? i : 0) * A.n + r;
+        const int64_t idx = r * A.S + (inb ? i : 0);
         const float x = inb ? T.xs[idx] : -INFINITY;
         const float z = tmin + A.step * ((float)i + jit);
         const float zn = tmin + A.step * ((float)(i + 1) + jit);
@@ -613,6 +606,7 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(co
     float *D1t = H2t;                        // h2 is dead once d2 exists
     const int chunk_n = chunk_rows(T);
     const int passes = (chunk_n + 15) / 16;
+    float gb1 = 0.0f, gb2 = 0.0f, gb3[3] = {0.0f, 0.0f, 0.0f};      // bias gradients: lane l sums unit l of d1 / d2 over this wave's samples
     for (int pass = blockIdx.x * kTrainWavesBwd + wave; pass < passes; pass += gridDim.x * kTrainWavesBwd) {
         const int local = pass * 16 + n;
         const bool live = local < chunk_n;
@@ -626,7 +620,7 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(co
         // d3 = dL/dc * sigmoid' ; dL/dc = G_ray * w
         float d3[3];
         {
-            const float *cc = T.c + ((int64_t)i * A.n + r) * 3;
+            const float *cc = T.c + ((int64_t)r * A.S + i) * 3;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const float c = cc[j];
@@ -651,6 +645,16 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(co
         }
         tile_to_rows(D2t, 64, T.D2, 64, row, live, lane);
         tile_to_rows(D1t, 64, T.D1, 64, row, live, lane);
+        // column sums for the biases while the tiles are here (dead samples hold zeros); the rotation spreads a row's 16 reads
+        // over the banks
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int c = (s + (lane >> 1)) & 15;
+            gb2 += D2t[lane * 16 + c];
+            gb1 += D1t[lane * 16 + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gb3[j] += d3[j];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         dense16<false, 0, kFeat, 64, 64, kDfStride>(img + kBwdW1T, kLd2, kFeat, nullptr, D1t, DFt, nullptr, lane);   // df = W1'^T d1
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -721,11 +725,20 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(co
             }
         }
         if (live && q == 0) {
-            float *d = T.dt + ((int64_t)i * A.n + r) * 6;
+            float *d = T.dt + ((int64_t)r * A.S + i) * 6;
 #pragma unroll
             for (int k = 0; k < 6; ++k) d[k] = dt[k];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    atomicAdd(T.g_b1 + lane, gb1);
+    atomicAdd(T.g_b2 + lane, gb2);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float v = q == 0 ? gb3[j] : 0.0f;                 // the four quarters of a sample carry the same d3
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) v += __shfl_xor(v, d);
+        if (lane == 0) atomicAdd(T.g_b3 + j, v);
     }
 }
 
@@ -791,23 +804,6 @@ __global__ void __launch_bounds__(256) xty_block_kernel(const float *__restrict_
     }
 }
 
-// bias gradients: column sums of a row-major [rows, ld] matrix (cols <= 64); blocks walk 256-row slabs
-__global__ void __launch_bounds__(256) colsum_kernel(const float *__restrict__ X, int ld, int rows, int cols, float *out, const int32_t *rows_dev)
-{
-    if (rows_dev) rows = min(rows, *rows_dev);
-    __shared__ float sh[4][64];
-    const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
-    float s = 0.0f;
-    if (c < cols)
-        for (int r0 = blockIdx.x * 256; r0 < rows; r0 += gridDim.x * 256) {
-            const int r1 = min(rows, r0 + 256);
-            for (int r = r0 + part; r < r1; r += 4) s += X[(size_t)r * ld + c];
-        }
-    sh[part][c] = s;
-    __syncthreads();
-    if (part == 0 && c < cols) atomicAdd(out + c, (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]));
-}
-
 // ---- 7. density / gauge backward for every valid sample -----------------------------------------------------------------------
 // density_decoder is LINEAR, so the gradient of the 16 density channels of a texel is rank one:
 //     d loss / d plane_p[c][texel] = wd[16p+c] * D_p[texel],   D_p[texel] = sum over samples of (tap weight * dx)
@@ -831,78 +827,160 @@ __global__ void __launch_bounds__(256) train_project_density_kernel(const float 
     }
 }
 
+// What the scatter costs (profiles/micro/atomic_cost.hip, lds_atomic_cost.hip):
+//   * a global float atomic is priced per (instruction, 64-byte line): 21 G line-transactions/s for the whole device whether 1 or all
+//     16 floats of the line take part -- the per-sample scatter of round 1 (one 8- or 16-byte piece per sample and instruction) spent
+//     0.77 of its 0.90 ms there;
+//   * ds_add_f32 runs at ~3 cycles per ACTIVE LANE (193 cycles for a full wave; ds_add_u32: 5.6), a plain LDS read-add-write at 8.
+// So the scalar images D_p and the gauge-gradient planes are BLOCKED -- one 64-byte line = 4x4 texels of D_p / 4x2 texels x 2 channels
+// of a gauge plane: the 2x2 footprints along 64 half-texel steps of one ray touch ~10-20 such blocks whatever its direction -- and a
+// wave (64 consecutive steps of ONE ray) sums its taps in a wave-private LDS tile over the blocks of its bounding box before it sends
+// every touched block as ONE whole-line atomic.  The LDS sums are plain read-add-writes made collision-free: runs of consecutive lanes
+// in the SAME cell are added up in registers (segmented scan over the 16-lane DPP rows), and of the run leaders only those that win a
+// last-writer-wins election on their cell write in a round (distinct cells => distinct texels for every tap index; normally one round).
+constexpr int kScatCap = 128;                   // blocks of a wave tile (8 KB); a bounding box beyond it takes the per-tap path
+constexpr int kScatOwn = 256;                   // election slots per wave
+constexpr int kScatWaveFloats = kScatCap * 16 + kScatOwn;
+
+__device__ __forceinline__ int wave_min_i(int v) { return (int)wave_min((float)v); }       // |v| < 2^24
+__device__ __forceinline__ int wave_max_i(int v) { return -(int)wave_min((float)-v); }
+
+template <int D>
+__device__ __forceinline__ float row_shr_f(float v)      // lane (row, s) <- lane (row, s - D); 0 for s < D
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xf, 0xf, true));
+}
+template <int D>
+__device__ __forceinline__ int row_shr_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + D, 0xf, 0xf, true); }
+
+// BYS, CH: a block is 4 x (1 << BYS) texels x CH channels = 16 floats -- (2, 1) the D_p images, (1, 2) the gauge-gradient planes.
+template <int BYS, int CH>
+__device__ __forceinline__ int blocked_offset(int X, int Y, int bw)
+{
+    return ((Y >> BYS) * bw + (X >> 2)) * 16 + ((Y & ((1 << BYS) - 1)) * 4 + (X & 3)) * CH;
+}
+
+// (X, Y) = padded (column, row) of the cell's first tap, val[tap][channel] the contributions (tap = 2 * dy + dx), bw = blocks per row;
+// tile: kScatWaveFloats floats of wave-private LDS.  Every lane of the wave must call it (wave-uniform control flow inside).
+template <int BYS, int CH, int N = 4 * CH>
+__device__ __forceinline__ void scatter_blocked(float *tile, int lane, bool work, int X, int Y, float (&val)[N], float *gbuf, int bw)
+{
+    const int big = 1 << 20;
+    const int bx0 = wave_min_i(work ? X >> 2 : big), bx1 = wave_max_i(work ? (X + 1) >> 2 : -big);
+    const int by0 = wave_min_i(work ? Y >> BYS : big), by1 = wave_max_i(work ? (Y + 1) >> BYS : -big);
+    const int nbx = bx1 - bx0 + 1, nb = nbx * (by1 - by0 + 1);
+    if (nb > kScatCap) {                        // wave-uniform; rare (a gauge field that tears the ray apart)
+        if (work) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    if (val[k * CH + c] != 0.0f) atomicAdd(gbuf + blocked_offset<BYS, CH>(X + (k & 1), Y + (k >> 1), bw) + c, val[k * CH + c]);
+        }
+        return;
+    }
+    for (int e = lane * 4; e < nb * 16; e += 256) *reinterpret_cast<f32x4 *>(tile + e) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // runs of lanes in the same cell -> their last lane (inclusive segmented scan inside each 16-lane row)
+    const int cell = work ? (Y << 12) | X : -1 - lane;
+    const int prev = row_shr_i<1>(cell);
+    const bool head = ((lane & 15) == 0) | (cell != prev);
+    int f = head ? 1 : 0;
+#define NGF_SEG_STEP(D)                                                                                     \
+    {                                                                                                       \
+        const int fo = row_shr_i<D>(f);                                                                     \
+        _Pragma("unroll") for (int j = 0; j < N; ++j) { const float o = row_shr_f<D>(val[j]); val[j] += f ? 0.0f : o; }   \
+        f |= fo;                                                                                            \
+    }
+    NGF_SEG_STEP(1) NGF_SEG_STEP(2) NGF_SEG_STEP(4) NGF_SEG_STEP(8)
+#undef NGF_SEG_STEP
+    const int next_head = __builtin_amdgcn_update_dpp(1, head ? 1 : 0, 0x101, 0xf, 0xf, false);      // row_shl:1; lane 15 of a row keeps 1
+    bool pending = work & (next_head != 0);
+    int *own = reinterpret_cast<int *>(tile + kScatCap * 16);
+    const int slot = (X + 17 * Y) & (kScatOwn - 1);
+    int off[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int tx = X + (k & 1), ty = Y + (k >> 1);
+        off[k] = (((ty >> BYS) - by0) * nbx + ((tx >> 2) - bx0)) * 16 + ((ty & ((1 << BYS) - 1)) * 4 + (tx & 3)) * CH;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    while (__any(pending)) {
+        if (pending) own[slot] = lane;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const bool win = pending && own[slot] == lane;
+        if (win) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (CH == 1) {
+                    tile[off[k]] += val[k];
+                } else {
+                    f32x2 *q = reinterpret_cast<f32x2 *>(tile + off[k]);
+                    f32x2 t = *q;
+                    t[0] += val[2 * k]; t[1] += val[2 * k + 1];
+                    *q = t;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+        pending = pending & !win;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    const unsigned magic = (65536u + nbx - 1) / nbx;            // b / nbx == (b * magic) >> 16 for b < 128, nbx <= 128
+    const int sub = lane >> 4, e = lane & 15;
+    for (int b0 = 0; b0 < nb; b0 += 8) {                        // four blocks = four whole lines per instruction, two instructions in flight
+        const int ba = b0 + sub, bb = b0 + 4 + sub;
+        const float va = ba < nb ? tile[ba * 16 + e] : 0.0f;
+        const float vb = bb < nb ? tile[bb * 16 + e] : 0.0f;
+        if (va != 0.0f) {
+            const int q = (int)(((unsigned)ba * magic) >> 16), r = ba - q * nbx;
+            atomicAdd(gbuf + ((size_t)(by0 + q) * bw + (bx0 + r)) * 16 + e, va);
+        }
+        if (vb != 0.0f) {
+            const int q = (int)(((unsigned)bb * magic) >> 16), r = bb - q * nbx;
+            atomicAdd(gbuf + ((size_t)(by0 + q) * bw + (bx0 + r)) * 16 + e, vb);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs T)
 {
     const RenderArgs &A = T.R;
+    __shared__ __attribute__((aligned(16))) float s_tile[4][kScatWaveFloats];
     __shared__ float s_bd;
     if (threadIdx.x == 0) s_bd = 0.0f;
     __syncthreads();
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *tile = s_tile[wave];
     float bsum = 0.0f;
-    const int64_t total = (int64_t)A.S * A.n;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // wave-uniform trip count: the scatter below exchanges values between lanes
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < total; base += stride) {
-        // ray-major work order like the forward kernel: the scatter of a wave lands on the few cache lines along one ray
-        const int64_t wi0 = base + lane;
-        const bool inr = wi0 < total;
-        const int64_t wi = inr ? wi0 : total - 1;
-        const int64_t rr = wi / A.S;
-        const int64_t idx = (int64_t)(wi - rr * A.S) * A.n + rr;
-        float dx = inr ? T.dx[idx] : 0.0f;
+    // a wave item = 64 consecutive steps of ONE ray (the last chunk of a ray is short): its taps stay inside a small bounding box
+    const int chunks = (A.S + 63) / 64;
+    const int64_t items = A.n * chunks;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < items; item += (int64_t)gridDim.x * 4) {
+        const int64_t r = item / chunks;
+        const int i0 = (int)(item - r * chunks) * 64 + lane;
+        const bool inr = i0 < A.S;
+        const int i = inr ? i0 : A.S - 1;
+        const int64_t idx = r * A.S + i;
+        const float dx = inr ? T.dx[idx] : 0.0f;
         const bool active = inr && (T.w[idx] > A.thr);
         const bool work = (dx != 0.0f) | active;
         if (!__any(work)) continue;
-        const int i = (int)(idx / A.n);
-        const int64_t r = idx % A.n;
         float t[6], xn[3];
         list_sample_coords(A, r, i, t, xn);
         float dt[6];
         bsum += dx;
-        int didx[3];
-        float dw[3][4];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const Tex &tx = A.dens[p];
             BilG b = bilg_setup(t[2 * p], t[2 * p + 1], tx);
             const float *q = T.q_dens[p] + b.idx;
             const float v00 = q[0], v10 = q[1], v01 = q[tx.stride], v11 = q[tx.stride + 1];
-            didx[p] = b.idx;
-            dw[p][0] = b.w00 * dx; dw[p][1] = b.w10 * dx; dw[p][2] = b.w01 * dx; dw[p][3] = b.w11 * dx;
             dt[2 * p] = dx * (b.wy0 * (v10 - v00) + b.wy1 * (v11 - v01)) * b.sx;
             dt[2 * p + 1] = dx * (b.wx0 * (v01 - v00) + b.wx1 * (v11 - v10)) * b.sy;
-        }
-        // consecutive lanes are consecutive steps of one ray, half a texel apart: merge the contributions of lanes that hit the
-        // SAME cell inside aligned pairs, then quads, before anything goes to L2 (a merged lane's values become 0 and are skipped)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-#pragma unroll
-            for (int d = 1; d <= 2; d <<= 1) {
-                const int oi = __shfl_xor(didx[p], d);
-                const bool take = ((lane & d) == 0) & (oi == didx[p]) & ((lane & (d - 1)) == 0);      // receiver: lower lane of the pair / quad
-                const bool give = ((lane & d) != 0) & (oi == didx[p]) & ((lane & (d - 1)) == 0);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float ov = __shfl_xor(dw[p][k], d);
-                    dw[p][k] = take ? dw[p][k] + ov : (give ? 0.0f : dw[p][k]);
-                }
-            }
-        }
-        // density-gradient images: the two taps of a row are consecutive floats -> lane pairs write them together
-        // (32 samples x 2 floats per instruction: half as many cache lines per atomic instruction)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const int strd = A.dens[p].stride;
-#pragma unroll
-            for (int row = 0; row < 2; ++row) {
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int src = half * 32 + (lane >> 1), e = lane & 1;
-                    const int ii = __shfl(didx[p], src);
-                    const float va = __shfl(dw[p][2 * row], src), vb = __shfl(dw[p][2 * row + 1], src);
-                    const float val = e ? vb : va;
-                    if (val != 0.0f) atomicAdd(T.d_dens[p] + (size_t)ii + (size_t)row * strd + e, val);
-                }
+            if (!(A.ablate & 256)) {
+                float dw[4] = {b.w00 * dx, b.w10 * dx, b.w01 * dx, b.w11 * dx};
+                scatter_blocked<2, 1>(tile, lane, work, b.cx, b.cy, dw, T.d_dens[p], T.d_bw[p]);
             }
         }
         if (A.mode) {
@@ -920,37 +998,10 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
             const float u[3] = {xn[0], xn[1], xn[0]}, v[3] = {xn[1], xn[2], xn[2]};
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                const Tex &tx = A.gau[p];
-                Bil b = bil_setup(u[p], v[p], tx);
-                // the 8 contributions of this sample's cell: gv[tap][channel] = tap weight * gradient; same-cell lanes merged as above
-                float gv[4][2] = {{b.w00 * dg[p][0], b.w00 * dg[p][1]}, {b.w10 * dg[p][0], b.w10 * dg[p][1]},
-                                  {b.w01 * dg[p][0], b.w01 * dg[p][1]}, {b.w11 * dg[p][0], b.w11 * dg[p][1]}};
-#pragma unroll
-                for (int d = 1; d <= 2; d <<= 1) {
-                    const int oi = __shfl_xor(b.idx, d);
-                    const bool take = ((lane & d) == 0) & (oi == b.idx) & ((lane & (d - 1)) == 0);
-                    const bool give = ((lane & d) != 0) & (oi == b.idx) & ((lane & (d - 1)) == 0);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            const float ov = __shfl_xor(gv[k][c], d);
-                            gv[k][c] = take ? gv[k][c] + ov : (give ? 0.0f : gv[k][c]);
-                        }
-                }
-                // a row of the cell is 4 consecutive floats (2 texels x 2 channels): 16 samples x 4 floats per instruction
-#pragma unroll
-                for (int row = 0; row < 2; ++row) {
-#pragma unroll
-                    for (int sq = 0; sq < 4; ++sq) {
-                        const int src = sq * 16 + (lane >> 2), e = lane & 3;
-                        const int ii = __shfl(b.idx, src);
-                        const float v0 = __shfl(gv[2 * row][0], src), v1 = __shfl(gv[2 * row][1], src);
-                        const float v2 = __shfl(gv[2 * row + 1][0], src), v3 = __shfl(gv[2 * row + 1][1], src);
-                        const float val = e == 0 ? v0 : (e == 1 ? v1 : (e == 2 ? v2 : v3));
-                        if (val != 0.0f) atomicAdd(T.g_gau[p] + ((size_t)ii + (size_t)row * tx.stride) * 2 + e, val);
-                    }
-                }
+                Bil b = bil_setup(u[p], v[p], A.gau[p]);
+                float gv[8] = {b.w00 * dg[p][0], b.w00 * dg[p][1], b.w10 * dg[p][0], b.w10 * dg[p][1],
+                               b.w01 * dg[p][0], b.w01 * dg[p][1], b.w11 * dg[p][0], b.w11 * dg[p][1]};
+                if (!(A.ablate & 512)) scatter_blocked<1, 2>(tile, lane, work, b.cx, b.cy, gv, T.g_gau[p], T.g_bw[p]);
             }
         }
     }
@@ -961,8 +1012,21 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
     if (threadIdx.x == 0) atomicAdd(T.g_bd, s_bd);
 }
 
+// blocked gauge-gradient plane -> [texel][2] (what the Adam kernel and ngf_train_get_grad read); blockIdx.y = plane
+struct UnblockArgs { const float *src[3]; float *dst[3]; int32_t w2[3], h2[3], bw[3]; };
+__global__ void __launch_bounds__(256) train_unblock_gauge_kernel(const UnblockArgs U)
+{
+    const int p = blockIdx.y;
+    const int total = U.w2[p] * U.h2[p];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int y = i / U.w2[p], x = i - y * U.w2[p];
+        const f32x2 v = *reinterpret_cast<const f32x2 *>(U.src[p] + blocked_offset<1, 2>(x, y, U.bw[p]));
+        *reinterpret_cast<f32x2 *>(U.dst[p] + (size_t)i * 2) = v;
+    }
+}
+
 // expand the scalar gradient image of plane p: g_dens[texel][c] = wd[c] * D[texel]; g_wd[c] += sum_texels D[texel] * tex16[texel][c]
-__global__ void __launch_bounds__(256) train_density_finish_kernel(const float *__restrict__ D, const float *__restrict__ tex16,
+__global__ void __launch_bounds__(256) train_density_finish_kernel(const float *__restrict__ D, int w2, int bw, const float *__restrict__ tex16,
                                                                    const float *__restrict__ wd, int64_t texels, float *__restrict__ g_dens, float *g_wd)
 {
     __shared__ float sh[16];
@@ -973,7 +1037,8 @@ __global__ void __launch_bounds__(256) train_density_finish_kernel(const float *
     for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < texels; i += stride) {
-        const float d = D[i];
+        const int ty = (int)(i / w2), tx = (int)(i - (int64_t)ty * w2);
+        const float d = D[blocked_offset<2, 1>(tx, ty, bw)];          // D is blocked 4x4 (train_density_bwd_kernel)
         const f32x4 *v = reinterpret_cast<const f32x4 *>(tex16 + i * 16);
         f32x4 *g = reinterpret_cast<f32x4 *>(g_dens + i * 16);
 #pragma unroll
@@ -1021,21 +1086,64 @@ __global__ void __launch_bounds__(256) adam_dense_kernel(float *p, const float *
     }
 }
 
-// NCHW parameter [C,H,W]; gradient in the packed layouts: channels [0,cs) in ga (cs per texel), [cs,C) in gb (C-cs per texel)
-__global__ void __launch_bounds__(256) adam_plane_kernel(float *p, float *m, float *v, int C, int H, int W, const float *ga, int cs, const float *gb,
+// every MLP parameter in one launch: segment k = elements [begin[k], begin[k+1]) of the concatenation, each with its own step count / lr
+constexpr int kDenseParams = 9;
+struct AdamDenseAll {
+    float *p[kDenseParams], *m[kDenseParams], *v[kDenseParams];
+    const float *g[kDenseParams];
+    int32_t begin[kDenseParams + 1];           // begin[k+1] == begin[k] for a skipped parameter
+    AdamArgs a[kDenseParams];
+};
+
+__global__ void __launch_bounds__(256) adam_dense_all_kernel(const AdamDenseAll D)
+{
+    const int total = D.begin[kDenseParams];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < kDenseParams; ++j) k += (i >= D.begin[j]) ? 1 : 0;
+        const int e = i - D.begin[k];
+        float mi = D.m[k][e], vi = D.v[k][e];
+        D.p[k][e] = adam_one(D.p[k][e], D.g[k][e], mi, vi, D.a[k]);
+        D.m[k][e] = mi; D.v[k][e] = vi;
+    }
+}
+
+// NCHW parameter [C,H,W]; gradient AND the trainer's packed copy of the parameter in the packed layouts: channels [0,CS) in ga / ta
+// (CS per texel), [CS,C) in gb / tb (C-CS per texel).  A workgroup takes 64 texels of one row: the packed gradient rows go through LDS
+// so that every global access is a contiguous run (the parameter / moments along x, the packed arrays along the channels), and the
+// updated values leave the same way into the packed copy -- the next step's kernels read it without a re-pack.
+template <int C, int CS>
+__global__ void __launch_bounds__(256) adam_plane_kernel(float *p, float *m, float *v, int H, int W, const float *ga, const float *gb, float *ta, float *tb,
                                                          const AdamArgs a)
 {
-    const int64_t total = (int64_t)C * H * W;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int x = (int)(i % W), y = (int)((i / W) % H), c = (int)(i / ((int64_t)W * H));
-        const size_t texel = (size_t)(y + 1) * (W + 2) + (x + 1);
-        float g = c < cs ? ga[texel * cs + c] : gb[texel * (C - cs) + (c - cs)];
-        const float pv = p[i];
-        g += a.l1 * (pv > 0.0f ? 1.0f : (pv < 0.0f ? -1.0f : 0.0f));
-        float mi = m[i], vi = v[i];
-        p[i] = adam_one(pv, g, mi, vi, a);
-        m[i] = mi; v[i] = vi;
+    constexpr int CB = C - CS;
+    __shared__ float sg[64 * (C + 1)];
+    const int tiles_x = (W + 63) / 64;
+    for (int tile = blockIdx.x; tile < H * tiles_x; tile += gridDim.x) {
+        const int y = tile / tiles_x, x0 = (tile - y * tiles_x) * 64, nx = min(64, W - x0);
+        const size_t texel0 = (size_t)(y + 1) * (W + 2) + (x0 + 1);
+        for (int e = threadIdx.x; e < nx * CS; e += 256) sg[(e / CS) * (C + 1) + e % CS] = ga[texel0 * CS + e];
+        if (CB > 0)
+            for (int e = threadIdx.x; e < nx * CB; e += 256) sg[(e / (CB > 0 ? CB : 1)) * (C + 1) + CS + e % (CB > 0 ? CB : 1)] = gb[texel0 * CB + e];
+        __syncthreads();
+        for (int e = threadIdx.x; e < C * 64; e += 256) {
+            const int c = e >> 6, x = e & 63;
+            if (x < nx) {
+                const size_t i = ((size_t)c * H + y) * W + x0 + x;
+                const float pv = p[i];
+                const float g = sg[x * (C + 1) + c] + a.l1 * (pv > 0.0f ? 1.0f : (pv < 0.0f ? -1.0f : 0.0f));
+                float mi = m[i], vi = v[i];
+                const float pn = adam_one(pv, g, mi, vi, a);
+                p[i] = pn; m[i] = mi; v[i] = vi;
+                sg[x * (C + 1) + c] = pn;
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < nx * CS; e += 256) ta[texel0 * CS + e] = sg[(e / CS) * (C + 1) + e % CS];
+        if (CB > 0)
+            for (int e = threadIdx.x; e < nx * CB; e += 256) tb[texel0 * CB + e] = sg[(e / (CB > 0 ? CB : 1)) * (C + 1) + CS + e % (CB > 0 ? CB : 1)];
+        __syncthreads();
     }
 }
 

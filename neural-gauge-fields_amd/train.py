@@ -52,6 +52,8 @@ def _bind(L):
     L.ngf_train_get_grad.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.ngf_train_get_active.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.ngf_train_adam.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    L.ngf_train_adam_all.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    L.ngf_train_params_changed.argtypes = [C.c_void_p]
     if L.ngf_sizeof_train_desc() != C.sizeof(TrainDesc):
         raise RuntimeError("libngf_hip.so ABI mismatch (ngf_train_desc layout)")
     L._ngf_train_bound = True
@@ -156,6 +158,11 @@ class Trainer:
         except Exception:
             pass
 
+    def params_changed(self):
+        """Tell the trainer that plane / gauge-plane values were written by something other than ``optimizer_step`` (an in-place
+        edit, ``load_state_dict``): its channel-last copies are rebuilt on the next ``backward``."""
+        _lib.check(self.L.ngf_train_params_changed(self._h))
+
     def scratch_bytes(self) -> int:
         return int(self.L.ngf_trainer_bytes(self._h))
 
@@ -208,14 +215,16 @@ class Trainer:
     def optimizer_step(self):
         """optimizer.step() + the lr decay of main.py:298-299.  Gauge planes without a gradient (iteration <
         gauge_start) are skipped like torch.optim skips parameters whose .grad is None."""
+        counts = (C.c_int32 * 15)()
+        for k in range(15):
+            if (3 <= k < 6 and not self._gauge_on) or k in self.frozen:
+                continue                              # count 0 = skipped
+            self.steps[k] += 1
+            counts[k] = self.steps[k]
+        lrs = (C.c_float * 15)(*[float(x) for x in self.lr])
         with torch.cuda.device(self.dev):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            for k in range(15):
-                if (3 <= k < 6 and not self._gauge_on) or k in self.frozen:
-                    continue
-                self.steps[k] += 1
-                _lib.check(self.L.ngf_train_adam(self._h, k, self.steps[k], float(self.lr[k]), float(self.betas[0]), float(self.betas[1]),
-                                                 float(self.eps), float(self.l1), st))
+            _lib.check(self.L.ngf_train_adam_all(self._h, counts, lrs, float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.l1), st))
         self.field.invalidate()      # parameters changed behind torch's back: the eval image is re-packed on the next render
         self.lr = [x * self.lr_factor for x in self.lr]
 
