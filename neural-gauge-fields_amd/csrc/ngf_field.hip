@@ -1000,6 +1000,8 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
     if (carved != t->zero_bytes) return bail(fail(NGF_E_ARG, "trainer: zero arena layout mismatch"));
     T.wd = d->dens_w; T.bd = d->dens_b; T.basis = d->basis; T.w1 = d->w1; T.b1 = d->b1; T.w2 = d->w2; T.b2 = d->b2; T.w3 = d->w3; T.b3 = d->b3;
     T.g_wd = t->g_dense[TP_DENS_W]; T.g_bd = t->g_dense[TP_DENS_B];
+    if ((rc = tr_alloc(t, &T.prof, (size_t)16))) return bail(rc);
+    if (hipMemsetAsync(T.prof, 0, 16 * sizeof(unsigned long long), st) != hipSuccess) return bail(fail(NGF_E_HIP, "trainer setup failed"));
     T.g_b1 = t->g_dense[TP_B1]; T.g_b2 = t->g_dense[TP_B2]; T.g_b3 = t->g_dense[TP_B3];
     for (int k = 0; k < 3; ++k) {
         A.a0[k] = d->aabb[k];
@@ -1217,6 +1219,16 @@ extern "C" int ngf_train_adam(ngf_trainer *t, int32_t which, int32_t step_count,
                            d.exp_avg_sq[which], t->dense_n[which], a);
     }
     HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+// debug: the section clocks of the colour backward (ngf_debug_set("ablate", 1 << 20)), summed over waves since the last call
+extern "C" int ngf_train_debug_sections(ngf_trainer *t, uint64_t *out16)
+{
+    if (!t || !out16) return fail(NGF_E_ARG, "ngf_train_debug_sections: null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out16, t->proto.prof, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(t->proto.prof, 0, 16 * sizeof(uint64_t)));
     return NGF_OK;
 }
 

@@ -40,6 +40,8 @@ constexpr int kTrainWaves = 6;                 // waves per workgroup in the col
 constexpr int kTrainWavesBwd = 6;              // ... and in the colour backward kernel (its tiles alias, see kBwdTileFloats)
 constexpr int kFeat = 144;                     // colour features (3 planes x 48)
 constexpr int kIn1 = 159, kIn1Pad = 160;       // [g(144), view(15)] (+1 zero pad)
+constexpr int kTs = 17;                        // row stride of the wave tiles [k][kTs]: odd, so that BOTH the MFMA operand reads (16 samples of a row) and the
+                                               // row <-> global-row transposes (64 rows of one sample) spread over the banks (stride 16: 32 lanes per bank)
 constexpr int kLd1 = 164, kLd2 = 68;           // LDS row strides == 4 (mod 32): lane (row n, k = 4j+q) -> bank 4n+q, two lanes per bank
 // forward image : W1' [64][kLd1] (cols 144..158 = W1's view columns, 159 = 0) | W2 [64][kLd2] | W3 [3][64] | b1 [64] | b2 [64] | b3 [4]
 // backward image: W1'^T [144][kLd2] | W2^T [64][kLd2] | W3 [3][64]
@@ -76,6 +78,7 @@ struct TrainArgs {
     const int32_t *n_active_dev;      // non-NULL: the active count lives on the device (offset[n]); chunk_n is then only the capacity and
                                       // the kernels clip it themselves -- no host round trip between the scan and the colour kernels
     int32_t store;           // colour forward: also write F, V, H1, H2 rows of the chunk
+    unsigned long long *prof; // [16] section clocks of the colour backward (ablate bit 1 << 20; profiles/exp_train_sections.py), else unused
     float inv_count;         // 1 / (3 n): the mean of the MSE
 };
 
@@ -300,7 +303,7 @@ __device__ __forceinline__ void dense16(const float *__restrict__ W, int ldw, in
     // the B operands (this lane's sample, k = 4j + q) are the same for every row block: read the tile once
     float b[KS];
 #pragma unroll
-    for (int j = 0; j < KS; ++j) b[j] = in[(4 * j + q) * 16 + n];
+    for (int j = 0; j < KS; ++j) b[j] = in[(4 * j + q) * kTs + n];
     auto load_a = [&](int mb, float (&a)[KS]) {
         const int m = mb + n;                   // the A row this lane supplies
         const bool mok = m < Mvalid;
@@ -322,9 +325,9 @@ __device__ __forceinline__ void dense16(const float *__restrict__ W, int ldw, in
             float v = acc[r];
             if (bias && row < Mvalid) v += bias[row];
             if (ACT == 1) v = fmaxf(v, 0.0f);
-            if (ACT == 2) v = mask[row * 16 + n] > 0.0f ? v : 0.0f;
+            if (ACT == 2) v = mask[row * kTs + n] > 0.0f ? v : 0.0f;
             if (OUT_T) out[n * OUT_T + row] = v;
-            else out[row * 16 + n] = v;
+            else out[row * kTs + n] = v;
         }
     };
     // software pipeline over the row blocks, two per trip (a real loop: a full unroll hoists every block's loads and spills):
@@ -354,17 +357,28 @@ __device__ __forceinline__ void tile_to_rows(const float *tile, int K, float *ro
         const bool ok = __shfl((int)live, s) != 0;       // lane s holds sample s's liveness (lanes 0..15 = q 0)
         if (!ok) continue;
         const int64_t sl = __shfl((int)(slot & 0x7fffffff), s);
-        for (int k = lane; k < K; k += 64) rows[sl * ld + k] = tile[k * 16 + s];
+        for (int k = lane; k < K; k += 64) rows[sl * ld + k] = tile[k * kTs + s];
     }
 }
 
-__device__ __forceinline__ void rows_to_tile(const float *rows, int ld, int K, float *tile, int64_t slot, bool live, int lane)
+// global rows -> tile.  All 16 row reads of a lane are issued before the first LDS store: written as one loop the wave waited for every
+// load in turn (16 global latencies per tile -- a third of the colour backward's time, profiles/exp_train_sections.py)
+template <int K>
+__device__ __forceinline__ void rows_to_tiles2(const float *rows_a, const float *rows_b, int ld, float *tile_a, float *tile_b, int64_t slot, bool live, int lane)
 {
+    static_assert(K == 64, "one element per lane and sample");
+    float va[16], vb[16];
+#pragma unroll
     for (int s = 0; s < 16; ++s) {
         const bool ok = __shfl((int)live, s) != 0;
         const int64_t sl = __shfl((int)(slot & 0x7fffffff), s);
-        for (int k = lane; k < K; k += 64) tile[k * 16 + s] = ok ? rows[sl * ld + k] : 0.0f;
+        va[s] = ok ? rows_a[sl * ld + lane] : 0.0f;
+        vb[s] = ok ? rows_b[sl * ld + lane] : 0.0f;
     }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) tile_a[lane * kTs + s] = va[s];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) tile_b[lane * kTs + s] = vb[s];
 }
 
 // gauge-shifted coordinates of a list sample (recomputed: three 2-channel fetches, cheaper than 24 bytes of HBM per valid sample)
@@ -375,11 +389,11 @@ __device__ __forceinline__ void list_sample_coords(const RenderArgs &A, int64_t 
     triplane_gauge(A, xn, A.mode, t);
 }
 
-constexpr int kFwdTileFloats = (kIn1Pad + 64) * 16;                       // [F; view] (H2 goes there once layer 1 is done and F is stored), H1
+constexpr int kFwdTileFloats = (kIn1Pad + 64) * kTs;                       // [F; view] (H2 goes there once layer 1 is done and F is stored), H1
 constexpr int kDfStride = kFeat + 1;                                       // DF is kept sample-major (bank-conflict-free rows)
 // backward tiles per wave: [H1 | D2 | pad] is overwritten by DF^T once d1 exists and d2 / d1 have been written out; [H2, then D1]; tap table
-constexpr int kBwdTileFloats = 16 * kDfStride + 64 * 16 + 16 * 16;
-static_assert(16 * kDfStride >= 2 * 64 * 16, "DF^T must cover the H1 and D2 tiles it aliases");
+constexpr int kBwdTileFloats = 16 * kDfStride + 64 * kTs + 16 * 16;
+static_assert(16 * kDfStride >= 2 * 64 * kTs, "DF^T must cover the H1 and D2 tiles it aliases");
 
 // ---- per-step weight images -------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) train_fold_kernel(const TrainArgs T, float *fwd, float *bwd)
@@ -435,7 +449,7 @@ __global__ void __launch_bounds__(256) train_unfold_kernel(const TrainArgs T, fl
 }
 
 // ---- 3. colour forward over the active list -------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const TrainArgs T)
+__global__ void __launch_bounds__(kTrainWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) train_color_fwd_kernel(const TrainArgs T)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RenderArgs &A = T.R;
@@ -444,7 +458,7 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
     const float *img = smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
-    float *Ft = smem + ((kFwdImage + 3) & ~3) + wave * kFwdTileFloats, *H1t = Ft + kIn1Pad * 16, *H2t = Ft;
+    float *Ft = smem + ((kFwdImage + 3) & ~3) + wave * kFwdTileFloats, *H1t = Ft + kIn1Pad * kTs, *H2t = Ft;
     const int chunk_n = chunk_rows(T);
     const int passes = (chunk_n + 15) / 16;
     for (int pass = blockIdx.x * kTrainWaves + wave; pass < passes; pass += gridDim.x * kTrainWaves) {
@@ -466,7 +480,7 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
             for (int j = 0; j < 3; ++j) {
                 f32x4 v00 = q00[j], v10 = q00[12 + j], v01 = q01[j], v11 = q01[12 + j];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Ft[(p * 48 + 12 * q + 4 * j + e) * 16 + n] = live ? bil_mix(b, v00[e], v10[e], v01[e], v11[e]) : 0.0f;
+                for (int e = 0; e < 4; ++e) Ft[(p * 48 + 12 * q + 4 * j + e) * kTs + n] = live ? bil_mix(b, v00[e], v10[e], v01[e], v11[e]) : 0.0f;
             }
         }
         // the view inputs of layer 1 (networks.py:27-29): rows 144..159 of the input tile
@@ -474,7 +488,10 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
             float d[3] = {A.rays[r * 6 + 3], A.rays[r * 6 + 4], A.rays[r * 6 + 5]}, v[16];
             view_inputs(d, v);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) Ft[(kFeat + 4 * q + j) * 16 + n] = live ? v[4 * q + j] : 0.0f;
+            for (int j = 0; j < 4; ++j) {          // v[4q + j] by selects: a q-indexed read would put v into scratch memory
+                const float vq = q == 0 ? v[j] : (q == 1 ? v[4 + j] : (q == 2 ? v[8 + j] : v[12 + j]));
+                Ft[(kFeat + 4 * q + j) * kTs + n] = live ? vq : 0.0f;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         dense16<false, 1, 64, kIn1Pad, kIn1Pad>(img + kFwdW1, kLd1, 64, img + kFwdB1, Ft, H1t, nullptr, lane);      // relu(W1' f + W1v view + b1)
@@ -482,7 +499,7 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
         if (T.store) {          // the feature tile leaves LDS now: layer 2 writes its output over it
             const int64_t row = live ? local : 0;
             tile_to_rows(Ft, kFeat, T.F, kFeat, row, live, lane);
-            tile_to_rows(Ft + kFeat * 16, 16, T.V, 16, row, live, lane);
+            tile_to_rows(Ft + kFeat * kTs, 16, T.V, 16, row, live, lane);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         dense16<false, 1, 64, 64, 64>(img + kFwdW2, kLd2, 64, img + kFwdB2, H1t, H2t, nullptr, lane);
@@ -493,7 +510,7 @@ __global__ void __launch_bounds__(kTrainWaves * 64) train_color_fwd_kernel(const
         for (int j = 0; j < 3; ++j) {
             float s = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) s = fmaf(img[kFwdW3 + j * 64 + 16 * q + k], H2t[(16 * q + k) * 16 + n], s);
+            for (int k = 0; k < 16; ++k) s = fmaf(img[kFwdW3 + j * 64 + 16 * q + k], H2t[(16 * q + k) * kTs + n], s);
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
             s += img[kFwdB3 + j];
@@ -592,7 +609,7 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
 }
 
 // ---- 5. colour backward over the active list --------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(const TrainArgs T)
+__global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) train_color_bwd_kernel(const TrainArgs T)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RenderArgs &A = T.R;
@@ -601,12 +618,15 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(co
     const float *img = smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
-    float *H1t = smem + ((kBwdImage + 3) & ~3) + wave * kBwdTileFloats, *D2t = H1t + 64 * 16, *DFt = H1t, *H2t = H1t + 16 * kDfStride,
-          *tap = H2t + 64 * 16;              // tap[s][p] = {texel index, w00, w10, w01, w11}
+    float *H1t = smem + ((kBwdImage + 3) & ~3) + wave * kBwdTileFloats, *D2t = H1t + 64 * kTs, *DFt = H1t, *H2t = H1t + 16 * kDfStride,
+          *tap = H2t + 64 * kTs;              // tap[s][p] = {texel index, w00, w10, w01, w11}
     float *D1t = H2t;                        // h2 is dead once d2 exists
     const int chunk_n = chunk_rows(T);
     const int passes = (chunk_n + 15) / 16;
     float gb1 = 0.0f, gb2 = 0.0f, gb3[3] = {0.0f, 0.0f, 0.0f};      // bias gradients: lane l sums unit l of d1 / d2 over this wave's samples
+    const bool prof = (A.ablate & (1 << 20)) != 0;
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+#define NGF_SEC(k) if (prof) { const unsigned long long t1 = __builtin_readcyclecounter(); pc[k] += t1 - t0; t0 = t1; }
     for (int pass = blockIdx.x * kTrainWavesBwd + wave; pass < passes; pass += gridDim.x * kTrainWavesBwd) {
         const int local = pass * 16 + n;
         const bool live = local < chunk_n;
@@ -615,8 +635,11 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(co
         const int64_t r = T.list[2 * slot];
         const int i = T.list[2 * slot + 1];
         const float w = live ? T.list_w[slot] : 0.0f;
-        rows_to_tile(T.H1, 64, 64, H1t, row, live, lane);
-        rows_to_tile(T.H2, 64, 64, H2t, row, live, lane);
+        if (prof) t0 = __builtin_readcyclecounter();
+        // the sample's coordinates (rays -> gauge planes: two dependent global reads) are requested first and travel with the tile loads
+        float t[6], xn[3];
+        list_sample_coords(A, r, i, t, xn);
+        rows_to_tiles2<64>(T.H1, T.H2, 64, H1t, H2t, row, live, lane);
         // d3 = dL/dc * sigmoid' ; dL/dc = G_ray * w
         float d3[3];
         {
@@ -628,14 +651,16 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(co
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        NGF_SEC(0)
         // d2 = (W3^T d3) * [h2 > 0] on the VALU (3 terms per hidden unit)
         for (int k = 16 * q; k < 16 * q + 16; ++k) {
             float s = img[kBwdW3 + k] * d3[0] + img[kBwdW3 + 64 + k] * d3[1] + img[kBwdW3 + 128 + k] * d3[2];
-            D2t[k * 16 + n] = H2t[k * 16 + n] > 0.0f ? s : 0.0f;
+            D2t[k * kTs + n] = H2t[k * kTs + n] > 0.0f ? s : 0.0f;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         dense16<false, 2, 64, 64, 64>(img + kBwdW2T, kLd2, 64, nullptr, D2t, D1t, H1t, lane);              // d1 = (W2^T d2) * [h1 > 0]
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        NGF_SEC(1)
         // rows for the weight-gradient GEMMs (d2 leaves LDS here: its tile and h1's are about to become DF^T)
         if (live && q == 0) {
             float *d = T.D3 + row * 16;
@@ -645,22 +670,20 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(co
         }
         tile_to_rows(D2t, 64, T.D2, 64, row, live, lane);
         tile_to_rows(D1t, 64, T.D1, 64, row, live, lane);
-        // column sums for the biases while the tiles are here (dead samples hold zeros); the rotation spreads a row's 16 reads
-        // over the banks
+        // column sums for the biases while the tiles are here (dead samples hold zeros)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int c = (s + (lane >> 1)) & 15;
-            gb2 += D2t[lane * 16 + c];
-            gb1 += D1t[lane * 16 + c];
+        for (int c = 0; c < 16; ++c) {
+            gb2 += D2t[lane * kTs + c];
+            gb1 += D1t[lane * kTs + c];
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) gb3[j] += d3[j];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        NGF_SEC(2)
         dense16<false, 0, kFeat, 64, 64, kDfStride>(img + kBwdW1T, kLd2, kFeat, nullptr, D1t, DFt, nullptr, lane);   // df = W1'^T d1
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        NGF_SEC(3)
         // d loss / d t through the bilinear cell (lane (q, n): channels 12q..12q+11 of every plane of sample n) and the tap table
-        float t[6], xn[3];
-        list_sample_coords(A, r, i, t, xn);
         float dt[6];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -691,13 +714,14 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(co
             dt[2 * p] = du; dt[2 * p + 1] = dv;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        NGF_SEC(4)
         // feature gradients -> packed colour planes: the 48 channels of one tap are CONSECUTIVE floats, so the wave scatters
         // (sample, plane) by (sample, plane): 4 taps x 48 channels = 3 instructions of 64 lanes over 12 cache lines, instead of
         // every lane hitting its own line
         // (the list is in (ray, step) order: consecutive samples of a pass are half a texel apart, and runs of samples in the SAME
         // cell are summed in registers first and scattered once)
 #pragma unroll 1
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < ((A.ablate & 131072) ? 0 : 3); ++p) {
             const Tex &tx = A.app[p];
             int s0 = 0;
             while (s0 < 16) {
@@ -719,7 +743,7 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(co
                     const int e = u * 64 + lane;
                     const int tp_i = e / 48, c = e - 48 * tp_i;
                     const size_t off = ((size_t)idx + (tp_i & 1) + (tp_i >> 1) * (size_t)tx.stride) * 48 + c;
-                    if (acc3[u] != 0.0f) atomicAdd(T.g_app[p] + off, acc3[u]);
+                    if (acc3[u] != 0.0f && !(A.ablate & 65536)) atomicAdd(T.g_app[p] + off, acc3[u]);
                 }
                 s0 = s1;
             }
@@ -730,7 +754,12 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) train_color_bwd_kernel(co
             for (int k = 0; k < 6; ++k) d[k] = dt[k];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        NGF_SEC(5)
+        if (prof) pc[7] += 1;
     }
+#undef NGF_SEC
+    if (prof && lane == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(T.prof + k, pc[k]);
     atomicAdd(T.g_b1 + lane, gb1);
     atomicAdd(T.g_b2 + lane, gb2);
 #pragma unroll

@@ -5,6 +5,6 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for ab in ${ABS:-0 256 512 768}; do
   rm -rf gpurun_out/ktt && mkdir -p gpurun_out/ktt
   NGF_ABLATE=$ab timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/ktt -o kt -- python profiles/workload.py train_R1 20 > /dev/null 2>&1
-  echo "NGF_ABLATE=$ab: $(python profiles/summarize_rocpd.py $(find gpurun_out/ktt -name '*.db' | head -1) | grep train_density_bwd)"
+  echo "NGF_ABLATE=$ab: $(python profiles/summarize_rocpd.py $(find gpurun_out/ktt -name '*.db' | head -1) | grep -E "train_density_bwd|train_color_bwd")"
 done
 rm -rf gpurun_out/ktt
