@@ -461,6 +461,25 @@ def main():
                 it_ms = (time.perf_counter() - t0) / 10 * 1e3
                 tr_extra = {"ms_per_iteration": it_ms, "iterations_per_s": 1e3 / it_ms, "batch_rays": 4096, "samples_per_ray": Str,
                             "active_samples": trn.last_active, "scratch_GiB": trn.scratch_bytes() / 2 ** 30}
+                # what bounds the backward: global float atomics cost one transaction per (instruction, 64-byte line), 21 G/s for the whole
+                # device (profiles/micro/atomic_cost.hip -> profiles/r02_micro_atomic_cost.txt); one more iteration counts them
+                try:
+                    import ctypes as C
+                    from ngf_amd import _lib
+                    Lb = _lib.lib()
+                    Lb.ngf_train_debug_sections.argtypes = [C.c_void_p, C.c_void_p]
+                    cnt = (C.c_uint64 * 16)()
+                    with _lib.knobs(ablate=1 << 21):
+                        _lib.check(Lb.ngf_train_debug_sections(trn._h, cnt))
+                        trn.step(tr_rays, tr_rgb, 13, N_samples=Str)
+                        _lib.check(Lb.ngf_train_debug_sections(trn._h, cnt))
+                    n_d, n_c = int(cnt[8]), int(cnt[9])
+                    floor_ms = (n_d + n_c) / 21.0e9 * 1e3
+                    tr_extra["atomic_roof"] = {"line_transactions": {"density_gauge_backward": n_d, "colour_backward": n_c},
+                                               "peak_G_transactions_per_s": 21.0, "peak_source": "profiles/r02_micro_atomic_cost.txt",
+                                               "floor_ms": floor_ms, "floor_frac_of_iteration": floor_ms / it_ms}
+                except Exception as ex:
+                    tr_extra["atomic_roof"] = {"error": repr(ex)}
                 if args.cpu_seconds > 0:
                     from oracle import train as otrain
                     orc = otrain.EagerTrainer(pt_, gt_["aabb"], st_, gt_["near_far"], float(gt_["distance_scale"]), float(gt_["thr"]))

@@ -392,7 +392,7 @@ __device__ __forceinline__ void list_sample_coords(const RenderArgs &A, int64_t 
 constexpr int kFwdTileFloats = (kIn1Pad + 64) * kTs;                       // [F; view] (H2 goes there once layer 1 is done and F is stored), H1
 constexpr int kDfStride = kFeat + 1;                                       // DF is kept sample-major (bank-conflict-free rows)
 // backward tiles per wave: [H1 | D2 | pad] is overwritten by DF^T once d1 exists and d2 / d1 have been written out; [H2, then D1]; tap table
-constexpr int kBwdTileFloats = 16 * kDfStride + 64 * kTs + 16 * 16;
+constexpr int kBwdTileFloats = 16 * kDfStride + 64 * kTs + 16 * 16 + 16 * 48;
 static_assert(16 * kDfStride >= 2 * 64 * kTs, "DF^T must cover the H1 and D2 tiles it aliases");
 
 // ---- per-step weight images -------------------------------------------------------------------------------------------------
@@ -619,7 +619,8 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
     float *H1t = smem + ((kBwdImage + 3) & ~3) + wave * kBwdTileFloats, *D2t = H1t + 64 * kTs, *DFt = H1t, *H2t = H1t + 16 * kDfStride,
-          *tap = H2t + 64 * kTs;              // tap[s][p] = {texel index, w00, w10, w01, w11}
+          *tap = H2t + 64 * kTs,              // tap[s][p] = {cell (column | row << 16, padded), w00, w10, w01, w11}
+          *cache = tap + 16 * 16;            // [16 slots][48 channels]: the texel sums of the colour-plane scatter
     float *D1t = H2t;                        // h2 is dead once d2 exists
     const int chunk_n = chunk_rows(T);
     const int passes = (chunk_n + 15) / 16;
@@ -694,7 +695,7 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
             const f32x4 *q01 = q00 + (size_t)tx.stride * 12;
             if (q == 0) {
                 float *tp = tap + (n * 3 + p) * 5;
-                tp[0] = __int_as_float(b.idx);
+                tp[0] = __int_as_float(b.cx | (b.cy << 16));
                 tp[1] = live ? b.w00 : 0.0f; tp[2] = live ? b.w10 : 0.0f; tp[3] = live ? b.w01 : 0.0f; tp[4] = live ? b.w11 : 0.0f;
             }
             float du = 0.0f, dv = 0.0f;
@@ -715,38 +716,60 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         NGF_SEC(4)
-        // feature gradients -> packed colour planes: the 48 channels of one tap are CONSECUTIVE floats, so the wave scatters
-        // (sample, plane) by (sample, plane): 4 taps x 48 channels = 3 instructions of 64 lanes over 12 cache lines, instead of
-        // every lane hitting its own line
-        // (the list is in (ray, step) order: consecutive samples of a pass are half a texel apart, and runs of samples in the SAME
-        // cell are summed in registers first and scattered once)
+        // feature gradients -> packed colour planes.  A tap's 48 channels are 192 consecutive bytes = three whole lines, and the atomic
+        // unit charges per line (profiles/micro/atomic_cost.hip), so what counts is how often a texel is sent: the samples of a pass are
+        // consecutive active steps of a ray (half a texel apart), their 2x2 footprints share most texels.  Each wave keeps the sums of the
+        // last 4x4 texel neighbourhood in LDS (slot = (x & 3, y & 3), one lane per channel) and sends a texel once, when another texel
+        // claims its slot or at the end of the plane: 2.3x fewer line transactions than one send per (run of samples in a cell, tap).
+        const unsigned livem = (unsigned)(__ballot(live) & 0xffffull);        // lanes 0..15 carry q == 0: bit s = sample s of the pass
 #pragma unroll 1
         for (int p = 0; p < ((A.ablate & 131072) ? 0 : 3); ++p) {
             const Tex &tx = A.app[p];
-            int s0 = 0;
-            while (s0 < 16) {
-                const int idx = __float_as_int(tap[(s0 * 3 + p) * 5]);
-                float acc3[3] = {0.0f, 0.0f, 0.0f};
-                int s1 = s0;
-                do {
-                    const float *tp = tap + (s1 * 3 + p) * 5;
+            float *gp = T.g_app[p];
+            int tags = -1;                               // lane j: the texel whose sums live in slot j (-1: none)
+            // the plane's tap table in two registers (lane s: cell of sample s; lane 4s + k: weight k of sample s), read per sample with
+            // v_readlane instead of one LDS round trip each
+            const int cells = __float_as_int(tap[((lane & 15) * 3 + p) * 5]);
+            const float wts = tap[((lane >> 2) * 3 + p) * 5 + 1 + (lane & 3)];
 #pragma unroll
-                    for (int u = 0; u < 3; ++u) {
-                        const int e = u * 64 + lane;                 // 0..191 = tap * 48 + channel
-                        const int tp_i = e / 48, c = e - 48 * tp_i;
-                        acc3[u] = fmaf(tp[1 + tp_i], DFt[s1 * kDfStride + p * 48 + c], acc3[u]);
-                    }
-                    ++s1;
-                } while (s1 < 16 && __float_as_int(tap[(s1 * 3 + p) * 5]) == idx);
+            for (int s = 0; s < 16; ++s) {
+                if (!((livem >> s) & 1u)) continue;      // wave-uniform
+                const int cxy = __builtin_amdgcn_readlane(cells, s);
+                const int cx = cxy & 0xffff, cy = cxy >> 16;
+                const float g = lane < 48 ? DFt[s * kDfStride + p * 48 + lane] : 0.0f;
+                int slot[4], texel[4], old[4];
+                float cur[4];
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int e = u * 64 + lane;
-                    const int tp_i = e / 48, c = e - 48 * tp_i;
-                    const size_t off = ((size_t)idx + (tp_i & 1) + (tp_i >> 1) * (size_t)tx.stride) * 48 + c;
-                    if (acc3[u] != 0.0f && !(A.ablate & 65536)) atomicAdd(T.g_app[p] + off, acc3[u]);
+                for (int k = 0; k < 4; ++k) {            // the four taps of a cell sit in four different slots
+                    const int x = cx + (k & 1), y = cy + (k >> 1);
+                    slot[k] = (x & 3) + 4 * (y & 3);
+                    texel[k] = y * tx.stride + x;
+                    old[k] = __builtin_amdgcn_readlane(tags, slot[k]);
                 }
-                s0 = s1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cur[k] = lane < 48 ? cache[slot[k] * 48 + lane] : 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float nv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wts), 4 * s + k)) * g;
+                    if (old[k] == texel[k]) {
+                        nv += cur[k];
+                    } else {                             // wave-uniform: the slot changes hands, its previous owner is sent
+                        if (old[k] >= 0 && lane < 48 && cur[k] != 0.0f && !(A.ablate & 65536)) atomicAdd(gp + (size_t)old[k] * 48 + lane, cur[k]);
+                        if (old[k] >= 0 && (A.ablate & (1 << 21))) pc[6] += 3;
+                        tags = lane == slot[k] ? texel[k] : tags;
+                    }
+                    if (lane < 48) cache[slot[k] * 48 + lane] = nv;
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (int j = 0; j < 16; ++j) {
+                const int o = __builtin_amdgcn_readlane(tags, j);
+                if (o < 0) continue;
+                const float v = lane < 48 ? cache[j * 48 + lane] : 0.0f;
+                if (lane < 48 && v != 0.0f && !(A.ablate & 65536)) atomicAdd(gp + (size_t)o * 48 + lane, v);
+                if (A.ablate & (1 << 21)) pc[6] += 3;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         if (live && q == 0) {
             float *d = T.dt + ((int64_t)r * A.S + i) * 6;
@@ -760,6 +783,7 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
 #undef NGF_SEC
     if (prof && lane == 0)
         for (int k = 0; k < 8; ++k) atomicAdd(T.prof + k, pc[k]);
+    if ((A.ablate & (1 << 21)) && lane == 0) atomicAdd(T.prof + 9, pc[6]);
     atomicAdd(T.g_b1 + lane, gb1);
     atomicAdd(T.g_b2 + lane, gb2);
 #pragma unroll
@@ -892,7 +916,7 @@ __device__ __forceinline__ int blocked_offset(int X, int Y, int bw)
 // (X, Y) = padded (column, row) of the cell's first tap, val[tap][channel] the contributions (tap = 2 * dy + dx), bw = blocks per row;
 // tile: kScatWaveFloats floats of wave-private LDS.  Every lane of the wave must call it (wave-uniform control flow inside).
 template <int BYS, int CH, int N = 4 * CH>
-__device__ __forceinline__ void scatter_blocked(float *tile, int lane, bool work, int X, int Y, float (&val)[N], float *gbuf, int bw)
+__device__ __forceinline__ void scatter_blocked(float *tile, int lane, bool work, int X, int Y, float (&val)[N], float *gbuf, int bw, unsigned *lines = nullptr)
 {
     const int big = 1 << 20;
     const int bx0 = wave_min_i(work ? X >> 2 : big), bx1 = wave_max_i(work ? (X + 1) >> 2 : -big);
@@ -960,6 +984,11 @@ __device__ __forceinline__ void scatter_blocked(float *tile, int lane, bool work
         const int ba = b0 + sub, bb = b0 + 4 + sub;
         const float va = ba < nb ? tile[ba * 16 + e] : 0.0f;
         const float vb = bb < nb ? tile[bb * 16 + e] : 0.0f;
+        if (lines) {                            // profiling: one transaction per 16-lane group with a non-zero float
+            const unsigned long long ma = __ballot(va != 0.0f), mb = __ballot(vb != 0.0f);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) *lines += (((ma >> (16 * gq)) & 0xffffull) ? 1u : 0u) + (((mb >> (16 * gq)) & 0xffffull) ? 1u : 0u);
+        }
         if (va != 0.0f) {
             const int q = (int)(((unsigned)ba * magic) >> 16), r = ba - q * nbx;
             atomicAdd(gbuf + ((size_t)(by0 + q) * bw + (bx0 + r)) * 16 + e, va);
@@ -982,6 +1011,8 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *tile = s_tile[wave];
     float bsum = 0.0f;
+    const bool count_lines = (A.ablate & (1 << 21)) != 0;      // profiling: atomic line transactions -> T.prof[8]
+    unsigned n_lines = 0;
     // a wave item = 64 consecutive steps of ONE ray (the last chunk of a ray is short): its taps stay inside a small bounding box
     const int chunks = (A.S + 63) / 64;
     const int64_t items = A.n * chunks;
@@ -1009,7 +1040,7 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
             dt[2 * p + 1] = dx * (b.wx0 * (v01 - v00) + b.wx1 * (v11 - v10)) * b.sy;
             if (!(A.ablate & 256)) {
                 float dw[4] = {b.w00 * dx, b.w10 * dx, b.w01 * dx, b.w11 * dx};
-                scatter_blocked<2, 1>(tile, lane, work, b.cx, b.cy, dw, T.d_dens[p], T.d_bw[p]);
+                scatter_blocked<2, 1>(tile, lane, work, b.cx, b.cy, dw, T.d_dens[p], T.d_bw[p], count_lines ? &n_lines : nullptr);
             }
         }
         if (A.mode) {
@@ -1030,10 +1061,11 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
                 Bil b = bil_setup(u[p], v[p], A.gau[p]);
                 float gv[8] = {b.w00 * dg[p][0], b.w00 * dg[p][1], b.w10 * dg[p][0], b.w10 * dg[p][1],
                                b.w01 * dg[p][0], b.w01 * dg[p][1], b.w11 * dg[p][0], b.w11 * dg[p][1]};
-                if (!(A.ablate & 512)) scatter_blocked<1, 2>(tile, lane, work, b.cx, b.cy, gv, T.g_gau[p], T.g_bw[p]);
+                if (!(A.ablate & 512)) scatter_blocked<1, 2>(tile, lane, work, b.cx, b.cy, gv, T.g_gau[p], T.g_bw[p], count_lines ? &n_lines : nullptr);
             }
         }
     }
+    if (count_lines && lane == 0) atomicAdd(T.prof + 8, (unsigned long long)n_lines);
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) bsum += __shfl_xor(bsum, s);
     if (lane == 0) atomicAdd(&s_bd, bsum);
