@@ -237,7 +237,8 @@ int ngf_train_adam_all(ngf_trainer *t, const int32_t step_count[NGF_TRAIN_PARAMS
  * plane's memory by any other means (checkpoint load, in-place edit) call this: the next backward re-packs all of them. */
 int ngf_train_params_changed(ngf_trainer *t);
 /* profiling aid: with ngf_debug_set("ablate", 1 << 20) the colour backward adds its per-section clock counts (summed over
- * waves) to 8 counters; this reads and clears them (out16: 16 x uint64, host).  Synchronises the device. */
+ * waves) to 8 counters; with bit 1 << 21 the backward kernels count their atomic line transactions (counters 8, 9) and the
+ * scatter calls that took the per-tap path (10).  This reads and clears them (out16: 16 x uint64, host).  Synchronises. */
 int ngf_train_debug_sections(ngf_trainer *t, uint64_t *out16);
 
 /* ---- UV-Mapping (NeuTex) colour path: UV-Mapping/model/model.py:27-59 ----------------------------------------

@@ -241,3 +241,65 @@ def test_full_size_batch_matches_autograd_oracle():
         if k < 3:
             want = want - l1_term(params[name])
         assert rel(got, want) < 2 * GRAD_TOL, (name, rel(got, want))
+
+
+def test_scatter_takes_the_per_tap_path_when_a_ray_chunk_spans_too_many_blocks():
+    """train_density_bwd_kernel merges a wave's taps in an LDS tile over the blocks of its bounding box (<= 128 blocks).  Planes much
+    finer than the march step (200^2 planes, 8-voxel steps on a 32^3 grid: ~50 texels between neighbouring samples) overflow the
+    tile for every chunk, so the whole gradient goes through the per-tap fallback -- same oracle, same tolerance."""
+    from ngf_amd import geometry, synth
+    g = {"model": np.array("triplane"), "aabb": np.array([[-1.5] * 3, [1.5] * 3], np.float32), "grid": np.array([32] * 3),
+         "near_far": np.array([2.0, 6.0], np.float32), "step_ratio": np.float32(8.0), "distance_scale": np.float32(25), "thr": np.float32(1e-4)}
+    params = synth.triplane_params(5, ((200, 200),) * 3, (180, 180), preset="R1")
+    step = geometry.step_size(g["aabb"], g["grid"], 8.0)
+    f = field_for_case(g, params, None)
+    assert abs(float(f.stepSize) - float(step)) < 1e-9
+    frame = synth.lookat_rays(64, 64)
+    n, S = 300, 24
+    rays_np = frame[(synth.hash_uniform(11, 1, (n,)) * np.float32(frame.shape[0])).astype(np.int64)]
+    tgt_np = synth.hash_uniform(11, 2, (n, 3))
+    jit_np = synth.hash_uniform(11, 3, (n,))
+    orc = otrain.EagerTrainer(params, g["aabb"], step, g["near_far"], float(g["distance_scale"]), float(g["thr"]))
+    grads, rgb_loss, _, aux = orc.gradients(torch.from_numpy(rays_np), torch.from_numpy(tgt_np), S, torch.from_numpy(jit_np), True, 4)
+    tr = train.Trainer(f, batch_size=n, max_samples=S)
+    import ctypes as C
+    from ngf_amd import _lib
+    L = _lib.lib()
+    L.ngf_train_debug_sections.argtypes = [C.c_void_p, C.c_void_p]
+    cnt = (C.c_uint64 * 16)()
+    with _lib.knobs(ablate=1 << 21):                 # counts the whole-line atomics of the merged path
+        _lib.check(L.ngf_train_debug_sections(tr._h, cnt))
+        loss = tr.backward(torch.from_numpy(rays_np), torch.from_numpy(tgt_np), S, white_bg=True, iteration=4, jitter=torch.from_numpy(jit_np))
+        _lib.check(L.ngf_train_debug_sections(tr._h, cnt))
+    assert cnt[10] > 100, (cnt[8], cnt[10])          # counter 10: scatter calls that overflowed the tile and took the per-tap path
+    assert int(aux["active"].sum()) > 0 and tr.last_active == int(aux["active"].sum())
+    assert abs(loss.item() - rgb_loss) < 2e-6
+    for k, name in enumerate(train.PARAM_NAMES):
+        got = tr.gradient(k).cpu().numpy()
+        want = grads[name].numpy()
+        if k < 3:
+            want = want - l1_term(params[name])
+        assert rel(got, want) < GRAD_TOL, (name, rel(got, want))
+
+
+def test_params_changed_rebuilds_the_packed_copies():
+    """The trainer keeps channel-last copies of the planes that only its Adam kernel keeps current: an in-place edit needs
+    Trainer.params_changed().  After it, the gradients equal those of a trainer built on the edited field."""
+    g, params = load_train_case("train_r1")
+    f = field_for_case(g, params, None)
+    S = int(g["S"])
+    rays, tgt, jit = torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["rgb_train"]).cuda(), torch.from_numpy(g["jitter0"])
+    tr = train.Trainer(f, batch_size=rays.shape[0], max_samples=S)
+    tr.backward(rays, tgt, S, white_bg=True, iteration=0, jitter=jit)
+    g_before = tr.gradient("plane_xy").clone()
+    with torch.no_grad():
+        f.plane_xy.data.mul_(0.5)
+        f.gauge_yz.data.add_(0.01)
+    tr.params_changed()
+    tr.backward(rays, tgt, S, white_bg=True, iteration=0, jitter=jit)
+    fresh = train.Trainer(f, batch_size=rays.shape[0], max_samples=S)
+    fresh.backward(rays, tgt, S, white_bg=True, iteration=0, jitter=jit)
+    for name in ("plane_xy", "plane_yz", "gauge_yz", "rgb_decoder.mlp.0.weight", "density_decoder.weight"):
+        a, b = tr.gradient(name).cpu().numpy(), fresh.gradient(name).cpu().numpy()
+        assert rel(a, b) < GRAD_TOL, (name, rel(a, b))
+    assert rel(tr.gradient("plane_xy").cpu().numpy(), g_before.cpu().numpy()) > 1e-2        # the edit did change the gradient
