@@ -59,7 +59,8 @@ struct ngf_field {
 
 // ---- packing kernels -----------------------------------------------------------------------------
 // NCHW [C,H,W] channels [c0,c0+nc) -> zero-bordered channel-last [(H+2)][(W+2)][nc]
-__global__ void pack_plane_kernel(const float *__restrict__ src, int H, int W, int c0, int nc, float *__restrict__ dst)
+// perm = 1: the colour channels in the order of infoinv_split_channel (InfoInv NGF_F_SPLIT_BF16, nc = 72)
+__global__ void pack_plane_kernel(const float *__restrict__ src, int H, int W, int c0, int nc, float *__restrict__ dst, int perm = 0)
 {
     const size_t total = (size_t)(H + 2) * (W + 2) * nc;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -67,7 +68,7 @@ __global__ void pack_plane_kernel(const float *__restrict__ src, int H, int W, i
         const size_t tx = i / nc;
         const int x = (int)(tx % (W + 2)), y = (int)(tx / (W + 2));
         float v = 0.0f;
-        if (x >= 1 && x <= W && y >= 1 && y <= H) v = src[((size_t)(c0 + c) * H + (y - 1)) * W + (x - 1)];
+        if (x >= 1 && x <= W && y >= 1 && y <= H) v = src[((size_t)(c0 + (perm ? infoinv_split_channel(c) : c)) * H + (y - 1)) * W + (x - 1)];
         dst[i] = v;
     }
 }
@@ -263,16 +264,17 @@ static void build_rgb_image_bf16(int F, const std::vector<float> &basis, const s
     img[L::B3 + 3] = 0.0f;
 }
 
-// NGF_F_SPLIT_BF16 for InfoInv (ngf_infoinv.hpp mlp_pass_bf16_ii): LDS image (layer 2 fragments, biases, layer 3) and the streamed
-// layer-1 image [15 k-blocks][2 unit tiles][3 parts][64 lanes][8 bf16]; lane (i, hi), element e of k-block b holds the weight of
-// unit nt*32 + i for the lane half's (8 b + e)-th input: features (plane j/36, channel hi*36 + j%36), then its 8 view entries
+// NGF_F_SPLIT_BF16 for InfoInv (ngf_infoinv.hpp mlp_pass16_bf16_ii): A fragments as in build_rgb_image_bf16 -- lane (i, kq), element e of
+// k-block kb holds the weight of unit mt*16 + i for the lane quarter's (8 kb + e)-th input: 18 channels of each plane in the PACKED
+// channel order (infoinv_split_channel), its 4 view entries, 6 zero pads.  Layer 1: hi / mid parts in the LDS image
+// [mt][kb][2][lane][8 bf16], lo parts in the streamed image [kb][mt][lane][8 bf16]; layer 2: [mt][kb][3][lane][8 bf16].
 static void build_rgb_image_bf16_ii(int F, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
                                     const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3, const std::vector<float> &b3,
-                                    float *img, std::vector<float> &w1pack)
+                                    float *img, std::vector<float> &lopack)
 {
     using L = MlpLayoutBf16II;
-    const int IN = F + 15, HALF = F / 6;
-    std::vector<double> w1f((size_t)64 * (F + 16), 0.0);
+    const int IN = F + 15, APPc = F / 3;
+    std::vector<double> w1f((size_t)64 * (F + 16), 0.0);       // W1' = [W1[:, :F] . basis | W1[:, F:F+15] | 0]
     for (int n = 0; n < 64; ++n) {
         for (int k = 0; k < F; ++k) {
             double s = 0.0;
@@ -281,36 +283,40 @@ static void build_rgb_image_bf16_ii(int F, const std::vector<float> &basis, cons
         }
         for (int k = 0; k < 15; ++k) w1f[(size_t)n * (F + 16) + F + k] = w1[(size_t)n * IN + F + k];
     }
-    auto unit = [](int k, int hi) { return (k >> 4) * 32 + ((k & 15) & 3) + 8 * ((k & 15) >> 2) + 4 * hi; };      // accumulator order of the 32x32 tile pair
-    w1pack.assign(kW1PackII, 0.0f);
-    uint16_t *p16 = reinterpret_cast<uint16_t *>(w1pack.data());
-    for (int b = 0; b < L::KB1; ++b)
-        for (int nt = 0; nt < 2; ++nt)
+    auto hidden = [](int mt, int r, int kq) { return mt * 16 + 4 * kq + r; };
+    uint16_t *h16 = reinterpret_cast<uint16_t *>(img);
+    lopack.assign(kW1LoPackII, 0.0f);
+    uint16_t *l16 = reinterpret_cast<uint16_t *>(lopack.data());
+    for (int mt = 0; mt < 4; ++mt)
+        for (int kb = 0; kb < L::KB1; ++kb)
             for (int l = 0; l < 64; ++l)
                 for (int e = 0; e < 8; ++e) {
-                    const int hi = l >> 5, n = nt * 32 + (l & 31), j = 8 * b + e;
+                    const int kq = l >> 4, n = mt * 16 + (l & 15), j = kb * 8 + e;
                     float wv = 0.0f;
-                    if (j < 3 * HALF) wv = (float)w1f[(size_t)n * (F + 16) + (j / HALF) * (2 * HALF) + hi * HALF + (j % HALF)];
-                    else if (j < 3 * HALF + 8) wv = (float)w1f[(size_t)n * (F + 16) + F + hi * 8 + (j - 3 * HALF)];
+                    if (j < 54) wv = (float)w1f[(size_t)n * (F + 16) + (j / 18) * APPc + infoinv_split_channel(kq * 18 + j % 18)];
+                    else if (j < 58) wv = (float)w1f[(size_t)n * (F + 16) + F + kq * 4 + (j - 54)];      // view entry (entry 15 = zero pad column)
                     uint16_t p3[3];
                     split3(wv, p3);
-                    for (int part = 0; part < 3; ++part) p16[((((size_t)b * 2 + nt) * 3 + part) * 64 + l) * 8 + e] = p3[part];
+                    for (int part = 0; part < 2; ++part)
+                        h16[((size_t)L::W1 + ((((size_t)mt * L::KB1 + kb) * 2 + part) * 64 + l) * 4) * 2 + e] = p3[part];
+                    l16[((((size_t)kb * 4 + mt) * 64 + l) * 4) * 2 + e] = p3[2];
                 }
-    uint16_t *h16 = reinterpret_cast<uint16_t *>(img + L::W2);
-    for (int mt = 0; mt < 2; ++mt)
-        for (int q = 0; q < L::KB2; ++q)
+    for (int mt = 0; mt < 4; ++mt)
+        for (int kb = 0; kb < L::KB2; ++kb)
             for (int l = 0; l < 64; ++l)
                 for (int e = 0; e < 8; ++e) {
+                    const int kq = l >> 4, n = mt * 16 + (l & 15), j = kb * 8 + e;
                     uint16_t p3[3];
-                    split3(w2[(size_t)(mt * 32 + (l & 31)) * 64 + unit(8 * q + e, l >> 5)], p3);
-                    for (int part = 0; part < 3; ++part) h16[((((size_t)mt * L::KB2 + q) * 3 + part) * 64 + l) * 8 + e] = p3[part];
+                    split3(w2[(size_t)n * 64 + hidden(j >> 2, j & 3, kq)], p3);
+                    for (int part = 0; part < 3; ++part)
+                        h16[((size_t)L::W2 + ((((size_t)mt * L::KB2 + kb) * 3 + part) * 64 + l) * 4) * 2 + e] = p3[part];
                 }
-    for (int hi = 0; hi < 2; ++hi)
-        for (int k = 0; k < 32; ++k) {
-            const int n = unit(k, hi);
-            img[L::B1 + hi * 32 + k] = b1[n];
-            img[L::B2 + hi * 32 + k] = b2[n];
-            for (int c = 0; c < 3; ++c) img[L::W3 + c * 64 + hi * 32 + k] = w3[(size_t)c * 64 + n];
+    for (int kq = 0; kq < 4; ++kq)
+        for (int k = 0; k < 16; ++k) {
+            const int n = hidden(k >> 2, k & 3, kq);
+            img[L::B1 + kq * 16 + k] = b1[n];
+            img[L::B2 + kq * 16 + k] = b2[n];
+            for (int c = 0; c < 3; ++c) img[L::W3 + c * 64 + kq * 16 + k] = w3[(size_t)c * 64 + n];
         }
     for (int c = 0; c < 3; ++c) img[L::B3 + c] = b3[c];
     img[L::B3 + 3] = 0.0f;
@@ -519,7 +525,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     }
     A.blob = f->blob;
     A.blob_floats = (int)img.size();
-    if (no_fold || split_ii) {        // the matrix the shade streams from L2 (level-0 basis / InfoInv split layer 1)
+    if (no_fold || split_ii) {        // the matrix the shade streams from L2 (level-0 basis / lo parts of InfoInv's split layer 1)
         if ((rc = alloc_f(&f->basis_pack, bpack.size(), f))) return bail(rc);
         if (hipMemcpyAsync(f->basis_pack, bpack.data(), bpack.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess)
             return bail(fail(NGF_E_HIP, "uploading the packed basis matrix failed"));
@@ -543,7 +549,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
         if (bake) bake_density_kernel<<<1024, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, d->dens_w1 + p * d->dens_dim, f->tex[p]);
         else pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, 0, d->dens_dim, f->tex[p]);
         if (bake_c) bake_color_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, wp_dev + (size_t)p * 64 * f->app, f->tex[3 + p]);
-        else pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, f->tex[3 + p]);
+        else pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, f->tex[3 + p], split_ii ? 1 : 0);
         A.dens[p] = Tex{f->tex[p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
         A.app[p] = Tex{f->tex[3 + p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
         if (tri) {
@@ -710,7 +716,11 @@ static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
 
 static int render_common(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
-    if (f->model == NGF_MODEL_INFOINV) return (f->flags & NGF_F_SPLIT_BF16) ? launch_policy<InfoInvSplitPolicy>(f, A, st) : launch_policy<InfoInvPolicy>(f, A, st);
+    if (f->model == NGF_MODEL_INFOINV) {
+        if (!(f->flags & NGF_F_SPLIT_BF16)) return launch_policy<InfoInvPolicy>(f, A, st);
+        if (knob(KNOB_TILE_W) > 16 || knob(KNOB_SPLIT) == 0) return fail(NGF_E_ARG, "InfoInv NGF_F_SPLIT_BF16 renders with split tiles of at most 16 rays");
+        return launch_policy<InfoInvSplitPolicy>(f, A, st);
+    }
     if (f->flags & NGF_F_NO_FOLD) return launch_policy<TriPlaneNoFoldPolicy>(f, A, st);
     if (f->flags & NGF_F_SPLIT_BF16) {
         if (knob(KNOB_TILE_W) > 8 || knob(KNOB_SPLIT) == 0) return fail(NGF_E_ARG, "NGF_F_SPLIT_BF16 renders with split tiles of 4 or 8 rays");

@@ -15,6 +15,7 @@
 namespace ngf {
 
 constexpr int kInfoInvWaves = 8;
+constexpr int kInfoInvSplitWaves = 8;        // NGF_F_SPLIT_BF16: 102 KB of MLP images + 5.4 KB per wave
 
 struct InfoInvDensLayout {                  // floats, relative to MlpLayout<72>::TOTAL inside the blob
     static constexpr int D1 = 0;                    // [36 k-steps][64 lanes] : W1[l&31][2t + (l>>5)]
@@ -53,177 +54,177 @@ __device__ __forceinline__ void swap32(float &a, float &b)
     b = __uint_as_float(r[1]);
 }
 
-// ---- NGF_F_SPLIT_BF16 for InfoInv: rgb_decoder (216 features + view -> 64 -> 64 -> 3) on v_mfma_f32_32x32x16_bf16 -----------------
-// Same technique as ngf_shade_bf16.hpp (3-term bf16 splits, six products per fp32 product, fp32 accumulate) on the 32-sample /
-// two-lanes-per-sample pass of mlp_pass<72>: lane (s, hi) supplies 8 of its inputs per k-block (k = 8 hi + e of the instruction's
-// 16), 15 k-blocks cover its 108 features + 8 view inputs (+4 zero pads).  Layer 1's A fragments (92 KB) do not fit LDS next to the
-// density MLP: they stream from L2 as [k-block][2 unit tiles][3 parts][lane][8 bf16], requested one stage (a gather wait + 48
-// interpolations) before their MFMAs.  Layer 2 (4 k-blocks) keeps its fragments in LDS.  180 + 48 bf16 MFMAs of 8 passes replace
-// 232 + 64 fp32 MFMAs of 16 passes per 32 samples.
-// MEASURED (profiles/r02_infoinv_split.txt): correct (max |rgb - fp32 path| < 2e-6) but NOT faster -- 13.77 ms vs 13.56 ms per frame.
-// The two-lanes-per-sample pass already carries 32 accumulators + 36 PE factors + 48 gather registers per lane; the fragments and
-// splits push it past the 256 registers two waves per SIMD have (88 spills), and with one wave per SIMD (no spills) it is
-// 14.8 ms.  Kept as a tested variant behind the flag; the way forward is a four-lanes-per-sample pass (16 accumulators, 18 channels
-// per lane and plane), see DESIGN.md section 9.
-struct MlpLayoutBf16II {                      // LDS image (floats)
-    static constexpr int KB1 = 15, KB2 = 4;
-    static constexpr int W2 = 0;                              // [2 mt][4 kb][3 parts][64 lanes][4]
-    static constexpr int B1 = W2 + 2 * KB2 * 3 * 64 * 4;      // [2 hi][32] fp32, accumulator order
+// ---- NGF_F_SPLIT_BF16 for InfoInv: rgb_decoder layer 1 (216 features + 15 view inputs -> 64) on v_mfma_f32_16x16x32_bf16 ---------------
+// The technique of ngf_shade_bf16.hpp (3-term bf16 splits, six products per fp32 product, fp32 accumulate, fp32-level error) on the
+// 16-sample / FOUR-lanes-per-sample pass: lane (s, kq) owns 16 accumulators and supplies 64 of the 256 padded inputs -- 18 channels of
+// each plane, its 4 view entries, 6 zero pads -- as eight 8-element B fragments.  Layer 2 runs the same way (two k-blocks), layer 3 on
+// the VALU.  The hi and mid parts of layer 1 (64 KB), layer 2 (24 KB) and the density MLP make a 102 KB LDS image with room for eight
+// waves per CU; layer 1's lo parts (32 KB, the term that only meets x.hi) stream from L2, one k-block pair ahead of their MFMAs.
+//   * The colour channels of a plane are PERMUTED at pack time (pack_plane_kernel, perm = 1) so that a lane's 18 channels are 72
+//     contiguous bytes: position kq*18 + (hi*3 + axis)*3 + j holds channel hi*36 + axis*12 + 3 kq + j, i.e. lane-quarter kq owns the
+//     octaves 3kq .. 3kq+2 of the positional encoding of every axis, sine and cosine (Field.py:72-84: feature c is multiplied by
+//     sin / cos (x_axis 2^f)).  Its 18 factors are three sincosf at octave 3kq and two angle doublings each -- the two-lanes-per-sample
+//     pass computes all twelve octaves of the three axes in every lane.
+//   * A plane's four taps arrive in two rows; the bilinear sum is accumulated in the order of bil_mix (w00 v00, + w10 v10, + w01 v01,
+//     + w11 v11), so the features are bit-identical to the fp32 path's and 36 registers of gather are in flight instead of 72.
+// The first version of this flag (two lanes per sample on v_mfma_f32_32x32x16_bf16, layer 1 streamed from L2) was register-bound and
+// not faster (profiles/r02_infoinv_split.txt).
+struct MlpLayoutBf16II {                      // LDS image (floats); a bf16x8 fragment = 4 floats
+    static constexpr int KB1 = 8, KB2 = 2;
+    static constexpr int W1 = 0;                              // [4 mt][8 kb][2 parts: hi, mid][64 lanes][4]
+    static constexpr int W2 = W1 + 4 * KB1 * 2 * 64 * 4;      // [4 mt][2 kb][3 parts][64 lanes][4]
+    static constexpr int B1 = W2 + 4 * KB2 * 3 * 64 * 4;      // [4 kq][16] fp32, accumulator order
     static constexpr int B2 = B1 + 64;
-    static constexpr int W3 = B2 + 64;                        // [3][2 hi][32]
+    static constexpr int W3 = B2 + 64;                        // [3][4 kq][16]
     static constexpr int B3 = W3 + 192;
     static constexpr int TOTAL = B3 + 4;
 };
-constexpr int kW1PackII = MlpLayoutBf16II::KB1 * 2 * 3 * 64 * 4;      // floats of the streamed layer-1 image
+constexpr int kW1LoPackII = MlpLayoutBf16II::KB1 * 4 * 64 * 4;      // floats of the streamed image: layer 1's lo parts [kb][mt][lane][8 bf16]
+// packed position (0..71) of a plane's colour channels -> channel of the reference layout
+__host__ __device__ __forceinline__ int infoinv_split_channel(int pos)
+{
+    const int kq = pos / 18, r = pos % 18, g = r / 3, j = r % 3;        // g = hi*3 + axis
+    return (g / 3) * 36 + (g % 3) * 12 + 3 * kq + j;
+}
 
-// k-block b of the streamed layer-1 image, both unit tiles, one part (0 = hi, 1 = mid, 2 = lo): 8 registers
-struct APartII { bf16x8 t0, t1; };
-__device__ __forceinline__ APartII apart_ii_load(const float *pack, int b, int part, int lane)
+struct GatherRowII { f32x4 a[2][4]; f32x2 b[2]; };               // one row of a cell: two taps x 18 channels (36 registers)
+__device__ __forceinline__ void gather_row_ii(const float *base, GatherRowII &g)
 {
-    const bf16x8 *p = reinterpret_cast<const bf16x8 *>(pack) + ((size_t)b * 6) * 64 + lane;
-    return APartII{p[part * 64], p[(3 + part) * 64]};
+    // base: the lane's 18 channels of the row's first tap; the second tap is the next texel (72 channels on)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float *p = base + t * 72;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g.a[t][q] = *reinterpret_cast<const f32x4 *>(p + 4 * q);
+        g.b[t] = *reinterpret_cast<const f32x2 *>(p + 16);
+    }
 }
-#define NGF_MFMA_BF16_32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-// the six products of order <= 2 for both unit tiles; lo, mid, hi = the k-block's A parts (smallest terms first)
-__device__ __forceinline__ void six_products_ii(const APartII &lo, const APartII &mid, const APartII &hi, const Split8 &x, f32x16 &c0, f32x16 &c1)
-{
-    c0 = NGF_MFMA_BF16_32(lo.t0, x.h, c0);   c1 = NGF_MFMA_BF16_32(lo.t1, x.h, c1);
-    c0 = NGF_MFMA_BF16_32(hi.t0, x.l, c0);   c1 = NGF_MFMA_BF16_32(hi.t1, x.l, c1);
-    c0 = NGF_MFMA_BF16_32(mid.t0, x.m, c0);  c1 = NGF_MFMA_BF16_32(mid.t1, x.m, c1);
-    c0 = NGF_MFMA_BF16_32(mid.t0, x.h, c0);  c1 = NGF_MFMA_BF16_32(mid.t1, x.h, c1);
-    c0 = NGF_MFMA_BF16_32(hi.t0, x.m, c0);   c1 = NGF_MFMA_BF16_32(hi.t1, x.m, c1);
-    c0 = NGF_MFMA_BF16_32(hi.t0, x.h, c0);   c1 = NGF_MFMA_BF16_32(hi.t1, x.h, c1);
-}
-struct AFragII { APartII hi, mid, lo; };
-__device__ __forceinline__ void afrag_ii_load(const float *pack, int b, int lane, AFragII &f)
-{
-    f.hi = apart_ii_load(pack, b, 0, lane);
-    f.mid = apart_ii_load(pack, b, 1, lane);
-    f.lo = apart_ii_load(pack, b, 2, lane);
-}
-__device__ __forceinline__ void six_products_ii(const AFragII &f, const Split8 &x, f32x16 &c0, f32x16 &c1) { six_products_ii(f.lo, f.mid, f.hi, x, c0, c1); }
 
-__device__ __forceinline__ void mlp_pass_bf16_ii(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const float *vf, int lane,
-                                                 int mode, float rgb[3])
+// layer 1's lo parts of one k-block (the term that only meets x.hi), streamed from L2: 16 registers
+struct LoFragII { bf16x8 t[4]; };
+__device__ __forceinline__ void lo_load_ii(const float *pack, int kb, int lane, LoFragII &f)
+{
+    const bf16x8 *p = reinterpret_cast<const bf16x8 *>(pack) + (size_t)kb * 4 * 64 + lane;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) f.t[mt] = p[mt * 64];
+}
+// acc[mt] += W1[mt][kb] . x: hi / mid fragments from LDS (w = image + kb offset + lane), lo from `lo`; the unit tiles two at a time
+__device__ __forceinline__ void kblock_ii(const float *w, const LoFragII &lo, const Split8 &x, f32x4 acc[4])
+{
+    constexpr int MT = MlpLayoutBf16II::KB1 * 2 * 64 * 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        AFrag a0, a1;
+        a0.h = *reinterpret_cast<const bf16x8 *>(w + (2 * h) * MT);      a0.m = *reinterpret_cast<const bf16x8 *>(w + (2 * h) * MT + 64 * 4);      a0.l = lo.t[2 * h];
+        a1.h = *reinterpret_cast<const bf16x8 *>(w + (2 * h + 1) * MT);  a1.m = *reinterpret_cast<const bf16x8 *>(w + (2 * h + 1) * MT + 64 * 4);  a1.l = lo.t[2 * h + 1];
+        six_products2(a0, a1, x, acc[2 * h], acc[2 * h + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v, int lane,
+                                                   int mode, float rgb[3])
 {
     using L = MlpLayoutBf16II;
-    constexpr int APP = 72, HALF = 36, CH = 3, CPP = 3, NST = 9;
-    blob = per_pass(blob);
-    const int hi = lane >> 5;
-    f32x4 raw[4][CH];
-    auto issue = [&](int st) {
-        const int p = st / CPP, q0 = (st % CPP) * CH;
-        const Tex &t = A.app[p];
-        const Bil b = bil_setup(rec[2 + 2 * p], rec[3 + 2 * p], t);
-        const f32x4 *t00 = reinterpret_cast<const f32x4 *>(t.p + (size_t)b.idx * APP + hi * HALF) + q0;
-        const f32x4 *t01 = t00 + (size_t)t.stride * (APP / 4);
-#pragma unroll
-        for (int q = 0; q < CH; ++q) {
-            raw[0][q] = t00[q];
-            raw[1][q] = t00[APP / 4 + q];
-            raw[2][q] = t01[q];
-            raw[3][q] = t01[APP / 4 + q];
-        }
-    };
-    issue(0);
+    blob = per_pass16(blob);
+    const int kq = lane >> 4;
+    constexpr int KB_STRIDE = 2 * 64 * 4;
+    const float *w1 = blob + L::W1 + lane * 4;
+    GatherRowII g;
+    Bil b = bil_setup(rec[2], rec[3], A.app[0]);
+    gather_row_ii(A.app[0].p + (size_t)b.idx * 72 + kq * 18, g);
+    LoFragII lo0, lo1;                         // k-blocks 2i / 2i+1: each is re-requested for block +2 as soon as it has been used
+    lo_load_ii(A.basis_pack, 0, lane, lo0);
+    lo_load_ii(A.basis_pack, 1, lane, lo1);
     __builtin_amdgcn_sched_barrier(0);
-    f32x16 acc0, acc1;
+    f32x4 acc[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        acc0[r] = blob[L::B1 + hi * 32 + r];
-        acc1[r] = blob[L::B1 + hi * 32 + 16 + r];
-    }
-    // plane_feature * PE_12(xyz): this lane needs the 36 factors of its half (hi = 0: sines, hi = 1: cosines), once per pass
-    float pe[36];
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(blob + L::B1 + kq * 16 + mt * 4);
+    // the positional factors of the lane's channels are sin / cos (x_axis 2^(3kq + j)), xyz = cat(xy, yz[:, 1:]): one sincosf per axis
+    // at octave 3kq, the two doublings are redone per plane (6 registers instead of 18)
+    float bs[3] = {0.0f, 0.0f, 0.0f}, bc[3] = {1.0f, 1.0f, 1.0f};
     if (mode) {
-        const float pe_xyz[3] = {rec[2], rec[3], rec[5]};                          // xyz = cat(xy, yz[:,1:])
+        const float pe_xyz[3] = {rec[2], rec[3], rec[5]};
+        const float scale = (float)(1 << (3 * kq));
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float sn[12], cs[12];
-            pe_ladder<12>(pe_xyz[k], sn, cs);
-#pragma unroll
-            for (int f = 0; f < 12; ++f) pe[k * 12 + f] = hi ? cs[f] : sn[f];
-        }
+        for (int k = 0; k < 3; ++k) sincosf(pe_xyz[k] * scale, &bs[k], &bc[k]);
     }
-    float carry[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    AFragII F0;
+    float left[4];                             // inputs of a plane that did not fill a k-block yet
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int st = 0; st < NST; ++st) {
-        const int p = st / CPP, q0 = (st % CPP) * CH;
-        const int b0 = 3 * (st >> 1) + ((st & 1) ? 1 : 0);            // first k-block this stage completes
+    for (int p = 0; p < 3; ++p) {
+        float f[18];
+        // row 0: w00 v00, then + w10 v10
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[4 * q + e] = fmaf(b.w10, g.a[1][q][e], b.w00 * g.a[0][q][e]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) f[16 + e] = fmaf(b.w10, g.b[1][e], b.w00 * g.b[0][e]);
         __builtin_amdgcn_sched_barrier(0);
-        afrag_ii_load(A.basis_pack, b0, lane, F0);                    // requested before the stage's gather is waited for
+        gather_row_ii(A.app[p].p + ((size_t)b.idx + A.app[p].stride) * 72 + kq * 18, g);
         __builtin_amdgcn_sched_barrier(0);
-        float feat[4 * CH];
-        {
-            const Bil b = bil_setup(rec[2 + 2 * p], rec[3 + 2 * p], A.app[p]);
+        // row 1: + w01 v01, + w11 v11 (bil_mix's order), then the positional factor
 #pragma unroll
-            for (int q = 0; q < CH; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) feat[4 * q + e] = bil_mix(b, raw[0][q][e], raw[1][q][e], raw[2][q][e], raw[3][q][e]);
+            for (int e = 0; e < 4; ++e) f[4 * q + e] = fmaf(b.w11, g.a[1][q][e], fmaf(b.w01, g.a[0][q][e], f[4 * q + e]));
+#pragma unroll
+        for (int e = 0; e < 2; ++e) f[16 + e] = fmaf(b.w11, g.b[1][e], fmaf(b.w01, g.b[0][e], f[16 + e]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (p < 2) {                           // the next plane's first row travels behind this plane's MFMAs
+            b = bil_setup(rec[4 + 2 * p], rec[5 + 2 * p], A.app[p + 1]);
+            gather_row_ii(A.app[p + 1].p + (size_t)b.idx * 72 + kq * 18, g);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (st + 1 < NST) issue(st + 1);
         __builtin_amdgcn_sched_barrier(0);
         if (mode) {
 #pragma unroll
-            for (int jj = 0; jj < 4 * CH; ++jj) feat[jj] = feat[jj] * pe[4 * q0 + jj];
-        }
-        if (!(st & 1)) {
-            six_products_ii(F0, split8(feat), acc0, acc1);
+            for (int k = 0; k < 3; ++k) {
+                float sn = bs[k], cs = bc[k];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) carry[e] = feat[8 + e];
-        } else {
-            const float xa[8] = {carry[0], carry[1], carry[2], carry[3], feat[0], feat[1], feat[2], feat[3]};
-            six_products_ii(F0, split8(xa), acc0, acc1);
-            __builtin_amdgcn_sched_barrier(0);
-            afrag_ii_load(A.basis_pack, b0 + 1, lane, F0);            // the stage's second k-block: behind the twelve MFMAs just issued
-            __builtin_amdgcn_sched_barrier(0);
-            six_products_ii(F0, split8(feat + 4), acc0, acc1);
+                for (int j = 0; j < 3; ++j) {
+                    f[k * 3 + j] *= sn; f[9 + k * 3 + j] *= cs;
+                    const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
+                    sn = s2; cs = c2;
+                }
+            }
         }
+        // inputs so far: 18 p + the 2 p leftovers of the planes before; whole k-blocks go to the matrix pipe now
+        if (p == 0) {
+            kblock_ii(w1 + 0 * KB_STRIDE, lo0, split8(f), acc);      lo_load_ii(A.basis_pack, 2, lane, lo0);  __builtin_amdgcn_sched_barrier(0);
+            kblock_ii(w1 + 1 * KB_STRIDE, lo1, split8(f + 8), acc);  lo_load_ii(A.basis_pack, 3, lane, lo1);  __builtin_amdgcn_sched_barrier(0);
+            left[0] = f[16]; left[1] = f[17];
+        } else if (p == 1) {
+            const float x2[8] = {left[0], left[1], f[0], f[1], f[2], f[3], f[4], f[5]};
+            kblock_ii(w1 + 2 * KB_STRIDE, lo0, split8(x2), acc);     lo_load_ii(A.basis_pack, 4, lane, lo0);  __builtin_amdgcn_sched_barrier(0);
+            kblock_ii(w1 + 3 * KB_STRIDE, lo1, split8(f + 6), acc);  lo_load_ii(A.basis_pack, 5, lane, lo1);  __builtin_amdgcn_sched_barrier(0);
+            left[0] = f[14]; left[1] = f[15]; left[2] = f[16]; left[3] = f[17];
+        } else {
+            const float x4[8] = {left[0], left[1], left[2], left[3], f[0], f[1], f[2], f[3]};
+            kblock_ii(w1 + 4 * KB_STRIDE, lo0, split8(x4), acc);     lo_load_ii(A.basis_pack, 6, lane, lo0);  __builtin_amdgcn_sched_barrier(0);
+            kblock_ii(w1 + 5 * KB_STRIDE, lo1, split8(f + 4), acc);  lo_load_ii(A.basis_pack, 7, lane, lo1);  __builtin_amdgcn_sched_barrier(0);
+            const float x6[8] = {f[12], f[13], f[14], f[15], f[16], f[17], v[0], v[1]};
+            kblock_ii(w1 + 6 * KB_STRIDE, lo0, split8(x6), acc);
+            const float x7[8] = {v[2], v[3], 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            kblock_ii(w1 + 7 * KB_STRIDE, lo1, split8(x7), acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    {   // k-blocks 13, 14: the last four features + the lane's eight view inputs (+ four zero pads)
-        __builtin_amdgcn_sched_barrier(0);
-        afrag_ii_load(A.basis_pack, 13, lane, F0);
-        const f32x4 va = *reinterpret_cast<const f32x4 *>(vf + hi * 8), vb = *reinterpret_cast<const f32x4 *>(vf + hi * 8 + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        const float xa[8] = {carry[0], carry[1], carry[2], carry[3], va[0], va[1], va[2], va[3]};
-        const float xb[8] = {vb[0], vb[1], vb[2], vb[3], 0.0f, 0.0f, 0.0f, 0.0f};
-        six_products_ii(F0, split8(xa), acc0, acc1);
-        __builtin_amdgcn_sched_barrier(0);
-        afrag_ii_load(A.basis_pack, 14, lane, F0);
-        __builtin_amdgcn_sched_barrier(0);
-        six_products_ii(F0, split8(xb), acc0, acc1);
+    // layer 2 on the bf16 pipe as in mlp_pass16_bf16: the lane's 16 hidden activations are its two B fragments; layer 3 on the VALU
+    f32x4 c[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) c[mt] = *reinterpret_cast<const f32x4 *>(blob + L::B2 + kq * 16 + mt * 4);
+    {
+        constexpr int KB2_STRIDE = 3 * 64 * 4, MT2 = L::KB2 * KB2_STRIDE;
+        const float *w2 = blob + L::W2 + lane * 4;
+        float h[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) h[k] = relu1(acc[k >> 2][k & 3]);
+        kblock_bf16<MT2>(w2, split8(h), c);
+        kblock_bf16<MT2>(w2 + KB2_STRIDE, split8(h + 8), c);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // layer 2: the lane's 32 hidden activations as four B fragments; A fragments from LDS
-    f32x16 c0, c1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        c0[r] = blob[L::B2 + hi * 32 + r];
-        c1[r] = blob[L::B2 + hi * 32 + 16 + r];
-    }
-    const float *w2 = blob + L::W2 + lane * 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float h[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const int k = 8 * q + e; h[e] = relu1(k < 16 ? acc0[k & 15] : acc1[k & 15]); }
-        auto frag = [&](int mt, int part) { return *reinterpret_cast<const bf16x8 *>(w2 + ((mt * L::KB2 + q) * 3 + part) * 64 * 4); };
-        const APartII ahi{frag(0, 0), frag(1, 0)}, amid{frag(0, 1), frag(1, 1)}, alo{frag(0, 2), frag(1, 2)};
-        six_products_ii(alo, amid, ahi, split8(h), c0, c1);
-    }
-    // layer 3 on the VALU as in mlp_tail
-    const float *w3 = blob + L::W3 + hi * 32;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) s = fmaf(w3[c * 64 + k], relu1(k < 16 ? c0[k & 15] : c1[k & 15]), s);
-        s = s + __shfl_xor(s, 32);
-        s = s + blob[L::B3 + c];
-        rgb[c] = 1.0f / (1.0f + expf(-s));
-    }
+    mlp_layer3_16(blob, L::W3, L::B3, lane, c, rgb);
 }
 
 template <bool SPLIT>
@@ -231,15 +232,15 @@ struct InfoInvPolicyT {
     static constexpr int RGB_FLOATS = SPLIT ? MlpLayoutBf16II::TOTAL : MlpLayout<72>::TOTAL;      // the density image follows the colour image in LDS
     static constexpr int APP = 72;
     static constexpr bool INFOINV = true;
-    static constexpr int WAVES = kInfoInvWaves;
+    static constexpr int WAVES = SPLIT ? kInfoInvSplitWaves : kInfoInvWaves;
     static constexpr bool PROFILE = false;
     static constexpr bool VLDS = true;
     static constexpr bool VIEW_FOLD = false;
     static constexpr bool STAGED = false;
     static constexpr int STAGE_FLOATS = 0;
-    static constexpr int VFEAT_FLOATS = kWave * kViewFeat;
+    static constexpr int VFEAT_FLOATS = SPLIT ? 16 * kViewFeat : kWave * kViewFeat;     // split: tiles of <= 16 rays (render_common checks)
     static constexpr int NSTEP = 1;
-    static constexpr int BATCH = kBatch;
+    static constexpr int BATCH = SPLIT ? kBatch16 : kBatch;
     static constexpr int RING = 128;
 
     // called by all 64 lanes; returns sigma of the lane's own sample (0 when !valid)
@@ -319,7 +320,7 @@ struct InfoInvPolicyT {
     __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
                                                  const float *, int lane, float c[3], unsigned long long * = nullptr)
     {
-        if constexpr (SPLIT) mlp_pass_bf16_ii(A, smem, rec, vf, lane, A.mode, c);
+        if constexpr (SPLIT) mlp_pass16_bf16_ii(A, smem, rec, *reinterpret_cast<const f32x4 *>(vf + (lane >> 4) * 4), lane, A.mode, c);
         else mlp_pass<72, true, 3>(A, smem, rec, vf, lane, A.mode, c);
     }
 };

@@ -512,6 +512,14 @@ __global__ void __launch_bounds__(512 / NS) uv_render_kernel(const UvArgs A)
     const int lane = threadIdx.x & 63;
     float *act = smem + (threadIdx.x >> 6) * (NS * kUvWaveLds);
     const int S = A.S;
+    if constexpr (SPLIT) {
+        // block2.0 has 76 k-steps = 9.5 k-blocks: its tenth k-block also reads rows 76..79, which nothing else writes.  Their weights
+        // are zero, but LDS keeps whatever the previous kernel left there (a NaN or Inf pattern would poison the sums): zero them once.
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int t = 76; t < kUvActSteps; ++t) act[s * kUvWaveLds + t * 64 + lane] = 0.0f;
+    }
     unsigned long long st_samples = 0, st_pass = 0;
     const float dt = (float)(2.0 / S), dtj = (float)((2.0 / S) * 0.05);     // renderer.py:107-117 (python floats)
     for (;;) {
