@@ -358,7 +358,7 @@ def main():
                         ("triplane", "R0", {"bake": True}, "_bake_density", "_bd"),
                         ("triplane", "R2", {"bake": True, "bake_color": True}, "_bake_density_color", "_bdc"),
                         ("infoinv", "R1", {}, "", ""),
-                        ("infoinv", "R1", {"split_bf16": True}, "_split_bf16", "_split"))           # correct but not faster: register-bound (profiles/r02_infoinv_split.txt)
+                        ("infoinv", "R1", {"split_bf16": True}, "_split_bf16", "_split"))           # rgb_decoder on bf16 MFMA, four lanes per sample (profiles/r02_infoinv_split.txt)
             for mdl, preset, flags, tag, ptag_sfx in variants:
                 try:
                     fx, _, _, _ = build_field(mdl, preset, device, **flags)

@@ -1,6 +1,10 @@
 // ngf_field.hip -- C ABI (include/ngf.h), TriPlane / InfoInv part: field handle, render / march / decode / alpha-mask / ray
 // entry points and the training step (they share the plane packing kernels).  No torch, no CPU fallback: every entry point
 // runs HIP kernels or fails.  Build: see Makefile (hipcc --offload-arch=gfx950 -O3 -ffp-contract=off).
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "ngf_host.hpp"
 #include "ngf_infoinv.hpp"
 #include "ngf_render.hpp"
@@ -27,6 +31,21 @@ static const char *const g_knob_name[ngf::KNOB_COUNT] = {"tile_w", "split", "wav
 static bool g_knob_init = [] { for (auto &k : g_knob) k.store(-1); return true; }();
 
 int ngf::knob(int id) { return g_knob[id].load(std::memory_order_relaxed); }
+
+hipError_t ngf::ensure_dynamic_lds(const void *kernel, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> done;         // (device, kernel) -> largest size set so far
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = done[{dev, kernel}];
+    if (have >= bytes && have != 0) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
 
 extern "C" int ngf_debug_set(const char *name, int32_t value)
 {
@@ -613,7 +632,7 @@ static int launch_render(K kernel, K kernel_split, const ngf_field *f, RenderArg
     A.tile_w = tw;
     A.tile_shift = tw == 64 ? 6 : tw == 32 ? 5 : tw == 16 ? 4 : tw == 8 ? 3 : 2;
     K k = split ? kernel_split : kernel;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k), lds_bytes));
     const int64_t tiles = (A.n + tw - 1) / tw;
     int64_t grid = (tiles + waves - 1) / waves;
     if (grid > f->num_cus) grid = f->num_cus;
@@ -645,11 +664,7 @@ static int launch_pc(const ngf_field *f, RenderArgs &A, hipStream_t st)
     A.tile_w = TW;
     A.tile_shift = TW == 8 ? 3 : 2;
     auto k = render_pc_kernel<P, NM, NS, TW>;
-    static bool attr_set = false;             // per instantiation
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k), lds));
     const int64_t tiles = (A.n + TW - 1) / TW;
     int64_t grid = (tiles + NM - 1) / NM;
     if (grid > f->num_cus) grid = f->num_cus;
@@ -777,7 +792,7 @@ extern "C" int ngf_field_decode_rgb(const ngf_field *f, const float *coords, con
     int grid = (int)((nb + 3) / 4);
     if (grid > 4 * f->num_cus) grid = 4 * f->num_cus;
     auto go = [&](auto kern) -> int {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, coords, dirs, n, rgb);
         return NGF_OK;
     };
@@ -802,10 +817,10 @@ static int launch_alpha(const ngf_field *f, const float *xyz, const Lattice &L, 
         const size_t lds = (size_t)((A.blob_floats + 3) & ~3) * sizeof(float);
         if (grid > (int64_t)f->num_cus) grid = f->num_cus;
         if (f->flags & NGF_F_SPLIT_BF16) {        // same density MLP, other offset of its image in the LDS blob
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(alpha_kernel<InfoInvSplitPolicy>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(alpha_kernel<InfoInvSplitPolicy>), lds));
             hipLaunchKernelGGL(alpha_kernel<InfoInvSplitPolicy>, dim3((unsigned)grid), dim3(256), lds, st, A, xyz, L, n, length, alpha);
         } else {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(alpha_kernel<InfoInvPolicy>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(alpha_kernel<InfoInvPolicy>), lds));
             hipLaunchKernelGGL(alpha_kernel<InfoInvPolicy>, dim3((unsigned)grid), dim3(256), lds, st, A, xyz, L, n, length, alpha);
         }
     } else if (f->flags & NGF_F_BAKE_DENSITY) {
@@ -1124,12 +1139,8 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
                  lds_b = (size_t)(((kBwdImage + 3) & ~3) + kTrainWavesBwd * kBwdTileFloats) * sizeof(float);
     static_assert((((kFwdImage + 3) & ~3) + kTrainWaves * kFwdTileFloats) * 4 <= 160 * 1024, "colour forward LDS");
     static_assert((((kBwdImage + 3) & ~3) + kTrainWavesBwd * kBwdTileFloats) * 4 <= 160 * 1024, "colour backward LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(train_color_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(train_color_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-        attr_set = true;
-    }
+    HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(train_color_fwd_kernel), lds_f));
+    HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(train_color_bwd_kernel), lds_b));
     const int32_t *cnt = no_sync ? T.offset + n : nullptr;
     T.n_active_dev = cnt;
     const int64_t list_len = no_sync ? pairs : n_active;          // upper bound of the list length the loops below are sized for

@@ -268,15 +268,15 @@ extern "C" int ngf_uv_render(const ngf_uv *m, const float *campos_host, const fl
     int tiles = 2;
     if (knob(KNOB_UV_TILES) >= 0) tiles = knob(KNOB_UV_TILES);
     if (tiles == 2 && A.split_bf16) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(uv_render_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(uv_render_kernel<2, true>), lds));
         hipLaunchKernelGGL((uv_render_kernel<2, true>), dim3((unsigned)grid), dim3(256), lds, st, A);
     } else if (tiles == 2) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(uv_render_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(uv_render_kernel<2, false>), lds));
         hipLaunchKernelGGL((uv_render_kernel<2, false>), dim3((unsigned)grid), dim3(256), lds, st, A);
     } else if (tiles == 1 && A.split_bf16) {
         return fail(NGF_E_ARG, "NGF_UV_F_SPLIT_BF16 runs the two-rays-per-wave kernel only (knob uv_tiles must stay 2)");
     } else if (tiles == 1) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(uv_render_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(uv_render_kernel<1, false>), lds));
         hipLaunchKernelGGL((uv_render_kernel<1, false>), dim3((unsigned)grid), dim3(512), lds, st, A);
     } else {
         return fail(NGF_E_ARG, "knob uv_tiles must be 1 or 2");
