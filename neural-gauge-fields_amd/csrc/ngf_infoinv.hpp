@@ -302,15 +302,15 @@ struct InfoInvPolicyT {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const float w = d2[k * 64];
-            g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, fmaxf(h0[k], 0.0f), g0, 0, 0, 0);
-            g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, fmaxf(h1[k], 0.0f), g1, 0, 0, 0);
+            g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, relu1(h0[k]), g0, 0, 0, 0);
+            g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, relu1(h1[k]), g1, 0, 0, 0);
         }
         float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float w = img[D::W3 + hi * 16 + r];
-            s0 = fmaf(w, fmaxf(g0[r], 0.0f), s0);
-            s1 = fmaf(w, fmaxf(g1[r], 0.0f), s1);
+            s0 = fmaf(w, relu1(g0[r]), s0);
+            s1 = fmaf(w, relu1(g1[r]), s1);
         }
         s0 = s0 + __shfl_xor(s0, 32);
         s1 = s1 + __shfl_xor(s1, 32);

@@ -84,7 +84,7 @@ __device__ __forceinline__ void mlp_tail(const float *__restrict__ blob, int oW2
     const float *w2b = blob + oW2 + 32 * 64 + lane;
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
-        float h = fmaxf(k < 16 ? acc0[k & 15] : acc1[k & 15], 0.0f);
+        float h = relu1(k < 16 ? acc0[k & 15] : acc1[k & 15]);
         c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[k * 64], h, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2b[k * 64], h, c1, 0, 0, 0);
     }
@@ -95,7 +95,7 @@ __device__ __forceinline__ void mlp_tail(const float *__restrict__ blob, int oW2
         float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
-            float h = fmaxf(k < 16 ? c0[k & 15] : c1[k & 15], 0.0f);
+            float h = relu1(k < 16 ? c0[k & 15] : c1[k & 15]);
             s = fmaf(w3[c * 64 + k], h, s);
         }
         s = s + __shfl_xor(s, 32);
