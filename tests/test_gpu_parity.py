@@ -527,6 +527,21 @@ def test_alpha_mask_build_and_ray_filter():
     assert bool(torch.isfinite(out["rgb_map"]).all())
 
 
+def test_split_bf16_fields_build_the_same_alpha_mask():
+    """NGF_F_SPLIT_BF16 only changes the colour MLP: density queries of a split field (other LDS image layout, permuted colour
+    channels for InfoInv) must be bit-identical to the fp32 field's -- compute_alpha / getDenseAlpha of both models."""
+    for name in ("infoinv_alpha_mask", "triplane_alpha_mask"):
+        g, params, step, _ = load_case(name)
+        mgrid = tuple(int(v) for v in g["mgrid"])
+        fa, fb = field_for_case(g, params, None), field_for_case(g, params, None, split_bf16=True)
+        a, _ = fa.getDenseAlpha(mgrid)
+        b, _ = fb.getDenseAlpha(mgrid)
+        assert torch.equal(a, b), name
+        if "pts" in g:
+            pts = torch.from_numpy(g["pts"]).cuda()
+            assert torch.equal(fa.compute_alpha(pts, 0.37), fb.compute_alpha(pts, 0.37)), name
+
+
 def test_infoinv_alpha_api_takes_the_infoinv_flag():
     """InfoInv tree: compute_alpha / getDenseAlpha / updateAlphaMask(..., infoinv=True|False) (InfoInv/models/FieldBase.py:140-193;
     InfoInv/main.py:325 calls field.updateAlphaMask(tuple(reso_mask), infoinv=infoinv)) against the reference's own outputs in
