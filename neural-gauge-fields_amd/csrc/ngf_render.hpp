@@ -350,7 +350,8 @@ struct TriPlaneBf16Policy : TriPlanePolicy<BAKE_D, false, WAVES_, 1> {
                                                  const float od[3], int lane, float c[3], unsigned long long * = nullptr, const float * = nullptr)
     {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(vf + (lane >> 4) * 4);
-        mlp_pass16_bf16(A, smem, rec, v, lane, c);
+        if constexpr (WAVES_ > 8) mlp_pass16_bf16_rows(A, smem, rec, v, lane, c);       // the 168-register form (12 waves per CU)
+        else mlp_pass16_bf16(A, smem, rec, v, lane, c);
     }
 };
 

@@ -163,4 +163,96 @@ __device__ __forceinline__ void mlp_pass16_bf16(const RenderArgs &A, const float
     mlp_layer3_16(blob, L::W3, L::B3, lane, c, rgb);
 }
 
+// ---- the same pass in the register budget of 12 waves per CU (168) ------------------------------------------------------------------
+// mlp_pass16_bf16 keeps a plane's four taps (48 registers) and four tiles' fragments (48) in flight and needs ~240 registers with the
+// march state around it.  Here a cell's taps arrive in two ROWS of 24 registers -- the bilinear sum is accumulated in bil_mix's order
+// (w00 v00, + w10 v10, + w01 v01, + w11 v11), so the features are the same bits -- and the A fragments come two tiles at a time.
+// Same k-blocks, same order of the six products per accumulator: bit-identical colours.
+struct GatherRow16 { f32x4 a[2][3]; };          // one row of a cell: two taps x 12 channels
+__device__ __forceinline__ void gather_row16(const float *base, GatherRow16 &g)
+{
+    // base: the lane's channels [4kq, 4kq+4) of the row's first tap; +16 per quad of channels, +48 for the second tap
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) g.a[t][q] = *reinterpret_cast<const f32x4 *>(base + t * 48 + 16 * q);
+}
+template <int MT_STRIDE>
+__device__ __forceinline__ void kblock_bf16_pairs16(const float *w, const Split8 &x, f32x4 acc[4])
+{
+    {
+        const AFrag a0 = afrag_load<MT_STRIDE>(w, 0), a1 = afrag_load<MT_STRIDE>(w, 1);
+        six_products2(a0, a1, x, acc[0], acc[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const AFrag a2 = afrag_load<MT_STRIDE>(w, 2), a3 = afrag_load<MT_STRIDE>(w, 3);
+        six_products2(a2, a3, x, acc[2], acc[3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void mlp_pass16_bf16_rows(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v, int lane, float rgb[3])
+{
+    using L = MlpLayoutBf16;
+    blob = per_pass16(blob);
+    const int kq = lane >> 4;
+    constexpr int KB_STRIDE = 3 * 64 * 4, MT1 = L::KB1 * KB_STRIDE, MT2 = L::KB2 * KB_STRIDE;
+    const float *w1 = blob + L::W1 + lane * 4, *w2 = blob + L::W2 + lane * 4;
+    GatherRow16 g;
+    Bil b = bil_setup(rec[2], rec[3], A.app[0]);
+    gather_row16(A.app[0].p + (size_t)b.idx * 48 + 4 * kq, g);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(blob + L::B1 + kq * 16 + mt * 4);
+    float left[4];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        float f[12];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[4 * q + e] = fmaf(b.w10, g.a[1][q][e], b.w00 * g.a[0][q][e]);
+        __builtin_amdgcn_sched_barrier(0);
+        gather_row16(A.app[p].p + ((size_t)b.idx + A.app[p].stride) * 48 + 4 * kq, g);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[4 * q + e] = fmaf(b.w11, g.a[1][q][e], fmaf(b.w01, g.a[0][q][e], f[4 * q + e]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (p < 2) {                           // the next plane's first row travels behind this plane's MFMAs
+            b = bil_setup(rec[4 + 2 * p], rec[5 + 2 * p], A.app[p + 1]);
+            gather_row16(A.app[p + 1].p + (size_t)b.idx * 48 + 4 * kq, g);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (p == 0) {                          // k-block 0: plane 0 [0..7]
+            kblock_bf16_pairs16<MT1>(w1, split8(f), acc);
+            left[0] = f[8]; left[1] = f[9]; left[2] = f[10]; left[3] = f[11];
+        } else if (p == 1) {                   // k-blocks 1, 2: plane 0 [8..11] + plane 1 [0..3], plane 1 [4..11]
+            const float xa[8] = {left[0], left[1], left[2], left[3], f[0], f[1], f[2], f[3]};
+            kblock_bf16_pairs16<MT1>(w1 + KB_STRIDE, split8(xa), acc);
+            kblock_bf16_pairs16<MT1>(w1 + 2 * KB_STRIDE, split8(f + 4), acc);
+        } else {                               // k-blocks 3, 4: plane 2 [0..7], plane 2 [8..11] + the four view inputs
+            kblock_bf16_pairs16<MT1>(w1 + 3 * KB_STRIDE, split8(f), acc);
+            const float xb[8] = {f[8], f[9], f[10], f[11], v[0], v[1], v[2], v[3]};
+            kblock_bf16_pairs16<MT1>(w1 + 4 * KB_STRIDE, split8(xb), acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4 c[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) c[mt] = *reinterpret_cast<const f32x4 *>(blob + L::B2 + kq * 16 + mt * 4);
+    {
+        float h[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) h[k] = relu1(acc[k >> 2][k & 3]);
+        kblock_bf16_pairs16<MT2>(w2, split8(h), c);
+        kblock_bf16_pairs16<MT2>(w2 + KB_STRIDE, split8(h + 8), c);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mlp_layer3_16(blob, L::W3, L::B3, lane, c, rgb);
+}
+
 }  // namespace ngf

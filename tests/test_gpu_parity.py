@@ -202,6 +202,11 @@ def test_split_bf16_colour_mlp_keeps_fp32_accuracy(name, bake_density):
     for n in (1, 7, 65):                                                                 # ragged launches
         c = fs(rays[:n], N_samples=S, white_bg=white, **kw)
         assert torch.equal(c["rgb_map"], a["rgb_map"][:n])
+    # the 12-waves-per-CU form of the pass (taps in two rows, fragments two tiles at a time: mlp_pass16_bf16_rows) is the same arithmetic
+    from ngf_amd._lib import knobs
+    with knobs(waves=12):
+        a12 = fs(rays, N_samples=S, white_bg=white, **kw)
+    assert torch.equal(a12["rgb_map"], a["rgb_map"]) and torch.equal(a12["depth_map"], a["depth_map"])
     # the colour stage alone, per sample
     from ngf_amd import synth
     n = 203
