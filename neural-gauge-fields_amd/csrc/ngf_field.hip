@@ -522,7 +522,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "hipStreamSynchronize failed in ngf_field_create"));
 
     const int rgb_floats = tri ? (split_bf16 ? MlpLayoutBf16::TOTAL : no_fold ? MlpLayout16NoFold::TOTAL : (bake_c ? MlpLayout16Baked::TOTAL : MlpLayout16<48>::TOTAL)) : (split_ii ? MlpLayoutBf16II::TOTAL : MlpLayout<72>::TOTAL);
-    const int dens_floats = tri ? 0 : InfoInvDensLayout::TOTAL;
+    const int dens_floats = tri ? 0 : (split_ii ? InfoInvDensLayoutBf16::TOTAL : InfoInvDensLayout::TOTAL);
     std::vector<float> img((size_t)rgb_floats + dens_floats, 0.0f), wp;
     std::vector<float> bpack;
     if (split_bf16) build_rgb_image_bf16(F, basis, w1, b1, w2, b2, w3, b3, img.data());
@@ -530,7 +530,8 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     else if (tri) build_rgb_image16(F, bake_c, basis, w1, b1, w2, b2, w3, b3, img.data(), wp);
     else if (split_ii) build_rgb_image_bf16_ii(F, basis, w1, b1, w2, b2, w3, b3, img.data(), bpack);
     else build_rgb_image(F, basis, w1, b1, w2, b2, w3, b3, img.data());
-    if (!tri) build_infoinv_density_image(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
+    if (!tri && split_ii) build_infoinv_density_image_bf16(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
+    else if (!tri) build_infoinv_density_image(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
     if ((rc = alloc_f(&f->blob, img.size(), f))) return bail(rc);
     if (hipMemcpyAsync(f->blob, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess)
         return bail(fail(NGF_E_HIP, "uploading the MLP image failed"));

@@ -8,6 +8,8 @@
 // inputs; v_permlane32_swap of (input 2t, input 2t+1) produces, in one instruction, the B operand of
 // both column tiles (tile 0: lane (s,hi) carries input 2t+hi of sample s; tile 1: of sample 32+s).
 #pragma once
+#include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "ngf_render.hpp"
@@ -39,6 +41,65 @@ inline void build_infoinv_density_image(const std::vector<float> &w1, const std:
     for (int hi = 0; hi < 2; ++hi)
         for (int r = 0; r < 16; ++r) {
             const int n = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            img[D::B1 + hi * 16 + r] = b1[n];
+            img[D::B2 + hi * 16 + r] = b2[n];
+            img[D::W3 + hi * 16 + r] = w3[n];
+        }
+    img[D::B3] = b3[0];
+    img[D::B3 + 1] = img[D::B3 + 2] = img[D::B3 + 3] = 0.0f;
+}
+
+// NGF_F_SPLIT_BF16: the density MLP of the march on v_mfma_f32_32x32x16_bf16 with 3-term split operands (sigma_bf16 below).
+// A fragments: lane (i = l & 31, hi = l >> 5), element e of k-block kb holds W[i][16 kb + 8 hi + e] -- layer 1 over the 72 inputs in
+// their natural order (plane p, channel c -> 24 p + c; 8 zero pads), layer 2 over the hidden units in the accumulator order of the lane
+// half (k = 8 q + e  ->  unit (k & 3) + 8 (k >> 2) + 4 hi), so that a lane's own ReLU'd accumulators are its B fragments.
+struct InfoInvDensLayoutBf16 {              // floats (a bf16x8 fragment = 4 floats), relative to MlpLayoutBf16II::TOTAL inside the blob
+    static constexpr int KB1 = 5, KB2 = 2;
+    static constexpr int D1 = 0;                    // [5 kb][3 parts][64 lanes][4]
+    static constexpr int D2 = D1 + KB1 * 3 * 64 * 4;   // [2 kb][3 parts][64 lanes][4]
+    static constexpr int B1 = D2 + KB2 * 3 * 64 * 4;   // [2 hi][16]
+    static constexpr int B2 = B1 + 32;
+    static constexpr int W3 = B2 + 32;
+    static constexpr int B3 = W3 + 32;
+    static constexpr int TOTAL = B3 + 4;
+};
+
+inline void infoinv_split3(float x, uint16_t out[3])
+{
+    auto f2bf = [](float v) { uint32_t u; memcpy(&u, &v, 4); const uint32_t r = 0x7fffu + ((u >> 16) & 1u); return (uint16_t)((u + r) >> 16); };
+    auto bf2f = [](uint16_t h) { const uint32_t u = (uint32_t)h << 16; float v; memcpy(&v, &u, 4); return v; };
+    out[0] = f2bf(x);
+    const float r1 = x - bf2f(out[0]);
+    out[1] = f2bf(r1);
+    const float r2 = r1 - bf2f(out[1]);
+    out[2] = f2bf(r2);
+}
+
+inline void build_infoinv_density_image_bf16(const std::vector<float> &w1, const std::vector<float> &b1, const std::vector<float> &w2,
+                                             const std::vector<float> &b2, const std::vector<float> &w3, const std::vector<float> &b3,
+                                             float *img)
+{
+    using D = InfoInvDensLayoutBf16;
+    uint16_t *h16 = reinterpret_cast<uint16_t *>(img);
+    auto unit = [](int k, int hi) { return (k & 3) + 8 * (k >> 2) + 4 * hi; };
+    for (int kb = 0; kb < D::KB1; ++kb)
+        for (int l = 0; l < 64; ++l)
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * kb + 8 * (l >> 5) + e;
+                uint16_t p3[3];
+                infoinv_split3(k < 72 ? w1[(size_t)(l & 31) * 72 + k] : 0.0f, p3);
+                for (int part = 0; part < 3; ++part) h16[((size_t)D::D1 + (((size_t)kb * 3 + part) * 64 + l) * 4) * 2 + e] = p3[part];
+            }
+    for (int q = 0; q < D::KB2; ++q)
+        for (int l = 0; l < 64; ++l)
+            for (int e = 0; e < 8; ++e) {
+                uint16_t p3[3];
+                infoinv_split3(w2[(size_t)(l & 31) * 32 + unit(8 * q + e, l >> 5)], p3);
+                for (int part = 0; part < 3; ++part) h16[((size_t)D::D2 + (((size_t)q * 3 + part) * 64 + l) * 4) * 2 + e] = p3[part];
+            }
+    for (int hi = 0; hi < 2; ++hi)
+        for (int r = 0; r < 16; ++r) {
+            const int n = unit(r, hi);
             img[D::B1 + hi * 16 + r] = b1[n];
             img[D::B2 + hi * 16 + r] = b2[n];
             img[D::W3 + hi * 16 + r] = w3[n];
@@ -227,6 +288,135 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
     mlp_layer3_16(blob, L::W3, L::B3, lane, c, rgb);
 }
 
+// ---- NGF_F_SPLIT_BF16: the density MLP (72 -> 32 -> 32 -> 1, every in-box sample) on the bf16 matrix pipe -------------------------------
+// Lane l owns sample l and its 72 inputs.  A k-block is 16 inputs: the lane splits them into (hi, mid, lo) bf16 parts, packs inputs 0..7
+// and 8..15 into one fragment each, and v_permlane32_swap of the two turns them into the B fragments of BOTH column tiles (tile 0: lane
+// (s, half) carries inputs 8 half .. 8 half + 7 of sample s; tile 1: of sample 32 + s).  Six products per tile and k-block, fp32
+// accumulate, smallest terms first -- 84 bf16 MFMAs of 32 cycles per 64 samples instead of 104 fp32 MFMAs of 64 cycles.
+#define NGF_MFMA_BF16_32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+struct SplitPair { Split8 t0, t1; };            // the B fragments of the two column tiles
+__device__ __forceinline__ void swap_frag(bf16x8 &a, bf16x8 &b)
+{
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        auto q = __builtin_amdgcn_permlane32_swap(ua[r], ub[r], false, false);
+        ua[r] = q[0]; ub[r] = q[1];
+    }
+    a = __builtin_bit_cast(bf16x8, ua); b = __builtin_bit_cast(bf16x8, ub);
+}
+// x[0..15]: the lane's own 16 inputs of the k-block
+__device__ __forceinline__ SplitPair split_pair(const float x[16])
+{
+    SplitPair s;
+    s.t0 = split8(x);
+    s.t1 = split8(x + 8);
+    swap_frag(s.t0.h, s.t1.h); swap_frag(s.t0.m, s.t1.m); swap_frag(s.t0.l, s.t1.l);
+    return s;
+}
+// w: the k-block's A fragments [3 parts][64 lanes][4] (+ lane * 4)
+__device__ __forceinline__ void dens_kblock(const float *w, const Split8 &x0, const Split8 &x1, f32x16 &c0, f32x16 &c1)
+{
+    const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(w), am = *reinterpret_cast<const bf16x8 *>(w + 64 * 4), al = *reinterpret_cast<const bf16x8 *>(w + 2 * 64 * 4);
+    c0 = NGF_MFMA_BF16_32(al, x0.h, c0);  c1 = NGF_MFMA_BF16_32(al, x1.h, c1);
+    c0 = NGF_MFMA_BF16_32(ah, x0.l, c0);  c1 = NGF_MFMA_BF16_32(ah, x1.l, c1);
+    c0 = NGF_MFMA_BF16_32(am, x0.m, c0);  c1 = NGF_MFMA_BF16_32(am, x1.m, c1);
+    c0 = NGF_MFMA_BF16_32(am, x0.h, c0);  c1 = NGF_MFMA_BF16_32(am, x1.h, c1);
+    c0 = NGF_MFMA_BF16_32(ah, x0.m, c0);  c1 = NGF_MFMA_BF16_32(ah, x1.m, c1);
+    c0 = NGF_MFMA_BF16_32(ah, x0.h, c0);  c1 = NGF_MFMA_BF16_32(ah, x1.h, c1);
+}
+
+// called by all 64 lanes; img: the density image (InfoInvDensLayoutBf16) in LDS; returns sigma of the lane's own sample (0 when !valid)
+__device__ __forceinline__ float infoinv_sigma_bf16(const RenderArgs &A, const float *img, bool valid, const float x[3], int lane, float t[6])
+{
+    using D = InfoInvDensLayoutBf16;
+    const int hi = lane >> 5;
+    t[0] = x[0]; t[1] = x[1]; t[2] = x[1]; t[3] = x[2]; t[4] = x[0]; t[5] = x[2];
+    if (!__any(valid)) return 0.0f;
+    float pe[24];
+    if (A.mode) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pe_ladder<4>(x[k], pe + k * 4, pe + 12 + k * 4);
+    }
+    f32x16 h0, h1;   // column tile 0 (samples of lanes 0..31) and 1 (lanes 32..63)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h0[r] = h1[r] = img[D::B1 + hi * 16 + r];
+    const float *d1 = img + D::D1 + lane * 4;
+    constexpr int KBS = 3 * 64 * 4;
+    float carry[8];                                // the 8 inputs of a plane that wait for the next plane's first 8
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const Tex &tx = A.dens[p];
+        float feat[24];
+        if (valid) {
+            Bil b = bil_setup(t[2 * p], t[2 * p + 1], tx);
+            const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + (size_t)b.idx * 24);
+            const f32x4 *q01 = q00 + (size_t)tx.stride * 6;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                f32x4 v00 = q00[q], v10 = q00[6 + q], v01 = q01[q], v11 = q01[6 + q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) feat[4 * q + e] = bil_mix(b, v00[e], v10[e], v01[e], v11[e]);
+            }
+            if (A.mode) {
+#pragma unroll
+                for (int c = 0; c < 24; ++c) feat[c] = feat[c] * pe[c];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 24; ++c) feat[c] = 0.0f;
+        }
+        // inputs 24 p .. 24 p + 23 -> k-blocks of 16: [p0 0..15] [p0 16..23 | p1 0..7] [p1 8..23] [p2 0..15] [p2 16..23 | 0 x 8]
+        // (a branch-free, software-pipelined form -- MFMAs of block b under the interpolation of block b + 1 -- was slower: 10.7 vs 10.4 ms)
+        if (p == 0) {
+            const SplitPair s = split_pair(feat);
+            dens_kblock(d1, s.t0, s.t1, h0, h1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) carry[e] = feat[16 + e];
+        } else if (p == 1) {
+            float xk[16];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xk[e] = carry[e]; xk[8 + e] = feat[e]; }
+            const SplitPair s = split_pair(xk);
+            dens_kblock(d1 + KBS, s.t0, s.t1, h0, h1);
+            const SplitPair s2 = split_pair(feat + 8);
+            dens_kblock(d1 + 2 * KBS, s2.t0, s2.t1, h0, h1);
+        } else {
+            const SplitPair s = split_pair(feat);
+            dens_kblock(d1 + 3 * KBS, s.t0, s.t1, h0, h1);
+            float xk[16];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xk[e] = feat[16 + e]; xk[8 + e] = 0.0f; }
+            const SplitPair s2 = split_pair(xk);
+            dens_kblock(d1 + 4 * KBS, s2.t0, s2.t1, h0, h1);
+        }
+    }
+    // layer 2: the lane's ReLU'd accumulators (hidden units in the accumulator order of its half) are its B fragments, tile by tile
+    f32x16 g0, g1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g0[r] = g1[r] = img[D::B2 + hi * 16 + r];
+    const float *d2 = img + D::D2 + lane * 4;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float a0[8], a1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a0[e] = relu1(h0[8 * q + e]); a1[e] = relu1(h1[8 * q + e]); }
+        dens_kblock(d2 + q * KBS, split8(a0), split8(a1), g0, g1);
+    }
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float w = img[D::W3 + hi * 16 + r];
+        s0 = fmaf(w, relu1(g0[r]), s0);
+        s1 = fmaf(w, relu1(g1[r]), s1);
+    }
+    s0 = s0 + __shfl_xor(s0, 32);
+    s1 = s1 + __shfl_xor(s1, 32);
+    const float f = (hi ? s1 : s0) + img[D::B3];
+    return valid ? softplus_shift(f) : 0.0f;
+}
+
 template <bool SPLIT>
 struct InfoInvPolicyT {
     static constexpr int RGB_FLOATS = SPLIT ? MlpLayoutBf16II::TOTAL : MlpLayout<72>::TOTAL;      // the density image follows the colour image in LDS
@@ -247,6 +437,7 @@ struct InfoInvPolicyT {
     __device__ static __forceinline__ float sigma(const RenderArgs &A, const float *smem, bool valid, const float x[3], int lane,
                                                   float t[6])
     {
+        if constexpr (SPLIT) return infoinv_sigma_bf16(A, per_pass(smem) + RGB_FLOATS, valid, x, lane, t);
         using D = InfoInvDensLayout;
         const float *img = per_pass(smem) + RGB_FLOATS;
         const int hi = lane >> 5;

@@ -144,9 +144,9 @@ def test_split_march_is_bit_identical(name):
 
 @pytest.mark.parametrize("name", INFOINV)
 def test_infoinv_split_bf16_keeps_fp32_accuracy(name):
-    """NGF_F_SPLIT_BF16 on the InfoInv tree: rgb_decoder (216 features + view -> 64 -> 64 -> 3) as 3-term split bf16 products on
-    v_mfma_f32_32x32x16_bf16, layer 1 streamed from L2 (csrc/ngf_infoinv.hpp mlp_pass_bf16_ii); the density MLP and the march are
-    the default's.  Same tolerances against oracle and reference goldens, within fp32 rounding noise of the fp32-MFMA path."""
+    """NGF_F_SPLIT_BF16 on the InfoInv tree: rgb_decoder (216 features + view -> 64 -> 64 -> 3, csrc/ngf_infoinv.hpp
+    mlp_pass16_bf16_ii) AND the density MLP of the march (72 -> 32 -> 32 -> 1, infoinv_sigma_bf16) as 3-term split bf16 products with
+    fp32 accumulation.  Same tolerances against oracle and reference goldens, within fp32 rounding noise of the fp32-MFMA path."""
     g, params, step, mask = load_case(name)
     orc = oracle_for_case(g, params, step, mask)
     fs = field_for_case(g, params, mask, split_bf16=True)
@@ -160,8 +160,10 @@ def test_infoinv_split_bf16_keeps_fp32_accuracy(name):
     ea = _close(a["rgb_map"].cpu().numpy(), o_rgb, "split-bf16 rgb vs oracle")
     _close(a["rgb_map"].cpu().numpy(), g["rgb_map"], "split-bf16 rgb vs reference golden")
     assert ea < 5e-6
-    assert torch.equal(a["depth_map"], b["depth_map"])
-    assert float((a["rgb_map"] - b["rgb_map"]).abs().max()) < 2e-6
+    _close(a["depth_map"].cpu().numpy(), o_depth, "split-bf16 depth vs oracle")
+    # sigma now comes from split products too: depth and colour sit within fp32 rounding noise of the fp32 path instead of on it
+    assert float((a["depth_map"] - b["depth_map"]).abs().max()) < 2e-5 * float(b["depth_map"].abs().max())
+    assert float((a["rgb_map"] - b["rgb_map"]).abs().max()) < 5e-6
     from ngf_amd import synth
     n = 203
     coords = (synth.hash_uniform(79, 1, (n, 6)) * np.float32(2.2) - np.float32(1.1)).astype(np.float32)
@@ -172,9 +174,9 @@ def test_infoinv_split_bf16_keeps_fp32_accuracy(name):
     got = fs.decode_rgb(torch.from_numpy(coords), torch.from_numpy(dirs), mode=mode).cpu().numpy()
     ref = fd.decode_rgb(torch.from_numpy(coords), torch.from_numpy(dirs), mode=mode).cpu().numpy()
     assert np.abs(got - ref).max() < 2e-6
-    # the alpha-mask helpers run the (unchanged) density MLP from the other LDS image layout
+    # the alpha-mask helpers run the split density MLP: fp32-level agreement with the fp32 one
     pts = torch.from_numpy((synth.hash_uniform(79, 3, (64, 3)) * np.float32(3.0) - np.float32(1.5)).astype(np.float32)).cuda()
-    assert torch.equal(fs.compute_alpha(pts, 0.3), fd.compute_alpha(pts, 0.3))
+    np.testing.assert_allclose(fs.compute_alpha(pts, 0.3).cpu().numpy(), fd.compute_alpha(pts, 0.3).cpu().numpy(), rtol=2e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize("bake_density", [False, True])
@@ -533,18 +535,21 @@ def test_alpha_mask_build_and_ray_filter():
 
 
 def test_split_bf16_fields_build_the_same_alpha_mask():
-    """NGF_F_SPLIT_BF16 only changes the colour MLP: density queries of a split field (other LDS image layout, permuted colour
-    channels for InfoInv) must be bit-identical to the fp32 field's -- compute_alpha / getDenseAlpha of both models."""
+    """Density queries of NGF_F_SPLIT_BF16 fields (compute_alpha / getDenseAlpha): TriPlane's density path is untouched by the flag
+    (bit-identical); InfoInv's density MLP runs on split bf16 products too -- the reference's own dense alpha at the usual tolerance."""
     for name in ("infoinv_alpha_mask", "triplane_alpha_mask"):
         g, params, step, _ = load_case(name)
         mgrid = tuple(int(v) for v in g["mgrid"])
         fa, fb = field_for_case(g, params, None), field_for_case(g, params, None, split_bf16=True)
         a, _ = fa.getDenseAlpha(mgrid)
         b, _ = fb.getDenseAlpha(mgrid)
-        assert torch.equal(a, b), name
-        if "pts" in g:
+        if name.startswith("triplane"):
+            assert torch.equal(a, b), name
+        else:
+            np.testing.assert_allclose(b.cpu().numpy(), g["dense_alpha_on"], rtol=2e-4, atol=2e-7)
+            np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-5, atol=1e-7)
             pts = torch.from_numpy(g["pts"]).cuda()
-            assert torch.equal(fa.compute_alpha(pts, 0.37), fb.compute_alpha(pts, 0.37)), name
+            np.testing.assert_allclose(fb.compute_alpha(pts, 0.37).cpu().numpy(), g["alpha_pts_on"], rtol=2e-4, atol=2e-7)
 
 
 def test_infoinv_alpha_api_takes_the_infoinv_flag():
