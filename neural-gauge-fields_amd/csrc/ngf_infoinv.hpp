@@ -208,7 +208,7 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
         const float pe_xyz[3] = {rec[2], rec[3], rec[5]};
         const float scale = (float)(1 << (3 * kq));
 #pragma unroll
-        for (int k = 0; k < 3; ++k) sincosf(pe_xyz[k] * scale, &bs[k], &bc[k]);
+        for (int k = 0; k < 3; ++k) sincos_small(pe_xyz[k] * scale, bs[k], bc[k]);
     }
     float left[4];                             // inputs of a plane that did not fill a k-block yet
     __builtin_amdgcn_sched_barrier(0);

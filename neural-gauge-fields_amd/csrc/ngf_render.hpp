@@ -104,17 +104,17 @@ __device__ __forceinline__ void mlp_tail(const float *__restrict__ blob, int oW2
     }
 }
 
-// sin / cos of x * 2^f for f = 0..F-1 (the InfoInv positional encodings, networks.py:227-237): an accurate sincosf at every
+// sin / cos of x * 2^f for f = 0..F-1 (the InfoInv positional encodings, networks.py:227-237): an accurate sincos (sincos_small, <= 1.6 ulp) at every
 // fourth octave and three angle doublings from each (sin 2a = 2 sc, cos 2a = (c - s)(c + s)); a doubling at most doubles the
 // absolute error, so every value stays within ~8 ulp of 1 (5e-7) while 2F sinf/cosf calls with large-argument range reduction
-// become F/4 sincosf calls.
+// become F/4 sincos evaluations.
 template <int F>
 __device__ __forceinline__ void pe_ladder(float x, float sn[F], float cs[F])
 {
 #pragma unroll
     for (int base = 0; base < F; base += 4) {
         float s, c;
-        sincosf(x * (float)(1 << base), &s, &c);
+        sincos_small(x * (float)(1 << base), s, c);
         sn[base] = s; cs[base] = c;
 #pragma unroll
         for (int j = 1; j < 4 && base + j < F; ++j) {

@@ -47,22 +47,6 @@ __device__ __forceinline__ const float *per_pass16(const float *blob)
     return blob + z;
 }
 
-// sin/cos for |x| <= 2 (view directions are unit vectors, the encoding uses d and 2d): Cody-Waite reduction by pi/2
-// + the cephes single-precision kernels, <= 2 ulp.  Used when the per-ray view inputs are not cached in LDS.
-__device__ __forceinline__ void sincos_small(float x, float &s, float &c)
-{
-    const float k = rintf(x * 0.636619772f);
-    float r = fmaf(-k, 1.5707962513e+00f, x);
-    r = fmaf(-k, 7.5497894159e-08f, r);
-    const float z = r * r;
-    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
-    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
-    const int q = (int)k & 3;
-    const float s0 = (q & 1) ? cp : sp, c0 = (q & 1) ? sp : cp;
-    s = (q & 2) ? -s0 : s0;
-    c = ((q + 1) & 2) ? -c0 : c0;
-}
-
 // the 4 view inputs lane-quarter kq supplies: entries kq*4 .. kq*4+3 of [d(3), sin(d_x, 2d_x, d_y, 2d_y, d_z, 2d_z), cos(same), 0]
 __device__ __forceinline__ f32x4 view_entries16(const float d[3], int kq)
 {

@@ -396,7 +396,7 @@ __device__ __forceinline__ float pe_entry(const float x[3], int f)
     const float xd = dim == 0 ? x[0] : (dim == 1 ? x[1] : x[2]);
     const float arg = xd * (float)(1 << fr);
     float s, c;
-    sincosf(arg, &s, &c);
+    sincos_small(arg, s, c);
     const float raw = f == 0 ? x[0] : (f == 1 ? x[1] : x[2]);
     return f < D ? raw : (g < N ? s : c);
 }
