@@ -65,12 +65,15 @@ def physical_roofs(pmc, k_ms, share=1.0):
     t = k_ms * 1e-3
     out = {"source": pmc["file"], "pmc_stale": pmc["stale"], "kernel_ms_under_pmc": pmc.get("kernel_ms_under_pmc")}
     if "mfma_busy_frac" in pmc and "valu_busy_frac" in pmc:
+        issue = pmc.get("mfma_issue_frac", 0.0)
         out["simd_vector_datapath"] = {
-            "mfma_busy_frac": pmc["mfma_busy_frac"], "valu_busy_frac": pmc["valu_busy_frac"],
-            "frac": pmc["mfma_busy_frac"] + pmc["valu_busy_frac"],
-            "note": "fp32 MFMA and fp32 VALU execute on the same SIMD datapath on gfx950 and never overlap (profiles/micro/"
-                    "mfma_valu_overlap.hip, profiles/r02_micro_mfma_valu_overlap.txt: 8.75 ms + 3.07 ms run together in 11.63 ms), so "
-                    "their busy cycles add; this sum is the binding roof of the kernel"}
+            "mfma_busy_frac": pmc["mfma_busy_frac"], "valu_busy_frac": pmc["valu_busy_frac"], "mfma_issue_frac_inside_valu_busy": issue,
+            "frac": pmc["mfma_busy_frac"] + max(pmc["valu_busy_frac"] - issue, 0.0),
+            "note": "MFMA (fp32 and bf16) and VALU instructions of a SIMD execute one after the other on gfx950 (profiles/micro/"
+                    "mfma_valu_overlap.hip, profiles/r02_micro_mfma_valu_overlap.txt: 8.75 ms of fp32 MFMA + 3.07 ms of VALU run together in "
+                    "11.63 ms; bf16: 4.44 + 3.07 -> 7.39), so their busy cycles add and this sum is the binding roof of the kernel.  "
+                    "SQ_ACTIVE_INST_VALU also counts the issue cycles of the MFMA instructions (profiles/r02_counter_semantics.txt: 4 of "
+                    "every 33 fp32 / 16 bf16 MFMA cycles); they are subtracted here"}
     if "ta_busy_frac" in pmc:
         out["texture_addresser_busy_frac"] = pmc["ta_busy_frac"]
     if "lds_busy_frac" in pmc:

@@ -104,6 +104,17 @@ if m.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0) > 0:
     out["mfma_bf16_flops_per_dispatch"] = m["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512
     print(f"MFMA bf16 flops/dispatch = {out['mfma_bf16_flops_per_dispatch']:.4g} -> {out['mfma_bf16_flops_per_dispatch'] / (ms * 1e-3) / 1e12:.1f} TFLOP/s "
           f"= {100 * out['mfma_bf16_flops_per_dispatch'] / (ms * 1e-3) / 2500e12:.1f} % of the ~2500 TFLOP/s dense bf16 matrix peak")
+if "GRBM_GUI_ACTIVE" in m and "valu_busy_frac" in out and "mfma_busy_frac" in out:
+    # SQ_ACTIVE_INST_VALU also counts the ISSUE cycles of MFMA instructions (profiles/exp_counter_semantics.sh on the micro-benchmark:
+    # a wave that only issues v_mfma_f32_16x16x4_f32 shows 12.4 % "VALU busy" next to 99.6 % MFMA busy = 4 issue cycles of 33;
+    # bf16 16x16x32: 24.5 % next to 97.8 % = 4 of 16).  Issue cycles per flop are the same for the two tile shapes of a type:
+    # 4 cycles per 2048 fp32 flops (8 per 4096), 4 per 16384 bf16 flops (8 per 32768).
+    issue = (out.get("mfma_flops_per_dispatch", 0.0) / 2048.0 + out.get("mfma_bf16_flops_per_dispatch", 0.0) / 16384.0) * 4.0
+    out["mfma_issue_frac"] = issue / (m["GRBM_GUI_ACTIVE"] / 8.0 * 1024)
+    out["valu_busy_excl_mfma_issue_frac"] = max(out["valu_busy_frac"] - out["mfma_issue_frac"], 0.0)
+    out["simd_busy_frac"] = out["mfma_busy_frac"] + out["valu_busy_excl_mfma_issue_frac"]
+    print(f"MFMA issue  = {100 * out['mfma_issue_frac']:.1f} % of the SIMD cycles are inside VALU busy as well -> VALU without it {100 * out['valu_busy_excl_mfma_issue_frac']:.1f} %, "
+          f"SIMD busy (MFMA + other VALU) = {100 * out['simd_busy_frac']:.1f} %")
 if "SQ_VALU_MFMA_COEXEC_CYCLES" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
     out["mfma_valu_coexec_frac_of_mfma_busy"] = m["SQ_VALU_MFMA_COEXEC_CYCLES"] / max(m["SQ_VALU_MFMA_BUSY_CYCLES"], 1.0)
     print(f"VALU / MFMA co-execution = {100 * out['mfma_valu_coexec_frac_of_mfma_busy']:.1f} % of the MFMA-busy cycles (SQ_VALU_MFMA_COEXEC_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES)")
