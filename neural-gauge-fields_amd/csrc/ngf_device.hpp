@@ -18,7 +18,6 @@ namespace ngf {
 constexpr int kWave = 64;
 constexpr int kRing = 128;          // wave-private queue of active samples (records)
 constexpr int kRecFloats = 8;       // {ray lane, weight, t_xy(2), t_yz(2), t_xz(2)}
-constexpr int kBatch = 32;          // samples per MLP pass = one 32-wide MFMA column tile
 constexpr int kViewFeat = 16;       // [d(3), sin(6), cos(6), 0]
 
 // A packed texture: channel-last texels with a one-texel zero border (zeros padding of

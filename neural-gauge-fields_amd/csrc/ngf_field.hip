@@ -159,50 +159,9 @@ __global__ void generate_rays_dtu_kernel(int W, float fx, float fy, float cx, fl
     }
 }
 
-// ---- MLP image -------------------------------------------------------------------------------------
-// Builds the LDS image described in ngf_render.hpp (MlpLayout) from the reference's rgb_decoder
-// weights.  basis (no bias, no activation; networks.py:17,26) is pre-composed with layer 1 in fp64:
-// W1' = W1[:, :F] @ basis.  Row/column permutations put every MFMA operand at [k-step][lane].
-static void build_rgb_image(int F, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
-                            const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3,
-                            const std::vector<float> &b3, float *img)
-{
-    const int IN = F + 15, HALF = F / 6, KT = 3 * HALF + 8;
-    std::vector<double> w1f((size_t)64 * (F + 16), 0.0);
-    for (int n = 0; n < 64; ++n) {
-        for (int k = 0; k < F; ++k) {
-            double s = 0.0;
-            for (int j = 0; j < F; ++j) s += (double)w1[(size_t)n * IN + j] * (double)basis[(size_t)j * F + k];
-            w1f[(size_t)n * (F + 16) + k] = s;
-        }
-        for (int k = 0; k < 15; ++k) w1f[(size_t)n * (F + 16) + F + k] = w1[(size_t)n * IN + F + k];
-    }
-    auto kmap = [&](int t, int hi) {
-        if (t < 3 * HALF) return (t / HALF) * (2 * HALF) + hi * HALF + (t % HALF);
-        return F + hi * 8 + (t - 3 * HALF);
-    };
-    const int oW1 = 0, oW2 = oW1 + 2 * KT * 64, oB1 = oW2 + 2 * 32 * 64, oB2 = oB1 + 64, oW3 = oB2 + 64, oB3 = oW3 + 192;
-    for (int nt = 0; nt < 2; ++nt)
-        for (int t = 0; t < KT; ++t)
-            for (int l = 0; l < 64; ++l)
-                img[oW1 + ((size_t)nt * KT + t) * 64 + l] = (float)w1f[(size_t)(nt * 32 + (l & 31)) * (F + 16) + kmap(t, l >> 5)];
-    for (int mt = 0; mt < 2; ++mt)
-        for (int k = 0; k < 32; ++k)
-            for (int l = 0; l < 64; ++l) {
-                const int n = (k >> 4) * 32 + ((k & 15) & 3) + 8 * ((k & 15) >> 2) + 4 * (l >> 5);
-                img[oW2 + ((size_t)mt * 32 + k) * 64 + l] = w2[(size_t)(mt * 32 + (l & 31)) * 64 + n];
-            }
-    for (int hi = 0; hi < 2; ++hi)
-        for (int k = 0; k < 32; ++k) {
-            const int n = (k >> 4) * 32 + ((k & 15) & 3) + 8 * ((k & 15) >> 2) + 4 * hi;
-            img[oB1 + hi * 32 + k] = b1[n];
-            img[oB2 + hi * 32 + k] = b2[n];
-            for (int c = 0; c < 3; ++c) img[oW3 + c * 64 + hi * 32 + k] = w3[(size_t)c * 64 + n];
-        }
-    for (int c = 0; c < 3; ++c) img[oB3 + c] = b3[c];
-    img[oB3 + 3] = 0.0f;
-}
-
+// ---- MLP images ------------------------------------------------------------------------------------
+// LDS images of rgb_decoder: basis (no bias, no activation; networks.py:17,26) is pre-composed with layer 1 in fp64,
+// W1' = W1[:, :F] @ basis; row / column permutations put every MFMA operand at [k-step][lane].
 // 16-wide (v_mfma_f32_16x16x4_f32) image of rgb_decoder for TriPlane (ngf_shade16.hpp).  Lane (s, kq): hidden
 // unit of accumulator (mt, r) is n = mt*16 + 4*kq + r.  With bake = true the plane part of layer 1 goes to the
 // texture baker instead: wp[p][n][c] = W1'[n][p*APPc + c] (natural unit order: channel n of a baked texel = unit n).
@@ -330,6 +289,45 @@ static void build_rgb_image_bf16_ii(int F, const std::vector<float> &basis, cons
                     for (int part = 0; part < 3; ++part)
                         h16[((size_t)L::W2 + ((((size_t)mt * L::KB2 + kb) * 3 + part) * 64 + l) * 4) * 2 + e] = p3[part];
                 }
+    for (int kq = 0; kq < 4; ++kq)
+        for (int k = 0; k < 16; ++k) {
+            const int n = hidden(k >> 2, k & 3, kq);
+            img[L::B1 + kq * 16 + k] = b1[n];
+            img[L::B2 + kq * 16 + k] = b2[n];
+            for (int c = 0; c < 3; ++c) img[L::W3 + c * 64 + kq * 16 + k] = w3[(size_t)c * 64 + n];
+        }
+    for (int c = 0; c < 3; ++c) img[L::B3 + c] = b3[c];
+    img[L::B3 + 3] = 0.0f;
+}
+
+// InfoInv default (ngf_infoinv.hpp mlp_pass16_ii): MlpLayout16<72>; k-step t of lane quarter kq is its t-th input -- 18 channels of each
+// plane in the PACKED channel order (infoinv_split_channel), then its 4 view entries
+static void build_rgb_image16_ii(int F, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
+                                 const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3, const std::vector<float> &b3,
+                                 float *img)
+{
+    using L = MlpLayout16<72>;
+    const int IN = F + 15, APPc = F / 3;
+    std::vector<double> w1f((size_t)64 * (F + 16), 0.0);       // W1' = [W1[:, :F] . basis | W1[:, F:F+15] | 0]
+    for (int n = 0; n < 64; ++n) {
+        for (int k = 0; k < F; ++k) {
+            double s = 0.0;
+            for (int j = 0; j < F; ++j) s += (double)w1[(size_t)n * IN + j] * (double)basis[(size_t)j * F + k];
+            w1f[(size_t)n * (F + 16) + k] = s;
+        }
+        for (int k = 0; k < 15; ++k) w1f[(size_t)n * (F + 16) + F + k] = w1[(size_t)n * IN + F + k];
+    }
+    auto hidden = [](int mt, int r, int kq) { return mt * 16 + 4 * kq + r; };
+    for (int mt = 0; mt < 4; ++mt)
+        for (int t = 0; t < L::KT; ++t)
+            for (int l = 0; l < 64; ++l) {
+                const int kq = l >> 4, n = mt * 16 + (l & 15);
+                const int col = t < 54 ? (t / 18) * APPc + infoinv_split_channel(kq * 18 + t % 18) : F + kq * 4 + (t - 54);
+                img[L::W1 + ((size_t)mt * L::KT + t) * 64 + l] = (float)w1f[(size_t)n * (F + 16) + col];
+            }
+    for (int mt = 0; mt < 4; ++mt)
+        for (int t = 0; t < 16; ++t)
+            for (int l = 0; l < 64; ++l) img[L::W2 + ((size_t)mt * 16 + t) * 64 + l] = w2[(size_t)(mt * 16 + (l & 15)) * 64 + hidden(t >> 2, t & 3, l >> 4)];
     for (int kq = 0; kq < 4; ++kq)
         for (int k = 0; k < 16; ++k) {
             const int n = hidden(k >> 2, k & 3, kq);
@@ -521,7 +519,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     }
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "hipStreamSynchronize failed in ngf_field_create"));
 
-    const int rgb_floats = tri ? (split_bf16 ? MlpLayoutBf16::TOTAL : no_fold ? MlpLayout16NoFold::TOTAL : (bake_c ? MlpLayout16Baked::TOTAL : MlpLayout16<48>::TOTAL)) : (split_ii ? MlpLayoutBf16II::TOTAL : MlpLayout<72>::TOTAL);
+    const int rgb_floats = tri ? (split_bf16 ? MlpLayoutBf16::TOTAL : no_fold ? MlpLayout16NoFold::TOTAL : (bake_c ? MlpLayout16Baked::TOTAL : MlpLayout16<48>::TOTAL)) : (split_ii ? MlpLayoutBf16II::TOTAL : MlpLayout16<72>::TOTAL);
     const int dens_floats = tri ? 0 : (split_ii ? InfoInvDensLayoutBf16::TOTAL : InfoInvDensLayout::TOTAL);
     std::vector<float> img((size_t)rgb_floats + dens_floats, 0.0f), wp;
     std::vector<float> bpack;
@@ -529,7 +527,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     else if (no_fold) build_rgb_image16_nofold(F, basis, w1, b1, w2, b2, w3, b3, img.data(), bpack);
     else if (tri) build_rgb_image16(F, bake_c, basis, w1, b1, w2, b2, w3, b3, img.data(), wp);
     else if (split_ii) build_rgb_image_bf16_ii(F, basis, w1, b1, w2, b2, w3, b3, img.data(), bpack);
-    else build_rgb_image(F, basis, w1, b1, w2, b2, w3, b3, img.data());
+    else build_rgb_image16_ii(F, basis, w1, b1, w2, b2, w3, b3, img.data());
     if (!tri && split_ii) build_infoinv_density_image_bf16(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
     else if (!tri) build_infoinv_density_image(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
     if ((rc = alloc_f(&f->blob, img.size(), f))) return bail(rc);
@@ -569,7 +567,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
         if (bake) bake_density_kernel<<<1024, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, d->dens_w1 + p * d->dens_dim, f->tex[p]);
         else pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, 0, d->dens_dim, f->tex[p]);
         if (bake_c) bake_color_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, wp_dev + (size_t)p * 64 * f->app, f->tex[3 + p]);
-        else pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, f->tex[3 + p], split_ii ? 1 : 0);
+        else pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, f->tex[3 + p], tri ? 0 : 1);
         A.dens[p] = Tex{f->tex[p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
         A.app[p] = Tex{f->tex[3 + p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
         if (tri) {
@@ -733,9 +731,12 @@ static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
 static int render_common(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
     if (f->model == NGF_MODEL_INFOINV) {
-        if (!(f->flags & NGF_F_SPLIT_BF16)) return launch_policy<InfoInvPolicy>(f, A, st);
-        if (knob(KNOB_TILE_W) > 16 || knob(KNOB_SPLIT) == 0) return fail(NGF_E_ARG, "InfoInv NGF_F_SPLIT_BF16 renders with split tiles of at most 16 rays");
-        return launch_policy<InfoInvSplitPolicy>(f, A, st);
+        const bool wide = knob(KNOB_TILE_W) > 16 || knob(KNOB_SPLIT) == 0;      // debug knobs only: launch_render never picks more than 16 rays per tile
+        if (f->flags & NGF_F_SPLIT_BF16) {
+            if (wide) return fail(NGF_E_ARG, "InfoInv NGF_F_SPLIT_BF16 renders with split tiles of at most 16 rays");
+            return launch_policy<InfoInvSplitPolicy>(f, A, st);
+        }
+        return wide ? launch_policy<InfoInvWidePolicy>(f, A, st) : launch_policy<InfoInvPolicy>(f, A, st);
     }
     if (f->flags & NGF_F_NO_FOLD) return launch_policy<TriPlaneNoFoldPolicy>(f, A, st);
     if (f->flags & NGF_F_SPLIT_BF16) {

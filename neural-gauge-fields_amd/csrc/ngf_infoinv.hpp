@@ -16,10 +16,10 @@
 
 namespace ngf {
 
-constexpr int kInfoInvWaves = 8;
+constexpr int kInfoInvWaves = 12;
 constexpr int kInfoInvSplitWaves = 8;        // NGF_F_SPLIT_BF16: 102 KB of MLP images + 5.4 KB per wave
 
-struct InfoInvDensLayout {                  // floats, relative to MlpLayout<72>::TOTAL inside the blob
+struct InfoInvDensLayout {                  // floats, relative to MlpLayout16<72>::TOTAL inside the blob
     static constexpr int D1 = 0;                    // [36 k-steps][64 lanes] : W1[l&31][2t + (l>>5)]
     static constexpr int D2 = D1 + 36 * 64;         // [16 k-steps][64 lanes] : W2[l&31][row(t, l>>5)]
     static constexpr int B1 = D2 + 16 * 64;         // [2 hi][16]
@@ -288,6 +288,84 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
     mlp_layer3_16(blob, L::W3, L::B3, lane, c, rgb);
 }
 
+// ---- the default (fp32) colour pass: 16 samples per pass, FOUR lanes per sample, v_mfma_f32_16x16x4_f32 -----------------------------------
+// The data flow of mlp_pass16_bf16_ii with fp32 MFMAs (MlpLayout16<72>: W1 [4 mt][58 k-steps][64 lanes], one input of every lane per
+// k-step): permuted channels (72 contiguous bytes per lane and tap), a lane's 18 positional factors from three sincos + two doublings,
+// taps in two rows.  A lane carries 16 accumulators instead of the 32 (+36 factors, +48 gather registers) of round 1's
+// two-lanes-per-sample pass on v_mfma_f32_32x32x2_f32, so the kernel fits the 168 registers of TWELVE waves per CU: the same matrix work,
+// more waves to cover the gather and LDS latency that left the SIMDs idle 15 % of the time at eight.
+__device__ __forceinline__ void mlp_pass16_ii(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v, int lane, int mode,
+                                              float rgb[3])
+{
+    using L = MlpLayout16<72>;
+    blob = per_pass16(blob);
+    const int kq = lane >> 4;
+    const float *w1 = blob + L::W1 + lane;
+    GatherRowII g;
+    Bil b = bil_setup(rec[2], rec[3], A.app[0]);
+    gather_row_ii(A.app[0].p + (size_t)b.idx * 72 + kq * 18, g);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(blob + L::B1 + kq * 16 + mt * 4);
+    float bs[3] = {0.0f, 0.0f, 0.0f}, bc[3] = {1.0f, 1.0f, 1.0f};
+    if (mode) {
+        const float pe_xyz[3] = {rec[2], rec[3], rec[5]};
+        const float scale = (float)(1 << (3 * kq));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sincos_small(pe_xyz[k] * scale, bs[k], bc[k]);
+    }
+    // the view inputs first: their MFMAs run while plane 0's first row is on its way
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = NGF_MFMA16(w1[(mt * L::KT + 54 + e) * 64], v[e], acc[mt]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        float f[18];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[4 * q + e] = fmaf(b.w10, g.a[1][q][e], b.w00 * g.a[0][q][e]);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) f[16 + e] = fmaf(b.w10, g.b[1][e], b.w00 * g.b[0][e]);
+        __builtin_amdgcn_sched_barrier(0);
+        gather_row_ii(A.app[p].p + ((size_t)b.idx + A.app[p].stride) * 72 + kq * 18, g);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[4 * q + e] = fmaf(b.w11, g.a[1][q][e], fmaf(b.w01, g.a[0][q][e], f[4 * q + e]));
+#pragma unroll
+        for (int e = 0; e < 2; ++e) f[16 + e] = fmaf(b.w11, g.b[1][e], fmaf(b.w01, g.b[0][e], f[16 + e]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (p < 2) {                           // the next plane's first row travels behind this plane's 72 MFMAs
+            b = bil_setup(rec[4 + 2 * p], rec[5 + 2 * p], A.app[p + 1]);
+            gather_row_ii(A.app[p + 1].p + (size_t)b.idx * 72 + kq * 18, g);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (mode) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float sn = bs[k], cs = bc[k];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    f[k * 3 + j] *= sn; f[9 + k * 3 + j] *= cs;
+                    const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
+                    sn = s2; cs = c2;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 18; ++i)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = NGF_MFMA16(w1[(mt * L::KT + p * 18 + i) * 64], f[i], acc[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    mlp_tail16(blob, L::W2, L::B2, L::W3, L::B3, lane, acc, rgb);
+}
+
 // ---- NGF_F_SPLIT_BF16: the density MLP (72 -> 32 -> 32 -> 1, every in-box sample) on the bf16 matrix pipe -------------------------------
 // Lane l owns sample l and its 72 inputs.  A k-block is 16 inputs: the lane splits them into (hi, mid, lo) bf16 parts, packs inputs 0..7
 // and 8..15 into one fragment each, and v_permlane32_swap of the two turns them into the B fragments of BOTH column tiles (tile 0: lane
@@ -417,20 +495,22 @@ __device__ __forceinline__ float infoinv_sigma_bf16(const RenderArgs &A, const f
     return valid ? softplus_shift(f) : 0.0f;
 }
 
-template <bool SPLIT>
+// WIDE: tiles of up to 64 rays (the unsplit, one-ray-per-lane march: test / debug knobs only) -- the per-ray view inputs of 64 rays take
+// 4 KB per wave, so eight waves per CU; the default keeps the view inputs of 16 rays and runs twelve.
+template <bool SPLIT, bool WIDE = false>
 struct InfoInvPolicyT {
-    static constexpr int RGB_FLOATS = SPLIT ? MlpLayoutBf16II::TOTAL : MlpLayout<72>::TOTAL;      // the density image follows the colour image in LDS
+    static constexpr int RGB_FLOATS = SPLIT ? MlpLayoutBf16II::TOTAL : MlpLayout16<72>::TOTAL;      // the density image follows the colour image in LDS
     static constexpr int APP = 72;
     static constexpr bool INFOINV = true;
-    static constexpr int WAVES = SPLIT ? kInfoInvSplitWaves : kInfoInvWaves;
+    static constexpr int WAVES = (SPLIT || WIDE) ? kInfoInvSplitWaves : kInfoInvWaves;        // 8 (split: 247 registers; wide tiles: LDS) / 12
     static constexpr bool PROFILE = false;
     static constexpr bool VLDS = true;
     static constexpr bool VIEW_FOLD = false;
     static constexpr bool STAGED = false;
     static constexpr int STAGE_FLOATS = 0;
-    static constexpr int VFEAT_FLOATS = SPLIT ? 16 * kViewFeat : kWave * kViewFeat;     // split: tiles of <= 16 rays (render_common checks)
+    static constexpr int VFEAT_FLOATS = (WIDE ? kWave : 16) * kViewFeat;     // view inputs of the tile's rays (render_common picks the policy)
     static constexpr int NSTEP = 1;
-    static constexpr int BATCH = SPLIT ? kBatch16 : kBatch;
+    static constexpr int BATCH = kBatch16;
     static constexpr int RING = 128;
 
     // called by all 64 lanes; returns sigma of the lane's own sample (0 when !valid)
@@ -511,11 +591,13 @@ struct InfoInvPolicyT {
     __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
                                                  const float *, int lane, float c[3], unsigned long long * = nullptr)
     {
-        if constexpr (SPLIT) mlp_pass16_bf16_ii(A, smem, rec, *reinterpret_cast<const f32x4 *>(vf + (lane >> 4) * 4), lane, A.mode, c);
-        else mlp_pass<72, true, 3>(A, smem, rec, vf, lane, A.mode, c);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(vf + (lane >> 4) * 4);
+        if constexpr (SPLIT) mlp_pass16_bf16_ii(A, smem, rec, v, lane, A.mode, c);
+        else mlp_pass16_ii(A, smem, rec, v, lane, A.mode, c);
     }
 };
 using InfoInvPolicy = InfoInvPolicyT<false>;
+using InfoInvWidePolicy = InfoInvPolicyT<false, true>;
 using InfoInvSplitPolicy = InfoInvPolicyT<true>;
 
 }  // namespace ngf

@@ -10,15 +10,16 @@
 //          (FieldBase.py:118-137, 251-288; Field.py:53-91).  Lanes whose weight exceeds the
 //          threshold append a 32-byte record to the wave's LDS queue (ballot + prefix popcount),
 //          so the queue is ordered by (step, lane).
-//   shade  when >= 32 records are queued (or the march has ended): the colour path for 32
-//          samples (Field.py:93-105, networks.py:25-32).  Two lanes share a sample: lane (s, hi)
-//          gathers channels [hi*24, hi*24+24) of the four bilinear taps of each colour plane and
-//          is column s / k-slice hi of the B operand of v_mfma_f32_32x32x2_f32; the A operand is
-//          the pre-composed layer-1 matrix read from LDS.  Layer 2 consumes the accumulators in
-//          place, layer 3 (64->3) is a 32-term VALU dot per lane + one cross-half add.  The
-//          weighted colours go to a 32-entry LDS result list and every lane, as ray owner, adds
-//          the entries that carry its lane id in queue order -- the per-ray sum over samples is
-//          sequential in the sample index, deterministic, and uses no atomics.
+//   shade  when >= 16 records are queued (or the march has ended): the colour path for 16
+//          samples (Field.py:93-105, networks.py:25-32).  Four lanes share a sample: lane (s, kq)
+//          gathers a quarter of the channels of the four bilinear taps of each colour plane and is
+//          column s / k-slice kq of the B operand of v_mfma_f32_16x16x4_f32 (ngf_shade16.hpp; InfoInv:
+//          ngf_infoinv.hpp; the bf16 forms: ngf_shade_bf16.hpp); the A operand is the pre-composed
+//          layer-1 matrix read from LDS.  Layer 2 consumes the accumulators in place, layer 3 (64->3)
+//          is a 16-term VALU dot per lane + two cross-quarter adds.  The weighted colours go to a
+//          16-entry LDS result list and every lane, as ray owner, adds the entries that carry its
+//          lane id in queue order -- the per-ray sum over samples is sequential in the sample index,
+//          deterministic, and uses no atomics.
 //
 // Nothing of size [n,S,*] is ever materialised in HBM.
 #pragma once
@@ -45,19 +46,6 @@ __device__ __forceinline__ void view_inputs(const float d[3], float v[16])
     v[15] = 0.0f;
 }
 
-template <int APP>
-struct MlpLayout {                        // offsets into the packed MLP image (floats)
-    static constexpr int HALF = APP / 2;          // colour channels per plane per lane-half
-    static constexpr int KT = 3 * HALF + 8;       // layer-1 k-steps (2 inputs per step): 80 | 116
-    static constexpr int W1 = 0;                  // [2 ntile][KT][64 lanes]
-    static constexpr int W2 = W1 + 2 * KT * 64;   // [2 mtile][32][64 lanes]
-    static constexpr int B1 = W2 + 2 * 32 * 64;   // [2 hi][32]
-    static constexpr int B2 = B1 + 64;            // [2 hi][32]
-    static constexpr int W3 = B2 + 64;            // [3][2 hi][32]
-    static constexpr int B3 = W3 + 192;           // [4]
-    static constexpr int TOTAL = B3 + 4;
-};
-
 // The MLP image in LDS is read-only after the initial barrier, so LICM would hoist every per-lane weight /
 // bias read (160+ values) out of the persistent loops and pin them in VGPRs for the whole kernel (they
 // then spill).  Adding an opaque zero to the pointer once per pass keeps those reads inside the pass.
@@ -66,42 +54,6 @@ __device__ __forceinline__ const float *per_pass(const float *blob)
     int z = 0;
     asm volatile("" : "+v"(z));
     return blob + z;
-}
-
-// layers 2 and 3 of rgb_decoder, shared by both shade variants
-__device__ __forceinline__ void mlp_tail(const float *__restrict__ blob, int oW2, int oB2, int oW3, int oB3, int lane,
-                                         const f32x16 &acc0, const f32x16 &acc1, float rgb[3])
-{
-    const int hi = lane >> 5;
-    // layer 2: B operand = ReLU(layer-1 accumulators) of the own sample, A = W2 rows permuted to match
-    f32x16 c0, c1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        c0[r] = blob[oB2 + hi * 32 + r];
-        c1[r] = blob[oB2 + hi * 32 + 16 + r];
-    }
-    const float *w2a = blob + oW2 + lane;
-    const float *w2b = blob + oW2 + 32 * 64 + lane;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        float h = relu1(k < 16 ? acc0[k & 15] : acc1[k & 15]);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[k * 64], h, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2b[k * 64], h, c1, 0, 0, 0);
-    }
-    // layer 3 on the VALU: each half holds 32 of the 64 hidden activations of its sample
-    const float *w3 = blob + oW3 + hi * 32;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            float h = relu1(k < 16 ? c0[k & 15] : c1[k & 15]);
-            s = fmaf(w3[c * 64 + k], h, s);
-        }
-        s = s + __shfl_xor(s, 32);
-        s = s + blob[oB3 + c];
-        rgb[c] = 1.0f / (1.0f + expf(-s));
-    }
 }
 
 // sin / cos of x * 2^f for f = 0..F-1 (the InfoInv positional encodings, networks.py:227-237): an accurate sincos (sincos_small, <= 1.6 ulp) at every
@@ -123,109 +75,6 @@ __device__ __forceinline__ void pe_ladder(float x, float sn[F], float cs[F])
             sn[base + j] = s; cs[base + j] = c;
         }
     }
-}
-
-// ---- shade: rgb_decoder on 32 queued samples ---------------------------------------------------
-// rec: this lane's record (lane s = lane&31 of the batch), vf: the owner ray's 16 view features.
-// Returns sigmoid colour of the lane's sample (identical in both halves).
-template <int APP, bool INFOINV, int CH = (APP == 48 ? 6 : 3)>
-__device__ __forceinline__ void mlp_pass(const RenderArgs &A, const float *blob, const float rec[kRecFloats],
-                                         const float *vf, int lane, int mode, float rgb[3])
-{
-    using L = MlpLayout<APP>;
-    blob = per_pass(blob);
-    constexpr int NQ = L::HALF / 4;          // float4 loads per tap per lane (6 | 9)
-    constexpr int CPP = NQ / CH;             // pipeline stages per plane
-    constexpr int NST = 3 * CPP;
-    static_assert(NQ % CH == 0, "chunk size must divide the per-tap load count");
-    const int hi = lane >> 5;
-    const float *w1a = blob + L::W1 + lane;
-    const float *w1b = blob + L::W1 + L::KT * 64 + lane;
-
-    // Explicit software pipeline (hipcc otherwise issues the gathers just-in-time, 4 loads per 8 MFMAs,
-    // and exposes ~18 memory latencies per pass): the 4 taps x CH float4 of stage s+1 are requested
-    // before the 8*CH MFMAs of stage s are issued, so one gather is always in flight behind the matrix
-    // work.  sched_barrier(0) pins the stage order.
-    f32x4 raw[4][CH];
-    auto issue = [&](int st) {
-        const int p = st / CPP, q0 = (st % CPP) * CH;
-        const Tex &t = A.app[p];
-        const Bil b = bil_setup(rec[2 + 2 * p], rec[3 + 2 * p], t);
-        const f32x4 *t00 = reinterpret_cast<const f32x4 *>(t.p + (size_t)b.idx * APP + hi * L::HALF) + q0;
-        const f32x4 *t01 = t00 + (size_t)t.stride * (APP / 4);
-#pragma unroll
-        for (int q = 0; q < CH; ++q) {
-            raw[0][q] = t00[q];
-            raw[1][q] = t00[APP / 4 + q];
-            raw[2][q] = t01[q];
-            raw[3][q] = t01[APP / 4 + q];
-        }
-    };
-    issue(0);
-    __builtin_amdgcn_sched_barrier(0);
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        acc0[r] = blob[L::B1 + hi * 32 + r];
-        acc1[r] = blob[L::B1 + hi * 32 + 16 + r];
-    }
-    {   // view-direction inputs first (they overlap the first gather)
-        const f32x4 va = *reinterpret_cast<const f32x4 *>(vf + hi * 8), vb = *reinterpret_cast<const f32x4 *>(vf + hi * 8 + 4);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int t_ = 3 * L::HALF + j;
-            const float x = j < 4 ? va[j & 3] : vb[j & 3];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[t_ * 64], x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[t_ * 64], x, acc1, 0, 0, 0);
-        }
-    }
-    // plane_feature * PE_12(xyz) (InfoInv/models/Field.py:72-84): the same 72 factors multiply all three planes; this lane needs
-    // the 36 of its half (hi = 0: sines, hi = 1: cosines), computed once per pass
-    float pe[INFOINV ? 36 : 1];
-    if (INFOINV) {
-        const float pe_xyz[3] = {rec[2], rec[3], rec[5]};                          // xyz = cat(xy, yz[:,1:])
-        if (mode) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                float sn[12], cs[12];
-                pe_ladder<12>(pe_xyz[k], sn, cs);
-#pragma unroll
-                for (int f = 0; f < 12; ++f) pe[k * 12 + f] = hi ? cs[f] : sn[f];
-            }
-        }
-    }
-
-#pragma unroll
-    for (int st = 0; st < NST; ++st) {
-        const int p = st / CPP, q0 = (st % CPP) * CH;
-        __builtin_amdgcn_sched_barrier(0);
-        float feat[4 * CH];
-        {
-            const Bil b = bil_setup(rec[2 + 2 * p], rec[3 + 2 * p], A.app[p]);
-#pragma unroll
-            for (int q = 0; q < CH; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) feat[4 * q + e] = bil_mix(b, raw[0][q][e], raw[1][q][e], raw[2][q][e], raw[3][q][e]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (st + 1 < NST) issue(st + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (INFOINV) {
-            // plane_feature * PE_12(xyz): channel c = hi*36 + j ; c < 36 -> sin(x_{c/12} * 2^(c%12)), else cos
-            if (mode) {
-#pragma unroll
-                for (int jj = 0; jj < 4 * CH; ++jj) feat[jj] = feat[jj] * pe[4 * q0 + jj];
-            }
-        }
-#pragma unroll
-        for (int jj = 0; jj < 4 * CH; ++jj) {
-            const int t_ = p * L::HALF + 4 * q0 + jj;
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[t_ * 64], feat[jj], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1b[t_ * 64], feat[jj], acc1, 0, 0, 0);
-        }
-    }
-    mlp_tail(blob, L::W2, L::B2, L::W3, L::B3, lane, acc0, acc1, rgb);
 }
 
 // ---- TriPlane density at the gauge-shifted coordinates ------------------------------------------

@@ -1,7 +1,7 @@
 // ngf_shade16.hpp -- the colour MLP on v_mfma_f32_16x16x4_f32: 16 samples per pass, FOUR lanes per sample.
 //
-// Why a second shade formulation: with v_mfma_f32_32x32x2_f32 (ngf_render.hpp, two lanes per sample) a lane
-// carries 32 accumulators and gathers 24 (baked: 32) channels per tap, which pins the fused kernel at
+// Why this formulation: with v_mfma_f32_32x32x2_f32 (round 1's first shade, two lanes per sample; removed in round 2 when InfoInv
+// moved to the 16-sample form too) a lane carries 32 accumulators and gathers 24 (baked: 32) channels per tap, which pins the fused kernel at
 // ~220-250 VGPRs = 2 waves per SIMD, too few to overlap the march (TA / latency bound) with the shade
 // (matrix-pipe bound).  Here lane (s = l&15, kq = l>>4) owns 16 accumulators and gathers 12 (baked: 16)
 // channels per tap: the same matrix work per sample, about half the registers per lane.
