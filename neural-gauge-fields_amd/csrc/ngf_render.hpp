@@ -23,11 +23,28 @@
 //
 // Nothing of size [n,S,*] is ever materialised in HBM.
 #pragma once
+#include <cstddef>
+
 #include "ngf_device.hpp"
 #include "ngf_shade16.hpp"
 #include "ngf_shade_bf16.hpp"
 
 namespace ngf {
+
+// A Tex of the kernel's RenderArgs (byte offset `off` inside it), re-read from the kernel-argument segment on the scalar memory pipe at
+// the point of use.  RenderArgs holds nine Tex (63 dwords) next to 48 decoder weights: kept live across the march loop they overflow the
+// SGPR file and hipcc parks texture pointers in VGPR lanes -- ~38 v_readlane per march step on the vector pipe, which is the binding one
+// (measured: R1 frame 9.93 -> 9.82 ms, same bits).  REQUIRES the RenderArgs to be the kernel's first argument (offset 0 of the kernarg
+// segment): true for every kernel of this library (TrainArgs starts with its RenderArgs, static_assert in ngf_train.hpp).
+__device__ __forceinline__ Tex karg_tex(size_t off)
+{
+    typedef const __attribute__((address_space(4))) Tex *tptr_t;
+    tptr_t t = (tptr_t)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + off);
+    asm volatile("" : "+s"(t));
+    Tex r;
+    r.p = t->p; r.W = t->W; r.H = t->H; r.stride = t->stride; r.fw = t->fw; r.fh = t->fh;
+    return r;
+}
 
 // LDS carve (floats): [blob | per wave: ring of RING records, result list, view inputs of the 64 rays]
 template <typename P> constexpr int wave_lds_floats() { return P::RING * kRecFloats + P::BATCH * 4 + P::VFEAT_FLOATS + P::STAGE_FLOATS; }
@@ -84,7 +101,7 @@ __device__ __forceinline__ float triplane_density_feature(const RenderArgs &A, c
     float f = 0.0f;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        const Tex &tx = A.dens[p];
+        const Tex tx = karg_tex(offsetof(RenderArgs, dens) + p * sizeof(Tex));
         Bil b = bil_setup(t[2 * p], t[2 * p + 1], tx);
         if (BAKED) {
             const float *q = tx.p + b.idx;
@@ -93,12 +110,18 @@ __device__ __forceinline__ float triplane_density_feature(const RenderArgs &A, c
             const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + (size_t)b.idx * 16);
             const f32x4 *q01 = q00 + (size_t)tx.stride * 4;
             float d00 = 0.0f, d10 = 0.0f, d01 = 0.0f, d11 = 0.0f;
+            // the plane's 16 decoder weights are re-read from the kernel-argument segment here (one s_load_dwordx16 on the scalar
+            // memory pipe): kept live across the march loop the 48 of them crowd the SGPR file and hipcc parks texture pointers in
+            // VGPR lanes, ~36 v_readlane per march step on the (binding) vector pipe
+            typedef const __attribute__((address_space(4))) float *kptr_t;
+            kptr_t wdp = (kptr_t)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RenderArgs, wd)) + p * 16;
+            asm volatile("" : "+s"(wdp));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 v00 = q00[q], v10 = q00[4 + q], v01 = q01[q], v11 = q01[4 + q];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float w = A.wd[p * 16 + 4 * q + e];
+                    float w = wdp[4 * q + e];
                     d00 = fmaf(w, v00[e], d00);
                     d10 = fmaf(w, v10[e], d10);
                     d01 = fmaf(w, v01[e], d01);
@@ -119,7 +142,7 @@ __device__ __forceinline__ void triplane_gauge(const RenderArgs &A, const float 
         float d[3][2];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            const Tex &tx = A.gau[p];
+            const Tex tx = karg_tex(offsetof(RenderArgs, gau) + p * sizeof(Tex));
             Bil b = bil_setup(u[p], v[p], tx);
             const f32x2 *g = reinterpret_cast<const f32x2 *>(tx.p) + b.idx;
             f32x2 g00 = g[0], g10 = g[1], g01 = g[tx.stride], g11 = g[tx.stride + 1];

@@ -82,6 +82,8 @@ struct TrainArgs {
     float inv_count;         // 1 / (3 n): the mean of the MSE
 };
 
+static_assert(offsetof(TrainArgs, R) == 0, "karg_tex (ngf_render.hpp) reads the RenderArgs at offset 0 of the kernel arguments");
+
 // ---- geometry of sample (ray r, step i): Base.sample_ray + normalize_coord + compute_gauge --------------------------------
 // returns valid; xn = normalised position (compute_gauge and the gauge gradient start from it)
 __device__ __forceinline__ int chunk_rows(const TrainArgs &T)
