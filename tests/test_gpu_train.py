@@ -303,3 +303,35 @@ def test_params_changed_rebuilds_the_packed_copies():
         a, b = tr.gradient(name).cpu().numpy(), fresh.gradient(name).cpu().numpy()
         assert rel(a, b) < GRAD_TOL, (name, rel(a, b))
     assert rel(tr.gradient("plane_xy").cpu().numpy(), g_before.cpu().numpy()) > 1e-2        # the edit did change the gradient
+
+
+def test_single_parameter_adam_entry_point():
+    """ngf_train_adam (one parameter per call; optimizer_step goes through ngf_train_adam_all) for an MLP parameter and a plane:
+    the same restated torch.optim.Adam update, and the plane's packed copy follows (the next backward needs no re-pack)."""
+    import ctypes as C
+    from ngf_amd import _lib
+    g, params = load_train_case("train_r1")
+    f = field_for_case(g, params, None)
+    S = int(g["S"])
+    rays, tgt, jit = torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["rgb_train"]).cuda(), torch.from_numpy(g["jitter0"])
+    tr = train.Trainer(f, batch_size=rays.shape[0], max_samples=S)
+    tr.backward(rays, tgt, S, white_bg=True, iteration=0, jitter=jit)
+    L = _lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for name in ("rgb_decoder.mlp.2.weight", "plane_yz"):
+        k = train.PARAM_NAMES.index(name)
+        before, gk = tr.params[k].detach().clone(), tr.gradient(k)
+        if k < 3:
+            gk = gk + 8e-5 * torch.sign(before) / before.numel()
+        want, m, v = otrain.adam_update(before, gk, torch.zeros_like(before), torch.zeros_like(before), 1, tr.lr[k])
+        _lib.check(L.ngf_train_adam(tr._h, k, 1, float(tr.lr[k]), 0.9, 0.99, 1e-8, 8e-5, st))
+        err = (tr.params[k].detach() - want).abs().max().item()
+        assert err < 2e-6 * max(1.0, before.abs().max().item()) + 1e-3 * tr.lr[k], (name, err)
+        assert torch.allclose(tr.exp_avg[k], m, rtol=1e-5, atol=1e-12)
+    # the packed copy of plane_yz was updated by the kernel: a second backward equals that of a trainer built on the updated field
+    tr.backward(rays, tgt, S, white_bg=True, iteration=0, jitter=jit)
+    fresh = train.Trainer(f, batch_size=rays.shape[0], max_samples=S)
+    fresh.backward(rays, tgt, S, white_bg=True, iteration=0, jitter=jit)
+    for name in ("plane_yz", "plane_xy", "rgb_decoder.mlp.0.weight"):
+        a, b = tr.gradient(name).cpu().numpy(), fresh.gradient(name).cpu().numpy()
+        assert rel(a, b) < GRAD_TOL, (name, rel(a, b))
