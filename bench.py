@@ -46,49 +46,136 @@ def so_sha16():
     return hashlib.sha256(open(_lib.SO_PATH, "rb").read()).hexdigest()[:16]
 
 
+PMC_ROUNDS = ("r03", "r02")
+
+
 def load_pmc(tag):
-    """profiles/r02_<tag>_pmc.json (profiles/collect.sh + summarize_pmc.py, committed) or None; `stale` = collected with another build."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", f"r02_{tag}_pmc.json")))
-    except Exception:
-        return None
-    d["file"] = f"profiles/r02_{tag}_pmc.json"
-    d["stale"] = d.get("so_sha16") != so_sha16()
-    return d
+    """profiles/<round>_<tag>_pmc.json of the newest round that has one (profiles/collect.sh + summarize_pmc.py, committed) or None;
+    `stale` = collected with another build of the library than the one loaded now."""
+    for rnd in PMC_ROUNDS:
+        rel = f"profiles/{rnd}_{tag}_pmc.json"
+        try:
+            d = json.load(open(os.path.join(ROOT, rel)))
+        except Exception:
+            continue
+        d["file"] = rel
+        d["stale"] = d.get("so_sha16") != so_sha16()
+        return d
+    return None
+
+
+NOTES = {
+    "simd_vector_datapath": "MFMA (fp32 and bf16) and VALU instructions of a SIMD execute one after the other on gfx950 (profiles/micro/"
+                            "mfma_valu_overlap.hip, profiles/r02_micro_mfma_valu_overlap.txt: 8.75 ms of fp32 MFMA + 3.07 ms of VALU run together in "
+                            "11.63 ms; bf16: 4.44 + 3.07 -> 7.39), so their busy cycles add and this sum is the binding roof of the kernel.  "
+                            "SQ_ACTIVE_INST_VALU also counts the issue cycles of the MFMA instructions (profiles/r02_counter_semantics.txt: 4 of "
+                            "every 33 fp32 / 16 bf16 MFMA cycles); they are subtracted.",
+    "hbm_fabric": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; includes Infinity-Cache hits",
+    "algorithmic_d3": "model, not a bound (SURVEY 8 D3 accounting: every bilinear tap counted once, no cache credit; the 52 MB texture set is "
+                      "L1/L2/Infinity-Cache resident, so this exceeds the HBM peak by construction)",
+    "flops_counted": "EXECUTED fp32 MFMA flops (v_mfma_f32_16x16x4_f32: passes x MFMAs x 2048; equals rocprofv3 "
+                     "SQ_INSTS_VALU_MFMA_MOPS_F32 x 512), layer 1 pre-composed with `basis`, per-ray view fold",
+    "physical": "busy fractions are counter ratios of the committed rocprofv3 --pmc run of the same workload (file named in `source`, "
+                "`pmc_stale` = collected with another build); rates divide the counters' bytes by THIS run's kernel time",
+}
 
 
 def physical_roofs(pmc, k_ms, share=1.0):
-    """Physically bounded utilisation figures of the launch, every one <= 1 by construction.  Busy fractions are counter ratios
-    of the rocprofv3 run of this workload; rates divide the counters' bytes by THIS run's measured kernel time."""
+    """Physically bounded utilisation figures of the launch, every one <= 1 by construction, as bare numbers (prose: NOTES).  Busy
+    fractions are counter ratios of the rocprofv3 run of this workload; rates divide the counters' bytes by THIS run's kernel time."""
     if pmc is None:
-        return {"note": "no rocprofv3 --pmc summary of this workload under profiles/"}
+        return None
     t = k_ms * 1e-3
     out = {"source": pmc["file"], "pmc_stale": pmc["stale"], "kernel_ms_under_pmc": pmc.get("kernel_ms_under_pmc")}
     if "mfma_busy_frac" in pmc and "valu_busy_frac" in pmc:
         issue = pmc.get("mfma_issue_frac", 0.0)
-        out["simd_vector_datapath"] = {
-            "mfma_busy_frac": pmc["mfma_busy_frac"], "valu_busy_frac": pmc["valu_busy_frac"], "mfma_issue_frac_inside_valu_busy": issue,
-            "frac": pmc["mfma_busy_frac"] + max(pmc["valu_busy_frac"] - issue, 0.0),
-            "note": "MFMA (fp32 and bf16) and VALU instructions of a SIMD execute one after the other on gfx950 (profiles/micro/"
-                    "mfma_valu_overlap.hip, profiles/r02_micro_mfma_valu_overlap.txt: 8.75 ms of fp32 MFMA + 3.07 ms of VALU run together in "
-                    "11.63 ms; bf16: 4.44 + 3.07 -> 7.39), so their busy cycles add and this sum is the binding roof of the kernel.  "
-                    "SQ_ACTIVE_INST_VALU also counts the issue cycles of the MFMA instructions (profiles/r02_counter_semantics.txt: 4 of "
-                    "every 33 fp32 / 16 bf16 MFMA cycles); they are subtracted here"}
+        out.update({"mfma_busy": pmc["mfma_busy_frac"], "valu_busy_raw": pmc["valu_busy_frac"], "mfma_issue_in_valu": issue,
+                    "simd_busy": pmc["mfma_busy_frac"] + max(pmc["valu_busy_frac"] - issue, 0.0)})
     if "ta_busy_frac" in pmc:
-        out["texture_addresser_busy_frac"] = pmc["ta_busy_frac"]
+        out["ta_busy"] = pmc["ta_busy_frac"]
     if "lds_busy_frac" in pmc:
-        out["lds_busy_frac"] = pmc["lds_busy_frac"]
+        out["lds_busy"] = pmc["lds_busy_frac"]
     if "l2_read_bytes_per_launch" in pmc:
         l2 = pmc["l2_read_bytes_per_launch"] * share / t / 1e12
-        out["l2"] = {"read_TBps": l2, "peak_TBps": L2_PEAK_TBS, "frac": l2 / L2_PEAK_TBS, "hit_frac": pmc.get("l2_hit_frac"), "l1_hit_frac": pmc.get("l1_hit_frac")}
+        out.update({"l2_read_TBps": l2, "l2_frac": l2 / L2_PEAK_TBS, "l2_hit": pmc.get("l2_hit_frac"), "l1_hit": pmc.get("l1_hit_frac")})
     if "hbm_traffic_bytes_per_launch" in pmc:
         hb = pmc["hbm_traffic_bytes_per_launch"] * share / t / 1e9
-        out["hbm_fabric"] = {"GBps": hb, "peak_GBps": HBM_PEAK_GBS, "frac": hb / HBM_PEAK_GBS,
-                             "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; includes Infinity-Cache hits"}
-    for k in ("sq_wait_inst_any_frac", "sq_wait_any_frac", "sq_active_inst_any_frac", "vgpr", "scratch_bytes_per_lane", "lds_bytes"):
+        out.update({"hbm_fabric_GBps": hb, "hbm_frac": hb / HBM_PEAK_GBS})
+    for k in ("vgpr", "scratch_bytes_per_lane", "lds_bytes"):
         if k in pmc:
             out[k] = pmc[k]
     return out
+
+
+def _r(x, nd=4):
+    """Round floats for the compact line (significant digits, not decimals)."""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+LINE_LIMIT = 4096
+FIXED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+
+
+def compact_line(result: dict) -> str:
+    """The ONE JSON line the driver parses (it keeps an ~8 KB tail of stdout): fixed keys, config, roofline (numbers only),
+    cpu_baseline, parity, the multi-GPU figures -- never more than LINE_LIMIT bytes.  Everything else (extras, notes, the
+    algorithmic D3 model) goes to bench_extras.json."""
+    out = {k: result[k] for k in FIXED_KEYS}
+    for k in ("value", "ms_per_step"):
+        out[k] = _r(out[k], 6)
+    out["config"] = result["config"]
+    rf = result.get("roofline") or {}
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "flops_per_launch", "active_samples_per_ray",
+            "evaluated_samples_per_ray")
+    crf = {k: _r(rf.get(k), 5) for k in keep if k in rf}
+    ph = rf.get("physical")
+    if ph:
+        crf["physical"] = _r({k: ph[k] for k in ("simd_busy", "mfma_busy", "valu_busy_raw", "mfma_issue_in_valu", "ta_busy", "l2_hit", "hbm_frac",
+                                               "pmc_stale", "source", "vgpr", "scratch_bytes_per_lane") if k in ph})
+    out["roofline"] = crf
+    if "cpu_baseline" in result:
+        cb = result["cpu_baseline"]
+        out["cpu_baseline"] = {"value": _r(cb["value"], 5), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:160]}
+    if "parity" in result:
+        out["parity"] = _r(result["parity"], 4)
+    for k in ("gathered_frame_bit_identical_to_single_gpu_render", "all_gather_ms", "all_gather_bytes_per_rank", "shard_kernel_ms",
+              "speedup_vs_cpu_port"):
+        if k in result:
+            out[k] = _r(result[k], 5)
+    if "extras" in result:      # headline numbers of the other configs only; the full entries are in the side file
+        out["extras_Mray_s"] = {k: _r(v["Mray/s"], 4) for k, v in result["extras"].items() if isinstance(v, dict) and "Mray/s" in v}
+        tr = result["extras"].get("train_step_R1", {})
+        if "ms_per_iteration" in tr:
+            out["train_ms_per_iteration"] = _r(tr["ms_per_iteration"], 4)
+        out["extras_file"] = "bench_extras.json"
+    line = json.dumps(out, separators=(",", ":"))
+    for k in ("extras_Mray_s", "parity", "speedup_vs_cpu_port"):     # never reached with today's keys; a guard, not a plan
+        if len(line) <= LINE_LIMIT:
+            break
+        out.pop(k, None)
+        line = json.dumps(out, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:
+        raise RuntimeError(f"bench line is {len(line)} bytes (> {LINE_LIMIT}): the driver would not parse it")
+    return line
+
+
+def write_side_file(result: dict):
+    """Full result (extras, notes, D3 model) next to bench.py and, when the directory exists, under gpurun_out/."""
+    full = dict(result)
+    full["notes"] = NOTES
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_extras.json"), "w") as fh:
+                    json.dump(full, fh, indent=1)
+            except OSError:
+                pass
 
 
 def build_field(model, preset, device, bake=False, bake_color=False, no_fold=False, split_bf16=False):
@@ -288,17 +375,13 @@ def main():
         # InfoInv runs its density MLP on the matrix pipe inside the march, so the executed flops are not a function of the pass
         # count alone: take SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 of the PMC run of this very workload
         mfma_flops = pmc.get("mfma_flops_per_dispatch")
-    alg = {"tag": "model, not a bound (SURVEY 8 D3 accounting: every bilinear tap counted once, no cache credit; the 52 MB texture set is "
-                  "L1/L2/Infinity-Cache resident, so this exceeds the HBM peak by construction)",
-           "unit": "GB/s", "achieved": achieved, "peak": HBM_PEAK_GBS, "frac_of_hbm_peak": achieved / HBM_PEAK_GBS, "bytes_per_launch": bytes_launch,
+    alg = {"unit": "GB/s", "achieved": achieved, "peak": HBM_PEAK_GBS, "frac_of_hbm_peak": achieved / HBM_PEAK_GBS, "bytes_per_launch": bytes_launch,
            "flops_per_launch": (S * 550.0 + s_active * 71400.0) * n_local if model == "triplane" else None}
     if mfma_flops is not None:
         tf = mfma_flops / (k_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
                     "traffic": None if pmc is None else pmc.get("hbm_traffic_bytes_per_launch", 0.0) * n_local / n_total,
-                    "flops_per_launch": mfma_flops,
-                    "flops_counted": "EXECUTED fp32 MFMA flops (v_mfma_f32_16x16x4_f32: passes x MFMAs x 2048; equals rocprofv3 "
-                                     "SQ_INSTS_VALU_MFMA_MOPS_F32 x 512), layer 1 pre-composed with `basis`, per-ray view fold"}
+                    "flops_per_launch": mfma_flops}
     else:
         # no matrix work counted (e.g. InfoInv without a PMC summary): the physical HBM-side figure, or nothing -- never the model bytes
         hb = None if pmc is None or "hbm_traffic_bytes_per_launch" not in pmc else pmc["hbm_traffic_bytes_per_launch"] * n_local / n_total
@@ -374,12 +457,10 @@ def main():
                     px = load_pmc(f"{mdl}_{preset}{ptag_sfx}")
                     entry = {"Mray/s": n_total / ms / 1e3, "kernel_ms": ms, "active_samples_per_ray": sa}
                     if flags.get("split_bf16") and mdl == "infoinv":
-                        entry["note"] = "rgb_decoder as 3-term split bf16 products on v_mfma_f32_32x32x16_bf16; density MLP unchanged"
+                        entry["note"] = "rgb_decoder and density MLP as 3-term split bf16 products on v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16"
                     elif flags.get("split_bf16"):
                         bf = sx[2] * 168 * 2 * 16 * 16 * 32                    # executed bf16 MFMA flops: 168 v_mfma_f32_16x16x32_bf16 per pass
-                        entry.update({"executed_bf16_mfma_TFLOPs": bf / (ms * 1e-3) / 1e12, "bf16_mfma_frac_of_2500": bf / (ms * 1e-3) / 1e12 / 2500.0,
-                                      "note": "six bf16 products per fp32 product (3-term split, fp32 accumulate): fp32-level error, "
-                                              "max |rgb - fp32 path| < 2e-6 (tests/test_gpu_parity.py::test_split_bf16_colour_mlp_keeps_fp32_accuracy)"})
+                        entry.update({"executed_bf16_mfma_TFLOPs": bf / (ms * 1e-3) / 1e12, "bf16_mfma_frac_of_2500": bf / (ms * 1e-3) / 1e12 / 2500.0})
                     else:
                         if mdl == "triplane":
                             per_pass = 548 if flags.get("no_fold") else (64 if flags.get("bake_color") else 208)
@@ -414,9 +495,7 @@ def main():
                     e = {"Mray/s": n_uv / ms / 1e3, "kernel_ms": ms, "rays": int(n_uv), "in_cube_samples_per_ray": us[0] / n_uv,
                          "algorithmic_TFLOPs_all_64_samples (model)": n_uv * 64 * 2 * 1334592.0 / (ms * 1e-3) / 1e12}
                     if split:
-                        e.update({"fp32_equivalent_TFLOPs": flops / (ms * 1e-3) / 1e12, "physical": physical_roofs(load_pmc("uv_sphere_split"), ms),
-                                  "note": "256-unit layers (94 % of the MACs) as six bf16 MFMA products per fp32 product, fp32 accumulate; "
-                                          "max |colour - fp32 kernel| 2.4e-7 on the golden cases (tests/test_gpu_uv.py)"})
+                        e.update({"fp32_equivalent_TFLOPs": flops / (ms * 1e-3) / 1e12, "physical": physical_roofs(load_pmc("uv_sphere_split"), ms)})
                     else:
                         e.update({"executed_TFLOPs": flops / (ms * 1e-3) / 1e12, "mfma_frac_of_157.3": flops / (ms * 1e-3) / 157.3e12,
                                   "physical": physical_roofs(load_pmc("uv_sphere"), ms)})
@@ -507,7 +586,8 @@ def main():
         except Exception:
             pass
         sys.stdout.flush()
-        print(json.dumps(result), flush=True)
+        write_side_file(result)
+        print(compact_line(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,85 @@
+"""The final stdout line of bench.py must be parseable by the driver, which keeps an ~8 KB tail of stdout: round 2's line was
+29 KB (extras inline, one 600-character note repeated 16 times) and the record held no value.  These tests drive bench.py's own
+line builder (`compact_line`, `physical_roofs`, `load_pmc`) with a result of the shape main() assembles -- every optional block
+present, every extras entry present -- and bound its size."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _fat_result(monkeypatch):
+    monkeypatch.setattr(bench, "so_sha16", lambda: "0" * 16)
+    pmc = bench.load_pmc("triplane_R1")
+    assert pmc is not None, "profiles/ holds no PMC summary of the headline workload"
+    phys = bench.physical_roofs(pmc, 9.8123456789)
+    extras = {}
+    for i in range(24):         # main() has 16 today
+        extras[f"triplane_R{i}_some_long_variant_tag_split_bf16"] = {
+            "Mray/s": 65.123456789 + i, "kernel_ms": 9.87654321, "active_samples_per_ray": 46.3121515625,
+            "executed_mfma_TFLOPs": 82.123456, "physical": phys, "note": "x" * 600}
+    extras["train_step_R1"] = {"ms_per_iteration": 1.23456789, "atomic_roof": {"floor_ms": 0.35, "note": "y" * 600}}
+    extras["broken"] = {"error": "RuntimeError('" + "z" * 2000 + "')"}
+    return {
+        "metric": "Mray/sec (800x800 lego-style frame, 192 samples/ray)", "value": 65.30420130967548, "unit": "Mray/s", "n_gpus": 8,
+        "steps": 20, "warmup": 5, "ms_per_step": 9.800288299447857, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "TriPlane 800x800 frame, S=192, preset R1 (seeded random planes 256^2, dense density preset), gauge on, white_bg",
+                   "rays_per_step": 640000, "samples_per_ray": 192,
+                   "sharding": "rays x8 (10-row blocks, round robin) + double-buffered RCCL all_gather", "bake_density": 0, "bake_color": 0,
+                   "knobs": "waves=12,tile_w=8,kernel=1"},
+        "roofline": {"bound": "mfma", "achieved": 82.29929213137213, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.5231995685401915,
+                     "traffic": 720829197.7142856, "flops_per_launch": 807705214976.0, "physical": phys, "kernel": "ngf::render_kernel",
+                     "kernel_ms": 9.814242553710937, "active_samples_per_ray": 46.3121515625, "evaluated_samples_per_ray": 141.418665625,
+                     "mlp_passes": 1889939.0, "algorithmic_d3": {"unit": "GB/s", "achieved": 17778.6, "bytes_per_launch": 174483966208.0}},
+        "cpu_baseline": {"value": 0.009773045519438195, "unit": "Mray/s", "cores": 32, "kind": "port",
+                         "host": "AMD EPYC 9575F 64-Core Processor, 256 logical CPUs; thread counts tried: 8/16/32/64, fastest kept",
+                         "sample": "29 chunks x 4096 rays of the same frame, torch-eager port of Base.forward, 12.2 s"},
+        "parity": {"max_abs_err_vs_cpu_port": 1.1920928955078125e-06, "max_rel_err_vs_cpu_port": 2.337068735869252e-06,
+                   "psnr_vs_cpu_port_db": 132.50515620545707, "cpu_active_fraction": 0.24215088836077986},
+        "speedup_vs_cpu_port": 6682.07276634372, "gathered_frame_bit_identical_to_single_gpu_render": True, "all_gather_ms": 0.123456789,
+        "all_gather_bytes_per_rank": 1280000, "shard_kernel_ms": 1.456789, "extras": extras}
+
+
+def test_compact_line_fits_the_driver_tail(monkeypatch):
+    res = _fat_result(monkeypatch)
+    line = bench.compact_line(res)
+    assert len(line) < bench.LINE_LIMIT <= 4096 and "\n" not in line
+    d = json.loads(line)
+    for k in bench.FIXED_KEYS:
+        assert k in d
+    assert d["value"] == pytest.approx(res["value"], rel=1e-5) and d["ms_per_step"] == pytest.approx(res["ms_per_step"], rel=1e-5)
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+        assert k in rf
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3)
+    ph = rf["physical"]
+    for k in ("simd_busy", "mfma_busy", "valu_busy_raw", "ta_busy", "l2_hit"):
+        assert isinstance(ph[k], float) and 0.0 <= ph[k] <= 1.5
+    assert not any(isinstance(v, str) and len(v) > 80 for v in ph.values())          # numbers and a file name, no prose
+    cb = d["cpu_baseline"]
+    assert set(cb) == {"value", "unit", "cores", "kind", "sample"} and cb["kind"] in ("port", "reference")
+    assert d["all_gather_ms"] > 0 and d["gathered_frame_bit_identical_to_single_gpu_render"] is True
+    assert len(d["extras_Mray_s"]) == 24 and d["train_ms_per_iteration"] > 0
+    assert "extras" not in d and "notes" not in d
+
+
+def test_compact_line_refuses_to_grow(monkeypatch):
+    res = _fat_result(monkeypatch)
+    res["config"]["workload"] = "w" * 5000
+    with pytest.raises(RuntimeError):
+        bench.compact_line(res)
+
+
+def test_side_file_keeps_everything(monkeypatch, tmp_path):
+    res = _fat_result(monkeypatch)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.write_side_file(res)
+    full = json.load(open(tmp_path / "bench_extras.json"))
+    assert len(full["extras"]) == 26 and "simd_vector_datapath" in full["notes"]
+    assert full["roofline"]["algorithmic_d3"]["bytes_per_launch"] == res["roofline"]["algorithmic_d3"]["bytes_per_launch"]
