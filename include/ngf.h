@@ -278,13 +278,27 @@ int ngf_uv_render(const ngf_uv *m, const float *campos_host, const float *raydir
                   const float *jitter_u, int64_t n_rays, int32_t n_samples, float *color, float *transmittance,
                   float *dbg_sigma, float *dbg_col, uint64_t *stats, void *hip_stream);
 
+/* The same for n_cams cameras in ONE launch, camera positions / backgrounds in HBM -- no host pointer, nothing to wait for
+ * (NeuTex.forward's call pattern, UV-Mapping/test.py:108-114, is one call per 1024-ray chunk: a per-call D2H read of the camera would
+ * synchronise the stream every chunk): campos_dev [n_cams,3], bg_dev [n_cams,3] or NULL, raydir [n_cams*rays_per_cam,3], jitter_u
+ * [n_cams*rays_per_cam,S]; ray r is seen from camera r / rays_per_cam.  Outputs as ngf_uv_render, for all rays. */
+int ngf_uv_render_batch(const ngf_uv *m, const float *campos_dev, const float *raydir, const float *bg_dev, const float *jitter_u,
+                        int32_t n_cams, int64_t rays_per_cam, int32_t n_samples, float *color, float *transmittance,
+                        float *dbg_sigma, float *dbg_col, uint64_t *stats, void *hip_stream);
+
 /* Experiment / test knobs of the launch code (tile shapes, kernel variants, A/B ablations used by the bit-identity tests and the
  * scripts under profiles/).  Process-wide; value -1 restores the library default.  The library never reads the environment:
  * this explicit call is the only way to change what a launch does.  Names: "tile_w" (64/32/16/8/4), "split" (0/1), "waves",
  * "nstep", "profile", "ablate" (bit mask, see ngf_device.hpp), "uv_tiles" (1/2), "kernel" (0 = fused march+shade waves, 1 =
- * specialised march / shade waves), "stage" (1 = LDS-staged density strips). */
+ * specialised march / shade waves), "stage" (1 = LDS-staged density strips), "poison" (bit 0: before every kernel of the library
+ * a launch fills the LDS of every CU with the quiet-NaN pattern 0x7FC0DEAD, so that a read of LDS the kernel did not write shows up
+ * as NaN instead of depending on the previous kernel; bit 1: the allocations of a new handle are filled with the pattern before
+ * they are packed).  The knobs are independent atomics: setting one while another thread launches is safe, but a launch sees
+ * whatever values are current when it reads them -- they are test / experiment switches, not a per-call API. */
 int ngf_debug_set(const char *name, int32_t value);
 int32_t ngf_debug_get(const char *name);
+/* the "poison" bit-0 launch on its own: fill the LDS of every CU with 0x7FC0DEAD on `hip_stream` (tests) */
+int ngf_debug_dirty_lds(void *hip_stream);
 
 const char *ngf_last_error(void);
 int ngf_abi_version(void);

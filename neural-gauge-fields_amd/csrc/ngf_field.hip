@@ -27,7 +27,7 @@ int ngf::fail(int code, const char *fmt, ...)
 }
 
 static std::atomic<int> g_knob[ngf::KNOB_COUNT];
-static const char *const g_knob_name[ngf::KNOB_COUNT] = {"tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage"};
+static const char *const g_knob_name[ngf::KNOB_COUNT] = {"tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage", "poison"};
 static bool g_knob_init = [] { for (auto &k : g_knob) k.store(-1); return true; }();
 
 int ngf::knob(int id) { return g_knob[id].load(std::memory_order_relaxed); }
@@ -45,6 +45,52 @@ hipError_t ngf::ensure_dynamic_lds(const void *kernel, size_t bytes)
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e == hipSuccess) have = bytes;
     return e;
+}
+
+// ---- knob "poison": LDS / allocation poisoning (ngf_host.hpp) ---------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) dirty_lds_kernel(unsigned pattern, int words, int spin)
+{
+    extern __shared__ unsigned dirty_smem[];
+    for (int i = threadIdx.x; i < words; i += blockDim.x) dirty_smem[i] = pattern;
+    __syncthreads();
+    // hold the CU's LDS for a moment so that the other blocks of the grid land on the other CUs (one 160 KB block per CU at a time)
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < (unsigned long long)spin) __builtin_amdgcn_s_sleep(8);
+    if (dirty_smem[(threadIdx.x * 97) % words] != pattern) __builtin_trap();
+}
+
+int ngf::poison_lds(hipStream_t st)
+{
+    if (knob(KNOB_POISON) < 0 || !(knob(KNOB_POISON) & 1)) return NGF_OK;
+    constexpr int kBytes = 160 * 1024;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount;
+    }
+    HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(dirty_lds_kernel), kBytes));
+    hipLaunchKernelGGL(dirty_lds_kernel, dim3(2 * cus), dim3(1024), kBytes, st, kPoisonPattern, kBytes / 4, 40000);
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+int ngf::poison_alloc(void *p, size_t bytes, hipStream_t st)
+{
+    if (knob(KNOB_POISON) < 0 || !(knob(KNOB_POISON) & 2) || !p) return NGF_OK;
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p, (int)kPoisonPattern, bytes / 4, st));
+    return NGF_OK;
+}
+
+extern "C" int ngf_debug_dirty_lds(void *hip_stream)
+{
+    const int old = g_knob[ngf::KNOB_POISON].load();
+    g_knob[ngf::KNOB_POISON].store(1);
+    const int rc = ngf::poison_lds((hipStream_t)hip_stream);
+    g_knob[ngf::KNOB_POISON].store(old);
+    return rc;
 }
 
 extern "C" int ngf_debug_set(const char *name, int32_t value)
@@ -440,11 +486,11 @@ static void build_rgb_image16(int F, bool bake, const std::vector<float> &basis,
 }
 
 
-static int alloc_f(float **p, size_t n, ngf_field *f)
+static int alloc_f(float **p, size_t n, ngf_field *f, hipStream_t st)
 {
     HIP_TRY(hipMalloc((void **)p, n * sizeof(float)));
     f->bytes += (int64_t)(n * sizeof(float));
-    return NGF_OK;
+    return poison_alloc(*p, n * sizeof(float), st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -530,7 +576,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     else build_rgb_image16_ii(F, basis, w1, b1, w2, b2, w3, b3, img.data());
     if (!tri && split_ii) build_infoinv_density_image_bf16(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
     else if (!tri) build_infoinv_density_image(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
-    if ((rc = alloc_f(&f->blob, img.size(), f))) return bail(rc);
+    if ((rc = alloc_f(&f->blob, img.size(), f, st))) return bail(rc);
     if (hipMemcpyAsync(f->blob, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess)
         return bail(fail(NGF_E_HIP, "uploading the MLP image failed"));
     float *wp_dev = nullptr;
@@ -544,7 +590,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     A.blob = f->blob;
     A.blob_floats = (int)img.size();
     if (no_fold || split_ii) {        // the matrix the shade streams from L2 (level-0 basis / lo parts of InfoInv's split layer 1)
-        if ((rc = alloc_f(&f->basis_pack, bpack.size(), f))) return bail(rc);
+        if ((rc = alloc_f(&f->basis_pack, bpack.size(), f, st))) return bail(rc);
         if (hipMemcpyAsync(f->basis_pack, bpack.data(), bpack.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess)
             return bail(fail(NGF_E_HIP, "uploading the packed basis matrix failed"));
         A.basis_pack = f->basis_pack;
@@ -560,7 +606,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
         const int H = d->plane_h[p], W = d->plane_w[p];
         const size_t texels = (size_t)(H + 2) * (W + 2);
         const int dc = bake ? 1 : d->dens_dim;
-        if ((rc = alloc_f(&f->tex[p], texels * dc, f)) || (rc = alloc_f(&f->tex[3 + p], texels * app_c, f))) {
+        if ((rc = alloc_f(&f->tex[p], texels * dc, f, st)) || (rc = alloc_f(&f->tex[3 + p], texels * app_c, f, st))) {
             if (wp_dev) (void)hipFree(wp_dev);
             return bail(rc);
         }
@@ -572,7 +618,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
         A.app[p] = Tex{f->tex[3 + p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
         if (tri) {
             const int gh = d->gauge_h[p], gw = d->gauge_w[p];
-            if ((rc = alloc_f(&f->tex[6 + p], (size_t)(gh + 2) * (gw + 2) * 2, f))) {
+            if ((rc = alloc_f(&f->tex[6 + p], (size_t)(gh + 2) * (gw + 2) * 2, f, st))) {
                 if (wp_dev) (void)hipFree(wp_dev);
                 return bail(rc);
             }
@@ -616,6 +662,7 @@ static int launch_render(K kernel, K kernel_split, const ngf_field *f, RenderArg
     const unsigned slot = f->next_counter.fetch_add(1) % kCounters;
     A.tile_counter = f->counters + slot;
     HIP_TRY(hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned), st));
+    if (int rc = poison_lds(st)) return rc;
     // Split march (render_kernel<P, true>): a tile holds tile_w rays and every ray is marched by 64 / tile_w lanes on
     // consecutive steps (bit-identical results).  Small tiles shorten the critical path of a tile and even out the
     // tiles-per-wave quantisation, which bounds small launches (one rank's shard of a frame, the reference's 4096-ray
@@ -660,6 +707,7 @@ static int launch_pc(const ngf_field *f, RenderArgs &A, hipStream_t st)
     const unsigned slot = f->next_counter.fetch_add(1) % kCounters;
     A.tile_counter = f->counters + slot;
     HIP_TRY(hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned), st));
+    if (int rc = poison_lds(st)) return rc;
     A.tile_w = TW;
     A.tile_shift = TW == 8 ? 3 : 2;
     auto k = render_pc_kernel<P, NM, NS, TW>;
@@ -793,6 +841,7 @@ extern "C" int ngf_field_decode_rgb(const ngf_field *f, const float *coords, con
     const int64_t nb = (n + 15) / 16;
     int grid = (int)((nb + 3) / 4);
     if (grid > 4 * f->num_cus) grid = 4 * f->num_cus;
+    if (int prc = poison_lds(st)) return prc;
     auto go = [&](auto kern) -> int {
         HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, coords, dirs, n, rgb);
@@ -813,6 +862,7 @@ static int launch_alpha(const ngf_field *f, const float *xyz, const Lattice &L, 
 {
     RenderArgs A = f->proto;
     A.mode = mode ? 1 : 0;
+    if (int rc = poison_lds(st)) return rc;
     int64_t grid = (n + 255) / 256;
     if (grid > 8 * (int64_t)f->num_cus) grid = 8 * (int64_t)f->num_cus;
     if (f->model == NGF_MODEL_INFOINV) {
@@ -1100,6 +1150,7 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
     T.target = rgb_train;
     T.inv_count = 1.0f / (3.0f * (float)n);
     A.ablate = knob(KNOB_ABLATE) > 0 ? knob(KNOB_ABLATE) : 0;      // timing experiments only (profiles/exp_train_ablate.sh)
+    if (int prc = poison_lds(st)) return prc;
     // parameters -> packed textures where the trainer's copy is not current (ngf_train_adam writes the copy along with the parameter;
     // ngf_train_params_changed marks every copy stale); gradient buffers -> 0
     for (int p = 0; p < 3; ++p) {

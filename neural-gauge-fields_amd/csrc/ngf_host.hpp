@@ -24,10 +24,17 @@ static constexpr int kCounters = 256;      // launches in flight per handle (til
 
 // Experiment / test knobs (ngf_debug_set, include/ngf.h).  Process-wide, set ONLY through the explicit ABI call -- never read
 // from the environment, so a stray variable in a user's shell cannot change what a launch computes.  -1 = library default.
-enum Knob { KNOB_TILE_W = 0, KNOB_SPLIT, KNOB_WAVES, KNOB_NSTEP, KNOB_PROFILE, KNOB_ABLATE, KNOB_UV_TILES, KNOB_KERNEL, KNOB_STAGE, KNOB_COUNT };
+enum Knob { KNOB_TILE_W = 0, KNOB_SPLIT, KNOB_WAVES, KNOB_NSTEP, KNOB_PROFILE, KNOB_ABLATE, KNOB_UV_TILES, KNOB_KERNEL, KNOB_STAGE, KNOB_POISON, KNOB_COUNT };
 int knob(int id);                          // current value (ngf_field.hip)
 // hipFuncSetAttribute(kernel, MaxDynamicSharedMemorySize, bytes) once per (device, kernel) and size, not on every launch (ngf_field.hip)
 hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);
+// Knob "poison" (tests / hunting state-dependent reads; default off).  Bit 0: before every kernel of the library a "dirty" launch fills
+// the whole LDS of every CU with the quiet-NaN pattern 0x7FC0DEAD, so a kernel that reads LDS it did not write (k-padding rows, ragged
+// last passes, a missing wave-level fence) turns NaN instead of depending on what the previous kernel left there.  Bit 1: every device
+// allocation of a handle is filled with the same pattern before it is packed (unwritten borders / pads show up the same way).
+constexpr unsigned kPoisonPattern = 0x7FC0DEADu;
+int poison_lds(hipStream_t st);                              // no-op unless knob poison & 1 (ngf_field.hip)
+int poison_alloc(void *p, size_t bytes, hipStream_t st);     // no-op unless knob poison & 2
 
 }  // namespace ngf
 

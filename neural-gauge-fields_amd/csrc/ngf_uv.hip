@@ -244,24 +244,13 @@ extern "C" int ngf_uv_texture_edit(const ngf_uv *m, const float *uv, const float
     return NGF_OK;
 }
 
-extern "C" int ngf_uv_render(const ngf_uv *m, const float *campos_host, const float *raydir, const float *bg_host, const float *jitter_u,
-                             int64_t n_rays, int32_t n_samples, float *color, float *transmittance, float *dbg_sigma, float *dbg_col,
-                             uint64_t *stats, void *hip_stream)
+static int uv_launch(const ngf_uv *m, UvArgs &A, hipStream_t st)
 {
-    if (!m || !campos_host || !raydir || !jitter_u || !color || !transmittance) return fail(NGF_E_ARG, "ngf_uv_render: null argument");
-    if (n_rays < 0 || n_samples <= 0) return fail(NGF_E_ARG, "ngf_uv_render: n_rays=%lld n_samples=%d", (long long)n_rays, n_samples);
-    if ((dbg_sigma == nullptr) != (dbg_col == nullptr)) return fail(NGF_E_ARG, "ngf_uv_render: dbg_sigma and dbg_col go together");
-    if (n_rays == 0) return NGF_OK;
-    hipStream_t st = (hipStream_t)hip_stream;
-    UvArgs A = m->proto;
-    A.raydir = raydir; A.U = jitter_u; A.color = color; A.trans = transmittance; A.dbg_sigma = dbg_sigma; A.dbg_col = dbg_col;
-    A.R = n_rays; A.S = n_samples; A.stats = (unsigned long long *)stats;
-    for (int k = 0; k < 3; ++k) { A.campos[k] = campos_host[k]; A.bg[k] = bg_host ? bg_host[k] : 0.0f; }
-    A.has_bg = bg_host ? 1 : 0;
     const unsigned slot = m->next_counter.fetch_add(1) % kCounters;
     A.ray_counter = m->counters + slot;
     HIP_TRY(hipMemsetAsync(A.ray_counter, 0, sizeof(unsigned), st));
-    int64_t grid = (n_rays + 7) / 8;
+    if (int rc = poison_lds(st)) return rc;
+    int64_t grid = (A.R + 7) / 8;
     if (grid > (int64_t)m->num_cus) grid = m->num_cus;
     const size_t lds = (size_t)8 * kUvWaveLds * sizeof(float);
     // two rays per wave (every weight load feeds two MFMAs, 4 waves per CU) unless ngf_debug_set("uv_tiles", 1) (one ray per wave, 8 waves)
@@ -285,3 +274,40 @@ extern "C" int ngf_uv_render(const ngf_uv *m, const float *campos_host, const fl
     return NGF_OK;
 }
 
+extern "C" int ngf_uv_render(const ngf_uv *m, const float *campos_host, const float *raydir, const float *bg_host, const float *jitter_u,
+                             int64_t n_rays, int32_t n_samples, float *color, float *transmittance, float *dbg_sigma, float *dbg_col,
+                             uint64_t *stats, void *hip_stream)
+{
+    if (!m || !campos_host || !raydir || !jitter_u || !color || !transmittance) return fail(NGF_E_ARG, "ngf_uv_render: null argument");
+    if (n_rays < 0 || n_samples <= 0) return fail(NGF_E_ARG, "ngf_uv_render: n_rays=%lld n_samples=%d", (long long)n_rays, n_samples);
+    if (n_rays >= (int64_t)1 << 31) return fail(NGF_E_ARG, "ngf_uv_render: at most 2^31 - 1 rays per call");
+    if ((dbg_sigma == nullptr) != (dbg_col == nullptr)) return fail(NGF_E_ARG, "ngf_uv_render: dbg_sigma and dbg_col go together");
+    if (n_rays == 0) return NGF_OK;
+    UvArgs A = m->proto;
+    A.raydir = raydir; A.U = jitter_u; A.color = color; A.trans = transmittance; A.dbg_sigma = dbg_sigma; A.dbg_col = dbg_col;
+    A.R = n_rays; A.S = n_samples; A.stats = (unsigned long long *)stats;
+    for (int k = 0; k < 3; ++k) { A.campos[k] = campos_host[k]; A.bg[k] = bg_host ? bg_host[k] : 0.0f; }
+    A.has_bg = bg_host ? 1 : 0;
+    A.cam_dev = nullptr; A.bg_dev = nullptr; A.rays_per_cam = 1;
+    return uv_launch(m, A, (hipStream_t)hip_stream);
+}
+
+extern "C" int ngf_uv_render_batch(const ngf_uv *m, const float *campos_dev, const float *raydir, const float *bg_dev, const float *jitter_u,
+                                   int32_t n_cams, int64_t rays_per_cam, int32_t n_samples, float *color, float *transmittance,
+                                   float *dbg_sigma, float *dbg_col, uint64_t *stats, void *hip_stream)
+{
+    if (!m || !campos_dev || !raydir || !jitter_u || !color || !transmittance) return fail(NGF_E_ARG, "ngf_uv_render_batch: null argument");
+    if (n_cams < 0 || rays_per_cam < 0 || n_samples <= 0)
+        return fail(NGF_E_ARG, "ngf_uv_render_batch: n_cams=%d rays_per_cam=%lld n_samples=%d", n_cams, (long long)rays_per_cam, n_samples);
+    if ((dbg_sigma == nullptr) != (dbg_col == nullptr)) return fail(NGF_E_ARG, "ngf_uv_render_batch: dbg_sigma and dbg_col go together");
+    const int64_t n_rays = (int64_t)n_cams * rays_per_cam;
+    if (n_rays >= (int64_t)1 << 31) return fail(NGF_E_ARG, "ngf_uv_render_batch: at most 2^31 - 1 rays per call");
+    if (n_rays == 0) return NGF_OK;
+    UvArgs A = m->proto;
+    A.raydir = raydir; A.U = jitter_u; A.color = color; A.trans = transmittance; A.dbg_sigma = dbg_sigma; A.dbg_col = dbg_col;
+    A.R = n_rays; A.S = n_samples; A.stats = (unsigned long long *)stats;
+    for (int k = 0; k < 3; ++k) A.campos[k] = A.bg[k] = 0.0f;
+    A.has_bg = 0;
+    A.cam_dev = campos_dev; A.bg_dev = bg_dev; A.rays_per_cam = (uint32_t)rays_per_cam;
+    return uv_launch(m, A, (hipStream_t)hip_stream);
+}

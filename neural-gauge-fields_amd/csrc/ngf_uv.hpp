@@ -32,7 +32,11 @@ struct UvArgs {
     unsigned long long *stats;  // {in-cube samples, passes} or NULL
     int64_t R;
     int32_t S, sphere, has_bg, pad_;
-    float campos[3], bg[3];
+    float campos[3], bg[3];     // one camera by value (ngf_uv_render: host pointers) ...
+    const float *cam_dev;       // ... or [n_cams,3] camera positions in HBM (ngf_uv_render_batch: no host round trip); NULL = by value
+    const float *bg_dev;        // [n_cams,3] background colours in HBM or NULL (then `bg` / has_bg decide)
+    uint32_t rays_per_cam;      // ray r belongs to camera r / rays_per_cam
+    uint32_t pad3_;
     // texture editing (decoder.py:79-121): cubemap_ [6,R,R,C] (sphere) or square [H,W,C], NULL = plain texture branch
     const float *tex;
     int32_t tex_h, tex_w, tex_c, tex_mode;
@@ -527,7 +531,7 @@ __global__ void __launch_bounds__(512 / NS) uv_render_kernel(const UvArgs A)
         if (lane == 0) ray0 = atomicAdd(A.ray_counter, (unsigned)NS);
         ray0 = __builtin_amdgcn_readfirstlane(ray0);
         if ((int64_t)ray0 >= A.R) break;
-        float d[NS][3], t0[NS], T[NS], rc[NS][3];
+        float d[NS][3], t0[NS], T[NS], rc[NS][3], cp[NS][3];
         double cum[NS];
         bool rlive[NS];
         size_t rayi[NS];
@@ -537,10 +541,14 @@ __global__ void __launch_bounds__(512 / NS) uv_render_kernel(const UvArgs A)
             rayi[j] = rlive[j] ? (size_t)ray0 + j : (size_t)ray0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) d[j][k] = A.raydir[rayi[j] * 3 + k];
+            // the ray's camera: by value, or row (ray / rays_per_cam) of the device table (wave-uniform index: scalar loads)
+            const uint32_t ci = A.cam_dev ? (uint32_t)rayi[j] / A.rays_per_cam : 0u;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) cp[j][k] = A.cam_dev ? A.cam_dev[(size_t)ci * 3 + k] : A.campos[k];
             // slab test (renderer.py:90-105)
             float t1[3], t2[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { t1[k] = (-1.0f - A.campos[k]) / d[j][k]; t2[k] = (1.0f - A.campos[k]) / d[j][k]; }
+            for (int k = 0; k < 3; ++k) { t1[k] = (-1.0f - cp[j][k]) / d[j][k]; t2[k] = (1.0f - cp[j][k]) / d[j][k]; }
             const float tmin = fmaxf(fminf(t1[0], t2[0]), fmaxf(fminf(t1[1], t2[1]), fminf(t1[2], t2[2])));
             const float tmax = fminf(fmaxf(t1[0], t2[0]), fminf(fmaxf(t1[1], t2[1]), fmaxf(t1[2], t2[2])));
             t0[j] = fmaxf((tmin < tmax) ? tmin : 0.0f, 0.0f);
@@ -569,7 +577,7 @@ __global__ void __launch_bounds__(512 / NS) uv_render_kernel(const UvArgs A)
                 valid[j] = in && rlive[j];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    p[j][k] = A.campos[k] + d[j][k] * mid;
+                    p[j][k] = cp[j][k] + d[j][k] * mid;
                     valid[j] = valid[j] && (p[j][k] > -1.0f) && (p[j][k] < 1.0f);
                 }
                 vm[j] = __ballot(valid[j]);
@@ -651,7 +659,8 @@ __global__ void __launch_bounds__(512 / NS) uv_render_kernel(const UvArgs A)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     float c = rc[j][k];
-                    if (A.has_bg) c += A.bg[k] * T[j];
+                    if (A.bg_dev) c += A.bg_dev[(size_t)((uint32_t)rayi[j] / A.rays_per_cam) * 3 + k] * T[j];
+                    else if (A.has_bg) c += A.bg[k] * T[j];
                     c = powf(c * 1.0f + 1e-5f, (float)(1.0 / 2.2));          // simple_tone_map (renderer.py:7-8)
                     A.color[rayi[j] * 3 + k] = fminf(fmaxf(c, 0.0f), 1.0f);
                 }

@@ -21,13 +21,23 @@ from . import _lib
 COLORMAP_JET = 2          # cv2.COLORMAP_JET
 
 
+# the first rising entries of Jet::r as printed in OpenCV's colormap.cpp (index 96 .. 104 of 256)
+PUBLISHED_JET_R_96 = (0.00588235294117645, 0.02156862745098032, 0.03725490196078418, 0.05294117647058827, 0.06862745098039214,
+                      0.084313725490196, 0.1000000000000001, 0.115686274509804, 0.1313725490196078)
+
+
 def jet_lut() -> np.ndarray:
     """cv2.COLORMAP_JET as a [256,3] uint8 table in B,G,R order.
 
-    Restated from OpenCV's published table (imgproc/src/colormap.cpp, class Jet): channel value =
-    clamp(1.5 - |4 i/255 - c|, 0, 1) with c = 3 (red), 2 (green), 1 (blue), converted with cvRound(255 v).  255 v is
-    382.5 - |4 i - 255 c| exactly, so the table is evaluated in integers/halves here (round half to even).
-    PARITY UNPINNED for this table only: cv2 is not in the image, so it could not be compared with cv2.applyColorMap.
+    OpenCV's `class Jet` (imgproc/src/colormap.cpp; "equals the GNU Octave colormap jet") holds three 256-entry float arrays over the
+    breakpoints linspace(0, 1, 256) -- unlike most of its maps, which hold 64 entries that `linear_colormap` interpolates -- so
+    `interp1` onto the same 256 points returns the entries themselves, and `convertTo(CV_8U, 255)` rounds them with cvRound (half to
+    even).  The printed entries are clamp(1.5 - |4 i/255 - c|, 0, 1) with c = 3 (red), 2 (green), 1 (blue) evaluated in double
+    (r[96..104] = 0.00588235294117645, 0.02156862745098032, 0.03725490196078418, 0.05294117647058827, 0.06862745098039214,
+    0.084313725490196, 0.1000000000000001, 0.115686274509804, 0.1313725490196078: PUBLISHED_JET_R_96 below, checked in
+    tests/test_evalout_oracle.py).  255 v = 382.5 - |4 i - 255 c| is a half-integer on every ramp entry, and so is OpenCV's float32
+    product float32(v) * 255.0f (checked for all 256 x 3 entries): both round half to even, so the table is evaluated in halves here.
+    Pinned to those published table values, not to a run of cv2.applyColorMap (cv2 is not in the image).
     """
     i = np.arange(256, dtype=np.float64)
     ch = [np.clip(382.5 - np.abs(4.0 * i - 255.0 * c), 0.0, 255.0) for c in (1, 2, 3)]       # B, G, R

@@ -141,11 +141,19 @@ class Trainer:
         self.release()
         self._h = out
         self._shape_key = self._key()
+        self._versions = self._param_versions()
 
     def _key(self):
         f = self.field
         return (tuple((p.data_ptr(), tuple(p.shape)) for p in self.params), float(f.stepSize), tuple(f.aabb.reshape(-1).tolist()),
                 None if f.alphaMask is None else f.alphaMask.alpha_volume.data_ptr())
+
+    def _param_versions(self):
+        """torch's in-place version counters of the six plane / gauge-plane tensors (the ones the trainer keeps packed copies of).
+        The raw-pointer Adam kernel does not bump them -- and it writes the packed copy itself -- so a counter that moved since the
+        last backward / optimizer_step means somebody else wrote the tensor in place: load_state_dict, a torch optimizer driving a
+        ``frozen=`` parameter, ``.mul_()``.  (``.data`` writes and raw-pointer writes bump nothing: ``params_changed()`` is for them.)"""
+        return tuple(int(p._version) for p in self.params[:6])
 
     def release(self):
         if getattr(self, "_h", None) is not None:
@@ -178,6 +186,9 @@ class Trainer:
         ``jitter`` [n] and ``coin`` (a float in [0,1)) replace torch.rand_like / torch.rand((1,)) for parity tests."""
         if self._key() != self._shape_key:
             raise RuntimeError("the field's parameters were re-allocated (up_sampling / shrink / load): build a new Trainer")
+        if self._param_versions() != self._versions:      # an in-place write from outside: the packed copies are stale
+            self.params_changed()
+            self._versions = self._param_versions()
         rays = rays_train.to(device=self.dev, dtype=torch.float32).contiguous()
         tgt = rgb_train.to(device=self.dev, dtype=torch.float32).contiguous()
         n = rays.shape[0]

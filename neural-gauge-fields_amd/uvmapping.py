@@ -192,17 +192,18 @@ class NeuTex(nn.Module):
         dbg_c = torch.zeros((N, R, S, 3), device=dev) if debug else None
         stats = torch.zeros(2, dtype=torch.int64, device=dev) if collect_stats else None
         h = self.handle()
-        cam = camera_position.detach().cpu().to(torch.float32)
-        bg = None if background_color is None else background_color.detach().cpu().to(torch.float32)
+        # camera positions / backgrounds travel as device tensors ([N,3] in HBM): no `.cpu()`, so a chunked caller (the reference
+        # renders 1024 rays per call, UV-Mapping/test.py:108-114) never synchronises, and the N cameras of a batch are ONE launch
+        cam = camera_position.detach().to(dev, torch.float32).contiguous()
+        bg = None if background_color is None else background_color.detach().to(dev, torch.float32).contiguous()
+        if tuple(cam.shape) != (N, 3) or (bg is not None and tuple(bg.shape) != (N, 3)):
+            raise ValueError(f"camera_position / background_color must be [N,3] with N = {N}")
         with torch.cuda.device(dev):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            for n in range(N):
-                cp = (C.c_float * 3)(*cam[n].tolist())
-                bp = None if bg is None else (C.c_float * 3)(*bg[n].tolist())
-                _lib.check(_lib.lib().ngf_uv_render(
-                    h, cp, rd[n].data_ptr(), bp, U[n].data_ptr(), R, S, color[n].data_ptr(), trans[n].data_ptr(),
-                    None if dbg_s is None else dbg_s[n].data_ptr(), None if dbg_c is None else dbg_c[n].data_ptr(),
-                    None if stats is None else stats.data_ptr(), st))
+            _lib.check(_lib.lib().ngf_uv_render_batch(
+                h, cam.data_ptr(), rd.data_ptr(), None if bg is None else bg.data_ptr(), U.data_ptr(), N, R, S, color.data_ptr(), trans.data_ptr(),
+                None if dbg_s is None else dbg_s.data_ptr(), None if dbg_c is None else dbg_c.data_ptr(),
+                None if stats is None else stats.data_ptr(), st))
         out = {"color": color, "transmittance": trans}
         if collect_stats:
             self.last_stats = stats

@@ -3,8 +3,8 @@ cpu_baseline leg may import this; the product path never does).
 
 numpy/scipy restatement of the reference's host-side frame post-processing:
     frame_u8                (rgb_map.clamp(0,1).numpy()*255).astype('uint8')      TriPlane/main.py:98,117
-    visualize_depth_numpy   TriPlane/utils.py:32-47  (the colour table is passed in: cv2 is absent, see
-                            ngf_amd.evalout.jet_lut -- that table alone is parity-unpinned)
+    visualize_depth_numpy   TriPlane/utils.py:32-47  (the colour table is passed in: cv2 is absent; jet_lut restates OpenCV's
+                            published Jet table, pinned to its printed entries in tests/test_evalout_oracle.py, not to a cv2 run)
     mse / psnr              TriPlane/main.py:105-106
     rgb_ssim                TriPlane/utils.py:109-155
 Pinned by tests/golden/evalout.npz (outputs of the reference's own rgb_ssim / visualize_depth_numpy arithmetic run in

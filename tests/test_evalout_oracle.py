@@ -45,3 +45,26 @@ def test_jet_table_shape_and_landmarks():
     # every ramp moves in steps of 4 levels
     d = np.abs(np.diff(lut.astype(int), axis=0))
     assert set(np.unique(d)) <= {0, 1, 2, 3, 4}
+
+
+def test_jet_table_reproduces_the_published_entries():
+    """evalout.jet_lut against the entries OpenCV prints for Jet::r (colormap.cpp): the closed form is the table, and the uint8
+    conversion (cvRound(255 v), half to even) of those entries is what the LUT holds; symmetry gives the other channels."""
+    from ngf_amd import evalout
+    lut = evalout.jet_lut()
+    assert lut.shape == (256, 3) and lut.dtype == np.uint8
+    for k, v in enumerate(evalout.PUBLISHED_JET_R_96):
+        i = 96 + k
+        assert abs((1.5 - abs(4.0 * i / 255.0 - 3.0)) - v) < 1e-15
+        # OpenCV holds the entries as float32 and converts with cvRound(float32(v) * 255.0f) (convertTo CV_32F -> CV_8U): every ramp
+        # entry lands on an exact .5 in float32 and rounds half to even -- the halves arithmetic of jet_lut
+        p = np.float32(v) * np.float32(255.0)
+        assert p - np.floor(p) == 0.5 and lut[i, 2] == int(np.rint(p))
+    assert np.all(lut[:96, 2] == 0) and lut[255, 2] == 128 and lut[0, 0] == 128          # dark blue -> dark red, 0.5 at both ends
+    assert np.array_equal(lut[:, 0], lut[::-1, 2])                                        # blue is red mirrored
+    assert np.array_equal(lut[:, 1], lut[::-1, 1]) and lut[127, 1] == 255 and lut[128, 1] == 255
+    # the whole table through OpenCV's float32 pipeline (entries as float32, x 255.0f in float32, cvRound)
+    i = np.arange(256, dtype=np.float64)
+    for col, c in ((0, 1.0), (1, 2.0), (2, 3.0)):
+        v32 = np.clip(1.5 - np.abs(4.0 * i / 255.0 - c), 0.0, 1.0).astype(np.float32)
+        assert np.array_equal(np.rint(v32 * np.float32(255.0)).astype(np.uint8), lut[:, col])

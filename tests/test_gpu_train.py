@@ -305,6 +305,31 @@ def test_params_changed_rebuilds_the_packed_copies():
     assert rel(tr.gradient("plane_xy").cpu().numpy(), g_before.cpu().numpy()) > 1e-2        # the edit did change the gradient
 
 
+def test_in_place_writes_are_seen_without_params_changed():
+    """an in-place write through torch (load_state_dict, `.mul_()` under no_grad, a torch optimizer on a frozen= parameter)
+    bumps the tensor's version counter; backward() notices and re-packs by itself.  Only `.data` / raw-pointer writes need
+    params_changed()."""
+    g, params = load_train_case("train_r1")
+    f = field_for_case(g, params, None)
+    S = int(g["S"])
+    rays, tgt, jit = torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["rgb_train"]).cuda(), torch.from_numpy(g["jitter0"])
+    tr = train.Trainer(f, batch_size=rays.shape[0], max_samples=S)
+    tr.step(rays, tgt, 0, S, jitter=jit)                       # the trainer's own Adam: versions untouched, copies current
+    v0 = tr._param_versions()
+    sd = {k: v.clone() for k, v in f.state_dict().items()}
+    with torch.no_grad():
+        sd["plane_xy"].mul_(0.5)
+        sd["gauge_yz"].add_(0.01)
+    f.load_state_dict(sd)                                      # copy_ in place: same storage, version + 1
+    assert tr._param_versions() != v0
+    tr.backward(rays, tgt, S, white_bg=True, iteration=0, jitter=jit)
+    fresh = train.Trainer(f, batch_size=rays.shape[0], max_samples=S)
+    fresh.backward(rays, tgt, S, white_bg=True, iteration=0, jitter=jit)
+    for name in ("plane_xy", "plane_yz", "gauge_yz", "rgb_decoder.mlp.0.weight", "density_decoder.weight"):
+        a, b = tr.gradient(name).cpu().numpy(), fresh.gradient(name).cpu().numpy()
+        assert rel(a, b) < GRAD_TOL, (name, rel(a, b))
+
+
 def test_single_parameter_adam_entry_point():
     """ngf_train_adam (one parameter per call; optimizer_step goes through ngf_train_adam_all) for an MLP parameter and a plane:
     the same restated torch.optim.Adam update, and the plane's packed copy follows (the next backward needs no re-pack)."""

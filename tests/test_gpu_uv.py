@@ -1,7 +1,8 @@
 """UV-Mapping (NeuTex) colour path on the GPU against the C oracle and the golden vectors captured from the
 reference's sub-modules.  The path is ill-conditioned by construction (PE with 2^9 on positions and on uv feeds an
 11-layer MLP): a 1-ulp change of a sample position moves a sample colour by ~1e-3.  Per-sample quantities are
-therefore compared with a looser bound than the TriPlane path; the composited pixels still agree to ~1e-4."""
+therefore compared with a looser bound than the TriPlane path; the composited pixels are held to PIX_TOL = 2e-5 against the oracle AND
+the reference's golden pixels (north_star: 1e-4; measured 4e-6 -- a 5x regression fails here)."""
 import numpy as np
 import pytest
 
@@ -10,6 +11,11 @@ from oracle.oracle import OracleUV
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
+
+PIX_TOL = 2e-5          # composited pixels vs oracle / reference golden
+T_TOL = 1e-5            # transmittance
+SIGMA_RTOL = 5e-4       # per-sample density (relative)
+PCOL_TOL = 5e-3         # per-sample colour (absolute): the ill-conditioned quantity
 
 
 @pytest.mark.parametrize("name", ["uv_sphere", "uv_square"])
@@ -27,13 +33,15 @@ def test_uv_matches_oracle_and_reference(name):
     sigma, pcol = out["sigma"][0].cpu().numpy(), out["point_color"][0].cpu().numpy()
     valid = dbg["valid"].astype(bool)
     assert np.array_equal(sigma != 0, valid), "in-cube mask differs"
-    np.testing.assert_allclose(sigma[valid], dbg["sigma"][valid], rtol=5e-4, atol=1e-6)
-    assert np.abs(pcol[valid] - dbg["col"][valid]).max() < 5e-3
+    np.testing.assert_allclose(sigma[valid], dbg["sigma"][valid], rtol=SIGMA_RTOL, atol=1e-6)
+    e_s = float(np.max(np.abs(sigma[valid] - dbg["sigma"][valid]) / (np.abs(dbg["sigma"][valid]) + 1e-6)))
+    e_p = np.abs(pcol[valid] - dbg["col"][valid]).max()
+    assert e_p < PCOL_TOL
     e_t = np.abs(trans - o_trans).max()
     e_c = np.abs(color - o_color).max()
     e_r = np.abs(color - g["color"]).max()
-    print(f"{name}: max|T-oracle| {e_t:.2e}  max|color-oracle| {e_c:.2e}  max|color-reference| {e_r:.2e}")
-    assert e_t < 2e-5 and e_c < 5e-4 and e_r < 5e-4
+    print(f"{name}: max|T-oracle| {e_t:.2e}  max|color-oracle| {e_c:.2e}  max|color-reference| {e_r:.2e}  per-sample: sigma rel {e_s:.2e} colour {e_p:.2e}")
+    assert e_t < T_TOL and e_c < PIX_TOL and e_r < PIX_TOL
     # deterministic
     out2 = m(torch.from_numpy(g["campos"])[None], torch.from_numpy(g["raydir"])[None], torch.from_numpy(g["bg"])[None],
              jitter_u=torch.from_numpy(g["U"])[None])
@@ -49,8 +57,44 @@ def test_uv_no_background_and_short_chunks():
     U = g["U"][:7, :24].copy()
     o_color, o_trans = orc.render(g["campos"], g["raydir"][:7], U, bg=None)
     out = m(torch.from_numpy(g["campos"])[None], torch.from_numpy(g["raydir"][:7])[None], None, jitter_u=torch.from_numpy(U)[None])
-    assert np.abs(out["color"][0].cpu().numpy() - o_color).max() < 5e-4
-    assert np.abs(out["transmittance"][0].cpu().numpy() - o_trans).max() < 2e-5
+    assert np.abs(out["color"][0].cpu().numpy() - o_color).max() < PIX_TOL
+    assert np.abs(out["transmittance"][0].cpu().numpy() - o_trans).max() < T_TOL
+
+
+def test_batch_of_cameras_is_one_launch_and_matches_per_camera_calls():
+    """NeuTex.forward with N > 1 (model.py:27: camera_position [N,3], ray_direction [N,R,3], background_color [N,3]): ONE
+    ngf_uv_render_batch launch with the cameras as a device table -- the same bits as N single-camera calls, as the host-pointer
+    entry point ngf_uv_render, and the oracle's pixels per camera; an odd R makes a wave's two rays straddle two cameras."""
+    import ctypes as C
+    from ngf_amd import _lib, synth, uvmapping
+    g, params = load_uv_case("uv_sphere")
+    orc = OracleUV(params, "sphere")
+    S, R = 32, 37
+    net = uvmapping.NeuTex(primitive_type="sphere", sample_num=S, device="cuda")
+    net.load_params(params)
+    cams = np.stack([g["campos"], g["campos"] * np.float32(0.9) + np.float32(0.05), -g["campos"]]).astype(np.float32)
+    bgs = np.stack([g["bg"], np.array([0.1, 0.7, 0.3], np.float32), np.zeros(3, np.float32)])
+    dirs = np.stack([g["raydir"][:R], g["raydir"][R:2 * R], -g["raydir"][:R]]).astype(np.float32)
+    U = synth.hash_uniform(12, 5, (3, R, S))
+    out = net(torch.from_numpy(cams).cuda(), torch.from_numpy(dirs).cuda(), torch.from_numpy(bgs).cuda(), jitter_u=torch.from_numpy(U).cuda())
+    L, h = _lib.lib(), net.handle()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n in range(3):
+        one = net(torch.from_numpy(cams[n:n + 1]), torch.from_numpy(dirs[n:n + 1]), torch.from_numpy(bgs[n:n + 1]), jitter_u=torch.from_numpy(U[n:n + 1]))
+        assert torch.equal(one["color"][0], out["color"][n]) and torch.equal(one["transmittance"][0], out["transmittance"][n]), n
+        # the host-pointer entry point (ngf_uv_render) on the same camera
+        rd, Un = torch.from_numpy(dirs[n]).cuda(), torch.from_numpy(U[n]).cuda()
+        col, tr = torch.empty((R, 3), device="cuda"), torch.empty((R,), device="cuda")
+        _lib.check(L.ngf_uv_render(h, (C.c_float * 3)(*cams[n].tolist()), rd.data_ptr(), (C.c_float * 3)(*bgs[n].tolist()), Un.data_ptr(), R, S,
+                                   col.data_ptr(), tr.data_ptr(), None, None, None, st))
+        assert torch.equal(col, out["color"][n]) and torch.equal(tr, out["transmittance"][n]), n
+        o_color, o_trans = orc.render(cams[n], dirs[n], U[n], bg=bgs[n])
+        assert np.abs(out["color"][n].cpu().numpy() - o_color).max() < PIX_TOL, n
+        assert np.abs(out["transmittance"][n].cpu().numpy() - o_trans).max() < T_TOL, n
+    # no background: bg_dev NULL
+    nb = net(torch.from_numpy(cams).cuda(), torch.from_numpy(dirs).cuda(), None, jitter_u=torch.from_numpy(U).cuda())
+    o_color, _ = orc.render(cams[1], dirs[1], U[1], bg=None)
+    assert np.abs(nb["color"][1].cpu().numpy() - o_color).max() < PIX_TOL
 
 
 def test_two_rays_per_wave_is_bit_identical():
@@ -96,12 +140,12 @@ def test_uv_split_bf16_keeps_the_fp32_tolerances(name):
     valid = dbg["valid"].astype(bool)
     color, trans, sigma, pcol = res[True]
     assert np.array_equal(sigma != 0, valid), "in-cube mask differs"
-    np.testing.assert_allclose(sigma[valid], dbg["sigma"][valid], rtol=5e-4, atol=1e-6)
-    assert np.abs(pcol[valid] - dbg["col"][valid]).max() < 5e-3
+    np.testing.assert_allclose(sigma[valid], dbg["sigma"][valid], rtol=SIGMA_RTOL, atol=1e-6)
+    assert np.abs(pcol[valid] - dbg["col"][valid]).max() < PCOL_TOL
     e = {s: (np.abs(res[s][1] - o_trans).max(), np.abs(res[s][0] - o_color).max(), np.abs(res[s][0] - g["color"]).max()) for s in (False, True)}
     print(f"{name}: max|T-oracle| fp32 {e[False][0]:.2e} split {e[True][0]:.2e}; max|color-oracle| fp32 {e[False][1]:.2e} split {e[True][1]:.2e}; "
           f"max|color-reference| fp32 {e[False][2]:.2e} split {e[True][2]:.2e}; max|color split - fp32| {np.abs(res[True][0] - res[False][0]).max():.2e}")
-    assert e[True][0] < 2e-5 and e[True][1] < 5e-4 and e[True][2] < 5e-4
+    assert e[True][0] < T_TOL and e[True][1] < PIX_TOL and e[True][2] < PIX_TOL
     assert e[True][1] < 3 * e[False][1] + 2e-5             # no worse than the fp32 kernel's own rounding noise (x3 slack)
     with pytest.raises(RuntimeError):
         from ngf_amd import _lib
