@@ -293,7 +293,8 @@ int ngf_uv_render_batch(const ngf_uv *m, const float *campos_dev, const float *r
  * specialised march / shade waves), "stage" (1 = LDS-staged density strips), "poison" (bit 0: before every kernel of the library
  * a launch fills the LDS of every CU with the quiet-NaN pattern 0x7FC0DEAD, so that a read of LDS the kernel did not write shows up
  * as NaN instead of depending on the previous kernel; bit 1: the allocations of a new handle are filled with the pattern before
- * they are packed).  The knobs are independent atomics: setting one while another thread launches is safe, but a launch sees
+ * they are packed), "grid" (upper bound of the workgroups of a render launch: with 1 every wave of the only workgroup takes many tiles
+ * one after the other).  The knobs are independent atomics: setting one while another thread launches is safe, but a launch sees
  * whatever values are current when it reads them -- they are test / experiment switches, not a per-call API. */
 int ngf_debug_set(const char *name, int32_t value);
 int32_t ngf_debug_get(const char *name);

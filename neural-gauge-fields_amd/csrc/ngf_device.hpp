@@ -49,8 +49,9 @@ struct RenderArgs {
     int32_t S, white_bg, mode, skip_rgb;
     int32_t tile_w;        // rays per wave tile: 64, or 32 / 16 / 8 for small launches (more waves, shorter critical path)
     int32_t tile_shift;    // log2(tile_w); the split march gives every ray 64 >> tile_shift lanes (consecutive steps)
-    int32_t ablate;        // profiling only (NGF_ABLATE): 1 skip collect, 2 skip layers 2-3, 4 cached gathers, 16 raise wave priority in the shade pass,
-                           // 32 no early termination, 64 no empty-iteration skip (both exact: A/B timing and bit-identity tests)
+    int32_t ablate;        // debug instantiations only (render_kernel<.., DBG = true>): 32 no early termination, 64 no empty-iteration skip -- both
+                           // EXACT (A/B timing and the bit-identity tests).  Round 1-2's bits 1 / 2 / 4 / 16 (skip collect, skip layers 2-3, cached
+                           // gathers, wave priority) produced wrong images and are gone; the trainer keeps its own bits (ngf_train.hpp)
     float a0[3], a1[3], inv[3];
     float near_, far_, step, dscale, thr;
     Tex dens[3];           // TriPlane: 16-ch (faithful) or 1-ch (baked) density texels

@@ -27,7 +27,7 @@ int ngf::fail(int code, const char *fmt, ...)
 }
 
 static std::atomic<int> g_knob[ngf::KNOB_COUNT];
-static const char *const g_knob_name[ngf::KNOB_COUNT] = {"tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage", "poison"};
+static const char *const g_knob_name[ngf::KNOB_COUNT] = {"tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage", "poison", "grid"};
 static bool g_knob_init = [] { for (auto &k : g_knob) k.store(-1); return true; }();
 
 int ngf::knob(int id) { return g_knob[id].load(std::memory_order_relaxed); }
@@ -656,8 +656,10 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
 }
 
 // ---- launches ------------------------------------------------------------------------------------
+// kernel / kernel_split: the DBG = true instantiations (every feature); kernel_prod: the split kernel's production instantiation (no debug
+// outputs, ablation bits, statistics: render_kernel<P, true, false>) or null when the policy has none
 template <typename K>
-static int launch_render(K kernel, K kernel_split, const ngf_field *f, RenderArgs &A, int threads, size_t lds_bytes, hipStream_t st, int wide_tile)
+static int launch_render(K kernel, K kernel_split, K kernel_prod, const ngf_field *f, RenderArgs &A, int threads, size_t lds_bytes, hipStream_t st, int wide_tile)
 {
     const unsigned slot = f->next_counter.fetch_add(1) % kCounters;
     A.tile_counter = f->counters + slot;
@@ -678,10 +680,16 @@ static int launch_render(K kernel, K kernel_split, const ngf_field *f, RenderArg
     A.tile_w = tw;
     A.tile_shift = tw == 64 ? 6 : tw == 32 ? 5 : tw == 16 ? 4 : tw == 8 ? 3 : 2;
     K k = split ? kernel_split : kernel;
+#ifdef NGF_EXP_DUMP      // experiment build: `stats` is the dump buffer of the production kernel
+    if (split && kernel_prod) k = kernel_prod;
+#else
+    if (split && kernel_prod && !A.dbg_weight && !A.dbg_sigma && !A.stats && !A.skip_rgb && !A.ablate) k = kernel_prod;
+#endif
     HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k), lds_bytes));
     const int64_t tiles = (A.n + tw - 1) / tw;
     int64_t grid = (tiles + waves - 1) / waves;
     if (grid > f->num_cus) grid = f->num_cus;
+    if (knob(KNOB_GRID) > 0 && grid > knob(KNOB_GRID)) grid = knob(KNOB_GRID);      // tests: fewer workgroups -> every wave takes many tiles
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds_bytes, st, A);
     HIP_TRY(hipGetLastError());
@@ -694,8 +702,10 @@ static int launch_policy(const ngf_field *f, RenderArgs &A, hipStream_t st)
     const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + P::WAVES * wave_lds_floats<P>()) * sizeof(float);
     if (lds > 160 * 1024) return fail(NGF_E_ARG, "this waves-per-CU setting needs %zu bytes of LDS (> 160 KiB)", lds);
     constexpr int wide = P::INFOINV ? 16 : 8;          // measured best full-frame tile width (profiles/r01_split_march.txt; InfoInv: 30.3 vs 29.3 Mray/s)
-    if constexpr (P::NSTEP == 1) return launch_render(render_kernel<P, false>, render_kernel<P, true>, f, A, P::WAVES * kWave, lds, st, wide);
-    else return launch_render(render_kernel<P, false>, (decltype(&render_kernel<P, false>))nullptr, f, A, P::WAVES * kWave, lds, st, wide);
+    using KP = decltype(&render_kernel<P, false>);
+    if constexpr (P::NSTEP == 1 && P::PROD) return launch_render<KP>(render_kernel<P, false>, render_kernel<P, true>, render_kernel<P, true, false>, f, A, P::WAVES * kWave, lds, st, wide);
+    else if constexpr (P::NSTEP == 1) return launch_render<KP>(render_kernel<P, false>, render_kernel<P, true>, nullptr, f, A, P::WAVES * kWave, lds, st, wide);
+    else return launch_render<KP>(render_kernel<P, false>, nullptr, nullptr, f, A, P::WAVES * kWave, lds, st, wide);
 }
 
 // Specialised march / shade waves (ngf_render_pc.hpp): NM march waves + NS shade waves per CU.

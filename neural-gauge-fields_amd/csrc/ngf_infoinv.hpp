@@ -108,6 +108,32 @@ inline void build_infoinv_density_image_bf16(const std::vector<float> &w1, const
     img[D::B3 + 1] = img[D::B3 + 2] = img[D::B3 + 3] = 0.0f;
 }
 
+// One octave step of the positional factors: f_s *= sin, f_c *= cos, then the angle doubling (sin 2a = 2 sin cos, cos 2a = (cos - sin)(cos + sin)).
+// Written as SINGLE VALU instructions on purpose.  hipcc 7.2 packs the plain C++ form of this chain into v_pk_mul_f32 / v_pk_add_f32 with
+// op_sel / neg modifiers and v_pk_mov_b32, and with that code the NGF_F_SPLIT_BF16 colour pass was NOT deterministic: identical records,
+// factors and features (dumped per lane, profiles/r03_determinism.txt) gave layer-1 accumulators that differed at the 1e-3 level in about one
+// launch in 50 000 (one 4-ray tile each time; 1 in 5 with idle slots between the bf16 MFMAs), which is the once-in-forty-suite-runs failure
+// of round 2.  The same IEEE operations as un-packed instructions: 0 differences in 600 000 launches.  -DNGF_EXP_PACKED_PE restores the
+// compiler's code (profiles/exp_determinism_builds.sh); a stand-alone micro-benchmark of the instruction pattern
+// (profiles/micro/pk_hi_forward.hip) does not reproduce the effect, so the mechanism below the ISA is not known.
+__device__ __forceinline__ void pe_octave(float &fs, float &fc, float &sn, float &cs)
+{
+#ifdef NGF_EXP_PACKED_PE
+    fs *= sn; fc *= cs;
+    const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
+    sn = s2; cs = c2;
+#else
+    float t, d, e;
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(fs) : "v"(fs), "v"(sn));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(fc) : "v"(fc), "v"(cs));
+    asm volatile("v_add_f32 %0, %1, %1" : "=v"(t) : "v"(sn));               // 2 sin   (2.0f * sn, exact)
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(cs), "v"(sn));
+    asm volatile("v_add_f32 %0, %1, %2" : "=v"(e) : "v"(cs), "v"(sn));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(sn) : "v"(t), "v"(cs));      // (2 sin) cos -- the association of `2.0f * sn * cs`
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(cs) : "v"(d), "v"(e));
+#endif
+}
+
 __device__ __forceinline__ void swap32(float &a, float &b)
 {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
@@ -211,6 +237,9 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
         for (int k = 0; k < 3; ++k) sincos_small(pe_xyz[k] * scale, bs[k], bc[k]);
     }
     float left[4];                             // inputs of a plane that did not fill a k-block yet
+#ifdef NGF_EXP_DUMP
+    float fh[3];                               // hash of the plane's 18 features (after the positional factors)
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -243,13 +272,17 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
             for (int k = 0; k < 3; ++k) {
                 float sn = bs[k], cs = bc[k];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    f[k * 3 + j] *= sn; f[9 + k * 3 + j] *= cs;
-                    const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
-                    sn = s2; cs = c2;
-                }
+                for (int j = 0; j < 3; ++j) pe_octave(f[k * 3 + j], f[9 + k * 3 + j], sn, cs);
             }
         }
+#ifdef NGF_EXP_DUMP
+        {
+            unsigned hsh = 0;
+#pragma unroll
+            for (int i = 0; i < 18; ++i) hsh = (hsh * 31u) ^ __float_as_uint(f[i]);
+            fh[p] = __uint_as_float(hsh & 0x3fffffffu);
+        }
+#endif
         // inputs so far: 18 p + the 2 p leftovers of the planes before; whole k-blocks go to the matrix pipe now
         if (p == 0) {
             kblock_ii(w1 + 0 * KB_STRIDE, lo0, split8(f), acc);      lo_load_ii(A.basis_pack, 2, lane, lo0);  __builtin_amdgcn_sched_barrier(0);
@@ -286,6 +319,20 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
     }
     __builtin_amdgcn_sched_barrier(0);
     mlp_layer3_16(blob, L::W3, L::B3, lane, c, rgb);
+#ifdef NGF_EXP_DUMP     // experiment build (profiles/exp_determinism_dump.py): every lane's view of the pass -> A.stats[8 + (pass * 64 + lane) * 64 ..]
+    if (A.stats) {
+        unsigned long long id = 0;
+        if (lane == 0) id = atomicAdd(A.stats, 1ull);
+        id = __shfl(id, 0);
+        float *row = reinterpret_cast<float *>(A.stats + 8) + (id * 64 + lane) * 64;
+        row[0] = (float)lane; row[1] = rec[0]; row[2] = rec[1]; row[3] = rec[2]; row[4] = rec[3]; row[5] = rec[5];
+        row[6] = fh[0]; row[7] = fh[1]; row[8] = fh[2];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { row[9 + k] = acc[k >> 2][k & 3]; row[25 + k] = c[k >> 2][k & 3]; }
+        row[41] = rgb[0]; row[42] = rgb[1]; row[43] = rgb[2];
+        row[44] = bs[0]; row[45] = bs[1]; row[46] = bs[2]; row[47] = bc[0]; row[48] = bc[1]; row[49] = bc[2];
+    }
+#endif
 }
 
 // ---- the default (fp32) colour pass: 16 samples per pass, FOUR lanes per sample, v_mfma_f32_16x16x4_f32 -----------------------------------
@@ -350,11 +397,7 @@ __device__ __forceinline__ void mlp_pass16_ii(const RenderArgs &A, const float *
             for (int k = 0; k < 3; ++k) {
                 float sn = bs[k], cs = bc[k];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    f[k * 3 + j] *= sn; f[9 + k * 3 + j] *= cs;
-                    const float s2 = 2.0f * sn * cs, c2 = (cs - sn) * (cs + sn);
-                    sn = s2; cs = c2;
-                }
+                for (int j = 0; j < 3; ++j) pe_octave(f[k * 3 + j], f[9 + k * 3 + j], sn, cs);
             }
         }
 #pragma unroll
@@ -504,6 +547,7 @@ struct InfoInvPolicyT {
     static constexpr bool INFOINV = true;
     static constexpr int WAVES = (SPLIT || WIDE) ? kInfoInvSplitWaves : kInfoInvWaves;        // 8 (split: 247 registers; wide tiles: LDS) / 12
     static constexpr bool PROFILE = false;
+    static constexpr bool PROD = !WIDE;                           // has a production (DBG = false) instantiation of the split kernel
     static constexpr bool VLDS = true;
     static constexpr bool VIEW_FOLD = false;
     static constexpr bool STAGED = false;

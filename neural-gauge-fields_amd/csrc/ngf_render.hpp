@@ -63,6 +63,23 @@ __device__ __forceinline__ void view_inputs(const float d[3], float v[16])
     v[15] = 0.0f;
 }
 
+// The same 16 inputs for the rays of a split tile, written to the tile's LDS table by the K = 64 / tile_w lanes that share a ray
+// (lane (seg, ray)): the six sine / cosine arguments [d_x, 2 d_x, d_y, 2 d_y, d_z, 2 d_z] are dealt out over the segments -- one
+// sincos_small per lane for K >= 6 (|argument| <= 2: <= 1.6 ulp) instead of twelve libm calls in every lane (12 x ~90 VALU instructions
+// per tile, 5 % of the vector work of the headline frame) -- and segment 0 also stores d and the zero pad.
+__device__ __forceinline__ void view_inputs_tile(const float d[3], float *dst, int seg, int K)
+{
+    if (seg == 0) { dst[0] = d[0]; dst[1] = d[1]; dst[2] = d[2]; dst[15] = 0.0f; }
+    for (int a = seg; a < 6; a += K) {
+        const int dim = a >> 1;
+        const float dd = dim == 0 ? d[0] : (dim == 1 ? d[1] : d[2]);
+        float sn, cs;
+        sincos_small((a & 1) ? dd * 2.0f : dd, sn, cs);
+        dst[3 + a] = sn;
+        dst[9 + a] = cs;
+    }
+}
+
 // The MLP image in LDS is read-only after the initial barrier, so LICM would hoist every per-lane weight /
 // bias read (160+ values) out of the persistent loops and pin them in VGPRs for the whole kernel (they
 // then spill).  Adding an opaque zero to the pointer once per pass keeps those reads inside the pass.
@@ -168,6 +185,7 @@ __device__ __forceinline__ void triplane_gauge(const RenderArgs &A, const float 
 template <bool BAKE_D, bool BAKE_C, int WAVES_, int NSTEP_, bool PROFILE_ = false>
 struct TriPlanePolicy {
     static constexpr bool PROFILE = PROFILE_;
+    static constexpr bool PROD = WAVES_ == 12 && NSTEP_ == 1 && !PROFILE_;      // has a production (DBG = false) instantiation of the split kernel
     static constexpr bool INFOINV = false;
     static constexpr bool STAGED = false;                       // ngf_stage.hpp: LDS-staged texture strips
     static constexpr int STAGE_FLOATS = 0;
@@ -216,6 +234,7 @@ struct TriPlanePolicy {
 // only (the wave keeps the view inputs of 8 rays); 8 waves per CU (the pass needs ~200 registers).
 template <bool BAKE_D, int WAVES_ = 8>
 struct TriPlaneBf16Policy : TriPlanePolicy<BAKE_D, false, WAVES_, 1> {
+    static constexpr bool PROD = WAVES_ == 8;
     static constexpr bool VIEW_FOLD = false;
     static constexpr int VFEAT_FLOATS = 8 * kViewFeat;
     __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
@@ -229,6 +248,7 @@ struct TriPlaneBf16Policy : TriPlanePolicy<BAKE_D, false, WAVES_, 1> {
 
 // NGF_F_NO_FOLD (level 0): un-composed rgb_decoder, view inputs per sample; 8 waves per CU (the basis stage keeps 36 more accumulators)
 struct TriPlaneNoFoldPolicy : TriPlanePolicy<false, false, 8, 1> {
+    static constexpr bool PROD = false;
     static constexpr bool VIEW_FOLD = false;
     __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
                                                  const float od[3], int lane, float c[3], unsigned long long * = nullptr, const float * = nullptr)
@@ -244,9 +264,13 @@ struct TriPlaneNoFoldPolicy : TriPlanePolicy<false, false, 8, 1> {
 // take K CONSECUTIVE steps per iteration; transmittance, acc and depth are then chained lane to lane in step order, so each
 // ray sees exactly the sequential arithmetic of the unsplit march (results are bit-identical) while a tile's critical path
 // is K times shorter and all 64 lanes gather.
-template <typename P, bool SPLIT = false>
+// DBG = false is the production instantiation: the per-sample debug outputs (dbg_weight / dbg_sigma), the ablation bits, skip_rgb and
+// the statistics counters are compiled OUT (they cost scalar registers -- the kernel parks SGPRs in VGPR lanes -- and issue slots of a
+// kernel that is bound by its vector pipe); launch_render picks DBG = true whenever one of them is requested.
+template <typename P, bool SPLIT = false, bool DBG = true>
 __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs A)
 {
+    static_assert(DBG || !P::PROFILE, "the section profile is a debug instantiation");
     static_assert(!SPLIT || P::NSTEP == 1, "the split march is written for one step per lane per iteration");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     for (int i = threadIdx.x; i < A.blob_floats; i += blockDim.x) smem[i] = A.blob[i];
@@ -293,11 +317,15 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         tmin = fminf(fmaxf(tmin, A.near_), A.far_);
 
         if constexpr (P::VLDS) {   // view inputs of this lane's ray (networks.py:27-29), read back by the shade lanes
-            float v[16];
-            view_inputs(d, v);
-            f32x4 *dst = reinterpret_cast<f32x4 *>(vfeat + rl * kViewFeat);      // split march: K lanes store the same values
+            if constexpr (SPLIT) {
+                view_inputs_tile(d, vfeat + rl * kViewFeat, seg, K);            // the K lanes of a ray share the work
+            } else {
+                float v[16];
+                view_inputs(d, v);
+                f32x4 *dst = reinterpret_cast<f32x4 *>(vfeat + rl * kViewFeat);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dst[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                for (int q = 0; q < 4; ++q) dst[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            }
         }
         // tiles of <= 8 rays: fold the view part of layer 1 into one 64-float vector per ray (behind the 8 x 16 view inputs)
         bool view_fold = false;
@@ -311,6 +339,8 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         }
         float T = 1.0f, acc = 0.0f, dep = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
         int i = 0, head = 0, count = 0;
+        const float zmax = tmin + A.step * (float)(S + 1);      // bound of every z of the ray (exact early termination below)
+        const bool dbg_samples = DBG && A.dbg_weight;           // per-sample outputs requested (never in the production instantiation)
         for (;;) {
             [[maybe_unused]] unsigned long long t_sec = 0;
             if constexpr (P::PROFILE) t_sec = __builtin_readcyclecounter();
@@ -339,15 +369,15 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     if constexpr (NSTEP == 1) {
                         // no lane of the wave has a valid sample in this iteration (outside the box / in empty space of the alpha
                         // mask): sigma = alpha = w = 0 for all of them, T / acc / depth keep their values -> skip the whole step
-                        if (!A.dbg_weight && !(A.ablate & 64) && !__any(valid)) { empty_step = true; break; }
+                        if (!dbg_samples && !(DBG && (A.ablate & 64)) && !__any(valid)) { empty_step = true; break; }
                     }
                     if constexpr (SPLIT && P::STAGED) {
                         float *dscr = P::STAGE_FLOATS > 0 ? vfeat + kWave * kViewFeat : nullptr;
-                        sigma[u] = P::sigma_staged(A, vfeat, dscr, valid, x, lane, t[u], A.stats ? &st_staged : nullptr);
+                        sigma[u] = P::sigma_staged(A, vfeat, dscr, valid, x, lane, t[u], (DBG && A.stats) ? &st_staged : nullptr);
                     } else {
                         sigma[u] = P::sigma(A, smem, valid, x, lane, t[u]);
                     }
-                    st_valid += __popcll(__ballot(valid));
+                    if constexpr (DBG) st_valid += __popcll(__ballot(valid));
                 }
                 if (empty_step) {
                     i += NSTEP * K;
@@ -383,11 +413,11 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                         acc += w;
                         dep += w * z[u];
                     }
-                    if (A.dbg_weight && live && i + u + seg < S) {
+                    if (dbg_samples && live && i + u + seg < S) {
                         A.dbg_weight[ray * S + i + u + seg] = w;
                         A.dbg_sigma[ray * S + i + u + seg] = sigma[u];
                     }
-                    const bool active = (w > A.thr) && !A.skip_rgb;
+                    const bool active = (w > A.thr) && !(DBG && A.skip_rgb);
                     const unsigned long long m = __ballot(active);
                     if (active) {
                         const int slot = (head + count + __popcll(m & lt_mask)) & (RING - 1);
@@ -396,7 +426,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                         r[1] = f32x4{t[u][2], t[u][3], t[u][4], t[u][5]};
                     }
                     count += __popcll(m);
-                    st_active += __popcll(m);
+                    if constexpr (DBG) st_active += __popcll(m);
                 }
                 i += NSTEP * K;
                 // Exact early termination.  Every later sample has w <= T.  Once T < thr no later sample can be active (no colour
@@ -404,8 +434,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 // of its accumulator, i.e. a no-op in float32: the outputs cannot change by a single bit, so the rest of the ray is
                 // skipped -- wave-uniformly, when all rays of the tile are there (8-ray tiles of adjacent pixels).  Rays behind an
                 // opaque surface stop right after it.  Off for the per-sample debug outputs and with NGF_ABLATE=32.
-                if (!A.dbg_weight && !(A.ablate & 32)) {
-                    const float zmax = tmin + A.step * (float)(S + 1);
+                if (!dbg_samples && !(DBG && (A.ablate & 32))) {
                     const bool done = !live || ((T < A.thr) & (zmax > 0.0f) & (T < 0x1p-26f * fminf(acc, dep / zmax)));
                     if (!__any(!done)) i = S;
                 }
@@ -447,7 +476,9 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // every lane, as ray owner, adds its entries in queue (= sample) order; all reads are issued up front
                 // (broadcast ds_read_b128), no per-entry LDS round trip
-                if (!(A.ablate & 1)) {
+                // (an entry of another ray adds m * v = +0: the weighted colours are finite and the sums non-negative, so `x + 0` is
+                // `x` to the bit -- one select + three FMAs per entry instead of three selects + three adds)
+                {
 #pragma unroll
                     for (int q = 0; q < BATCH / 4; ++q) {
                         const f32x4 id = *reinterpret_cast<const f32x4 *>(res + 4 * q);
@@ -456,17 +487,17 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                         const f32x4 vb = *reinterpret_cast<const f32x4 *>(res + 3 * BATCH + 4 * q);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const bool mine = __float_as_int(id[e]) == lane;
-                            cr += mine ? vr[e] : 0.0f;
-                            cg += mine ? vg[e] : 0.0f;
-                            cb += mine ? vb[e] : 0.0f;
+                            const float m = __float_as_int(id[e]) == lane ? 1.0f : 0.0f;
+                            cr = fmaf(m, vr[e], cr);
+                            cg = fmaf(m, vg[e], cg);
+                            cb = fmaf(m, vb[e], cb);
                         }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 head = (head + nb) & (RING - 1);
                 count -= nb;
-                ++st_pass;
+                if constexpr (DBG) ++st_pass;
                 if constexpr (P::PROFILE) prof[5] += __builtin_readcyclecounter() - t_sec;     // result list + owner collect
             } else {
                 break;
@@ -483,9 +514,9 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
             }
             A.depth[ray] = dep + (1.0f - acc) * d[2];
         }
-        st_rays += __popcll(__ballot(live && seg == 0));
+        if constexpr (DBG) st_rays += __popcll(__ballot(live && seg == 0));
     }
-    if (A.stats && lane == 0) {
+    if (DBG && A.stats && lane == 0) {
         atomicAdd(A.stats + 0, st_valid);
         atomicAdd(A.stats + 1, st_active);
         atomicAdd(A.stats + 2, st_pass);

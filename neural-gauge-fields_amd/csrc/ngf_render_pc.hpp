@@ -247,7 +247,6 @@ __global__ void __launch_bounds__((NM + NS) * 64) render_pc_kernel(const RenderA
         // Per-ring consumer state lives in LDS (head / finished words, per-ray colour sums), so ONE copy of the pass code serves
         // all rings of this wave (an unrolled ring loop triples the code and the register pressure).
         const int sw = wave - NM;
-        if (A.ablate & 16) __builtin_amdgcn_s_setprio(2);
         unsigned long long st_pass = 0;
         [[maybe_unused]] unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // PROFILE: [1..6] pass sections as in render_kernel, [7] idle polling
         unsigned over_mask = 0;                 // bit qi: ring sw + NS qi is exhausted
@@ -326,7 +325,7 @@ __global__ void __launch_bounds__((NM + NS) * 64) render_pc_kernel(const RenderA
                 const float wr_ = r0[1] * c[0], wg_ = r0[1] * c[1], wb_ = r0[1] * c[2];
                 float cr = 0.0f, cg = 0.0f, cb = 0.0f;
                 if (lane < TW) { cr = lds_peekf(csum + lane * 3); cg = lds_peekf(csum + lane * 3 + 1); cb = lds_peekf(csum + lane * 3 + 2); }
-                if (!(A.ablate & 1)) collect16(own, wr_, wg_, wb_, lane, cr, cg, cb);
+                collect16(own, wr_, wg_, wb_, lane, cr, cg, cb);
                 if (lane < TW) { lds_pokef(csum + lane * 3, cr); lds_pokef(csum + lane * 3 + 1, cg); lds_pokef(csum + lane * 3 + 2, cb); }
                 if constexpr (P::PROFILE) prof[5] += __builtin_readcyclecounter() - t_sec;
                 ++st_pass;

@@ -115,7 +115,6 @@ __device__ __forceinline__ void gather16_issue(const RenderArgs &A, const float 
     constexpr int NQ = APP / 16;
     const Tex &t = A.app[P];
     g.b = bil_setup(rec[2 + 2 * P], rec[3 + 2 * P], t);
-    if (A.ablate & 4) g.b.idx = 64 + (kq << 2);        // profiling: every lane reads the same few (cached) texels
     // lane-quarter kq owns channels [16q + 4kq, 16q + 4kq + 4), q = 0..NQ-1: the four lanes of a sample read one
     // contiguous 64-byte piece per load instruction, so a wave-wide load touches 16 cache lines instead of ~32
     const f32x4 *t00 = reinterpret_cast<const f32x4 *>(t.p + (size_t)g.b.idx * APP) + kq;
@@ -231,7 +230,6 @@ __device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blo
     layer1_plane16<APP, 2>(blob, lane, feat, acc);
     __builtin_amdgcn_sched_barrier(0);
     NGF_TICK(2);                       // all layer-1 MFMAs issued
-    if (A.ablate & 2) { rgb[0] = acc[0][0]; rgb[1] = acc[1][1]; rgb[2] = acc[2][2] + acc[3][3]; return; }
     mlp_tail16(blob, L::W2, L::B2, L::W3, L::B3, lane, acc, rgb, tk);
     __builtin_amdgcn_sched_barrier(0);
     NGF_TICK(3);                       // layers 2-3 done
@@ -444,7 +442,6 @@ __device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const floa
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc[mt] = NGF_MFMA16(w1[(mt * 4 + j) * 64], v[j], acc[mt]);
     }
-    if (A.ablate & 2) { rgb[0] = acc[0][0]; rgb[1] = acc[1][1]; rgb[2] = acc[2][2] + acc[3][3]; return; }
     mlp_tail16(blob, L::W2, L::B2, L::W3, L::B3, lane, acc, rgb);
 }
 

@@ -68,14 +68,27 @@ __device__ __forceinline__ AFrag afrag_load(const float *w, int mt)
 }
 // six products for TWO unit tiles, their dependent accumulator chains interleaved (a chain of six MFMAs on one accumulator pays the
 // dependent-issue latency six times; two chains hide each other)
+#ifdef NGF_EXP_NOPS      // experiment build (profiles/exp_determinism_builds.sh): 32 idle issue slots around every bf16 MFMA pair -- raises the rate of
+                         // the packed-math nondeterminism of the InfoInv pass (pe_octave, ngf_infoinv.hpp) from 1 in 50 000 launches to 1 in 5
+#define NGF_EXP_GAP() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 15"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define NGF_EXP_GAP() do { } while (0)
+#endif
 __device__ __forceinline__ void six_products2(const AFrag &a, const AFrag &b, const Split8 &x, f32x4 &c0, f32x4 &c1)
 {
+    NGF_EXP_GAP();
     c0 = NGF_MFMA_BF16(a.l, x.h, c0);  c1 = NGF_MFMA_BF16(b.l, x.h, c1);          // smallest terms first
+    NGF_EXP_GAP();
     c0 = NGF_MFMA_BF16(a.h, x.l, c0);  c1 = NGF_MFMA_BF16(b.h, x.l, c1);
+    NGF_EXP_GAP();
     c0 = NGF_MFMA_BF16(a.m, x.m, c0);  c1 = NGF_MFMA_BF16(b.m, x.m, c1);
+    NGF_EXP_GAP();
     c0 = NGF_MFMA_BF16(a.m, x.h, c0);  c1 = NGF_MFMA_BF16(b.m, x.h, c1);
+    NGF_EXP_GAP();
     c0 = NGF_MFMA_BF16(a.h, x.m, c0);  c1 = NGF_MFMA_BF16(b.h, x.m, c1);
+    NGF_EXP_GAP();
     c0 = NGF_MFMA_BF16(a.h, x.h, c0);  c1 = NGF_MFMA_BF16(b.h, x.h, c1);
+    NGF_EXP_GAP();
 }
 template <int MT_STRIDE>
 __device__ __forceinline__ void kblock_bf16(const float *w, const Split8 &x, f32x4 acc[4])

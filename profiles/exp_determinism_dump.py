@@ -1,0 +1,67 @@
+"""What does a bad launch see?  NGF_EXP_DUMP build (profiles/exp_determinism_builds.sh): every lane of every colour pass of the InfoInv
+NGF_F_SPLIT_BF16 kernel writes {lane, record, scale, positional factors, colour} to a buffer.  Launch until the frame differs from the
+first one, then compare the two dumps sample by sample (rows matched by the record's coordinates).
+    NGF_LIB=neural-gauge-fields_amd/csrc/build/exp/dump/libngf_hip.so python profiles/exp_determinism_dump.py"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import ngf_amd  # noqa
+from ngf_amd import _lib
+_lib.SO_PATH = os.path.abspath(os.environ["NGF_LIB"])
+from helpers import field_for_case, load_case
+L = _lib.lib()
+g, params, step, mask = load_case("infoinv_r1_on")
+S = int(g["S"])
+rays = torch.from_numpy(g["rays"]).cuda()
+f = field_for_case(g, params, mask, split_bf16=True)
+h = f.handle()
+n = rays.shape[0]
+MAXP = 4096
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+def launch():
+    buf = torch.zeros(8 * 2 + MAXP * 64 * 64, dtype=torch.float32, device="cuda")       # 8 uint64 + rows
+    rgb, depth = torch.empty((n, 3), device="cuda"), torch.empty((n,), device="cuda")
+    _lib.check(L.ngf_field_render(h, rays.data_ptr(), n, S, 1, 1, None, rgb.data_ptr(), depth.data_ptr(), buf.data_ptr(), st))
+    torch.cuda.synchronize()
+    npass = int(buf[:2].view(torch.int64)[0].item())
+    rows = buf[16:16 + npass * 64 * 64].view(npass, 64, 64).cpu().numpy()
+    return rgb.cpu().numpy(), rows
+
+def table(rows):
+    out = {}
+    for p in range(rows.shape[0]):
+        for l in range(64):
+            r = rows[p, l]
+            key = (r[3].tobytes(), r[4].tobytes(), r[5].tobytes(), r[2].tobytes(), int(l) >> 4)      # x, y, z, weight, lane quarter
+            out.setdefault(key, []).append(r)
+    return out
+
+rgb0, rows0 = launch()
+t0 = table(rows0)
+print("passes in launch 0:", rows0.shape[0], "distinct (sample, quarter) keys:", len(t0))
+found = 0
+for it in range(1, 400):
+    rgb, rows = launch()
+    if np.array_equal(rgb, rgb0):
+        continue
+    found += 1
+    bad_rays = np.nonzero((rgb != rgb0).any(1))[0].tolist()
+    t1 = table(rows)
+    print(f"launch {it}: rays {bad_rays} differ; passes {rows.shape[0]}; keys only in one dump: {len(set(t0) ^ set(t1))}")
+    names = ["lane", "owner", "w", "x", "y", "z", "feat0", "feat1", "feat2"] + [f"acc{k}" for k in range(16)] + [f"c{k}" for k in range(16)] + ["r", "g", "b", "bs0", "bs1", "bs2", "bc0", "bc1", "bc2"]
+    shown = 0
+    for key in t0:
+        if key not in t1:
+            continue
+        a, b = t0[key][0], t1[key][0]
+        cols = [k for k in range(2, 50) if a[k].tobytes() != b[k].tobytes()]
+        if cols and shown < 6:
+            shown += 1
+            grp = sorted({names[k].rstrip("0123456789") for k in cols})
+            print("   sample x,y,z =", a[3], a[4], a[5], "quarter", key[4], "differs in", grp, f"({len(cols)} values)",
+                  "| first:", names[cols[0]], "good", float(a[cols[0]]), "bad", float(b[cols[0]]))
+    if found >= 3:
+        break
+print("bad launches examined:", found)
