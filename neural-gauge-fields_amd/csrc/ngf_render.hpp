@@ -56,9 +56,9 @@ __device__ __forceinline__ void view_inputs(const float d[3], float v[16])
 {
     v[0] = d[0]; v[1] = d[1]; v[2] = d[2];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        v[3 + 2 * k] = sinf(d[k]);   v[4 + 2 * k] = sinf(d[k] * 2.0f);
-        v[9 + 2 * k] = cosf(d[k]);   v[10 + 2 * k] = cosf(d[k] * 2.0f);
+    for (int k = 0; k < 3; ++k) {        // sincos_small (|argument| <= 2: <= 1.6 ulp), the same function view_inputs_tile uses: every tile shape sees the same bits
+        sincos_small(d[k], v[3 + 2 * k], v[9 + 2 * k]);
+        sincos_small(d[k] * 2.0f, v[4 + 2 * k], v[10 + 2 * k]);
     }
     v[15] = 0.0f;
 }

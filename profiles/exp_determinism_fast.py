@@ -42,7 +42,8 @@ for name, kw, split in (("infoinv_r1_on", {"infoinv": True}, True), ("infoinv_r1
     bad_r, bad_d, tiles = 0, 0, {}
     t0 = time.time()
     for it in range(N):
-        r = f(rays, N_samples=S, white_bg=True, **kw)["rgb_map"]
+        out = f(rays, N_samples=S, white_bg=True, **kw)
+        r = torch.cat([out["rgb_map"], out["depth_map"][:, None]], 1)          # [n, 4]: colour and depth
         d = f.decode_rgb(coords_t, dirs_t, mode=mode) if name.startswith("infoinv") else None
         if first_r is None:
             first_r = r.clone(); first_d = None if d is None else d.clone()

@@ -27,6 +27,9 @@ def pytest_sessionstart(session):
     # The library itself never reads the environment; this is the test harness doing it (profiles/exp_poison_hammer.sh).
     pz = os.environ.get("NGF_TEST_POISON", "")
     if pz:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()           # torch's HIP runtime first: loading libngf_hip.so before it left hipMemcpyAsync without a device
         _lib.check(_lib.lib().ngf_debug_set(b"poison", int(pz)))
 
 
