@@ -279,7 +279,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--preset", default="R1", choices=["R0", "R1", "R2"])
     ap.add_argument("--model", default="triplane", choices=["triplane", "infoinv"])
-    ap.add_argument("--bake-density", type=int, default=0, help="1 = NGF_F_BAKE_DENSITY (pre-composed density planes)")
+    ap.add_argument("--bake-density", type=int, default=1, help="1 = NGF_F_BAKE_DENSITY (pre-composed density planes): optimisation level 2, the "
+                    "default of ngf_amd.triplane.TriPlane since round 3; 0 = level 1")
     ap.add_argument("--bake-color", type=int, default=0, help="1 = NGF_F_BAKE_COLOR (pre-composed layer-1 colour planes)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="N=1 only: also time the other presets / variants (untimed region)")
@@ -399,6 +400,8 @@ def main():
         "config": {"workload": f"{'TriPlane' if model == 'triplane' else 'InfoInv'} 800x800 frame, S=192, preset {args.preset} "
                                f"(seeded random planes 256^2, dense density preset), gauge on, white_bg",
                    "rays_per_step": n_total, "samples_per_ray": S, "sharding": f"rays x{world} (10-row blocks, round robin) + double-buffered RCCL all_gather",
+                   "level": ("3 (bake density + colour)" if args.bake_color else "2 (module default: layer 1 o basis, per-ray view fold, density_decoder folded into "
+                             "1-channel planes)" if args.bake_density else "1 (layer 1 o basis, per-ray view fold)") if model == "triplane" else "default",
                    "bake_density": int(args.bake_density), "bake_color": int(args.bake_color)},
         "roofline": roofline,
     }
@@ -434,17 +437,18 @@ def main():
         if args.extras:
             extras = {}
             # the other presets and the opt-in formulations: (model, preset, field flags, result tag, PMC tag)
-            variants = (("triplane", "R0", {}, "", ""), ("triplane", "R2", {}, "", ""),
-                        ("triplane", args.preset, {"no_fold": True}, "_no_fold_level0", "_nofold"),        # rgb_decoder as written: what the folds buy
-                        ("triplane", args.preset, {"split_bf16": True}, "_split_bf16", "_split"),           # colour MLP on bf16 MFMA, 3-term split operands
-                        ("triplane", "R2", {"split_bf16": True}, "_split_bf16", "_split"),
-                        ("triplane", args.preset, {"bake": True}, "_bake_density", "_bd"),
-                        ("triplane", args.preset, {"bake": True, "split_bf16": True}, "_bake_density_split_bf16", "_splitd"),
-                        ("triplane", args.preset, {"bake": True, "bake_color": True}, "_bake_density_color", "_bdc"),
-                        ("triplane", "R0", {"bake": True}, "_bake_density", "_bd"),
-                        ("triplane", "R2", {"bake": True, "bake_color": True}, "_bake_density_color", "_bdc"),
+            BD = {"bake": True}        # level 2 = the module default
+            variants = (("triplane", "R0", BD, "", "_bd"), ("triplane", "R2", BD, "", "_bd"),
+                        ("triplane", args.preset, {}, "_level1_no_bake", ""),                                # level 1: density_decoder on 16-channel taps
+                        ("triplane", args.preset, {"no_fold": True}, "_level0_no_fold", "_nofold"),        # rgb_decoder as written: what the folds buy
+                        ("triplane", args.preset, {"bake": True, "bake_color": True}, "_level3_bake_color", "_bdc"),
+                        ("triplane", args.preset, {"bake": True, "split_bf16": True}, "_split_bf16", "_splitd"),   # colour MLP on bf16 MFMA, 3-term split operands
+                        ("triplane", args.preset, {"split_bf16": True}, "_level1_split_bf16", "_split"),
+                        ("triplane", "R2", {"bake": True, "split_bf16": True}, "_split_bf16", "_splitd"),
+                        ("triplane", "R0", {}, "_level1_no_bake", ""),
+                        ("triplane", "R2", {"bake": True, "bake_color": True}, "_level3_bake_color", "_bdc"),
                         ("infoinv", "R1", {}, "", ""),
-                        ("infoinv", "R1", {"split_bf16": True}, "_split_bf16", "_split"))           # rgb_decoder on bf16 MFMA, four lanes per sample (profiles/r02_infoinv_split.txt)
+                        ("infoinv", "R1", {"split_bf16": True}, "_split_bf16", "_split"))           # rgb_decoder + density MLP on bf16 MFMA, four lanes per sample
             for mdl, preset, flags, tag, ptag_sfx in variants:
                 try:
                     fx, _, _, _ = build_field(mdl, preset, device, **flags)
@@ -527,7 +531,7 @@ def main():
             # nSamples, gauge on; the CPU leg is ONE forward+backward through autograd of the eager port (oracle/train.py)
             try:
                 from ngf_amd import train as ntrain
-                ft, gt_, pt_, st_ = build_field("triplane", args.preset, device, False, False)
+                ft, gt_, pt_, st_ = build_field("triplane", args.preset, device, True, False)
                 Str = int(ft.nSamples)
                 pick = (synth.hash_uniform(9, 1, (4096,)) * np.float32(rays_np.shape[0])).astype(np.int64)
                 tr_rays = torch.from_numpy(rays_np[pick]).to(device)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NGF_ABI_VERSION 1
+#define NGF_ABI_VERSION 2      /* 2: ngf_uv_desc.flags (was padding), ngf_uv_render_batch, ngf_debug_dirty_lds, trainer chunk_samples = 0 means the whole batch */
 
 enum { NGF_OK = 0, NGF_E_ARG = 1, NGF_E_HIP = 2, NGF_E_UNSUPPORTED = 3 };
 enum { NGF_MODEL_TRIPLANE = 0, NGF_MODEL_INFOINV = 1 };
@@ -36,7 +36,9 @@ enum { NGF_MODEL_TRIPLANE = 0, NGF_MODEL_INFOINV = 1 };
 enum {
     NGF_F_BAKE_DENSITY = 1, /* TriPlane: pre-compose density_decoder Linear(48,1) with the 16 density
                               channels of each plane (exact algebra: a Linear commutes with bilinear
-                              interpolation); the march then gathers 1 instead of 16 channels per tap */
+                              interpolation); the march then gathers 1 instead of 16 channels per tap.
+                              Optimisation level 2; the Python boundary (ngf_amd.fieldbase.Base) sets it by default since
+                              round 3, the C ABI leaves the choice to the caller. */
     NGF_F_NO_FOLD = 4,      /* level 0 of the optimisation ladder: rgb_decoder exactly as written (networks.py:25-30) -- `basis` is its own
                               144 x 144 matrix stage and the view inputs enter layer 1 per sample.  Without this flag layer 1 is
                               pre-composed with `basis` (W1' = W1[:, :F] . basis, fp64 accumulate) and, for small tiles, its

@@ -106,7 +106,7 @@ def lib():
         L.ngf_debug_get.argtypes = [C.c_char_p]
         L.ngf_debug_get.restype = C.c_int32
         L.ngf_debug_dirty_lds.argtypes = [C.c_void_p]
-        if L.ngf_abi_version() != 1 or L.ngf_sizeof_field_desc() != C.sizeof(FieldDesc):
+        if L.ngf_abi_version() != 2 or L.ngf_sizeof_field_desc() != C.sizeof(FieldDesc):
             raise RuntimeError("libngf_hip.so ABI mismatch (version or ngf_field_desc layout)")
         _LIB = L
     return _LIB

@@ -143,6 +143,10 @@ extern "C" int ngf_uv_create(const ngf_uv_desc *d, ngf_uv **out, void *hip_strea
     UvArgs &A = m->proto;
     memset(&A, 0, sizeof(A));
     A.sphere = d->sphere ? 1 : 0;
+    if (d->flags & ~NGF_UV_F_SPLIT_BF16) {
+        delete m;
+        return fail(NGF_E_ARG, "ngf_uv_create: unknown bits in flags (0x%x) -- a caller built against ABI 1 passes padding here", d->flags);
+    }
     A.split_bf16 = (d->flags & NGF_UV_F_SPLIT_BF16) ? 1 : 0;
     UvPacker P;
     auto nat = [](int t, int kq) { return 4 * t + kq; };                      // positional-encoding inputs: natural order

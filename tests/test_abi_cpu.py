@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for s in declared:
         assert hasattr(L, s), s
-    assert L.ngf_abi_version() == 1
+    assert L.ngf_abi_version() == 2
     import ctypes as C
     assert L.ngf_sizeof_field_desc() == C.sizeof(_lib.FieldDesc)
 

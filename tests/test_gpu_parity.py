@@ -527,6 +527,39 @@ def test_full_frame_properties():
     _close(depth[torch.from_numpy(pick).cuda()].cpu().numpy(), o_depth, "full-frame depth vs oracle", atol=5e-5)
 
 
+def test_infoinv_full_frame_properties():
+    """BASELINE config 3 at full size (InfoInv, 800x800, S=192, dense preset, infoinv=True): the size-independent properties of
+    test_full_frame_properties + a strided oracle check, for the default kernel AND NGF_F_SPLIT_BF16 (VERDICT r2 missing #4)."""
+    from ngf_amd import synth
+    g, params, step = big_case("infoinv", "R1")
+    g["infoinv"] = np.array(1)
+    rays_np = synth.lookat_rays(800, 800)
+    rays = torch.from_numpy(rays_np).cuda()
+    idx = torch.arange(0, 640000, 97, device="cuda")
+    pick = idx.cpu().numpy()[::8]
+    orc = oracle_for_case(g, params, step, None)
+    o_rgb, o_depth = orc.render(rays_np[pick], 192)
+    frames = {}
+    for split in (False, True):
+        f = field_for_case(g, params, None, split_bf16=split)
+        full = f(rays, N_samples=192, white_bg=True, infoinv=True, collect_stats=True)
+        st = f.last_stats.cpu().numpy()
+        assert st[3] == 640000 and 0.05 < st[1] / (640000 * 192) < 0.5, st
+        rgb, depth = full["rgb_map"], full["depth_map"]
+        assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(depth).all())
+        assert float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0
+        sub = f(rays[idx], N_samples=192, white_bg=True, infoinv=True)          # rays are independent: a subset gives the same bits
+        assert torch.equal(sub["rgb_map"], rgb[idx]) and torch.equal(sub["depth_map"], depth[idx])
+        black = f(rays[idx], N_samples=192, white_bg=False, infoinv=True)["rgb_map"]
+        assert bool((sub["rgb_map"] + 1e-6 >= black).all())
+        sel = torch.from_numpy(pick).cuda()
+        _close(rgb[sel].cpu().numpy(), o_rgb, f"InfoInv full-frame rgb vs oracle (split={split})")
+        _close(depth[sel].cpu().numpy(), o_depth, f"InfoInv full-frame depth vs oracle (split={split})", atol=5e-5)
+        frames[split] = (rgb, depth)
+        f.release()
+    assert float((frames[True][0] - frames[False][0]).abs().max()) < 2e-5          # split-bf16 frame within fp32 rounding noise of the fp32-MFMA frame
+
+
 def test_alpha_mask_build_and_ray_filter():
     """Row N2: getDenseAlpha / updateAlphaMask / filtering_rays against the reference's own outputs."""
     g, params, step, _ = load_case("triplane_alpha_mask")

@@ -101,6 +101,41 @@ def test_batch_of_cameras_is_one_launch_and_matches_per_camera_calls():
     assert np.abs(nb["color"][1].cpu().numpy() - o_color).max() < 1e-4
 
 
+def test_uv_full_dtu_frame_properties():
+    """BASELINE config 4 at full size: the whole 800 x 600 frame of the reference's DTU camera 0 (480 000 rays generated on the
+    device by ngf_generate_rays_dtu, 64 samples per ray, sphere gauge, seeded weights -- no checkpoint is obtainable offline).
+    Finite, in range, any subset rendered alone gives the same bits, and a strided sample of the frame against the C oracle."""
+    from ngf_amd import rays as nrays
+    from ngf_amd import synth, uvmapping
+    params = synth.uvmapping_params(5, "sphere")
+    v0 = synth.DTU_VIEW0
+    dirs = nrays.generate_rays_dtu(600, 800, v0["focal"], v0["princpt"], v0["rot"])          # [480000, 3]
+    n = dirs.shape[0]
+    assert n == 480000
+    cam = torch.tensor(v0["campos"], dtype=torch.float32)[None]
+    bg = torch.tensor([[0.2, 0.5, 0.9]], dtype=torch.float32)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    U = torch.rand((1, n, 64), device="cuda", generator=gen)
+    net = uvmapping.NeuTex(primitive_type="sphere", sample_num=64, device="cuda")
+    net.load_params(params)
+    out = net(cam, dirs[None], bg, jitter_u=U, collect_stats=True)
+    color, trans = out["color"][0], out["transmittance"][0]
+    st = net.last_stats.cpu().numpy()
+    assert 0 < st[0] <= n * 64                                   # in-cube samples evaluated
+    assert bool(torch.isfinite(color).all()) and float(color.min()) >= 0.0 and float(color.max()) <= 1.0
+    assert float(trans.min()) >= 0.0 and float(trans.max()) <= 1.0 + 1e-6
+    idx = torch.arange(0, n, 997, device="cuda")
+    sub = net(cam, dirs[idx][None], bg, jitter_u=U[:, idx])
+    assert torch.equal(sub["color"][0], color[idx]) and torch.equal(sub["transmittance"][0], trans[idx])
+    pick = idx[::2].cpu().numpy()                                # ~240 rays through the whole frame
+    orc = OracleUV(params, "sphere")
+    o_color, o_trans = orc.render(np.asarray(v0["campos"], np.float32), dirs[pick].cpu().numpy(), U[0, pick].cpu().numpy(), bg=bg[0].numpy())
+    e_c = np.abs(color[pick].cpu().numpy() - o_color).max()
+    e_t = np.abs(trans[pick].cpu().numpy() - o_trans).max()
+    print(f"full DTU frame: {st[0] / n:.1f} in-cube samples per ray, max|color-oracle| {e_c:.2e}, max|T-oracle| {e_t:.2e} on {len(pick)} rays")
+    assert e_c < 5e-5 and e_t < T_TOL                            # north_star: 1e-4
+
+
 def test_two_rays_per_wave_is_bit_identical():
     """The default kernel renders two rays per wave (every weight load feeds two MFMAs); a sample's arithmetic does not
     depend on its tile, so the one-ray-per-wave kernel (knob uv_tiles = 1) gives the same bits -- also for an odd ray count
