@@ -71,10 +71,12 @@ __device__ __forceinline__ void view_inputs_tile(const float d[3], float *dst, i
 {
     if (seg == 0) { dst[0] = d[0]; dst[1] = d[1]; dst[2] = d[2]; dst[15] = 0.0f; }
     for (int a = seg; a < 6; a += K) {
+        // the argument as a sum of three products with 0 / 1 / 2 (exact): a select over d[] by a runtime index turns d[] into a stack array
         const int dim = a >> 1;
-        const float dd = dim == 0 ? d[0] : (dim == 1 ? d[1] : d[2]);
+        const float sc = (a & 1) ? 2.0f : 1.0f;
+        const float arg = (dim == 0 ? sc : 0.0f) * d[0] + (dim == 1 ? sc : 0.0f) * d[1] + (dim == 2 ? sc : 0.0f) * d[2];
         float sn, cs;
-        sincos_small((a & 1) ? dd * 2.0f : dd, sn, cs);
+        sincos_small(arg, sn, cs);
         dst[3 + a] = sn;
         dst[9 + a] = cs;
     }

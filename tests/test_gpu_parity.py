@@ -557,7 +557,10 @@ def test_infoinv_full_frame_properties():
         _close(depth[sel].cpu().numpy(), o_depth, f"InfoInv full-frame depth vs oracle (split={split})", atol=5e-5)
         frames[split] = (rgb, depth)
         f.release()
-    assert float((frames[True][0] - frames[False][0]).abs().max()) < 2e-5          # split-bf16 frame within fp32 rounding noise of the fp32-MFMA frame
+    # split-bf16 frame against the fp32-MFMA frame: rounding noise on almost every pixel; a sample whose weight sits within an ulp of the
+    # 1e-4 colour threshold may be classified differently by the two density evaluations (SURVEY section 7 hazard 3: <= 1e-4 x rgb)
+    d = (frames[True][0] - frames[False][0]).abs().max(dim=1).values
+    assert float(d.max()) < 1.5e-4 and float((d > 1e-5).float().mean()) < 1e-3, (float(d.max()), float((d > 1e-5).float().mean()))
 
 
 def test_alpha_mask_build_and_ray_filter():
