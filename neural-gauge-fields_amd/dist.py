@@ -1,10 +1,15 @@
 """Ray-sharded multi-GPU render (new; the reference is single-device apart from one nn.DataParallel
 wrapper, UV-Mapping/model/model.py:285).
 
-Rays of a frame are independent (no cross-ray term anywhere in Base.forward), so rank r renders the
-contiguous block [r*ceil(N/W), ...) with replicated parameters and the only exchange is ONE all-gather
-of the composited pixels ([n_rank, 4] fp32: rgb + depth; 10 MB per 800x800 frame) -- RCCL over xGMI
-when the process group's backend is "nccl".  One process per GPU, launched by torch.distributed.run.
+Rays of a frame are independent (no cross-ray term anywhere in Base.forward): every rank renders its share with
+replicated parameters and the only exchange is ONE all-gather of the composited pixels ([n_rank, 4] fp32: rgb + depth;
+10 MB per 800x800 frame) -- RCCL over xGMI when the process group's backend is "nccl".  One process per GPU, launched by
+torch.distributed.run.  Two partitions:
+  * `render_sharded` / `shard_bounds`: contiguous ray blocks [r*ceil(N/W), ...) -- the generic entry point for any ray list;
+  * `interleaved_rows` + `PipelinedGather` + `deinterleave` (what bench.py runs at N > 1): the frame's rows dealt out in 10-row
+    blocks round robin.  BASELINE.json's north_star words the partition as contiguous row blocks; contiguous 100-row shards of the
+    800x800 frame differ by 7 % in render time (background rows are cheap), and strong scaling pays for the slowest rank, so the
+    rows are interleaved and one strided device copy puts the gathered frame back in image order.
 """
 from __future__ import annotations
 

@@ -130,6 +130,72 @@ def test_sharded_render_world2_gloo(tmp_path):
     assert [open(tmp_path / f"ok{r}").read() for r in range(2)] == ["1", "1"]
 
 
+def _worker_rows(rank, world, port, tmp):
+    """The bench's data path at world 4 / 8 without a device: every rank fills its interleaved 10-row blocks of an 800 x 800 frame with
+    a value that encodes (row, column), the exchange is PipelinedGather's double-buffered all_gather (gloo), and the re-ordered frames
+    must be the row-major frame -- for three frames in flight, i.e. both buffers of the pipeline are reused."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H = W = 800
+    blk = 10
+    rows = ndist.interleaved_rows(H, world, rank, blk)
+    per = H * W // world
+    ok = sum(r1 - r0 for r0, r1 in rows) * W == per and len(rows) == H // (world * blk)
+    pipe = ndist.PipelinedGather(per, world, torch.device("cpu"))
+    ok = ok and pipe.send[0][0].numel() == 4 * per and pipe.recv[0].numel() == world * 4 * per          # one [per,4] operand per rank
+    got = []
+
+    def fill(k):
+        rr = torch.cat([torch.arange(r0, r1) for r0, r1 in rows]).view(-1, 1).expand(-1, W).reshape(-1)
+        cc = torch.arange(W).repeat(rr.numel() // W)
+        base = (rr * W + cc).to(torch.float32)                     # < 2^24: exact in float32
+        o_rgb, o_depth = pipe.buffers(k)
+        o_rgb.copy_(torch.stack([base, base + 0.25, base + 0.5], 1) + 1000000.0 * k)
+        o_depth.copy_(base + 0.75 + 1000000.0 * k)
+
+    for k in range(3):
+        fill(k)
+        pipe.submit(k)
+        if k > 0:
+            got.append(ndist.deinterleave(*pipe.frame(k - 1), H, W, world, blk))
+    got.append(ndist.deinterleave(*pipe.frame(2), H, W, world, blk))
+    pix = torch.arange(H * W, dtype=torch.float32)
+    for k, (g_rgb, g_depth) in enumerate(got):
+        ok = ok and torch.equal(g_rgb[:, 0], pix + 1000000.0 * k) and torch.equal(g_rgb[:, 2], pix + 0.5 + 1000000.0 * k)
+        ok = ok and torch.equal(g_depth, pix + 0.75 + 1000000.0 * k)
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_interleaved_row_exchange_world_4_and_8_gloo(tmp_path, world):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_rows, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(world)] == ["1"] * world
+
+
+def test_interleaved_rows_partition_the_frame():
+    """interleaved_rows for every world size bench.py accepts: the ranks' row sets are disjoint, cover the 800 rows, have equal
+    size, and deinterleave is the inverse permutation of the rank-major layout."""
+    H, W, blk = 800, 800, 10
+    for world in (1, 2, 4, 8):
+        sets = [ndist.interleaved_rows(H, world, r, blk) for r in range(world)]
+        rows = sorted(r for s_ in sets for (r0, r1) in s_ for r in range(r0, r1))
+        assert rows == list(range(H)) and len({sum(r1 - r0 for r0, r1 in s_) for s_ in sets}) == 1
+        order = torch.cat([torch.arange(r0 * W, r1 * W) for s_ in sets for (r0, r1) in s_]).to(torch.float32)      # rank-major pixel ids
+        rgb = torch.stack([order, order, order], 1)
+        back_rgb, back_depth = ndist.deinterleave(rgb, order.clone(), H, W, world, blk)
+        assert torch.equal(back_depth, torch.arange(H * W, dtype=torch.float32)) and torch.equal(back_rgb[:, 1], back_depth)
+    with pytest.raises(ValueError):
+        ndist.interleaved_rows(800, 3, 0, 10)
+
+
 def test_shard_bounds_cover_everything():
     for n in (0, 1, 7, 640000):
         for w in (1, 2, 4, 8):
