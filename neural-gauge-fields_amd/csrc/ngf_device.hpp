@@ -101,6 +101,15 @@ __device__ __forceinline__ Bil bil_setup(float u, float v, const Tex &t)
     return b;
 }
 
+// A texel address as (uniform base pointer) + (32-bit unsigned offset in floats): hipcc then issues the gather as
+// `global_load ... v_offset, s[base:base+1]` instead of building a 64-bit address per lane (v_ashrrev + two v_lshl_add_u64 per tap row --
+// quarter-rate instructions on the pipe that binds these kernels).  A packed texture is far below 2^32 bytes (ngf_field_create checks it).
+template <typename T>
+__device__ __forceinline__ const T *tex_at(const float *base, uint32_t float_index)
+{
+    return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(uint32_t)(float_index * 4u));
+}
+
 __device__ __forceinline__ float bil_mix(const Bil &b, float v00, float v10, float v01, float v11)
 {
     return fmaf(b.w11, v11, fmaf(b.w01, v01, fmaf(b.w10, v10, b.w00 * v00)));

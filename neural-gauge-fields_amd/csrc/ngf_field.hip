@@ -606,6 +606,8 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
         const int H = d->plane_h[p], W = d->plane_w[p];
         const size_t texels = (size_t)(H + 2) * (W + 2);
         const int dc = bake ? 1 : d->dens_dim;
+        if (texels * (size_t)(app_c > 96 ? app_c : 96) * sizeof(float) >= ((size_t)1 << 32))      // the kernels address a texture with 32-bit byte offsets (tex_at)
+            return bail(fail(NGF_E_UNSUPPORTED, "plane %d: %d x %d texels do not fit a 4 GiB packed texture", p, H, W));
         if ((rc = alloc_f(&f->tex[p], texels * dc, f, st)) || (rc = alloc_f(&f->tex[3 + p], texels * app_c, f, st))) {
             if (wp_dev) (void)hipFree(wp_dev);
             return bail(rc);

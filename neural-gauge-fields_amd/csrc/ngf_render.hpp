@@ -123,11 +123,11 @@ __device__ __forceinline__ float triplane_density_feature(const RenderArgs &A, c
         const Tex tx = karg_tex(offsetof(RenderArgs, dens) + p * sizeof(Tex));
         Bil b = bil_setup(t[2 * p], t[2 * p + 1], tx);
         if (BAKED) {
-            const float *q = tx.p + b.idx;
-            f += bil_mix(b, q[0], q[1], q[tx.stride], q[tx.stride + 1]);
+            const float *q = tex_at<float>(tx.p, (uint32_t)b.idx), *q1 = tex_at<float>(tx.p, (uint32_t)(b.idx + tx.stride));
+            f += bil_mix(b, q[0], q[1], q1[0], q1[1]);
         } else {
-            const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + (size_t)b.idx * 16);
-            const f32x4 *q01 = q00 + (size_t)tx.stride * 4;
+            const f32x4 *q00 = tex_at<f32x4>(tx.p, (uint32_t)b.idx * 16u);
+            const f32x4 *q01 = tex_at<f32x4>(tx.p, (uint32_t)(b.idx + tx.stride) * 16u);
             float d00 = 0.0f, d10 = 0.0f, d01 = 0.0f, d11 = 0.0f;
             // the plane's 16 decoder weights are re-read from the kernel-argument segment here (one s_load_dwordx16 on the scalar
             // memory pipe): kept live across the march loop the 48 of them crowd the SGPR file and hipcc parks texture pointers in
@@ -163,8 +163,8 @@ __device__ __forceinline__ void triplane_gauge(const RenderArgs &A, const float 
         for (int p = 0; p < 3; ++p) {
             const Tex tx = karg_tex(offsetof(RenderArgs, gau) + p * sizeof(Tex));
             Bil b = bil_setup(u[p], v[p], tx);
-            const f32x2 *g = reinterpret_cast<const f32x2 *>(tx.p) + b.idx;
-            f32x2 g00 = g[0], g10 = g[1], g01 = g[tx.stride], g11 = g[tx.stride + 1];
+            const f32x2 *g = tex_at<f32x2>(tx.p, (uint32_t)b.idx * 2u), *g1 = tex_at<f32x2>(tx.p, (uint32_t)(b.idx + tx.stride) * 2u);
+            f32x2 g00 = g[0], g10 = g[1], g01 = g1[0], g11 = g1[1];
             d[p][0] = bil_mix(b, g00[0], g10[0], g01[0], g11[0]);
             d[p][1] = bil_mix(b, g00[1], g10[1], g01[1], g11[1]);
         }

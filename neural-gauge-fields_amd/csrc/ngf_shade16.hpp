@@ -73,6 +73,10 @@ __device__ __forceinline__ f32x4 view_entries16(const float d[3], int kq)
 // v_max_i32, bit-identical results, 32 instructions fewer per pass.
 __device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
+// sigmoid (networks.py:31) with v_rcp_f32 (<= 1 ulp) instead of the IEEE division sequence (v_div_scale x2, v_rcp, 4 FMAs, v_div_fmas,
+// v_div_fixup: ~10 instructions per channel): the colour moves by <= 1 ulp of a value in (0, 1)
+__device__ __forceinline__ float sigmoid_rcp(float s) { return __builtin_amdgcn_rcpf(1.0f + expf(-s)); }
+
 // layers 2 and 3; acc[mt][r] = layer-1 pre-activation of hidden unit mt*16 + 4*kq + r
 __device__ __forceinline__ void mlp_tail16(const float *blob, int oW2, int oB2, int oW3, int oB3, int lane, const f32x4 acc[4],
                                            float rgb[3], unsigned long long *tk = nullptr)
@@ -98,7 +102,7 @@ __device__ __forceinline__ void mlp_tail16(const float *blob, int oW2, int oB2, 
         s = s + __shfl_xor(s, 16);
         s = s + __shfl_xor(s, 32);
         s = s + blob[oB3 + ch];
-        rgb[ch] = 1.0f / (1.0f + expf(-s));
+        rgb[ch] = sigmoid_rcp(s);
     }
 }
 
@@ -117,8 +121,8 @@ __device__ __forceinline__ void gather16_issue(const RenderArgs &A, const float 
     g.b = bil_setup(rec[2 + 2 * P], rec[3 + 2 * P], t);
     // lane-quarter kq owns channels [16q + 4kq, 16q + 4kq + 4), q = 0..NQ-1: the four lanes of a sample read one
     // contiguous 64-byte piece per load instruction, so a wave-wide load touches 16 cache lines instead of ~32
-    const f32x4 *t00 = reinterpret_cast<const f32x4 *>(t.p + (size_t)g.b.idx * APP) + kq;
-    const f32x4 *t01 = t00 + (size_t)t.stride * (APP / 4);
+    const f32x4 *t00 = tex_at<f32x4>(t.p, (uint32_t)g.b.idx * APP + 4u * kq);
+    const f32x4 *t01 = tex_at<f32x4>(t.p, (uint32_t)(g.b.idx + t.stride) * APP + 4u * kq);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         g.raw[0][q] = t00[4 * q];
@@ -369,8 +373,8 @@ __device__ __forceinline__ void baked16_issue(const RenderArgs &A, const float r
     const Tex &t = A.app[P];
     g.b = bil_setup(rec[2 + 2 * P], rec[3 + 2 * P], t);
     // channel 16*mt + 4*kq + r = hidden unit of accumulator (mt, r): natural order; 4 lanes read 64 contiguous bytes
-    const f32x4 *t00 = reinterpret_cast<const f32x4 *>(t.p + (size_t)g.b.idx * 64) + kq + 8 * H;
-    const f32x4 *t01 = t00 + (size_t)t.stride * 16;
+    const f32x4 *t00 = tex_at<f32x4>(t.p, (uint32_t)g.b.idx * 64u + 4u * (kq + 8 * H));
+    const f32x4 *t01 = tex_at<f32x4>(t.p, (uint32_t)(g.b.idx + t.stride) * 64u + 4u * (kq + 8 * H));
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         g.raw[0][q] = t00[4 * q];

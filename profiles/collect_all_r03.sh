@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round-3 evidence run (on the GPU box, through gpurun):  bash profiles/collect_all_r03.sh [quick]
+#   1. kernel-trace stats + PMC passes per workload (profiles/collect.sh) -> gpurun_out/r03_<workload>_{kernel_stats.txt,pmc.txt,pmc.json}
+#   2. the default bench line (compact) + its side file                 -> gpurun_out/r03_bench.json, r03_bench_extras.json
+#   3. the SAME command under rocprofv3 --kernel-trace --stats          -> gpurun_out/r03_kernel_stats_headline.txt
+#   4. the training iteration per kernel                                -> gpurun_out/r03_train_R1_kernel_stats.txt
+# Copy gpurun_out/r03_* into profiles/ afterwards (tracked).  Workload names: profiles/workload.py (`_bd` = level 2, the module default).
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+WLS="triplane_R1_bd triplane_R1 triplane_R0_bd triplane_R2_bd triplane_R1_bdc triplane_R1_splitd infoinv_R1 infoinv_R1_split"
+[ "$1" = quick ] && WLS="triplane_R1_bd"
+for wl in $WLS; do
+  bash profiles/collect.sh r03_$wl $wl "ngf::render_kernel" > /dev/null 2>&1
+done
+if [ "$1" != quick ]; then
+  bash profiles/collect.sh r03_uv_sphere uv_sphere "uv_render_kernel" > /dev/null 2>&1
+  bash profiles/collect.sh r03_uv_sphere_split uv_sphere_split "uv_render_kernel" > /dev/null 2>&1
+fi
+# the bench line embeds the PMC summaries of THIS build (bench.py reads profiles/r03_<workload>_pmc.json and checks the .so hash)
+cp gpurun_out/r03_*_pmc.json profiles/
+timeout 900 python bench.py --steps 20 --warmup 5 2>gpurun_out/r03_bench.err | grep '^{' > gpurun_out/r03_bench.json
+cp bench_extras.json gpurun_out/r03_bench_extras.json
+rm -rf gpurun_out/kt && mkdir -p gpurun_out/kt
+timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/kt -o kt -- python bench.py --steps 20 --warmup 5 --extras 0 --cpu-seconds 0 2>/dev/null | grep '^{' > gpurun_out/r03_bench_headline_under_rocprof.json
+python profiles/summarize_rocpd.py $(find gpurun_out/kt -name "*.db" | head -1) > gpurun_out/r03_kernel_stats_headline.txt
+rm -rf gpurun_out/kt
+if [ "$1" != quick ]; then
+  rm -rf gpurun_out/ktt && mkdir -p gpurun_out/ktt
+  timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/ktt -o kt -- python profiles/workload.py train_R1 20 > gpurun_out/r03_train_R1_kernel_stats.txt 2>/dev/null
+  python profiles/summarize_rocpd.py $(find gpurun_out/ktt -name "*.db" | head -1) >> gpurun_out/r03_train_R1_kernel_stats.txt
+  rm -rf gpurun_out/ktt
+fi
+ls gpurun_out | grep r03_ | head -80
