@@ -296,12 +296,16 @@ int ngf_uv_render_batch(const ngf_uv *m, const float *campos_dev, const float *r
  * a launch fills the LDS of every CU with the quiet-NaN pattern 0x7FC0DEAD, so that a read of LDS the kernel did not write shows up
  * as NaN instead of depending on the previous kernel; bit 1: the allocations of a new handle are filled with the pattern before
  * they are packed), "grid" (upper bound of the workgroups of a render launch: with 1 every wave of the only workgroup takes many tiles
- * one after the other).  The knobs are independent atomics: setting one while another thread launches is safe, but a launch sees
+ * one after the other), "xcd" (1: one tile queue per XCD with stealing; default 0: a single queue -- measured neutral on the
+ * SIMD-bound frames, profiles/r03_xcd_queues.txt).  The knobs are independent atomics: setting one while another thread launches is safe, but a launch sees
  * whatever values are current when it reads them -- they are test / experiment switches, not a per-call API. */
 int ngf_debug_set(const char *name, int32_t value);
 int32_t ngf_debug_get(const char *name);
 /* the "poison" bit-0 launch on its own: fill the LDS of every CU with 0x7FC0DEAD on `hip_stream` (tests) */
 int ngf_debug_dirty_lds(void *hip_stream);
+/* out8[x] = number of workgroups of a `workgroups`-wide launch that ran on XCD x (HW_REG_XCC_ID): the render launches keep one tile
+ * queue per XCD (knob "xcd": 1 / 0 forces it on / off) and rely on this id */
+int ngf_debug_xcd_histogram(unsigned *out8, int32_t workgroups, void *hip_stream);
 
 const char *ngf_last_error(void);
 int ngf_abi_version(void);

@@ -44,11 +44,15 @@ struct RenderArgs {
     float *dbg_sigma;      // [n,S] or NULL   (ngf_field_march)
     float *dbg_weight;     // [n,S] or NULL
     unsigned long long *stats;  // 4 counters or NULL
-    unsigned int *tile_counter; // zeroed before the launch
+    unsigned int *tile_counter; // queue heads, zeroed before the launch: [0] alone (one queue) or [0..7] (one queue per XCD, xcd_queues = 8)
     int64_t n;
     int32_t S, white_bg, mode, skip_rgb;
     int32_t tile_w;        // rays per wave tile: 64, or 32 / 16 / 8 for small launches (more waves, shorter critical path)
     int32_t tile_shift;    // log2(tile_w); the split march gives every ray 64 >> tile_shift lanes (consecutive steps)
+    int32_t xcd_queues;    // 8: the tile range is cut into 8 contiguous chunks, XCD x starts on chunk x and steals from the others when it is done
+                           // (each XCD has its own 4 MiB L2: its concurrent tiles then cover ONE compact ray range instead of an eighth of everybody's);
+                           // 0 / 1: one queue
+    uint32_t tiles;        // number of tiles of the launch
     int32_t ablate;        // debug instantiations only (render_kernel<.., DBG = true>): 32 no early termination, 64 no empty-iteration skip -- both
                            // EXACT (A/B timing and the bit-identity tests).  Round 1-2's bits 1 / 2 / 4 / 16 (skip collect, skip layers 2-3, cached
                            // gathers, wave priority) produced wrong images and are gone; the trainer keeps its own bits (ngf_train.hpp)
@@ -64,6 +68,32 @@ struct RenderArgs {
     float wd[48];          // TriPlane faithful density_decoder.weight
     float bd;              // density_decoder.bias
 };
+
+// The XCD (accelerator complex die, 0..7 on MI355X) this wave runs on: HW_REG_XCC_ID, bits [3:0].  s_getreg_b32 simm16 = (size-1) << 11 |
+// offset << 6 | id with id 20, offset 0, size 4.
+__device__ __forceinline__ int xcd_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); }
+
+// Next tile of a render launch for this wave (wave-uniform result).  `first` is the wave's memory of how many chunks, starting at its own,
+// are already exhausted: a chunk that ran dry stays dry, so it is not polled again.
+__device__ __forceinline__ bool next_tile(const RenderArgs &A, int xcd, int lane, int &first, unsigned &tile)
+{
+    if (A.xcd_queues <= 1) {
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(A.tile_counter, 1u);
+        tile = __builtin_amdgcn_readfirstlane(t);
+        return tile < A.tiles;
+    }
+    for (; first < 8; ++first) {
+        const unsigned c = (unsigned)(xcd + first) & 7u;
+        const unsigned lo = (unsigned)(((unsigned long long)c * A.tiles) >> 3), hi = (unsigned)(((unsigned long long)(c + 1) * A.tiles) >> 3);
+        if (hi == lo) continue;
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(A.tile_counter + c, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t < hi - lo) { tile = lo + t; return true; }
+    }
+    return false;
+}
 
 // ---- bilinear cell: ATen grid_sampler_2d, align_corners=True, padding_mode='zeros' -------------
 struct Bil {

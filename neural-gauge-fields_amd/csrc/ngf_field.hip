@@ -27,7 +27,7 @@ int ngf::fail(int code, const char *fmt, ...)
 }
 
 static std::atomic<int> g_knob[ngf::KNOB_COUNT];
-static const char *const g_knob_name[ngf::KNOB_COUNT] = {"tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage", "poison", "grid"};
+static const char *const g_knob_name[ngf::KNOB_COUNT] = {"tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage", "poison", "grid", "xcd"};
 static bool g_knob_init = [] { for (auto &k : g_knob) k.store(-1); return true; }();
 
 int ngf::knob(int id) { return g_knob[id].load(std::memory_order_relaxed); }
@@ -91,6 +91,22 @@ extern "C" int ngf_debug_dirty_lds(void *hip_stream)
     const int rc = ngf::poison_lds((hipStream_t)hip_stream);
     g_knob[ngf::KNOB_POISON].store(old);
     return rc;
+}
+
+// where do the workgroups of a launch land?  out[x] += 1 per workgroup on XCD x (tests: every XCD id 0..7 is seen, evenly)
+__global__ void xcd_histogram_kernel(unsigned *out)
+{
+    if (threadIdx.x == 0) atomicAdd(out + xcd_id(), 1u);
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < 20000ull) __builtin_amdgcn_s_sleep(8);      // keep the CU busy: one workgroup per CU like the render launches
+}
+extern "C" int ngf_debug_xcd_histogram(unsigned *out8, int32_t workgroups, void *hip_stream)
+{
+    if (!out8 || workgroups <= 0) return fail(NGF_E_ARG, "ngf_debug_xcd_histogram: bad argument");
+    HIP_TRY(hipMemsetAsync(out8, 0, 8 * sizeof(unsigned), (hipStream_t)hip_stream));
+    hipLaunchKernelGGL(xcd_histogram_kernel, dim3(workgroups), dim3(768), 0, (hipStream_t)hip_stream, out8);
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
 }
 
 extern "C" int ngf_debug_set(const char *name, int32_t value)
@@ -651,7 +667,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
             A.mask.inv[k] = 1.0f / (d->mask_aabb[3 + k] - d->mask_aabb[k]) * 2;   // invgridSize (FieldBase.py:29)
         }
     }
-    if (hipMalloc((void **)&f->counters, kCounters * sizeof(unsigned)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(counters) failed"));
+    if (hipMalloc((void **)&f->counters, (size_t)kCounters * kQueueHeads * sizeof(unsigned)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(counters) failed"));
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "packing failed: %s", hipGetErrorString(hipGetLastError())));
     *out = f;
     return NGF_OK;
@@ -664,8 +680,8 @@ template <typename K>
 static int launch_render(K kernel, K kernel_split, K kernel_prod, const ngf_field *f, RenderArgs &A, int threads, size_t lds_bytes, hipStream_t st, int wide_tile)
 {
     const unsigned slot = f->next_counter.fetch_add(1) % kCounters;
-    A.tile_counter = f->counters + slot;
-    HIP_TRY(hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned), st));
+    A.tile_counter = f->counters + (size_t)slot * kQueueHeads;
+    HIP_TRY(hipMemsetAsync(A.tile_counter, 0, kQueueHeads * sizeof(unsigned), st));
     if (int rc = poison_lds(st)) return rc;
     // Split march (render_kernel<P, true>): a tile holds tile_w rays and every ray is marched by 64 / tile_w lanes on
     // consecutive steps (bit-identical results).  Small tiles shorten the critical path of a tile and even out the
@@ -689,6 +705,13 @@ static int launch_render(K kernel, K kernel_split, K kernel_prod, const ngf_fiel
 #endif
     HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k), lds_bytes));
     const int64_t tiles = (A.n + tw - 1) / tw;
+    if (tiles >= ((int64_t)1 << 32)) return fail(NGF_E_ARG, "render launch of %lld tiles: split the ray list", (long long)tiles);
+    A.tiles = (uint32_t)tiles;
+    // One tile queue per XCD (knob "xcd" = 1) is built, bit-identical and OFF by default: it cuts the fabric traffic of the MLP-stress frame
+    // (R2: profiles/r03_triplane_R2_bd_xcd{0,1}_pmc.txt) but not its time -- these launches are bound by the SIMDs' own MFMA + VALU
+    // cycles, not by L2 misses (R1 / R2 / InfoInv within +-0.2 %) -- and the march-only frame loses 8 % to the stealing tail
+    // (profiles/r03_xcd_queues.txt).
+    A.xcd_queues = knob(KNOB_XCD) > 0 ? 8 : 1;
     int64_t grid = (tiles + waves - 1) / waves;
     if (grid > f->num_cus) grid = f->num_cus;
     if (knob(KNOB_GRID) > 0 && grid > knob(KNOB_GRID)) grid = knob(KNOB_GRID);      // tests: fewer workgroups -> every wave takes many tiles
@@ -717,9 +740,10 @@ static int launch_pc(const ngf_field *f, RenderArgs &A, hipStream_t st)
     const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + PcLds<NM>::TOTAL) * sizeof(float);
     if (lds > 160 * 1024) return fail(NGF_E_ARG, "the specialised kernel needs %zu bytes of LDS (> 160 KiB)", lds);
     const unsigned slot = f->next_counter.fetch_add(1) % kCounters;
-    A.tile_counter = f->counters + slot;
-    HIP_TRY(hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned), st));
+    A.tile_counter = f->counters + (size_t)slot * kQueueHeads;
+    HIP_TRY(hipMemsetAsync(A.tile_counter, 0, kQueueHeads * sizeof(unsigned), st));
     if (int rc = poison_lds(st)) return rc;
+    A.xcd_queues = 1;
     A.tile_w = TW;
     A.tile_shift = TW == 8 ? 3 : 2;
     auto k = render_pc_kernel<P, NM, NS, TW>;

@@ -291,12 +291,12 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
     [[maybe_unused]] unsigned long long st_staged = 0;          // STAGED: march iterations served from LDS strips (stats[13])
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // PROFILE only: cycles per section, summed over the wave's life
 
+    const int xcd = xcd_id();
+    int q_first = 0;
     for (;;) {
         unsigned int tile = 0;
-        if (lane == 0) tile = atomicAdd(A.tile_counter, 1u);
-        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (!next_tile(A, xcd, lane, q_first, tile)) break;
         const int64_t base = (int64_t)tile * A.tile_w;
-        if (base >= A.n) break;
         const int seg = SPLIT ? (lane >> A.tile_shift) : 0;              // which of the K consecutive steps this lane takes
         const int rl = SPLIT ? (lane & (A.tile_w - 1)) : lane;           // ray slot inside the tile (= owner id in the queues)
         const int K = SPLIT ? (64 >> A.tile_shift) : 1;

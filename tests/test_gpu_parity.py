@@ -527,6 +527,32 @@ def test_full_frame_properties():
     _close(depth[torch.from_numpy(pick).cuda()].cpu().numpy(), o_depth, "full-frame depth vs oracle", atol=5e-5)
 
 
+def test_xcd_tile_queues_are_bit_identical_and_xcds_are_visible():
+    """Round 3: with knob xcd = 1 a render launch keeps one tile queue per XCD (each XCD has its own L2; its waves then
+    work on ONE compact ray range and steal from the other chunks at the end).  Which wave renders a tile does not change the tile: knob xcd = 0 / 1 give the same bits, on the
+    full frame (all 8 queues + stealing), on a launch smaller than the resident waves, and on ragged sizes.  The kernels read the XCD id from
+    HW_REG_XCC_ID: ngf_debug_xcd_histogram must see all eight ids, evenly."""
+    from ngf_amd import _lib, synth
+    L = _lib.lib()
+    hist = torch.zeros(8, dtype=torch.int32, device="cuda")
+    _lib.check(L.ngf_debug_xcd_histogram(hist.data_ptr(), 256, torch.cuda.current_stream().cuda_stream))
+    h = hist.cpu().numpy()
+    assert h.sum() == 256 and (h > 0).all() and h.max() <= 2 * h.min(), h
+    g, params, step = big_case("triplane", "R1")
+    rays = torch.from_numpy(synth.lookat_rays(800, 800)).cuda()
+    for bake in (True, False):
+        f = field_for_case(g, params, None, bake=bake)
+        for n in (640000, 100003, 4096, 37):
+            with _lib.knobs(xcd=0):
+                a = f(rays[:n], N_samples=192, white_bg=True, iteration=30001)
+            with _lib.knobs(xcd=1):
+                b = f(rays[:n], N_samples=192, white_bg=True, iteration=30001)
+            c = f(rays[:n], N_samples=192, white_bg=True, iteration=30001)          # the launch code's own choice
+            assert torch.equal(a["rgb_map"], b["rgb_map"]) and torch.equal(a["depth_map"], b["depth_map"]), (bake, n)
+            assert torch.equal(a["rgb_map"], c["rgb_map"]) and torch.equal(a["depth_map"], c["depth_map"]), (bake, n)
+        f.release()
+
+
 def test_infoinv_full_frame_properties():
     """BASELINE config 3 at full size (InfoInv, 800x800, S=192, dense preset, infoinv=True): the size-independent properties of
     test_full_frame_properties + a strided oracle check, for the default kernel AND NGF_F_SPLIT_BF16 (VERDICT r2 missing #4)."""
