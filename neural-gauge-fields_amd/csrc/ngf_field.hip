@@ -1139,14 +1139,26 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
     t->chunk = d->chunk_samples > 0 ? d->chunk_samples : (int64_t)std::min<size_t>(cap, (size_t)9 << 20);
     if ((size_t)t->chunk > cap) t->chunk = (int64_t)((cap + 15) & ~(size_t)15);
     if (d->chunk_samples <= 0 && (size_t)t->chunk >= cap) t->chunk = (int64_t)((cap + 15) & ~(size_t)15);
-    const size_t ch = (size_t)t->chunk;
     if ((rc = tr_alloc(t, &T.xs, cap)) || (rc = tr_alloc(t, &T.w, cap)) || (rc = tr_alloc(t, &T.dx, cap)) || (rc = tr_alloc(t, &T.c, cap * 3)) ||
         (rc = tr_alloc(t, &T.dt, cap * 6)) || (rc = tr_alloc(t, &T.G, (size_t)d->max_rays * 3)) || (rc = tr_alloc(t, &T.count, (size_t)d->max_rays)) ||
         (rc = tr_alloc(t, &T.offset, (size_t)d->max_rays + 1)) || (rc = tr_alloc(t, &T.list, cap * 2)) || (rc = tr_alloc(t, &T.list_w, cap)) ||
-        (rc = tr_alloc(t, &T.F, ch * 144)) || (rc = tr_alloc(t, &T.V, ch * 16)) || (rc = tr_alloc(t, &T.H1, ch * 64)) || (rc = tr_alloc(t, &T.H2, ch * 64)) ||
-        (rc = tr_alloc(t, &T.D3, ch * 16)) || (rc = tr_alloc(t, &T.D2, ch * 64)) || (rc = tr_alloc(t, &T.D1, ch * 64)) ||
         (rc = tr_alloc(t, &t->fwd_image, (size_t)kFwdImage)) || (rc = tr_alloc(t, &t->bwd_image, (size_t)kBwdImage)))
         return bail(rc);
+    // The activation rows (432 floats per sample).  If the whole-batch default does not fit the free HBM, fall back to round 1's chunked
+    // mode (262 144 rows = 453 MB; the colour kernels then run chunk by chunk and the step reads the active count on the host) instead of
+    // failing the create -- an explicit chunk_samples is taken as asked.
+    for (int attempt = 0;; ++attempt) {
+        const size_t ch = (size_t)t->chunk, mark = t->allocs.size();
+        const int64_t bytes_mark = t->bytes;
+        if (!((rc = tr_alloc(t, &T.F, ch * 144)) || (rc = tr_alloc(t, &T.V, ch * 16)) || (rc = tr_alloc(t, &T.H1, ch * 64)) || (rc = tr_alloc(t, &T.H2, ch * 64)) ||
+              (rc = tr_alloc(t, &T.D3, ch * 16)) || (rc = tr_alloc(t, &T.D2, ch * 64)) || (rc = tr_alloc(t, &T.D1, ch * 64))))
+            break;
+        while (t->allocs.size() > mark) { (void)hipFree(t->allocs.back()); t->allocs.pop_back(); }
+        t->bytes = bytes_mark;
+        (void)hipGetLastError();
+        if (attempt > 0 || d->chunk_samples > 0 || ch <= ((size_t)1 << 18)) return bail(rc);
+        t->chunk = (int64_t)1 << 18;
+    }
     // the packed copies (their zero borders are written here and never again) and defined gradients before the first backward
     for (int p = 0; p < 3; ++p) {
         pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], d->plane_h[p], d->plane_w[p], 0, 16, t->tex_d[p]);

@@ -346,6 +346,8 @@ __device__ __forceinline__ void mlp_pass16_ii(const RenderArgs &A, const float *
 {
     using L = MlpLayout16<72>;
     blob = per_pass16(blob);
+    asm volatile("" : "+v"(lane));       // the lane-derived offsets (kq * 18, lane * 4, ...) are recomputed per pass: hoisted out of the persistent
+                                         // loops they lived in registers for the whole kernel and were what hipcc spilled (144 B of scratch per lane)
     const int kq = lane >> 4;
     const float *w1 = blob + L::W1 + lane;
     GatherRowII g;
@@ -564,6 +566,7 @@ struct InfoInvPolicyT {
         if constexpr (SPLIT) return infoinv_sigma_bf16(A, per_pass(smem) + RGB_FLOATS, valid, x, lane, t);
         using D = InfoInvDensLayout;
         const float *img = per_pass(smem) + RGB_FLOATS;
+        asm volatile("" : "+v"(lane));       // as in mlp_pass16_ii: lane-derived offsets are cheaper to recompute than to keep for the whole kernel
         const int hi = lane >> 5;
         // transform (Field.py:43-50): identity split
         t[0] = x[0]; t[1] = x[1]; t[2] = x[1]; t[3] = x[2]; t[4] = x[0]; t[5] = x[2];

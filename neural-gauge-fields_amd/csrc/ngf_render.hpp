@@ -35,7 +35,9 @@ namespace ngf {
 // the point of use.  RenderArgs holds nine Tex (63 dwords) next to 48 decoder weights: kept live across the march loop they overflow the
 // SGPR file and hipcc parks texture pointers in VGPR lanes -- ~38 v_readlane per march step on the vector pipe, which is the binding one
 // (measured: R1 frame 9.93 -> 9.82 ms, same bits).  REQUIRES the RenderArgs to be the kernel's first argument (offset 0 of the kernarg
-// segment): true for every kernel of this library (TrainArgs starts with its RenderArgs, static_assert in ngf_train.hpp).
+// segment): true for every kernel of this library (TrainArgs starts with its RenderArgs, static_assert in ngf_train.hpp), and CHECKED at
+// run time: alpha_kernel and the DBG instantiations of render_kernel (every test goes through them) trap when the descriptor read from the
+// kernarg segment is not the one in their `A`.
 __device__ __forceinline__ Tex karg_tex(size_t off)
 {
     typedef const __attribute__((address_space(4))) Tex *tptr_t;
@@ -273,6 +275,9 @@ template <typename P, bool SPLIT = false, bool DBG = true>
 __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs A)
 {
     static_assert(DBG || !P::PROFILE, "the section profile is a debug instantiation");
+    if constexpr (DBG) {       // karg_tex reads offset 0 of the kernel-argument segment: trap if a future kernel passes its RenderArgs elsewhere
+        if (karg_tex(offsetof(RenderArgs, dens)).p != A.dens[0].p) __builtin_trap();
+    }
     static_assert(!SPLIT || P::NSTEP == 1, "the split march is written for one step per lane per iteration");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     for (int i = threadIdx.x; i < A.blob_floats; i += blockDim.x) smem[i] = A.blob[i];
@@ -543,6 +548,7 @@ template <typename P>
 __global__ void __launch_bounds__(256) alpha_kernel(const RenderArgs A, const float *xyz, const Lattice L, int64_t n, float length, float *alpha)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (karg_tex(offsetof(RenderArgs, dens)).p != A.dens[0].p) __builtin_trap();      // the RenderArgs must be the first kernel argument (karg_tex)
     if constexpr (P::INFOINV) {
         for (int i = threadIdx.x; i < A.blob_floats; i += blockDim.x) smem[i] = A.blob[i];
         __syncthreads();
