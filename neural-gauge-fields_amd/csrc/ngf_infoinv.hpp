@@ -239,6 +239,7 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
     float left[4];                             // inputs of a plane that did not fill a k-block yet
 #ifdef NGF_EXP_DUMP
     float fh[3];                               // hash of the plane's 18 features (after the positional factors)
+    float xfrag[3];                            // hashes of the hi / mid / lo bf16 fragments of k-block 0, read back after its MFMAs
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -285,7 +286,29 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
 #endif
         // inputs so far: 18 p + the 2 p leftovers of the planes before; whole k-blocks go to the matrix pipe now
         if (p == 0) {
+#ifdef NGF_EXP_DUMP
+            const Split8 x0 = split8(f);
+            kblock_ii(w1 + 0 * KB_STRIDE, lo0, x0, acc);
+            {   // the B fragments as the MFMAs saw them (read back AFTER the k-block)
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 xh = __builtin_bit_cast(u32x4, x0.h), xm = __builtin_bit_cast(u32x4, x0.m), xl = __builtin_bit_cast(u32x4, x0.l);
+                unsigned hsh = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hsh = (hsh * 31u) ^ xh[i];
+                xfrag[0] = __uint_as_float(hsh & 0x3fffffffu);
+                hsh = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hsh = (hsh * 31u) ^ xm[i];
+                xfrag[1] = __uint_as_float(hsh & 0x3fffffffu);
+                hsh = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hsh = (hsh * 31u) ^ xl[i];
+                xfrag[2] = __uint_as_float(hsh & 0x3fffffffu);
+            }
+            lo_load_ii(A.basis_pack, 2, lane, lo0);  __builtin_amdgcn_sched_barrier(0);
+#else
             kblock_ii(w1 + 0 * KB_STRIDE, lo0, split8(f), acc);      lo_load_ii(A.basis_pack, 2, lane, lo0);  __builtin_amdgcn_sched_barrier(0);
+#endif
             kblock_ii(w1 + 1 * KB_STRIDE, lo1, split8(f + 8), acc);  lo_load_ii(A.basis_pack, 3, lane, lo1);  __builtin_amdgcn_sched_barrier(0);
             left[0] = f[16]; left[1] = f[17];
         } else if (p == 1) {
@@ -331,6 +354,7 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
         for (int k = 0; k < 16; ++k) { row[9 + k] = acc[k >> 2][k & 3]; row[25 + k] = c[k >> 2][k & 3]; }
         row[41] = rgb[0]; row[42] = rgb[1]; row[43] = rgb[2];
         row[44] = bs[0]; row[45] = bs[1]; row[46] = bs[2]; row[47] = bc[0]; row[48] = bc[1]; row[49] = bc[2];
+        row[50] = xfrag[0]; row[51] = xfrag[1]; row[52] = xfrag[2];
     }
 #endif
 }

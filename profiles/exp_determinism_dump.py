@@ -50,13 +50,13 @@ for it in range(1, 400):
     bad_rays = np.nonzero((rgb != rgb0).any(1))[0].tolist()
     t1 = table(rows)
     print(f"launch {it}: rays {bad_rays} differ; passes {rows.shape[0]}; keys only in one dump: {len(set(t0) ^ set(t1))}")
-    names = ["lane", "owner", "w", "x", "y", "z", "feat0", "feat1", "feat2"] + [f"acc{k}" for k in range(16)] + [f"c{k}" for k in range(16)] + ["r", "g", "b", "bs0", "bs1", "bs2", "bc0", "bc1", "bc2"]
+    names = ["lane", "owner", "w", "x", "y", "z", "feat0", "feat1", "feat2"] + [f"acc{k}" for k in range(16)] + [f"c{k}" for k in range(16)] + ["r", "g", "b", "bs0", "bs1", "bs2", "bc0", "bc1", "bc2", "xfrag_hi", "xfrag_mid", "xfrag_lo"]
     shown = 0
     for key in t0:
         if key not in t1:
             continue
         a, b = t0[key][0], t1[key][0]
-        cols = [k for k in range(2, 50) if a[k].tobytes() != b[k].tobytes()]
+        cols = [k for k in range(2, 53) if a[k].tobytes() != b[k].tobytes()]
         if cols and shown < 6:
             shown += 1
             grp = sorted({names[k].rstrip("0123456789") for k in cols})

@@ -103,6 +103,63 @@ __device__ __forceinline__ float reference2(float a0, float a1, float b0, float 
     return t;
 }
 
+// pattern 3: WRITE after write.  A packed op writes v[14:15]; DIST single instructions later an un-packed v_mov writes v14 / v15 again
+// (the compiler's code reuses the packed chain's temporaries as the bf16 fragment registers of the next split).  The final value must be the
+// v_mov's.  Neighbour waves (odd wave ids) keep the matrix pipe busy.
+template <int DIST>
+__device__ __forceinline__ void waw(float a0, float a1, float b0, float b1, float x0, float x1, float &r0, float &r1)
+{
+    if constexpr (DIST == 0)
+        asm volatile("v_mov_b32 v10, %2\n\tv_mov_b32 v11, %3\n\tv_mov_b32 v12, %4\n\tv_mov_b32 v13, %5\n\t"
+                     "v_pk_mul_f32 v[14:15], v[10:11], v[12:13]\n\t"
+                     "v_pk_add_f32 v[14:15], v[14:15], v[12:13] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                     "v_mov_b32 v14, %6\n\tv_mov_b32 v15, %7\n\t"
+                     "s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\t"
+                     "v_mov_b32 %0, v14\n\tv_mov_b32 %1, v15\n\t"
+                     : "=v"(r0), "=v"(r1) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(x0), "v"(x1) : "v10", "v11", "v12", "v13", "v14", "v15");
+    else
+        asm volatile("v_mov_b32 v10, %2\n\tv_mov_b32 v11, %3\n\tv_mov_b32 v12, %4\n\tv_mov_b32 v13, %5\n\t"
+                     "v_pk_mul_f32 v[14:15], v[10:11], v[12:13]\n\t"
+                     "v_pk_add_f32 v[14:15], v[14:15], v[12:13] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                     "v_add_f32 v16, v10, v11\n\tv_add_f32 v17, v12, v13\n\tv_mul_f32 v16, v16, v17\n\tv_add_f32 v17, v16, v10\n\t"
+                     "v_cvt_pk_bf16_f32 v14, %6, %7\n\tv_cvt_pk_bf16_f32 v15, %7, %6\n\t"
+                     "s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\t"
+                     "v_mov_b32 %0, v14\n\tv_mov_b32 %1, v15\n\t"
+                     : "=v"(r0), "=v"(r1) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(x0), "v"(x1) : "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17");
+}
+
+template <int DIST>
+__global__ void __launch_bounds__(512) k3(unsigned long long *bad, int iters, int neighbour)
+{
+    const int wave = threadIdx.x >> 6;
+    unsigned long long mism = 0;
+    if (neighbour && (wave & 1)) {
+        f32x4 c = {0, 0, 0, 0};
+        bf16x8 a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {8, 7, 6, 5, 4, 3, 2, 1};
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+        }
+        if (c[0] == 123.456f) bad[1] = 1;
+        return;
+    }
+    float x = 0.37f + 1e-3f * threadIdx.x + 1e-5f * blockIdx.x, y = 0.91f - 7e-4f * threadIdx.x;
+    for (int i = 0; i < iters; ++i) {
+        float r0, r1;
+        const float x0 = x * 3.0f + 1.0f, x1 = y * 5.0f - 2.0f;
+        waw<DIST>(x, y, y * 0.5f + 0.1f, x * 0.25f + 0.3f, x0, x1, r0, r1);
+        unsigned e0 = __float_as_uint(x0), e1 = __float_as_uint(x1);
+        if (DIST) {       // expected: the two v_cvt_pk_bf16_f32 results
+            const unsigned h0 = __float_as_uint((float)(__bf16)x0) >> 16, h1 = __float_as_uint((float)(__bf16)x1) >> 16;
+            e0 = h0 | (h1 << 16); e1 = h1 | (h0 << 16);
+        }
+        if (__float_as_uint(r0) != e0 || __float_as_uint(r1) != e1) ++mism;
+        x = x * 0.999f + 1e-4f * (i & 7); y = y * 1.0003f - 2e-4f * (i & 3);
+        if (y > 4.0f) y -= 3.0f;
+    }
+    if (mism) atomicAdd(bad, mism);
+}
+
 template <int GAP>
 __global__ void __launch_bounds__(512) k2(unsigned long long *bad, int iters)
 {
@@ -180,5 +237,17 @@ int main()
         printf("pattern 2 (own bf16 MFMAs, v_pk_mov_b32)    gap after packed ops: %s -> %llu mismatching results of %.3g\n", gap ? "s_nop 1" : "none   ", h[0],
                1024.0 * 512 * iters);
     }
+    for (int neighbour = 0; neighbour < 2; ++neighbour)
+        for (int dist = 0; dist < 2; ++dist) {
+            (void)hipMemset(bad, 0, 16);
+            const int iters = 200000;
+            if (dist == 0) k3<0><<<1024, 512>>>(bad, iters, neighbour);
+            else k3<1><<<1024, 512>>>(bad, iters, neighbour);
+            (void)hipDeviceSynchronize();
+            unsigned long long h[2];
+            (void)hipMemcpy(h, bad, 16, hipMemcpyDeviceToHost);
+            printf("pattern 3 (write after a packed write, %s, neighbour %s) -> %llu wrong final values of %.3g\n", dist ? "v_cvt_pk_bf16_f32 4 instructions later" : "v_mov right behind",
+                   neighbour ? "bf16 MFMA loop" : "same chain", h[0], 1024.0 * (neighbour ? 256 : 512) * iters);
+        }
     return 0;
 }
