@@ -615,10 +615,17 @@ struct InfoInvPolicyT {
                 const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + (size_t)b.idx * 24);
                 const f32x4 *q01 = q00 + (size_t)tx.stride * 6;
 #pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    f32x4 v00 = q00[q], v10 = q00[6 + q], v01 = q01[q], v11 = q01[6 + q];
+                for (int half = 0; half < 2; ++half) {      // twelve channels at a time: 48 instead of 96 registers of taps in flight (the fp32 kernel
+                                                            // runs at the 168 registers of twelve waves per CU; the wider form was what it spilled for)
+                    f32x4 v00[3], v10[3], v01[3], v11[3];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) feat[4 * q + e] = bil_mix(b, v00[e], v10[e], v01[e], v11[e]);
+                    for (int j = 0; j < 3; ++j) { const int q = 3 * half + j; v00[j] = q00[q]; v10[j] = q00[6 + q]; v01[j] = q01[q]; v11[j] = q01[6 + q]; }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) feat[4 * (3 * half + j) + e] = bil_mix(b, v00[j][e], v10[j][e], v01[j][e], v11[j][e]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (A.mode) {
 #pragma unroll
