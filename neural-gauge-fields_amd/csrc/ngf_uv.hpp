@@ -53,7 +53,16 @@ struct UvArgs {
     int32_t geo_qh, t1_qh, t2_q0, t2_qh;
 };
 
-__device__ __forceinline__ float act_fn(float x, float slope) { return fmaxf(x, 0.0f) + slope * fminf(x, 0.0f); }
+// Activations of the three MLPs.  ReLU (geometry, gauge: decoder.py:205-215, gauge_fields.py:20-33) as ONE integer maximum of the bit
+// pattern with 0 (ngf_shade16.hpp relu1); LeakyReLU(0.2) (texture, decoder.py:20-45) as max(x, 0.2 x): x for x >= 0, the single product
+// 0.2 x below -- the same bits as `x >= 0 ? x : 0.2 x`.  Round 2's generic `fmaxf(x,0) + slope * fminf(x,0)` cost five instructions per
+// value (640 per 256-unit layer and pass, ~4 % of the launch) because IEEE rules keep the compiler from folding the zero slope.
+template <int LEAKY>
+__device__ __forceinline__ float act_fn(float x)
+{
+    if constexpr (LEAKY) return fmaxf(x, 0.2f * x);
+    else return __int_as_float(max(__float_as_int(x), 0));
+}
 
 // ---- texture editing: TextureMlpDecoder.forward with cubemap_ set (decoder.py:79-121) -------------------------------------
 // F.grid_sample(texture [H,W,C] as [1,C,H,W], (u,v), bilinear, padding_mode='border', align_corners=False) for one point
@@ -357,15 +366,15 @@ __device__ __forceinline__ void dense256(const UvArgs &A, const float *w, const 
     else dense<16, NS>(w, bias, KT4, lane, act, out);
 }
 
-template <int NT, int NS>
-__device__ __forceinline__ void store_act(float *act, int lane, const f32x4 acc[NS][NT], float slope)
+template <int NT, int NS, int LEAKY>
+__device__ __forceinline__ void store_act(float *act, int lane, const f32x4 acc[NS][NT])
 {
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) act[s * kUvWaveLds + (mt * 4 + r) * 64 + lane] = act_fn(acc[s][mt][r], slope);
+            for (int r = 0; r < 4; ++r) act[s * kUvWaveLds + (mt * 4 + r) * 64 + lane] = act_fn<LEAKY>(acc[s][mt][r]);
 }
 
 // output layer with <= 3 units: packed [t][64 lanes] (rows >= n_out are zero); rows 0..3 land in lanes kq = 0
@@ -428,11 +437,11 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     // geometry: 63 -> 256 -> (10x) 256 -> 1, ReLU
     store_pe<3, 10, NS>(act, 0, 16, lane, p);
     dense<16, NS>(W + A.geo_w0, W + A.geo_b0, 16, lane, act, x);
-    store_act<16, NS>(act, lane, x, 0.0f);
+    store_act<16, NS, 0>(act, lane, x);
 #pragma unroll 1
     for (int l = 0; l < 10; ++l) {
         dense256<NS, SPLIT>(A, W + A.geo_wh + (size_t)l * 65536, W + A.geo_qh + (size_t)l * kUvQLayer, W + A.geo_bh + l * 256, 64, lane, act, x);
-        store_act<16, NS>(act, lane, x, 0.0f);
+        store_act<16, NS, 0>(act, lane, x);
     }
     {
         f32x4 o[NS];
@@ -446,13 +455,13 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
         f32x4 g4[NS][4], g[NS][8];
         store_pe<3, 10, NS>(act, 0, 16, lane, p);
         dense<4, NS>(W + A.ga_w0, W + A.ga_b0, 16, lane, act, g4);
-        store_act<4, NS>(act, lane, g4, 0.0f);
+        store_act<4, NS, 0>(act, lane, g4);
         dense<8, NS>(W + A.ga_w1, W + A.ga_b1, 16, lane, act, g);
-        store_act<8, NS>(act, lane, g, 0.0f);
+        store_act<8, NS, 0>(act, lane, g);
         dense<8, NS>(W + A.ga_w2, W + A.ga_b2, 32, lane, act, g);
-        store_act<8, NS>(act, lane, g, 0.0f);
+        store_act<8, NS, 0>(act, lane, g);
         dense<8, NS>(W + A.ga_w3, W + A.ga_b3, 32, lane, act, g);
-        store_act<8, NS>(act, lane, g, 0.0f);
+        store_act<8, NS, 0>(act, lane, g);
         f32x4 q[NS];
         dense_out<NS>(W + A.ga_wo, W + A.ga_bo, 32, lane, act, q);
 #pragma unroll
@@ -474,11 +483,11 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
         store_pe<2, 10, NS>(act, 0, 12, lane, uv);
         dense<16, NS>(W + A.t1_w0, W + A.t1_b0, 12, lane, act, x);
     }
-    store_act<16, NS>(act, lane, x, 0.2f);
+    store_act<16, NS, 1>(act, lane, x);
 #pragma unroll 1
     for (int l = 0; l < 5; ++l) {
         dense256<NS, SPLIT>(A, W + A.t1_wh + (size_t)l * 65536, W + A.t1_qh + (size_t)l * kUvQLayer, W + A.t1_bh + l * 256, 64, lane, act, x);
-        store_act<16, NS>(act, lane, x, 0.2f);
+        store_act<16, NS, 1>(act, lane, x);
     }
     // act[0..63] = block1 output h; color1 and block2 both read it
     f32x4 c1[NS], c2[NS];
@@ -486,11 +495,11 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     // block2: [h(256), v(3), PE6(v)(36)] -> 256 -> (3x) 256 -> 3
     store_pe<3, 6, NS>(act, 64, 12, lane, v);                 // 39 inputs + zero padding up to k-step 76
     dense256<NS, SPLIT>(A, W + A.t2_w0, W + A.t2_q0, W + A.t2_b0, 76, lane, act, x);            // 76 k-steps -> 10 k-blocks in split mode (act rows 76..79 are zero)
-    store_act<16, NS>(act, lane, x, 0.2f);
+    store_act<16, NS, 1>(act, lane, x);
 #pragma unroll 1
     for (int l = 0; l < 3; ++l) {
         dense256<NS, SPLIT>(A, W + A.t2_wh + (size_t)l * 65536, W + A.t2_qh + (size_t)l * kUvQLayer, W + A.t2_bh + l * 256, 64, lane, act, x);
-        store_act<16, NS>(act, lane, x, 0.2f);
+        store_act<16, NS, 1>(act, lane, x);
     }
     dense_out<NS>(W + A.t2_wo, W + A.t2_bo, 64, lane, act, c2);
 #pragma unroll
