@@ -308,6 +308,8 @@ def main():
 
     if args.knobs:
         from ngf_amd import _lib
+        if any(kv.split("=")[0].strip() in ("waves", "nstep", "profile", "kernel", "stage") for kv in args.knobs.split(",")):
+            _lib._LIB = _lib._load(_lib.SO_PATH_EXP)          # these knobs select experiment kernels (libngf_hip_exp.so)
         for kv in args.knobs.split(","):
             k_, v_ = kv.split("=")
             _lib.check(_lib.lib().ngf_debug_set(k_.strip().encode(), int(v_)))

@@ -9,7 +9,9 @@ import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SO_PATH = os.path.join(_CSRC, "libngf_hip.so")
+SO_PATH_EXP = os.path.join(_CSRC, "libngf_hip_exp.so")      # the same + the experiment kernels (csrc/Makefile): tests / profiles scripts only
 _LIB = None
+_LIBS = {}                                                    # path -> loaded library
 
 MODEL_TRIPLANE, MODEL_INFOINV = 0, 1
 F_BAKE_DENSITY = 1
@@ -53,18 +55,25 @@ UV_F_SPLIT_BF16 = 1
 
 def build(force: bool = False) -> str:
     """Compile libngf_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    args = ["make", "-j4", "-C", _CSRC, "libngf_hip.so"] + (["-B"] if force else [])
+    args = ["make", "-j4", "-C", _CSRC, "all"] + (["-B"] if force else [])
     subprocess.check_call(args, stdout=subprocess.DEVNULL)
     return SO_PATH
 
 
 def lib():
+    """The library every call of the package goes through: libngf_hip.so, or -- inside ``with library("exp")`` -- libngf_hip_exp.so."""
     global _LIB
     if _LIB is None:
-        if not os.path.exists(SO_PATH):
-            raise RuntimeError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        _LIB = _load(SO_PATH)
+    return _LIB
+
+
+def _load(path):
+    if path not in _LIBS:
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(the HIP extension is the only render path; there is no CPU fallback)")
-        L = C.CDLL(SO_PATH)
+        L = C.CDLL(path)
         L.ngf_last_error.restype = C.c_char_p
         L.ngf_abi_version.restype = C.c_int
         L.ngf_field_bytes.restype = C.c_int64
@@ -109,8 +118,28 @@ def lib():
         L.ngf_debug_xcd_histogram.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         if L.ngf_abi_version() != 2 or L.ngf_sizeof_field_desc() != C.sizeof(FieldDesc):
             raise RuntimeError("libngf_hip.so ABI mismatch (version or ngf_field_desc layout)")
-        _LIB = L
-    return _LIB
+        _LIBS[path] = L
+    return _LIBS[path]
+
+
+class library:
+    """``with _lib.library("exp"): ...`` -- route the package through libngf_hip_exp.so (the product kernels + the experiment kernels:
+    knobs kernel / stage / profile / nstep / waves) for the duration of the block.  The two libraries are separate images with separate
+    knob state: handles created inside the block must be used and released inside it.  Tests and profiles/ scripts only."""
+
+    def __init__(self, which="exp"):
+        self.path = SO_PATH_EXP if which == "exp" else SO_PATH
+
+    def __enter__(self):
+        global _LIB
+        self.prev = _LIB
+        _LIB = _load(self.path)
+        return _LIB
+
+    def __exit__(self, *exc):
+        global _LIB
+        _LIB = self.prev
+        return False
 
 
 def check(rc: int):
@@ -144,6 +173,9 @@ def knobs_from_env():
     """Opt-in for the experiment scripts under profiles/: map NGF_TILE_W / NGF_SPLIT / NGF_WAVES / NGF_NSTEP / NGF_PROFILE /
     NGF_ABLATE / NGF_UV_TILES / NGF_KERNEL / NGF_STAGE of the environment to ngf_debug_set calls (unset -> library default).
     Nothing in the product path calls this."""
+    global _LIB
+    if any(os.environ.get("NGF_" + k.upper()) not in (None, "", "-1") for k in ("waves", "nstep", "profile", "kernel", "stage")):
+        _LIB = _load(SO_PATH_EXP)          # these knobs select experiment kernels: the whole script runs on libngf_hip_exp.so
     L = lib()
     for k in ("tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage", "xcd", "grid"):
         v = os.environ.get("NGF_" + k.upper())

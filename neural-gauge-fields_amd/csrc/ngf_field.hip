@@ -8,8 +8,12 @@
 #include "ngf_host.hpp"
 #include "ngf_infoinv.hpp"
 #include "ngf_render.hpp"
+#ifdef NGF_EXPERIMENTS      // libngf_hip_exp.so only (make: second target): kernels that were built, measured and lost -- specialised march / shade
+                            // waves, LDS-staged texture strips -- and the tuning variants (8 / 16 waves, two steps per lane, section profile).  The
+                            // product library carries only kernels that can be the default; the experiment tests load the other one.
 #include "ngf_render_pc.hpp"
 #include "ngf_stage.hpp"
+#endif
 #include "ngf_train.hpp"
 
 using namespace ngf;
@@ -733,6 +737,7 @@ static int launch_policy(const ngf_field *f, RenderArgs &A, hipStream_t st)
     else return launch_render<KP>(render_kernel<P, false>, nullptr, nullptr, f, A, P::WAVES * kWave, lds, st, wide);
 }
 
+#ifdef NGF_EXPERIMENTS
 // Specialised march / shade waves (ngf_render_pc.hpp): NM march waves + NS shade waves per CU.
 template <typename P, int NM, int NS, int TW>
 static int launch_pc(const ngf_field *f, RenderArgs &A, hipStream_t st)
@@ -756,10 +761,17 @@ static int launch_pc(const ngf_field *f, RenderArgs &A, hipStream_t st)
     HIP_TRY(hipGetLastError());
     return NGF_OK;
 }
+#endif
 
 template <bool BD, bool BC>
 static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
+#ifndef NGF_EXPERIMENTS
+    // product library: the fused kernel, twelve waves per CU, one march step per lane (measured best, profiles/r01_sweep.txt)
+    if (knob(KNOB_KERNEL) > 0 || knob(KNOB_STAGE) > 0 || knob(KNOB_PROFILE) > 0 || knob(KNOB_NSTEP) > 1 || (knob(KNOB_WAVES) >= 0 && knob(KNOB_WAVES) != 12))
+        return fail(NGF_E_UNSUPPORTED, "knobs kernel / stage / profile / nstep / waves select experiment kernels: load libngf_hip_exp.so (built with -DNGF_EXPERIMENTS)");
+    return launch_policy<TriPlanePolicy<BD, BC, 12, 1>>(f, A, st);
+#else
     // default: the fused kernel (every wave marches and shades).  ngf_debug_set("kernel", 1) selects the specialised march / shade
     // waves of ngf_render_pc.hpp: bit-identical, but SLOWER on gfx950 (R1 frame 10.7-12.7 ms vs 10.0 ms, profiles/r02_pc_kernel.txt),
     // because fp32 MFMA and fp32 VALU execute on the same SIMD datapath and never overlap -- not across waves, not within a wave
@@ -810,6 +822,7 @@ static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
     case 16: return launch_policy<TriPlanePolicy<BD, BC, 16, 1>>(f, A, st);
     default: return fail(NGF_E_ARG, "knob waves must be 8, 12 or 16");
     }
+#endif
 }
 
 static int render_common(const ngf_field *f, RenderArgs &A, hipStream_t st)
@@ -827,8 +840,10 @@ static int render_common(const ngf_field *f, RenderArgs &A, hipStream_t st)
         if (knob(KNOB_TILE_W) > 8 || knob(KNOB_SPLIT) == 0) return fail(NGF_E_ARG, "NGF_F_SPLIT_BF16 renders with split tiles of 4 or 8 rays");
         // 8 waves per CU: the pass keeps 48 registers of A fragments next to the gather buffer -- at the 168 registers that 12 waves
         // leave it spills 84 and runs 12.8 ms instead of 8.4 ms (profiles/r02_split_bf16.txt)
+#ifdef NGF_EXPERIMENTS
         if (knob(KNOB_WAVES) == 12)
             return (f->flags & NGF_F_BAKE_DENSITY) ? launch_policy<TriPlaneBf16Policy<true, 12>>(f, A, st) : launch_policy<TriPlaneBf16Policy<false, 12>>(f, A, st);
+#endif
         return (f->flags & NGF_F_BAKE_DENSITY) ? launch_policy<TriPlaneBf16Policy<true, 8>>(f, A, st) : launch_policy<TriPlaneBf16Policy<false, 8>>(f, A, st);
     }
     const bool bd = f->flags & NGF_F_BAKE_DENSITY, bc = f->flags & NGF_F_BAKE_COLOR;

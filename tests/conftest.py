@@ -18,7 +18,7 @@ def pytest_sessionstart(session):
     import ngf_amd  # noqa: F401
     from ngf_amd import _lib
     from oracle import oracle
-    if not os.path.exists(_lib.SO_PATH):
+    if not (os.path.exists(_lib.SO_PATH) and os.path.exists(_lib.SO_PATH_EXP)):
         _lib.build()
     if not os.path.exists(os.path.join(ROOT, "oracle", "libngf_oracle.so")):
         oracle.build()

@@ -25,6 +25,10 @@ def test_library_exports_every_declared_symbol():
     assert L.ngf_abi_version() == 2
     import ctypes as C
     assert L.ngf_sizeof_field_desc() == C.sizeof(_lib.FieldDesc)
+    # the experiment library (product kernels + the experiment kernels; tests and profiles/ only) exports the same ABI
+    with _lib.library("exp") as X:
+        assert X is not L and all(hasattr(X, s) for s in declared) and X.ngf_abi_version() == 2
+    assert _lib.lib() is L
 
 
 def test_error_path_without_gpu():

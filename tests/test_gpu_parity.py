@@ -205,9 +205,13 @@ def test_split_bf16_colour_mlp_keeps_fp32_accuracy(name, bake_density):
         c = fs(rays[:n], N_samples=S, white_bg=white, **kw)
         assert torch.equal(c["rgb_map"], a["rgb_map"][:n])
     # the 12-waves-per-CU form of the pass (taps in two rows, fragments two tiles at a time: mlp_pass16_bf16_rows) is the same arithmetic
-    from ngf_amd._lib import knobs
-    with knobs(waves=12):
-        a12 = fs(rays, N_samples=S, white_bg=white, **kw)
+    # (an experiment kernel: libngf_hip_exp.so, its own handle)
+    from ngf_amd import _lib
+    with _lib.library("exp"):
+        fs12 = field_for_case(g, params, mask, bake=bake_density, split_bf16=True)
+        with _lib.knobs(waves=12):
+            a12 = fs12(rays, N_samples=S, white_bg=white, **kw)
+        fs12.release()
     assert torch.equal(a12["rgb_map"], a["rgb_map"]) and torch.equal(a12["depth_map"], a["depth_map"])
     # the colour stage alone, per sample
     from ngf_amd import synth
@@ -253,6 +257,13 @@ def test_no_fold_level0_matches_reference(name):
 
 @pytest.mark.parametrize("name", ["triplane_r1_gauge", "triplane_r2_nogauge", "triplane_r1_mask"])
 def test_lds_staged_strips_are_bit_identical(name):
+    """(runs on libngf_hip_exp.so: the product library carries only kernels that can be the default, csrc/Makefile)"""
+    from ngf_amd import _lib
+    with _lib.library("exp"):
+        _test_lds_staged_strips_are_bit_identical_impl(name)
+
+
+def _test_lds_staged_strips_are_bit_identical_impl(name):
     """The LDS-staged texture variant (csrc/ngf_stage.hpp, knob stage = 1): gauge strips (gauge on) / density strips (gauge off,
     8 waves per CU) are loaded once per tile iteration into LDS and tapped from there; the arithmetic on the fetched values is
     unchanged, so the pixels are the gather kernel's bit for bit, whether an iteration's rectangle fits the strip or falls back."""
@@ -273,7 +284,15 @@ def test_lds_staged_strips_are_bit_identical(name):
 @pytest.mark.parametrize("bake", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", TRIPLANE)
 def test_specialised_kernel_is_bit_identical(name, bake):
-    """The default TriPlane kernel splits the waves of a CU into march waves and shade waves (csrc/ngf_render_pc.hpp: LDS record
+    """(runs on libngf_hip_exp.so: the product library carries only kernels that can be the default, csrc/Makefile)"""
+    from ngf_amd import _lib
+    with _lib.library("exp"):
+        _test_specialised_kernel_is_bit_identical_impl(name, bake)
+
+
+def _test_specialised_kernel_is_bit_identical_impl(name, bake):
+    """The specialised variant (knob kernel = 1; NOT the default: it is bit-identical and slower) splits the waves of a CU
+    into march waves and shade waves (csrc/ngf_render_pc.hpp: LDS record
     queues, ray-major lanes with a DPP chain, per-ray colour sums in record order).  Every ray sees the arithmetic of the fused
     kernel in the same order, so the pixels are the fused kernel's bit for bit -- for both tile widths, ragged batches and
     S = 45 (not a multiple of any lanes-per-ray count)."""
@@ -299,6 +318,13 @@ def test_specialised_kernel_is_bit_identical(name, bake):
 
 
 def test_specialised_kernel_full_frame_bit_identical():
+    """(runs on libngf_hip_exp.so: the product library carries only kernels that can be the default, csrc/Makefile)"""
+    from ngf_amd import _lib
+    with _lib.library("exp"):
+        _test_specialised_kernel_full_frame_bit_identical_impl()
+
+
+def _test_specialised_kernel_full_frame_bit_identical_impl():
     """The same on the headline frame (640 000 rays, S = 192, R1 and the MLP-stress preset R2) and on an 80 000-ray shard."""
     from ngf_amd._lib import knobs
     from ngf_amd import rays as nrays, synth
