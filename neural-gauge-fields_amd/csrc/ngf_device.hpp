@@ -100,6 +100,8 @@ struct Bil {
     int32_t idx;                 // padded texel index of the (x0,y0) tap; +1, +stride, +stride+1 are the others
     int32_t cx, cy;              // the same tap as padded (column, row); only the LDS-staged variant reads them
     float w00, w10, w01, w11;    // (1-fx)(1-fy), fx(1-fy), (1-fx)fy, fx*fy ; all 0 when the cell is out of range
+    float wx1, wy1;              // the fractional parts the weights are made of, and whether the cell is in range: what a 12-float queue record
+    int32_t in;                  // carries per plane (bil_from_rec rebuilds the four weights with the same operations)
 };
 
 __device__ __forceinline__ Bil bil_setup(float u, float v, const Tex &t)
@@ -118,9 +120,10 @@ __device__ __forceinline__ Bil bil_setup(float u, float v, const Tex &t)
     float cx = fminf(fmaxf(fx, -1.0f), t.fw);
     float cy = fminf(fmaxf(fy, -1.0f), t.fh);
     bool in = (cx == fx) & (cy == fy);
+    Bil b;
+    b.wx1 = wx1; b.wy1 = wy1; b.in = in ? 1 : 0;
     wx0 = in ? wx0 : 0.0f;
     wx1 = in ? wx1 : 0.0f;
-    Bil b;
     b.cx = (int)cx + 1;
     b.cy = (int)cy + 1;
     b.idx = (int)__umul24((unsigned)b.cy, (unsigned)t.stride) + b.cx;      // both factors < 2^24: the full-rate 24-bit multiply
@@ -139,6 +142,30 @@ __device__ __forceinline__ const T *tex_at(const float *base, uint32_t float_ind
 {
     return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(uint32_t)(float_index * 4u));
 }
+
+// The cell of a queued sample from what its 12-float record carries (texel index, fractional parts, in-range bit): the four weights by the very
+// operations of bil_setup (1 - wx1, the two selects, four products), so they are its bits -- 8 instructions instead of ~28 per plane.
+__device__ __forceinline__ Bil bil_from_rec(int32_t idx, float wx1, float wy1, bool in)
+{
+    Bil b;
+    b.idx = idx; b.cx = 0; b.cy = 0; b.wx1 = wx1; b.wy1 = wy1; b.in = in ? 1 : 0;
+    float wx0 = 1.0f - wx1;
+    const float wy0 = 1.0f - wy1;
+    wx0 = in ? wx0 : 0.0f;
+    wx1 = in ? wx1 : 0.0f;
+    b.w00 = wx0 * wy0;
+    b.w10 = wx1 * wy0;
+    b.w01 = wx0 * wy1;
+    b.w11 = wx1 * wy1;
+    return b;
+}
+
+// the raw cell data of a 12-float queue record (three planes): the weights are rebuilt plane by plane, right before that plane's gather
+struct RecCells {
+    int32_t idx[3];
+    float wx1[3], wy1[3];
+    int32_t bits;                // in-range flag of plane p in bit 8 + p (bits 0..7: the owner ray's slot)
+};
 
 __device__ __forceinline__ float bil_mix(const Bil &b, float v00, float v10, float v01, float v11)
 {

@@ -574,6 +574,7 @@ struct InfoInvPolicyT {
     static constexpr int WAVES = (SPLIT || WIDE) ? kInfoInvSplitWaves : kInfoInvWaves;        // 8 (split: 247 registers; wide tiles: LDS) / 12
     static constexpr bool PROFILE = false;
     static constexpr bool PROD = !WIDE;                           // has a production (DBG = false) instantiation of the split kernel
+    static constexpr bool REC12 = false;
     static constexpr bool VLDS = true;
     static constexpr bool VIEW_FOLD = false;
     static constexpr bool STAGED = false;

@@ -116,14 +116,17 @@ __device__ __forceinline__ void pe_ladder(float x, float sn[F], float cs[F])
 }
 
 // ---- TriPlane density at the gauge-shifted coordinates ------------------------------------------
+// cells: if not null, the three bilinear cells of the fetch (the colour fetch of an active sample uses the same ones: same coordinates, plane of the
+// same size -- they travel in the 12-float queue record, REC12)
 template <bool BAKED>
-__device__ __forceinline__ float triplane_density_feature(const RenderArgs &A, const float t[6])
+__device__ __forceinline__ float triplane_density_feature(const RenderArgs &A, const float t[6], Bil *cells = nullptr)
 {
     float f = 0.0f;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const Tex tx = karg_tex(offsetof(RenderArgs, dens) + p * sizeof(Tex));
         Bil b = bil_setup(t[2 * p], t[2 * p + 1], tx);
+        if (cells) cells[p] = b;
         if (BAKED) {
             const float *q = tex_at<float>(tx.p, (uint32_t)b.idx), *q1 = tex_at<float>(tx.p, (uint32_t)(b.idx + tx.stride));
             f += bil_mix(b, q[0], q[1], q1[0], q1[1]);
@@ -199,14 +202,18 @@ struct TriPlanePolicy {
     static constexpr bool VLDS = WAVES_ <= 12;                  // per-ray view inputs cached in LDS (4 KB / wave) or recomputed per pass
     static constexpr int VFEAT_FLOATS = VLDS ? kWave * kViewFeat : 0;       // view inputs of up to 64 rays (+ the per-ray fold table of small tiles)
     static constexpr int RING = NSTEP_ == 1 ? 128 : 256;        // >= BATCH-1 + 64*NSTEP records
-    __device__ static __forceinline__ float sigma(const RenderArgs &A, const float *, bool valid, const float x[3], int, float t[6])
+    // REC12 (split kernel of the default twelve-wave policies): a queue record carries the sample's three bilinear cells (texel index, fractional
+    // parts, in-range bit) instead of its six coordinates, so a shade pass starts its gathers at once and spends 8 instead of ~28 instructions per
+    // plane on the cell -- all 64 lanes of a pass used to redo the three setups of their 16 samples that the march had already done.
+    static constexpr bool REC12 = WAVES_ == 12 && NSTEP_ == 1 && !BAKE_C && !PROFILE_;
+    __device__ static __forceinline__ float sigma(const RenderArgs &A, const float *, bool valid, const float x[3], int, float t[6], Bil *cells = nullptr)
     {
         // branch-free: out-of-box samples have out-of-range coordinates, for which bil_setup clamps the
         // texel index and zeroes the weights, so their gathers are safe and their result is discarded.
         // Without the branch the NSTEP independent steps share one basic block and their gathers overlap.
         float tt[6];
         triplane_gauge(A, x, A.mode, tt);
-        const float sg = softplus_shift(triplane_density_feature<BAKE_D>(A, tt));
+        const float sg = softplus_shift(triplane_density_feature<BAKE_D>(A, tt, cells));
 #pragma unroll
         for (int k = 0; k < 6; ++k) t[k] = valid ? tt[k] : 0.0f;
         return valid ? sg : 0.0f;
@@ -232,6 +239,15 @@ struct TriPlanePolicy {
         if constexpr (BAKE_C) mlp_pass16_baked(A, smem, rec, v, lane, c, pre);
         else mlp_pass16<48>(A, smem, rec, v, lane, c, tk, pre);
     }
+    // REC12 form: the cells come from the record
+    __device__ static __forceinline__ void shade12(const RenderArgs &A, const float *smem, const RecCells &cells, const float *vf, int lane, float c[3],
+                                                   const float *pre)
+    {
+        const float rec[kRecFloats] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (!pre) v = *reinterpret_cast<const f32x4 *>(vf + (lane >> 4) * 4);
+        if constexpr (!BAKE_C) mlp_pass16<48>(A, smem, rec, v, lane, c, nullptr, pre, &cells);
+    }
 };
 
 // NGF_F_SPLIT_BF16: the colour MLP on the bf16 matrix pipe with 3-term split operands (ngf_shade_bf16.hpp).  Split tiles of <= 8 rays
@@ -239,6 +255,7 @@ struct TriPlanePolicy {
 template <bool BAKE_D, int WAVES_ = 8>
 struct TriPlaneBf16Policy : TriPlanePolicy<BAKE_D, false, WAVES_, 1> {
     static constexpr bool PROD = WAVES_ == 8;
+    static constexpr bool REC12 = false;
     static constexpr bool VIEW_FOLD = false;
     static constexpr int VFEAT_FLOATS = 8 * kViewFeat;
     __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
@@ -253,6 +270,7 @@ struct TriPlaneBf16Policy : TriPlanePolicy<BAKE_D, false, WAVES_, 1> {
 // NGF_F_NO_FOLD (level 0): un-composed rgb_decoder, view inputs per sample; 8 waves per CU (the basis stage keeps 36 more accumulators)
 struct TriPlaneNoFoldPolicy : TriPlanePolicy<false, false, 8, 1> {
     static constexpr bool PROD = false;
+    static constexpr bool REC12 = false;
     static constexpr bool VIEW_FOLD = false;
     __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
                                                  const float od[3], int lane, float c[3], unsigned long long * = nullptr, const float * = nullptr)
@@ -285,10 +303,18 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int RING = P::RING, NSTEP = P::NSTEP, BATCH = P::BATCH;
-    float *wl = smem + ((A.blob_floats + 3) & ~3) + wave * wave_lds_floats<P>();
+    constexpr int NSTEP = P::NSTEP, BATCH = P::BATCH;
+    // R12: 12-float records (three cells instead of six coordinates) in a ring of 80 -- a march iteration leaves at most 15 + 64 = 79 queued, the
+    // ring index wraps by one compare-subtract instead of a mask.  The carve is SMALLER than the generic one of the policy (80 * 12 + 64 + 1024 =
+    // 2048 floats against 2112), so the launch code's LDS size covers both kernels and every tile width keeps its view table.
+    constexpr bool R12 = SPLIT && P::REC12;
+    constexpr int RING = R12 ? 80 : P::RING, RECF = R12 ? 12 : kRecFloats;
+    constexpr int WAVE_FLOATS = R12 ? RING * RECF + BATCH * 4 + P::VFEAT_FLOATS + P::STAGE_FLOATS : wave_lds_floats<P>();
+    static_assert(WAVE_FLOATS <= wave_lds_floats<P>(), "the R12 carve must fit the policy's LDS allocation");
+    auto wrap = [](int x) { return R12 ? (x >= RING ? x - RING : x) : (x & (RING - 1)); };      // ring index of head + (< RING)
+    float *wl = smem + ((A.blob_floats + 3) & ~3) + wave * WAVE_FLOATS;
     float *ring = wl;
-    float *res = wl + RING * kRecFloats;
+    float *res = wl + RING * RECF;
     float *vfeat = res + BATCH * 4;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const int S = A.S;
@@ -354,6 +380,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
             if (count < BATCH && i < S) {
                 // ---------------- march NSTEP steps (independent gathers, sequential transmittance) ----
                 float z[NSTEP], dist[NSTEP], sigma[NSTEP], t[NSTEP][6];
+                [[maybe_unused]] Bil cells[NSTEP][3];
                 bool empty_step = false;
 #pragma unroll
                 for (int u = 0; u < NSTEP; ++u) {
@@ -381,6 +408,8 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     if constexpr (SPLIT && P::STAGED) {
                         float *dscr = P::STAGE_FLOATS > 0 ? vfeat + kWave * kViewFeat : nullptr;
                         sigma[u] = P::sigma_staged(A, vfeat, dscr, valid, x, lane, t[u], (DBG && A.stats) ? &st_staged : nullptr);
+                    } else if constexpr (R12) {
+                        sigma[u] = P::sigma(A, smem, valid, x, lane, t[u], cells[u]);
                     } else {
                         sigma[u] = P::sigma(A, smem, valid, x, lane, t[u]);
                     }
@@ -427,10 +456,17 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     const bool active = (w > A.thr) && !(DBG && A.skip_rgb);
                     const unsigned long long m = __ballot(active);
                     if (active) {
-                        const int slot = (head + count + __popcll(m & lt_mask)) & (RING - 1);
-                        f32x4 *r = reinterpret_cast<f32x4 *>(ring + slot * kRecFloats);
-                        r[0] = f32x4{__int_as_float(rl), w, t[u][0], t[u][1]};
-                        r[1] = f32x4{t[u][2], t[u][3], t[u][4], t[u][5]};
+                        const int slot = wrap(head + wrap(count + __popcll(m & lt_mask)));
+                        f32x4 *r = reinterpret_cast<f32x4 *>(ring + slot * RECF);
+                        if constexpr (R12) {
+                            const Bil *c = cells[u];
+                            r[0] = f32x4{__int_as_float(rl | (c[0].in << 8) | (c[1].in << 9) | (c[2].in << 10)), w, __int_as_float(c[0].idx), __int_as_float(c[1].idx)};
+                            r[1] = f32x4{__int_as_float(c[2].idx), c[0].wx1, c[0].wy1, c[1].wx1};
+                            r[2] = f32x4{c[1].wy1, c[2].wx1, c[2].wy1, 0.0f};
+                        } else {
+                            r[0] = f32x4{__int_as_float(rl), w, t[u][0], t[u][1]};
+                            r[1] = f32x4{t[u][2], t[u][3], t[u][4], t[u][5]};
+                        }
                     }
                     count += __popcll(m);
                     if constexpr (DBG) st_active += __popcll(m);
@@ -451,11 +487,11 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 const int nb = count < BATCH ? count : BATCH;
                 const int s = lane & (BATCH - 1);
-                const int slot = (head + (s < nb ? s : 0)) & (RING - 1);
-                const f32x4 *r = reinterpret_cast<const f32x4 *>(ring + slot * kRecFloats);
+                const int slot = wrap(head + (s < nb ? s : 0));
+                const f32x4 *r = reinterpret_cast<const f32x4 *>(ring + slot * RECF);
                 const f32x4 r0 = r[0], r1 = r[1];
                 const float rec[kRecFloats] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
-                const int owner = __float_as_int(r0[0]);
+                const int owner = R12 ? (__float_as_int(r0[0]) & 0xff) : __float_as_int(r0[0]);
                 float od[3] = {0.0f, 0.0f, 0.0f};
                 if constexpr (!P::VLDS) { od[0] = __shfl(d[0], owner); od[1] = __shfl(d[1], owner); od[2] = __shfl(d[2], owner); }
                 float c[3];
@@ -469,13 +505,17 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     prof[4] += tk[4] - tk[2];      // layer 2: 64 MFMAs issued
                     prof[6] += tk[3] - tk[4];      // layer 3 (VALU dot, 2 cross-lane adds, sigmoid)
                     t_sec = tk[3];
+                } else if constexpr (R12) {
+                    const f32x4 r2 = r[2];
+                    const RecCells cl = {{__float_as_int(r0[2]), __float_as_int(r0[3]), __float_as_int(r1[0])}, {r1[1], r1[3], r2[1]}, {r1[2], r2[0], r2[2]}, __float_as_int(r0[0])};
+                    P::shade12(A, smem, cl, vfeat + owner * kViewFeat, lane, c, pre);
                 } else {
                     if constexpr (P::VIEW_FOLD) P::shade(A, smem, rec, vfeat + owner * kViewFeat, od, lane, c, nullptr, pre);
                     else P::shade(A, smem, rec, vfeat + owner * kViewFeat, od, lane, c);
                 }
                 // result list, structure-of-arrays: res[0..B) owner lane ids, then weighted r, g, b
                 if (lane < BATCH) {
-                    res[lane] = lane < nb ? r0[0] : __int_as_float(-1);
+                    res[lane] = lane < nb ? __int_as_float(owner) : __int_as_float(-1);
                     res[BATCH + lane] = r0[1] * c[0];
                     res[2 * BATCH + lane] = r0[1] * c[1];
                     res[3 * BATCH + lane] = r0[1] * c[2];
@@ -502,7 +542,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                head = (head + nb) & (RING - 1);
+                head = wrap(head + nb);
                 count -= nb;
                 if constexpr (DBG) ++st_pass;
                 if constexpr (P::PROFILE) prof[5] += __builtin_readcyclecounter() - t_sec;     // result list + owner collect

@@ -113,12 +113,14 @@ struct Gather16 {                 // one plane: 4 taps x (APP/16) float4
     Bil b;
 };
 
+// PRE: the cell comes ready-made (bil_from_rec: the march computed it for the density fetch at the same coordinates on a plane of the same size)
 template <int APP, int P>
-__device__ __forceinline__ void gather16_issue(const RenderArgs &A, const float rec[kRecFloats], int kq, Gather16<APP> &g)
+__device__ __forceinline__ void gather16_issue(const RenderArgs &A, const float rec[kRecFloats], int kq, Gather16<APP> &g, const RecCells *pre = nullptr)
 {
     constexpr int NQ = APP / 16;
     const Tex &t = A.app[P];
-    g.b = bil_setup(rec[2 + 2 * P], rec[3 + 2 * P], t);
+    if (pre) g.b = bil_from_rec(pre->idx[P], pre->wx1[P], pre->wy1[P], (pre->bits >> (8 + P)) & 1);
+    else g.b = bil_setup(rec[2 + 2 * P], rec[3 + 2 * P], t);
     // lane-quarter kq owns channels [16q + 4kq, 16q + 4kq + 4), q = 0..NQ-1: the four lanes of a sample read one
     // contiguous 64-byte piece per load instruction, so a wave-wide load touches 16 cache lines instead of ~32
     const f32x4 *t00 = tex_at<f32x4>(t.p, (uint32_t)g.b.idx * APP + 4u * kq);
@@ -191,14 +193,14 @@ __device__ __forceinline__ void view_fold16(const float *blob, const float *vfea
 
 template <int APP>
 __device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v,
-                                           int lane, float rgb[3], unsigned long long *tk = nullptr, const float *pre = nullptr)
+                                           int lane, float rgb[3], unsigned long long *tk = nullptr, const float *pre = nullptr, const RecCells *cells = nullptr)
 {
     using L = MlpLayout16<APP>;
     blob = per_pass16(blob);
     const int kq = lane >> 4;
     Gather16<APP> g;
     float feat[L::QCH];
-    gather16_issue<APP, 0>(A, rec, kq, g);
+    gather16_issue<APP, 0>(A, rec, kq, g, cells);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[4];
     if (pre) {      // per-ray b1 + W1[:, view] . view from the tile's table
@@ -219,13 +221,13 @@ __device__ __forceinline__ void mlp_pass16(const RenderArgs &A, const float *blo
     mix16<APP>(g, feat);
     __builtin_amdgcn_sched_barrier(0);
     NGF_TICK(1);                       // plane 0 arrived and interpolated
-    gather16_issue<APP, 1>(A, rec, kq, g);
+    gather16_issue<APP, 1>(A, rec, kq, g, cells);
     __builtin_amdgcn_sched_barrier(0);
     layer1_plane16<APP, 0>(blob, lane, feat, acc);
     __builtin_amdgcn_sched_barrier(0);
     mix16<APP>(g, feat);
     __builtin_amdgcn_sched_barrier(0);
-    gather16_issue<APP, 2>(A, rec, kq, g);
+    gather16_issue<APP, 2>(A, rec, kq, g, cells);
     __builtin_amdgcn_sched_barrier(0);
     layer1_plane16<APP, 1>(blob, lane, feat, acc);
     __builtin_amdgcn_sched_barrier(0);

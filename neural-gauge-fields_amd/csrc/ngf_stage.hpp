@@ -61,6 +61,7 @@ __device__ __forceinline__ CellRect cell_rect(const Tex &t, float ulo, float uhi
 template <int WAVES_>
 struct TriPlaneStagedPolicy : TriPlanePolicy<false, false, WAVES_, 1> {
     static constexpr bool PROD = false;
+    static constexpr bool REC12 = false;
     static constexpr bool STAGED = true;
     static constexpr int STAGE_FLOATS = WAVES_ <= 8 ? kStageDensCap * kStageDensStride : 0;      // density strip (8 waves per CU only: LDS)
 
