@@ -514,11 +514,13 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     else P::shade(A, smem, rec, vfeat + owner * kViewFeat, od, lane, c);
                 }
                 // result list, structure-of-arrays: res[0..B) owner lane ids, then weighted r, g, b
-                if (lane < BATCH) {
-                    res[lane] = lane < nb ? __int_as_float(owner) : __int_as_float(-1);
-                    res[BATCH + lane] = r0[1] * c[0];
-                    res[2 * BATCH + lane] = r0[1] * c[1];
-                    res[3 * BATCH + lane] = r0[1] * c[2];
+                // c[] holds the three logits in all four lanes of a sample: lane quarter kq applies the sigmoid to channel kq and writes that entry of
+                // the list (res[(1 + kq) * BATCH + s] is res[BATCH + lane]) -- one sigmoid per lane instead of three
+                if (lane < BATCH) res[lane] = lane < nb ? __int_as_float(owner) : __int_as_float(-1);
+                if (lane < 3 * BATCH) {
+                    const int kq_ = lane >> 4;
+                    const float logit = kq_ == 0 ? c[0] : (kq_ == 1 ? c[1] : c[2]);
+                    res[BATCH + lane] = r0[1] * sigmoid_rcp(logit);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // every lane, as ray owner, adds its entries in queue (= sample) order; all reads are issued up front
@@ -749,8 +751,8 @@ __global__ void __launch_bounds__(256) decode_rgb_kernel(const RenderArgs A, con
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         float c[3];
         const float dq2[3] = {dirs[q * 3], dirs[q * 3 + 1], dirs[q * 3 + 2]};
-        P::shade(A, smem, rec, vfeat + s * kViewFeat, dq2, lane, c);
-        if (lane < BATCH && ok) { out[q * 3] = c[0]; out[q * 3 + 1] = c[1]; out[q * 3 + 2] = c[2]; }
+        P::shade(A, smem, rec, vfeat + s * kViewFeat, dq2, lane, c);         // logits
+        if (lane < BATCH && ok) { out[q * 3] = sigmoid_rcp(c[0]); out[q * 3 + 1] = sigmoid_rcp(c[1]); out[q * 3 + 2] = sigmoid_rcp(c[2]); }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }

@@ -322,7 +322,7 @@ __global__ void __launch_bounds__((NM + NS) * 64) render_pc_kernel(const RenderA
                 // owners sit in row 0 of the wave, so entry e reaches all of them through a DPP row broadcast (no LDS, no SGPR
                 // round trip); fmaf(v, 1, c) = c + v and fmaf(v, 0, c) = c exactly (v is finite), i.e. the fused kernel's sums
                 const int own = s < nb ? owner : -1;
-                const float wr_ = r0[1] * c[0], wg_ = r0[1] * c[1], wb_ = r0[1] * c[2];
+                const float wr_ = r0[1] * sigmoid_rcp(c[0]), wg_ = r0[1] * sigmoid_rcp(c[1]), wb_ = r0[1] * sigmoid_rcp(c[2]);   // shade returns logits
                 float cr = 0.0f, cg = 0.0f, cb = 0.0f;
                 if (lane < TW) { cr = lds_peekf(csum + lane * 3); cg = lds_peekf(csum + lane * 3 + 1); cb = lds_peekf(csum + lane * 3 + 2); }
                 collect16(own, wr_, wg_, wb_, lane, cr, cg, cb);

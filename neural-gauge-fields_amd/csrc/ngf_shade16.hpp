@@ -77,7 +77,9 @@ __device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__fl
 // v_div_fixup: ~10 instructions per channel): the colour moves by <= 1 ulp of a value in (0, 1)
 __device__ __forceinline__ float sigmoid_rcp(float s) { return __builtin_amdgcn_rcpf(1.0f + expf(-s)); }
 
-// layers 2 and 3; acc[mt][r] = layer-1 pre-activation of hidden unit mt*16 + 4*kq + r
+// layers 2 and 3; acc[mt][r] = layer-1 pre-activation of hidden unit mt*16 + 4*kq + r.  `rgb` receives the three pre-sigmoid sums (identical in
+// the four lanes of a sample): every shade function of the library returns LOGITS since round 3 -- the fused kernel applies the sigmoid to ONE
+// channel per lane (lane quarter kq takes channel kq and writes its own entry of the result list) instead of three in all 64 lanes.
 __device__ __forceinline__ void mlp_tail16(const float *blob, int oW2, int oB2, int oW3, int oB3, int lane, const f32x4 acc[4],
                                            float rgb[3], unsigned long long *tk = nullptr)
 {
@@ -102,7 +104,7 @@ __device__ __forceinline__ void mlp_tail16(const float *blob, int oW2, int oB2, 
         s = s + __shfl_xor(s, 16);
         s = s + __shfl_xor(s, 32);
         s = s + blob[oB3 + ch];
-        rgb[ch] = sigmoid_rcp(s);
+        rgb[ch] = s;              // the LOGIT: the caller applies sigmoid_rcp (the render kernel to one channel per lane quarter)
     }
 }
 

@@ -115,7 +115,7 @@ __device__ __forceinline__ void mlp_layer3_16(const float *blob, int oW3, int oB
         s = s + __shfl_xor(s, 16);
         s = s + __shfl_xor(s, 32);
         s = s + blob[oB3 + ch];
-        rgb[ch] = sigmoid_rcp(s);
+        rgb[ch] = s;              // logit (see mlp_tail16)
     }
 }
 
