@@ -1154,7 +1154,7 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
     t->chunk = d->chunk_samples > 0 ? d->chunk_samples : (int64_t)std::min<size_t>(cap, (size_t)9 << 20);
     if ((size_t)t->chunk > cap) t->chunk = (int64_t)((cap + 15) & ~(size_t)15);
     if (d->chunk_samples <= 0 && (size_t)t->chunk >= cap) t->chunk = (int64_t)((cap + 15) & ~(size_t)15);
-    if ((rc = tr_alloc(t, &T.xs, cap)) || (rc = tr_alloc(t, &T.w, cap)) || (rc = tr_alloc(t, &T.dx, cap)) || (rc = tr_alloc(t, &T.c, cap * 3)) ||
+    if ((rc = tr_alloc(t, &T.et, cap)) || (rc = tr_alloc(t, &T.sg, cap)) || (rc = tr_alloc(t, &T.w, cap)) || (rc = tr_alloc(t, &T.dx, cap)) || (rc = tr_alloc(t, &T.c, cap * 3)) ||
         (rc = tr_alloc(t, &T.dt, cap * 6)) || (rc = tr_alloc(t, &T.G, (size_t)d->max_rays * 3)) || (rc = tr_alloc(t, &T.count, (size_t)d->max_rays)) ||
         (rc = tr_alloc(t, &T.offset, (size_t)d->max_rays + 1)) || (rc = tr_alloc(t, &T.list, cap * 2)) || (rc = tr_alloc(t, &T.list_w, cap)) ||
         (rc = tr_alloc(t, &t->fwd_image, (size_t)kFwdImage)) || (rc = tr_alloc(t, &t->bwd_image, (size_t)kBwdImage)))

@@ -60,7 +60,7 @@ struct TrainArgs {
     float *d_dens[3];        // scalar density-gradient images: D_p[texel] = sum_samples w_tap * dx, in 4x4-texel blocks (d_bw per row)
     int32_t d_bw[3], g_bw[3];                   // blocks per row of d_dens / g_gau (g_gau: 4x2-texel blocks of 2 channels)
     // ray-major dense per-sample buffers: index = ray * S + step (a wave's 64 consecutive steps of one ray are 64 consecutive floats)
-    float *xs, *w, *dx;      // [n,S]
+    float *et, *sg, *w, *dx; // [n,S]  et = exp(-sigma * dist * distance_scale) (1 - alpha), sg = softplus'(xs) (0 where the sample is invalid)
     float *c;                // [n,S,3]
     float *dt;               // [n,S,6]   d loss / d t from the colour path (active samples only)
     const float *target;     // [n,3]
@@ -155,6 +155,11 @@ __device__ __forceinline__ BilG bilg_setup(float u, float v, const Tex &t)
     return b;
 }
 
+__device__ __forceinline__ float softplus_pre(float u)          // F.softplus, threshold 20; softplus(-inf) = 0
+{
+    return u > 20.0f ? u : log1pf(expf(u));
+}
+
 // ---- 1. density features of every (step, ray) pair ---------------------------------------------------------------------
 __global__ void __launch_bounds__(256) train_density_kernel(const TrainArgs T)
 {
@@ -170,7 +175,8 @@ __global__ void __launch_bounds__(256) train_density_kernel(const TrainArgs T)
         float xn[3], z, dist, tt[6];
         const bool valid = sample_geometry(A, r, i, xn, z, dist);
         if (!valid) {                               // outside the box / in free space of the alpha mask: sigma = 0, no fetches
-            T.xs[idx] = -INFINITY;
+            T.et[idx] = 1.0f;
+            T.sg[idx] = 0.0f;
             continue;
         }
         triplane_gauge(A, xn, A.mode, tt);          // compute_gauge (Field.py:53-75), identity split when the gauge is off
@@ -184,15 +190,14 @@ __global__ void __launch_bounds__(256) train_density_kernel(const TrainArgs T)
             const float *q = T.q_dens[p] + b.idx;
             f += bil_mix(b, q[0], q[1], q[tx.stride], q[tx.stride + 1]);
         }
-        f = (f + T.bd[0]) + (-10.0f);
-        T.xs[idx] = f;
+        f = (f + T.bd[0]) + (-10.0f);               // xs = Linear(48,1) - 10, the pre-softplus density
+        // every per-sample transcendental is taken HERE, 3.6 M samples in parallel: the two sequential kernels (one wave per SIMD, nothing
+        // to hide an instruction's latency behind) only chain products and sums.  raw2alpha (FieldBase.py:12-19): alpha = 1 - et
+        T.et[idx] = expf(-softplus_pre(f) * (dist * A.dscale));
+        T.sg[idx] = f > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-f));       // softplus' for the compositing backward
     }
 }
 
-__device__ __forceinline__ float softplus_pre(float u)          // F.softplus, threshold 20; softplus(-inf) = 0
-{
-    return u > 20.0f ? u : log1pf(expf(u));
-}
 
 // the per-ray scalars every sequential sweep needs
 __device__ __forceinline__ float ray_tmin(const RenderArgs &A, int64_t r)
@@ -208,10 +213,14 @@ __device__ __forceinline__ float ray_tmin(const RenderArgs &A, int64_t r)
     return fminf(fmaxf(tmin, A.near_), A.far_);
 }
 
-// ---- 2. raw2alpha per ray; pass 0 counts the active samples, pass 1 writes weights and the ordered active list ----------
+// ---- 2. raw2alpha per ray; pass 0 writes weights / transmittances and counts the active samples, pass 1 the ordered active list ----
 // Sixteen lanes per ray (one DPP row), each on one of 16 consecutive steps: the loads and the exp/log of a block of steps run
 // in parallel and only the transmittance product is chained lane to lane IN STEP ORDER (row_shr:1), so weights are exactly
-// those of the sequential cumprod (FieldBase.py:16) while a 4096-ray batch fills 1024 waves instead of 64.
+// those of the sequential cumprod (FieldBase.py:16) while a 4096-ray batch fills 1024 waves instead of 64.  That is ONE wave per
+// SIMD: nothing hides a global load, so the loads of kScanAhead blocks are requested together (round 2 paid one exposed memory
+// latency per 16 steps: 56 per ray and pass, 0.8 us each -- the whole of the kernel's time).
+constexpr int kScanAhead = 8;
+
 __device__ __forceinline__ float row_shr1(float v, float fill)      // lane (row, s) <- lane (row, s-1); lane s = 0 gets `fill`
 {
     const int r = __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x111, 0xf, 0xf, false);
@@ -225,45 +234,68 @@ __global__ void __launch_bounds__(64) train_scan_kernel(const TrainArgs T, int p
     const int64_t r0 = (int64_t)blockIdx.x * 4 + rl;
     const bool live = r0 < A.n;
     const int64_t r = live ? r0 : A.n - 1;
-    const float tmin = ray_tmin(A, r);
-    const float jit = A.jitter ? A.jitter[r] : 0.0f;
-    float Tr = 1.0f;
     int cnt = 0;
-    const int base = pass ? T.offset[r] : 0;
-    for (int i0 = 0; i0 < A.S; i0 += 16) {
-        const int i = i0 + seg;
-        const bool inb = i < A.S;
-        const int64_t idx = r * A.S + (inb ? i : 0);
-        const float z = tmin + A.step * ((float)i + jit);
-        const float zn = tmin + A.step * ((float)(i + 1) + jit);
-        const float dist = (i < A.S - 1) ? (zn - z) : 0.0f;
-        const float sigma = inb ? softplus_pre(T.xs[idx]) : 0.0f;
-        const float alpha = 1.0f - expf(-sigma * (dist * A.dscale));
-        const float keep = (1.0f - alpha) + 1e-10f;             // steps past S: alpha = 0, keep rounds to 1
-        // T entering step i0+seg = Tr * keep_0 * ... * keep_{seg-1}, multiplied in that order: after round k lanes <= k are final
-        float Tin = Tr;
+    if (pass) {
+        // the weights are there: threshold, rank inside the ray, write
+        const int base = T.offset[r];
+        for (int i0 = 0; i0 < A.S; i0 += 16 * kScanAhead) {
+            float wv[kScanAhead];
 #pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            const float prev = row_shr1(Tin * keep, Tr);
-            Tin = seg > 0 ? prev : Tr;
-        }
-        const float w = alpha * Tin;
-        Tr = __shfl(Tin * keep, rl * 16 + 15);
-        const bool active = live && inb && (w > A.thr);
-        const unsigned m16 = (unsigned)((__ballot(active) >> (16 * rl)) & 0xffffull);
-        if (pass && live && inb) {
-            T.w[idx] = w;
-            T.dx[idx] = Tin;                                    // parked for the compositing backward
-            if (active) {
-                const int pos = base + cnt + __popc(m16 & ((1u << seg) - 1u));
-                T.list[2 * (int64_t)pos] = (int)r;
-                T.list[2 * (int64_t)pos + 1] = i;
-                T.list_w[pos] = w;
+            for (int u = 0; u < kScanAhead; ++u) {
+                const int i = i0 + 16 * u + seg;
+                wv[u] = i < A.S ? T.w[r * A.S + i] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < kScanAhead; ++u) {
+                const int i = i0 + 16 * u + seg;
+                const bool active = live && (i < A.S) && (wv[u] > A.thr);
+                const unsigned m16 = (unsigned)((__ballot(active) >> (16 * rl)) & 0xffffull);
+                if (active) {
+                    const int pos = base + cnt + __popc(m16 & ((1u << seg) - 1u));
+                    T.list[2 * (int64_t)pos] = (int)r;
+                    T.list[2 * (int64_t)pos + 1] = i;
+                    T.list_w[pos] = wv[u];
+                }
+                cnt += __popc(m16);
             }
         }
-        cnt += __popc(m16);
+        return;
     }
-    if (!pass && live && seg == 0) T.count[r] = cnt;
+    float Tr = 1.0f;
+    for (int i0 = 0; i0 < A.S; i0 += 16 * kScanAhead) {
+        float xv[kScanAhead];
+#pragma unroll
+        for (int u = 0; u < kScanAhead; ++u) {
+            const int i = i0 + 16 * u + seg;
+            xv[u] = i < A.S ? T.et[r * A.S + i] : 1.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < kScanAhead; ++u) {
+            if (i0 + 16 * u >= A.S) break;                          // wave-uniform
+            const int i = i0 + 16 * u + seg;
+            const bool inb = i < A.S;
+            const int64_t idx = r * A.S + (inb ? i : 0);
+            const float alpha = 1.0f - xv[u];
+            const float keep = (1.0f - alpha) + 1e-10f;             // steps past S: alpha = 0, keep rounds to 1
+            // T entering step i0+seg = Tr * keep_0 * ... * keep_{seg-1}, multiplied in that order: after round k lanes <= k are final
+            float Tin = Tr;
+#pragma unroll
+            for (int k = 1; k < 16; ++k) {
+                const float prev = row_shr1(Tin * keep, Tr);
+                Tin = seg > 0 ? prev : Tr;
+            }
+            const float w = alpha * Tin;
+            Tr = __shfl(Tin * keep, rl * 16 + 15);
+            const bool active = live && inb && (w > A.thr);
+            const unsigned m16 = (unsigned)((__ballot(active) >> (16 * rl)) & 0xffffull);
+            if (live && inb) {
+                T.w[idx] = w;
+                T.dx[idx] = Tin;                                    // parked for the compositing backward
+            }
+            cnt += __popc(m16);
+        }
+    }
+    if (live && seg == 0) T.count[r] = cnt;
 }
 
 // exclusive prefix of count[0..n) -> offset[0..n]; one block, sequential over chunks of 1024
@@ -535,6 +567,7 @@ __global__ void __launch_bounds__(kTrainWaves * 64) __attribute__((amdgpu_waves_
 // Sixteen lanes per ray as in the scan.  d loss / d alpha_i = dL/dw_i T_i - (sum_{j>i} w_j dL/dw_j) / (1 - alpha_i + 1e-10) with
 // dL/dw_j = G . (c_j [active] - bg) is the cumprod backward; the suffix sum is accumulated from the END of the ray in float64
 // (what ATen's reverse cumsum does on the CPU), T_i was parked in dx by the scan.
+constexpr int kCompAhead = 4;
 __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs T)
 {
     const RenderArgs &A = T.R;
@@ -544,13 +577,26 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
     const int64_t r = live ? r0 : A.n - 1;
     const float bg = A.white_bg ? 1.0f : 0.0f;
     float acc = 0.0f, rgb[3] = {0.0f, 0.0f, 0.0f};
-    for (int i = seg; i < A.S; i += 16) {
-        const int64_t idx = r * A.S + i;
-        const float w = T.w[idx];
-        acc += w;
-        if (w > A.thr) {
+    // one wave per SIMD: the loads of kCompAhead blocks are requested together (as in the scan); the colours are read whether the
+    // sample is active or not (inactive entries are never written: whatever they hold is dropped by the select below)
+    for (int i0 = seg; i0 < A.S; i0 += 16 * kCompAhead) {
+        float wv[kCompAhead], cv[kCompAhead][3];
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) rgb[ch] += w * T.c[idx * 3 + ch];
+        for (int u = 0; u < kCompAhead; ++u) {
+            const int i = i0 + 16 * u;
+            const int64_t idx = r * A.S + (i < A.S ? i : 0);
+            wv[u] = i < A.S ? T.w[idx] : 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) cv[u][ch] = T.c[idx * 3 + ch];
+        }
+#pragma unroll
+        for (int u = 0; u < kCompAhead; ++u) {
+            if (i0 + 16 * u >= A.S) continue;
+            acc += wv[u];
+            if (wv[u] > A.thr) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) rgb[ch] += wv[u] * cv[u][ch];
+            }
         }
     }
 #pragma unroll
@@ -575,34 +621,51 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
     const float tmin = ray_tmin(A, r);
     const float jit = A.jitter ? A.jitter[r] : 0.0f;
     double carry = 0.0;                                       // sum of the terms of all steps above the current block
-    for (int i0 = ((A.S - 1) / 16) * 16; i0 >= 0; i0 -= 16) {
-        const int i = i0 + seg;
-        const bool inb = i < A.S;
-        const int64_t idx = r * A.S + (inb ? i : 0);
-        const float x = inb ? T.xs[idx] : -INFINITY;
-        const float z = tmin + A.step * ((float)i + jit);
-        const float zn = tmin + A.step * ((float)(i + 1) + jit);
-        const float delta = ((i < A.S - 1) ? (zn - z) : 0.0f) * A.dscale;
-        const float e = expf(-softplus_pre(x) * delta);
-        const float alpha = 1.0f - e;
-        const float Ti = inb ? T.dx[idx] : 0.0f;
-        const float w = inb ? T.w[idx] : 0.0f;
-        float dw = -gbg;
-        if (w > A.thr) dw += G[0] * T.c[idx * 3] + G[1] * T.c[idx * 3 + 1] + G[2] * T.c[idx * 3 + 2];
-        const double term = inb ? (double)((dw * alpha) * Ti) : 0.0;     // autograd's order: dL/dT_j = dL/dw_j alpha_j, then times T_j
-        double incl = term;                                              // inclusive suffix sum over the row: steps >= seg
+    for (int j0 = ((A.S - 1) / 16) * 16; j0 >= 0; j0 -= 16 * kCompAhead) {
+        float xv[kCompAhead], sv[kCompAhead], tv[kCompAhead], wv[kCompAhead], cv[kCompAhead][3];
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            const double o = __shfl_down(incl, d, 16);
-            incl += (seg + d < 16) ? o : 0.0;
+        for (int u = 0; u < kCompAhead; ++u) {
+            const int i = j0 - 16 * u + seg;
+            const bool inb = (j0 - 16 * u >= 0) && (i < A.S);
+            const int64_t idx = r * A.S + (inb ? i : 0);
+            xv[u] = inb ? T.et[idx] : 1.0f;
+            sv[u] = inb ? T.sg[idx] : 0.0f;
+            tv[u] = inb ? T.dx[idx] : 0.0f;
+            wv[u] = inb ? T.w[idx] : 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) cv[u][ch] = T.c[idx * 3 + ch];
         }
-        const double suffix = carry + (incl - term);
-        const float keep = (1.0f - alpha) + 1e-10f;
-        const float dalpha = dw * Ti - (float)suffix / keep;
-        const float dsigma = dalpha * delta * e;                        // d alpha / d sigma = delta exp(-sigma delta)
-        const float sig = x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));   // softplus'
-        if (live && inb) T.dx[idx] = (x == -INFINITY) ? 0.0f : dsigma * sig;
-        carry += __shfl(incl, rl * 16);
+#pragma unroll
+        for (int u = 0; u < kCompAhead; ++u) {
+            const int i0 = j0 - 16 * u;
+            if (i0 < 0) break;                                           // wave-uniform
+            const int i = i0 + seg;
+            const bool inb = i < A.S;
+            const int64_t idx = r * A.S + (inb ? i : 0);
+            const float z = tmin + A.step * ((float)i + jit);
+            const float zn = tmin + A.step * ((float)(i + 1) + jit);
+            const float delta = ((i < A.S - 1) ? (zn - z) : 0.0f) * A.dscale;
+            const float e = xv[u];
+            const float alpha = 1.0f - e;
+            const float Ti = tv[u];
+            const float w = wv[u];
+            float dw = -gbg;
+            if (w > A.thr) dw += G[0] * cv[u][0] + G[1] * cv[u][1] + G[2] * cv[u][2];
+            const double term = inb ? (double)((dw * alpha) * Ti) : 0.0;     // autograd's order: dL/dT_j = dL/dw_j alpha_j, then times T_j
+            double incl = term;                                              // inclusive suffix sum over the row: steps >= seg
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const double o = __shfl_down(incl, d, 16);
+                incl += (seg + d < 16) ? o : 0.0;
+            }
+            const double suffix = carry + (incl - term);
+            const float keep = (1.0f - alpha) + 1e-10f;
+            const float dalpha = dw * Ti - (float)suffix / keep;
+            const float dsigma = dalpha * delta * e;                        // d alpha / d sigma = delta exp(-sigma delta)
+            const float sig = sv[u];                                         // softplus'; 0 where the sample is invalid
+            if (live && inb) T.dx[idx] = (sig == 0.0f) ? 0.0f : dsigma * sig;
+            carry += __shfl(incl, rl * 16);
+        }
     }
     // one double atomic per wave for the loss
 #pragma unroll
