@@ -1087,7 +1087,15 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
     // blocked gradient images (ngf_train.hpp, scatter_blocked): 16-float blocks of 4x4 texels (D_p) / 4x2 texels x 2 channels (gauge)
     auto dblk = [&](int p) { return (size_t)((d->plane_w[p] + 2 + 3) / 4) * ((d->plane_h[p] + 2 + 3) / 4) * 16; };
     auto gblk = [&](int p) { return (size_t)((d->gauge_w[p] + 2 + 3) / 4) * ((d->gauge_h[p] + 2 + 1) / 2) * 16; };
-    {   // the zero arena: [per plane: D_p, colour-plane gradient, gauge gradient] [MLP gradients] [M] [loss], 256-byte aligned pieces
+    // bins of the colour-plane scatter (ngf_train.hpp section 5b): 8x8 blocks of cells of the padded planes
+    int nbins = 0;
+    for (int p = 0; p < 3; ++p) {
+        T.bin_base[p] = nbins;
+        T.bin_nbx[p] = (d->plane_w[p] + 2 + 7) / 8;
+        nbins += T.bin_nbx[p] * ((d->plane_h[p] + 2 + 7) / 8);
+    }
+    T.nbins = nbins;
+    {   // the zero arena: [per plane: D_p, colour-plane gradient, gauge gradient] [MLP gradients] [M] [loss] [bin counters], 256-byte aligned pieces
         size_t total = 0;
         auto add = [&](size_t floats) { total += (floats * sizeof(float) + 255) & ~(size_t)255; };
         for (int p = 0; p < 3; ++p) {
@@ -1096,6 +1104,7 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
         }
         for (int k = TP_DENS_W; k < TP_COUNT; ++k) add((size_t)dn[k]);
         add((size_t)64 * 144); add(4);
+        add((size_t)nbins + 1);
         if ((rc = tr_alloc(t, &t->zero_arena, total))) return bail(rc);
         t->zero_bytes = total;
     }
@@ -1125,6 +1134,7 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
     }
     T.M = carve((size_t)64 * 144);
     T.loss = reinterpret_cast<double *>(carve(4));
+    T.bin_count = reinterpret_cast<int32_t *>(carve((size_t)nbins + 1));
     if (carved != t->zero_bytes) return bail(fail(NGF_E_ARG, "trainer: zero arena layout mismatch"));
     T.wd = d->dens_w; T.bd = d->dens_b; T.basis = d->basis; T.w1 = d->w1; T.b1 = d->b1; T.w2 = d->w2; T.b2 = d->b2; T.w3 = d->w3; T.b3 = d->b3;
     T.g_wd = t->g_dense[TP_DENS_W]; T.g_bd = t->g_dense[TP_DENS_B];
@@ -1157,16 +1167,21 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
     if ((rc = tr_alloc(t, &T.et, cap)) || (rc = tr_alloc(t, &T.sg, cap)) || (rc = tr_alloc(t, &T.w, cap)) || (rc = tr_alloc(t, &T.dx, cap)) || (rc = tr_alloc(t, &T.c, cap * 3)) ||
         (rc = tr_alloc(t, &T.dt, cap * 6)) || (rc = tr_alloc(t, &T.G, (size_t)d->max_rays * 3)) || (rc = tr_alloc(t, &T.count, (size_t)d->max_rays)) ||
         (rc = tr_alloc(t, &T.offset, (size_t)d->max_rays + 1)) || (rc = tr_alloc(t, &T.list, cap * 2)) || (rc = tr_alloc(t, &T.list_w, cap)) ||
-        (rc = tr_alloc(t, &t->fwd_image, (size_t)kFwdImage)) || (rc = tr_alloc(t, &t->bwd_image, (size_t)kBwdImage)))
+        (rc = tr_alloc(t, &t->fwd_image, (size_t)kFwdImage)) || (rc = tr_alloc(t, &t->bwd_image, (size_t)kBwdImage)) ||
+        (rc = tr_alloc(t, &T.bin_off, (size_t)nbins + 1)) || (rc = tr_alloc(t, &T.unit_total, (size_t)1)))
         return bail(rc);
-    // The activation rows (432 floats per sample).  If the whole-batch default does not fit the free HBM, fall back to round 1's chunked
+    // The activation rows (576 floats per sample + the 18 of its scatter pairs).  If the whole-batch default does not fit the free HBM, fall back to round 1's chunked
     // mode (262 144 rows = 453 MB; the colour kernels then run chunk by chunk and the step reads the active count on the host) instead of
     // failing the create -- an explicit chunk_samples is taken as asked.
     for (int attempt = 0;; ++attempt) {
         const size_t ch = (size_t)t->chunk, mark = t->allocs.size();
         const int64_t bytes_mark = t->bytes;
+        T.bin_cap = (int32_t)ch;
         if (!((rc = tr_alloc(t, &T.F, ch * 144)) || (rc = tr_alloc(t, &T.V, ch * 16)) || (rc = tr_alloc(t, &T.H1, ch * 64)) || (rc = tr_alloc(t, &T.H2, ch * 64)) ||
-              (rc = tr_alloc(t, &T.D3, ch * 16)) || (rc = tr_alloc(t, &T.D2, ch * 64)) || (rc = tr_alloc(t, &T.D1, ch * 64))))
+              (rc = tr_alloc(t, &T.D3, ch * 16)) || (rc = tr_alloc(t, &T.D2, ch * 64)) || (rc = tr_alloc(t, &T.D1, ch * 64)) ||
+              (rc = tr_alloc(t, &T.DF, ch * 144)) || (rc = tr_alloc(t, &T.pair_cell, ch * 3)) || (rc = tr_alloc(t, &T.pair_rank, ch * 3)) ||
+              (rc = tr_alloc(t, &T.pair_w, ch * 12)) || (rc = tr_alloc(t, &T.perm, ch * 3)) ||
+              (rc = tr_alloc(t, &T.units, ((size_t)nbins + ch * 3 / kBinChunk + 8) * 3))))
             break;
         while (t->allocs.size() > mark) { (void)hipFree(t->allocs.back()); t->allocs.pop_back(); }
         t->bytes = bytes_mark;
@@ -1277,7 +1292,13 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
             T.store = 1;
             hipLaunchKernelGGL(train_color_fwd_kernel, dim3(tr_grid(t, passes, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_f, st, T);
         }
+        T.bin_plain = single ? 1 : 0;
+        if (base > 0) HIP_TRY(hipMemsetAsync(T.bin_count, 0, ((size_t)T.nbins + 1) * sizeof(int32_t), st));      // the first chunk's counters: the zero arena
         hipLaunchKernelGGL(train_color_bwd_kernel, dim3(tr_grid(t, passes, kTrainWavesBwd, 1)), dim3(kTrainWavesBwd * 64), lds_b, st, T);
+        // colour-plane scatter: order the chunk's (plane, sample) pairs by bin, then one wave per unit (ngf_train.hpp section 5b)
+        hipLaunchKernelGGL(train_bin_prefix_kernel, dim3(1), dim3(1024), 0, st, T);
+        hipLaunchKernelGGL(train_bin_perm_kernel, dim3(tr_grid(t, 3 * (int64_t)T.chunk_n, 256)), dim3(256), 0, st, T);
+        hipLaunchKernelGGL(train_bin_scatter_kernel, dim3(2 * t->num_cus), dim3(256), 0, st, T);
         const int rows = T.chunk_n;
         int xg = (rows + 31) / 32;                      // 32-sample chunks; at most two workgroups per CU walk them
         if (xg > 2 * t->num_cus) xg = 2 * t->num_cus;

@@ -73,6 +73,15 @@ struct TrainArgs {
     float *F, *V, *H1, *H2, *D3, *D2, *D1;          // [chunk, 144|16|64|64|16|64|64]  (V = the 15 view inputs + 0)
     const float *fwd_image, *bwd_image;             // LDS images built by train_fold_kernel
     float *M;                                       // [64,144] = Delta1^T F, accumulated over the chunks
+    // colour-plane scatter by bins (section 5b): a bin = the cells of one 8x8 block of one colour plane
+    float *DF;                                      // [chunk, 144]  d loss / d colour features of the chunk's samples
+    int32_t *pair_cell, *pair_rank;                 // [3][bin_cap]  cell (column | row << 16, padded) of pair (plane, sample); its rank inside its bin (-1: no weight)
+    float *pair_w;                                  // [3][bin_cap][4]  the four tap weights
+    int32_t *bin_count, *bin_off;                   // [nbins + 1]
+    int32_t *perm;                                  // [3 * bin_cap]  sample rows ordered by bin
+    int32_t *units;                                 // [unit_cap][3]  (bin, first entry of perm, entries): at most kBinChunk entries per unit
+    int32_t *unit_total;                            // [1]
+    int32_t bin_base[3], bin_nbx[3], nbins, bin_cap;
     double *loss;            // [2]: sum of squared residuals, (unused)
     int32_t chunk_base, chunk_n;      // the slice of the active list this launch works on
     const int32_t *n_active_dev;      // non-NULL: the active count lives on the device (offset[n]); chunk_n is then only the capacity and
@@ -425,8 +434,8 @@ __device__ __forceinline__ void list_sample_coords(const RenderArgs &A, int64_t 
 
 constexpr int kFwdTileFloats = (kIn1Pad + 64) * kTs;                       // [F; view] (H2 goes there once layer 1 is done and F is stored), H1
 constexpr int kDfStride = kFeat + 1;                                       // DF is kept sample-major (bank-conflict-free rows)
-// backward tiles per wave: [H1 | D2 | pad] is overwritten by DF^T once d1 exists and d2 / d1 have been written out; [H2, then D1]; tap table
-constexpr int kBwdTileFloats = 16 * kDfStride + 64 * kTs + 16 * 16 + 16 * 48;
+// backward tiles per wave: [H1 | D2 | pad] is overwritten by DF^T once d1 exists and d2 / d1 have been written out; [H2, then D1]
+constexpr int kBwdTileFloats = 16 * kDfStride + 64 * kTs;
 static_assert(16 * kDfStride >= 2 * 64 * kTs, "DF^T must cover the H1 and D2 tiles it aliases");
 
 // ---- per-step weight images -------------------------------------------------------------------------------------------------
@@ -683,9 +692,7 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
     const float *img = smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 15, q = lane >> 4;
-    float *H1t = smem + ((kBwdImage + 3) & ~3) + wave * kBwdTileFloats, *D2t = H1t + 64 * kTs, *DFt = H1t, *H2t = H1t + 16 * kDfStride,
-          *tap = H2t + 64 * kTs,              // tap[s][p] = {cell (column | row << 16, padded), w00, w10, w01, w11}
-          *cache = tap + 16 * 16;            // [16 slots][48 channels]: the texel sums of the colour-plane scatter
+    float *H1t = smem + ((kBwdImage + 3) & ~3) + wave * kBwdTileFloats, *D2t = H1t + 64 * kTs, *DFt = H1t, *H2t = H1t + 16 * kDfStride;
     float *D1t = H2t;                        // h2 is dead once d2 exists
     const int chunk_n = chunk_rows(T);
     const int passes = (chunk_n + 15) / 16;
@@ -751,6 +758,7 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
         NGF_SEC(3)
         // d loss / d t through the bilinear cell (lane (q, n): channels 12q..12q+11 of every plane of sample n) and the tap table
         float dt[6];
+        int bin[3] = {-1, -1, -1};
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const Tex &tx = A.app[p];
@@ -758,10 +766,12 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
             const size_t base = (size_t)b.idx * 48 + 12 * q;
             const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + base);
             const f32x4 *q01 = q00 + (size_t)tx.stride * 12;
-            if (q == 0) {
-                float *tp = tap + (n * 3 + p) * 5;
-                tp[0] = __int_as_float(b.cx | (b.cy << 16));
-                tp[1] = live ? b.w00 : 0.0f; tp[2] = live ? b.w10 : 0.0f; tp[3] = live ? b.w01 : 0.0f; tp[4] = live ? b.w11 : 0.0f;
+            if (q == 0 && live) {          // the pair (plane, sample): its cell, its tap weights, its place in its bin (section 5b)
+                const bool any = (b.w00 != 0.0f) | (b.w10 != 0.0f) | (b.w01 != 0.0f) | (b.w11 != 0.0f);
+                const size_t pi = (size_t)p * T.bin_cap + row;
+                T.pair_cell[pi] = b.cx | (b.cy << 16);
+                *reinterpret_cast<f32x4 *>(T.pair_w + pi * 4) = f32x4{b.w00, b.w10, b.w01, b.w11};
+                bin[p] = any ? T.bin_base[p] + (b.cy >> 3) * T.bin_nbx[p] + (b.cx >> 3) : -1;
             }
             float du = 0.0f, dv = 0.0f;
 #pragma unroll
@@ -781,60 +791,44 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         NGF_SEC(4)
-        // feature gradients -> packed colour planes.  A tap's 48 channels are 192 consecutive bytes = three whole lines, and the atomic
-        // unit charges per line (profiles/micro/atomic_cost.hip), so what counts is how often a texel is sent: the samples of a pass are
-        // consecutive active steps of a ray (half a texel apart), their 2x2 footprints share most texels.  Each wave keeps the sums of the
-        // last 4x4 texel neighbourhood in LDS (slot = (x & 3, y & 3), one lane per channel) and sends a texel once, when another texel
-        // claims its slot or at the end of the plane: 2.3x fewer line transactions than one send per (run of samples in a cell, tap).
-        const unsigned livem = (unsigned)(__ballot(live) & 0xffffull);        // lanes 0..15 carry q == 0: bit s = sample s of the pass
-#pragma unroll 1
-        for (int p = 0; p < ((A.ablate & 131072) ? 0 : 3); ++p) {
-            const Tex &tx = A.app[p];
-            float *gp = T.g_app[p];
-            int tags = -1;                               // lane j: the texel whose sums live in slot j (-1: none)
-            // the plane's tap table in two registers (lane s: cell of sample s; lane 4s + k: weight k of sample s), read per sample with
-            // v_readlane instead of one LDS round trip each
-            const int cells = __float_as_int(tap[((lane & 15) * 3 + p) * 5]);
-            const float wts = tap[((lane >> 2) * 3 + p) * 5 + 1 + (lane & 3)];
+        // feature gradients: the rows leave for the bin-ordered scatter (train_bin_scatter_kernel) -- DF^T is sample-major, 64 lanes
+        // write 64 consecutive floats of one row
+        {
+            const unsigned livem = (unsigned)(__ballot(live) & 0xffffull);        // lanes 0..15 carry q == 0: bit s = sample s of the pass
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 if (!((livem >> s) & 1u)) continue;      // wave-uniform
-                const int cxy = __builtin_amdgcn_readlane(cells, s);
-                const int cx = cxy & 0xffff, cy = cxy >> 16;
-                const float g = lane < 48 ? DFt[s * kDfStride + p * 48 + lane] : 0.0f;
-                int slot[4], texel[4], old[4];
-                float cur[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {            // the four taps of a cell sit in four different slots
-                    const int x = cx + (k & 1), y = cy + (k >> 1);
-                    slot[k] = (x & 3) + 4 * (y & 3);
-                    texel[k] = y * tx.stride + x;
-                    old[k] = __builtin_amdgcn_readlane(tags, slot[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) cur[k] = lane < 48 ? cache[slot[k] * 48 + lane] : 0.0f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float nv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wts), 4 * s + k)) * g;
-                    if (old[k] == texel[k]) {
-                        nv += cur[k];
-                    } else {                             // wave-uniform: the slot changes hands, its previous owner is sent
-                        if (old[k] >= 0 && lane < 48 && cur[k] != 0.0f && !(A.ablate & 65536)) atomicAdd(gp + (size_t)old[k] * 48 + lane, cur[k]);
-                        if (old[k] >= 0 && (A.ablate & (1 << 21))) pc[6] += 3;
-                        tags = lane == slot[k] ? texel[k] : tags;
-                    }
-                    if (lane < 48) cache[slot[k] * 48 + lane] = nv;
-                }
+                float *dst = T.DF + (size_t)(pass * 16 + s) * kFeat;
+                dst[lane] = DFt[s * kDfStride + lane];
+                dst[64 + lane] = DFt[s * kDfStride + 64 + lane];
+                if (lane < kFeat - 128) dst[128 + lane] = DFt[s * kDfStride + 128 + lane];
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            for (int j = 0; j < 16; ++j) {
-                const int o = __builtin_amdgcn_readlane(tags, j);
-                if (o < 0) continue;
-                const float v = lane < 48 ? cache[j * 48 + lane] : 0.0f;
-                if (lane < 48 && v != 0.0f && !(A.ablate & 65536)) atomicAdd(gp + (size_t)o * 48 + lane, v);
-                if (A.ablate & (1 << 21)) pc[6] += 3;
+        }
+        // the pairs' places in their bins: the 16 samples of a pass mostly share a bin, so the first lane of every distinct bin asks for the
+        // places of all its lanes with ONE returning atomic (one per pair made the hot bins' counters the bottleneck of the kernel)
+        {
+            int leader[3], before[3], base[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int mine = (q == 0 && live) ? bin[p] : -1;
+                int total = 0;
+                leader[p] = 0; before[p] = 0;
+#pragma unroll
+                for (int j = 15; j >= 0; --j) {
+                    const int bj = __builtin_amdgcn_readlane(mine, j);
+                    const bool same = (bj == mine);
+                    leader[p] = same ? j : leader[p];
+                    before[p] += (same && j < lane) ? 1 : 0;
+                    total += same ? 1 : 0;
+                }
+                base[p] = 0;
+                if (mine >= 0 && leader[p] == lane) base[p] = atomicAdd(T.bin_count + mine, total);       // the three requests travel together
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int b0 = __shfl(base[p], leader[p]);
+                if (q == 0 && live) T.pair_rank[(size_t)p * T.bin_cap + row] = bin[p] >= 0 ? b0 + before[p] : -1;
+            }
         }
         if (live && q == 0) {
             float *d = T.dt + ((int64_t)r * A.S + i) * 6;
@@ -848,7 +842,6 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
 #undef NGF_SEC
     if (prof && lane == 0)
         for (int k = 0; k < 8; ++k) atomicAdd(T.prof + k, pc[k]);
-    if ((A.ablate & (1 << 21)) && lane == 0) atomicAdd(T.prof + 9, pc[6]);
     atomicAdd(T.g_b1 + lane, gb1);
     atomicAdd(T.g_b2 + lane, gb2);
 #pragma unroll
@@ -858,6 +851,180 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
         for (int d = 1; d < 16; d <<= 1) v += __shfl_xor(v, d);
         if (lane == 0) atomicAdd(T.g_b3 + j, v);
     }
+}
+
+// ---- 5b. colour-plane scatter, ordered by bins ------------------------------------------------------------------------------------
+// A global float atomic costs one transaction per (instruction, 64-byte line) at 21 G transactions/s for the whole device, whatever its
+// scope and wherever the line lives (profiles/micro/atomic_cost.hip, atomic_scope.hip) -- and a tap of a colour plane is 48 channels =
+// three lines.  Round 2 sent the taps from the colour backward itself through a 16-texel cache per wave: 4.4 M transactions per
+// iteration, 0.21 ms of floor under a 0.29 ms section.  The samples of a PASS share few texels (16 consecutive active steps of one
+// ray); the samples of the BATCH share nearly all of them (165 k samples x 4 taps on 65 k texels per plane).  So the pairs
+// (plane, sample) are ordered by bin -- a bin = the cells of one 8x8 block of a plane -- with a counting sort whose counting step
+// rides in the colour backward (one returning atomic per pair on the bin's counter: consecutive samples mostly share the bin, i.e.
+// the line), and one wave per unit (<= kBinChunk pairs of one bin) sums the block's 9x9 texels in LDS (plain read-add-writes, one
+// lane per channel) and sends every touched texel once: ~9x fewer transactions.
+constexpr int kBinChunk = 256;                     // pairs per unit
+constexpr int kBinTile = 81 * 48;                  // floats of a unit's LDS tile
+
+// exclusive prefix of bin_count -> bin_off, and the unit list; one workgroup
+__global__ void __launch_bounds__(1024) train_bin_prefix_kernel(const TrainArgs T)
+{
+    __shared__ int sc[1024], su[1024];
+    const int t = threadIdx.x;
+    const int per = (T.nbins + 1023) / 1024;
+    const int b0 = t * per, b1 = min(T.nbins, b0 + per);
+    int c = 0, u = 0;
+    for (int b = b0; b < b1; ++b) {
+        const int k = T.bin_count[b];
+        c += k;
+        u += (k + kBinChunk - 1) / kBinChunk;
+    }
+    sc[t] = c; su[t] = u;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {
+        const int ac = t >= s ? sc[t - s] : 0, au = t >= s ? su[t - s] : 0;
+        __syncthreads();
+        sc[t] += ac; su[t] += au;
+        __syncthreads();
+    }
+    int rc = sc[t] - c, ru = su[t] - u;
+    for (int b = b0; b < b1; ++b) {
+        const int k = T.bin_count[b];
+        T.bin_off[b] = rc;
+        for (int j = 0; j < k; j += kBinChunk) {
+            int32_t *un = T.units + (size_t)ru * 3;
+            un[0] = b; un[1] = rc + j; un[2] = min(kBinChunk, k - j);
+            ++ru;
+        }
+        rc += k;
+    }
+    if (t == 1023) { T.bin_off[T.nbins] = sc[1023]; *T.unit_total = su[1023]; }
+}
+
+// perm[bin_off[bin] + rank] = sample row, for every pair that has a weight
+__global__ void __launch_bounds__(256) train_bin_perm_kernel(const TrainArgs T)
+{
+    const int rows = chunk_rows(T);
+    const int total = 3 * rows;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int p = i / rows, n = i - p * rows;
+        const size_t pi = (size_t)p * T.bin_cap + n;
+        const int rank = T.pair_rank[pi];
+        if (rank < 0) continue;
+        const int cell = T.pair_cell[pi];
+        const int bin = T.bin_base[p] + ((cell >> 16) >> 3) * T.bin_nbx[p] + ((cell & 0xffff) >> 3);
+        T.perm[T.bin_off[bin] + rank] = n;
+    }
+}
+
+// one wave per unit
+__global__ void __launch_bounds__(256) train_bin_scatter_kernel(const TrainArgs T)
+{
+    __shared__ __attribute__((aligned(16))) float s_tile[4][kBinTile];
+    const RenderArgs &A = T.R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *tile = s_tile[wave];
+    const int nunits = *T.unit_total;
+    const bool count_lines = (A.ablate & (1 << 21)) != 0;      // profiling: atomic line transactions -> T.prof[9]
+    unsigned long long n_lines = 0;
+    const bool prof = (A.ablate & (1 << 20)) != 0;             // section clocks -> T.prof[11..15] (profiles/exp_train_sections.py)
+    unsigned long long pc[4] = {0, 0, 0, 0}, t0 = 0, n_units = 0;
+#define NGF_SEC(k) if (prof) { const unsigned long long t1 = __builtin_readcyclecounter(); pc[k] += t1 - t0; t0 = t1; }
+    const int ch = lane < 48 ? lane : 47;
+    for (int u = blockIdx.x * 4 + wave; u < nunits; u += gridDim.x * 4) {
+        if (prof) { t0 = __builtin_readcyclecounter(); ++n_units; }
+        const int bin = __builtin_amdgcn_readfirstlane(T.units[3 * u]), first = __builtin_amdgcn_readfirstlane(T.units[3 * u + 1]),
+                  len = __builtin_amdgcn_readfirstlane(T.units[3 * u + 2]);
+        const int p = bin >= T.bin_base[2] ? 2 : (bin >= T.bin_base[1] ? 1 : 0);
+        const int bl = bin - T.bin_base[p];
+        const int by = bl / T.bin_nbx[p], bx = bl - by * T.bin_nbx[p];
+        const int x0 = bx * 8, y0 = by * 8;
+        for (int e = lane * 4; e < kBinTile; e += 256) *reinterpret_cast<f32x4 *>(tile + e) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const int32_t *cellp = T.pair_cell + (size_t)p * T.bin_cap;
+        const float *wp = T.pair_w + (size_t)p * T.bin_cap * 4;
+        const float *df = T.DF + p * 48 + ch;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // lane l holds the records of pairs l, 64 + l, 128 + l, 192 + l (row, tile offset of the cell, weights): two rounds of loads for the
+        // whole unit; the rows' gradients then arrive 16 at a time, the next 16 requested before the current 16 are added
+        int rowr[4], offr[4];
+        f32x4 wr[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) rowr[jb] = (jb * 64 + lane < len) ? T.perm[first + jb * 64 + lane] : 0;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            const bool have = jb * 64 + lane < len;
+            const int cell = have ? cellp[rowr[jb]] : 0;
+            wr[jb] = have ? *reinterpret_cast<const f32x4 *>(wp + (size_t)rowr[jb] * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            offr[jb] = (((cell >> 16) - y0) * 9 + ((cell & 0xffff) - x0)) * 48;
+        }
+        NGF_SEC(0)
+        constexpr int SB = 32;                              // pairs per request group: two groups = 64 rows in flight per wave
+        const int nsb = (len + SB - 1) / SB;
+        auto pick = [&](const int (&v)[4], int jb) { return jb == 0 ? v[0] : (jb == 1 ? v[1] : (jb == 2 ? v[2] : v[3])); };
+        auto load_sb = [&](int sb, float (&g)[SB]) {
+            const int rsel = pick(rowr, sb >> 1), l0 = (sb & 1) * SB;
+#pragma unroll
+            for (int k = 0; k < SB; ++k) g[k] = df[(size_t)__builtin_amdgcn_readlane(rsel, l0 + k) * kFeat];
+        };
+        auto add_sb = [&](int sb, const float (&g)[SB]) {
+            const int jb = sb >> 1, l0 = (sb & 1) * SB;
+            const int osel = pick(offr, jb);
+            const f32x4 wsel = jb == 0 ? wr[0] : (jb == 1 ? wr[1] : (jb == 2 ? wr[2] : wr[3]));
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                if (sb * SB + k >= len) break;                  // wave-uniform
+                float *t00 = tile + __builtin_amdgcn_readlane(osel, l0 + k) + lane;
+                const float w00 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsel[0]), l0 + k));
+                const float w10 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsel[1]), l0 + k));
+                const float w01 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsel[2]), l0 + k));
+                const float w11 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsel[3]), l0 + k));
+                if (lane < 48) {
+                    const float a = t00[0], b = t00[48], c = t00[9 * 48], d = t00[10 * 48];
+                    t00[0] = a + w00 * g[k];
+                    t00[48] = b + w10 * g[k];
+                    t00[9 * 48] = c + w01 * g[k];
+                    t00[10 * 48] = d + w11 * g[k];
+                }
+            }
+        };
+        float ga[SB], gb[SB];
+        load_sb(0, ga);
+#pragma unroll 1
+        for (int sb = 0; sb < nsb; sb += 2) {
+            if (sb + 1 < nsb) load_sb(sb + 1, gb);
+            __builtin_amdgcn_sched_barrier(0);
+            add_sb(sb, ga);
+            __builtin_amdgcn_sched_barrier(0);
+            if (sb + 2 < nsb) load_sb(sb + 2, ga);
+            __builtin_amdgcn_sched_barrier(0);
+            if (sb + 1 < nsb) add_sb(sb + 1, gb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        NGF_SEC(1)
+        // every touched texel of the 9x9 tile once (texels past the padded plane cannot have been touched)
+        const Tex &tx = A.app[p];
+        float *gp = T.g_app[p];
+        for (int ty = 0; ty < 9; ++ty) {
+#pragma unroll
+            for (int tx_ = 0; tx_ < 9; ++tx_) {
+                const float v = lane < 48 ? tile[(ty * 9 + tx_) * 48 + lane] : 0.0f;
+                if (v != 0.0f) atomicAdd(gp + ((size_t)(y0 + ty) * tx.stride + (x0 + tx_)) * 48 + lane, v);
+                if (count_lines) {
+                    const unsigned long long mk = __ballot(v != 0.0f);
+                    n_lines += ((mk & 0xffffull) ? 1 : 0) + ((mk & 0xffff0000ull) ? 1 : 0) + ((mk & 0xffff00000000ull) ? 1 : 0);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        NGF_SEC(2)
+    }
+#undef NGF_SEC
+    if (prof && lane == 0) {
+        for (int k = 0; k < 3; ++k) atomicAdd(T.prof + 11 + k, pc[k]);
+        atomicAdd(T.prof + 15, n_units);
+    }
+    if (count_lines && lane == 0) atomicAdd(T.prof + 9, n_lines);
 }
 
 // ---- 6. weight gradients: out[M][N] += X^T . Y over `rows` samples (sample-major X [rows, ldx], Y [rows, ldy]) ------------------

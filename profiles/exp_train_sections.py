@@ -25,7 +25,7 @@ tr = train.Trainer(f, batch_size=4096, max_samples=S)
 for it in range(3):
     tr.step(rays, tgt, it, N_samples=S)
 names = ["rows -> tiles (H1, H2), d3", "d2 + layer-2 backward (MFMA)", "D3/D2/D1 rows out, bias sums", "df = W1'^T d1 (MFMA)", "coords, taps, d loss / d t",
-         "colour-plane scatter (atomics)"]
+         "DF rows out, places in the bins"]
 with _lib.knobs(ablate=(1 << 20) | (1 << 21)):
     out = (C.c_uint64 * 16)()
     _lib.check(L.ngf_train_debug_sections(tr._h, out))
@@ -39,5 +39,8 @@ print(f"{passes / n:.0f} passes of 16 samples per iteration; clocks per pass (10
 for k in range(6):
     print(f"  {names[k]:40s} {out[k] / passes:10.1f}   {100.0 * out[k] / tot:5.1f} %")
 print(f"  {'total':40s} {tot / passes:10.1f}")
+if out[15]:
+    print(f"train_bin_scatter_kernel: {out[15] / n:.0f} units per iteration; clocks per unit: zero tile + records {out[11] / out[15]:.1f}, "
+          f"gradient rows + LDS sums {out[12] / out[15]:.1f}, flush (atomics) {out[13] / out[15]:.1f}")
 print(f"atomic line transactions per iteration: density/gauge backward {out[8] / n:.0f}, colour backward {out[9] / n:.0f} "
       f"-> {(out[8] + out[9]) / n / 21.0e9 * 1e3:.3f} ms at the measured 21 G transactions/s (profiles/r02_micro_atomic_cost.txt)")
