@@ -1095,13 +1095,10 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
         nbins += T.bin_nbx[p] * ((d->plane_h[p] + 2 + 7) / 8);
     }
     T.nbins = nbins;
-    {   // the zero arena: [per plane: D_p, colour-plane gradient, gauge gradient] [MLP gradients] [M] [loss] [bin counters], 256-byte aligned pieces
+    {   // the zero arena: [per plane: D_p, gauge gradient] [MLP gradients] [M] [loss] [bin counters], 256-byte aligned pieces
         size_t total = 0;
         auto add = [&](size_t floats) { total += (floats * sizeof(float) + 255) & ~(size_t)255; };
-        for (int p = 0; p < 3; ++p) {
-            const size_t tex = (size_t)(d->plane_h[p] + 2) * (d->plane_w[p] + 2);
-            add(dblk(p)); add(tex * 48); add(gblk(p));
-        }
+        for (int p = 0; p < 3; ++p) { add(dblk(p)); add(gblk(p)); }
         for (int k = TP_DENS_W; k < TP_COUNT; ++k) add((size_t)dn[k]);
         add((size_t)64 * 144); add(4);
         add((size_t)nbins + 1);
@@ -1120,7 +1117,10 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
         if ((rc = tr_alloc(t, &t->tex_d[p], tex * 16)) || (rc = tr_alloc(t, &t->tex_a[p], tex * 48)) || (rc = tr_alloc(t, &t->tex_g[p], gtex * 2)) ||
             (rc = tr_alloc(t, &t->q_d[p], tex)) || (rc = tr_alloc(t, &t->g_d[p], tex * 16)) || (rc = tr_alloc(t, &t->g_g[p], gtex * 2)))
             return bail(rc);
-        t->d_d[p] = carve(dblk(p)); t->g_a[p] = carve(tex * 48); t->g_gb[p] = carve(gblk(p));
+        t->d_d[p] = carve(dblk(p)); t->g_gb[p] = carve(gblk(p));
+        // the colour planes' gradients are WRITTEN by train_bin_gather_kernel (every texel): no fill per step
+        if ((rc = tr_alloc(t, &t->g_a[p], tex * 48))) return bail(rc);
+        if (hipMemsetAsync(t->g_a[p], 0, tex * 48 * sizeof(float), st) != hipSuccess) return bail(fail(NGF_E_HIP, "trainer setup failed"));
         T.d_bw[p] = (W + 2 + 3) / 4; T.g_bw[p] = (gw + 2 + 3) / 4;
         A.dens[p] = Tex{t->tex_d[p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
         A.app[p] = Tex{t->tex_a[p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
@@ -1168,7 +1168,7 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
         (rc = tr_alloc(t, &T.dt, cap * 6)) || (rc = tr_alloc(t, &T.G, (size_t)d->max_rays * 3)) || (rc = tr_alloc(t, &T.count, (size_t)d->max_rays)) ||
         (rc = tr_alloc(t, &T.offset, (size_t)d->max_rays + 1)) || (rc = tr_alloc(t, &T.list, cap * 2)) || (rc = tr_alloc(t, &T.list_w, cap)) ||
         (rc = tr_alloc(t, &t->fwd_image, (size_t)kFwdImage)) || (rc = tr_alloc(t, &t->bwd_image, (size_t)kBwdImage)) ||
-        (rc = tr_alloc(t, &T.bin_off, (size_t)nbins + 1)) || (rc = tr_alloc(t, &T.unit_total, (size_t)1)))
+        (rc = tr_alloc(t, &T.bin_off, (size_t)nbins + 1)) || (rc = tr_alloc(t, &T.bin_unit, (size_t)nbins + 1)) || (rc = tr_alloc(t, &T.unit_total, (size_t)1)))
         return bail(rc);
     // The activation rows (576 floats per sample + the 18 of its scatter pairs).  If the whole-batch default does not fit the free HBM, fall back to round 1's chunked
     // mode (262 144 rows = 453 MB; the colour kernels then run chunk by chunk and the step reads the active count on the host) instead of
@@ -1181,7 +1181,8 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
               (rc = tr_alloc(t, &T.D3, ch * 16)) || (rc = tr_alloc(t, &T.D2, ch * 64)) || (rc = tr_alloc(t, &T.D1, ch * 64)) ||
               (rc = tr_alloc(t, &T.DF, ch * 144)) || (rc = tr_alloc(t, &T.pair_cell, ch * 3)) || (rc = tr_alloc(t, &T.pair_rank, ch * 3)) ||
               (rc = tr_alloc(t, &T.pair_w, ch * 12)) || (rc = tr_alloc(t, &T.perm, ch * 3)) ||
-              (rc = tr_alloc(t, &T.units, ((size_t)nbins + ch * 3 / kBinChunk + 8) * 3))))
+              (rc = tr_alloc(t, &T.units, ((size_t)nbins + ch * 3 / kBinChunk + 8) * 3)) ||
+              (rc = tr_alloc(t, &T.slab, ((size_t)nbins + ch * 3 / kBinChunk + 8) * kBinTile))))
             break;
         while (t->allocs.size() > mark) { (void)hipFree(t->allocs.back()); t->allocs.pop_back(); }
         t->bytes = bytes_mark;
@@ -1292,13 +1293,14 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
             T.store = 1;
             hipLaunchKernelGGL(train_color_fwd_kernel, dim3(tr_grid(t, passes, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_f, st, T);
         }
-        T.bin_plain = single ? 1 : 0;
+        T.bin_accumulate = base > 0 ? 1 : 0;
         if (base > 0) HIP_TRY(hipMemsetAsync(T.bin_count, 0, ((size_t)T.nbins + 1) * sizeof(int32_t), st));      // the first chunk's counters: the zero arena
         hipLaunchKernelGGL(train_color_bwd_kernel, dim3(tr_grid(t, passes, kTrainWavesBwd, 1)), dim3(kTrainWavesBwd * 64), lds_b, st, T);
         // colour-plane scatter: order the chunk's (plane, sample) pairs by bin, then one wave per unit (ngf_train.hpp section 5b)
         hipLaunchKernelGGL(train_bin_prefix_kernel, dim3(1), dim3(1024), 0, st, T);
         hipLaunchKernelGGL(train_bin_perm_kernel, dim3(tr_grid(t, 3 * (int64_t)T.chunk_n, 256)), dim3(256), 0, st, T);
         hipLaunchKernelGGL(train_bin_scatter_kernel, dim3(2 * t->num_cus), dim3(256), 0, st, T);
+        hipLaunchKernelGGL(train_bin_gather_kernel, dim3(4 * t->num_cus, 3), dim3(256), 0, st, T);
         const int rows = T.chunk_n;
         int xg = (rows + 31) / 32;                      // 32-sample chunks; at most two workgroups per CU walk them
         if (xg > 2 * t->num_cus) xg = 2 * t->num_cus;
@@ -1308,6 +1310,8 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         hipLaunchKernelGGL((xty_block_kernel<4, 1>), dim3(xg), dim3(256), 0, st, (const float *)T.D1, 64, (const float *)T.V, 16, rows, 64, 15, t->g_dense[TP_W1] + 144, 159, cnt);
         hipLaunchKernelGGL((xty_block_kernel<4, 9>), dim3(xg), dim3(256), 0, st, (const float *)T.D1, 64, (const float *)T.F, 144, rows, 64, 144, T.M, 144, cnt);
     }
+    if (list_len <= 0)          // no active sample and the host knows it: nothing wrote the colour planes' gradients
+        for (int p = 0; p < 3; ++p) HIP_TRY(hipMemsetAsync(t->g_a[p], 0, (size_t)(d.plane_h[p] + 2) * (d.plane_w[p] + 2) * 48 * sizeof(float), st));
     hipLaunchKernelGGL(train_unfold_kernel, dim3(96), dim3(256), 0, st, T, t->g_dense[TP_W1], t->g_dense[TP_BASIS]);
     hipLaunchKernelGGL(train_density_bwd_kernel, dim3(tr_grid(t, n * ((n_samples + 63) / 64), 4, 5)), dim3(256), 0, st, T);     // 33 KB of LDS: 4 workgroups per CU
     UnblockArgs U;

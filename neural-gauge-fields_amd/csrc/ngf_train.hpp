@@ -81,7 +81,10 @@ struct TrainArgs {
     int32_t *perm;                                  // [3 * bin_cap]  sample rows ordered by bin
     int32_t *units;                                 // [unit_cap][3]  (bin, first entry of perm, entries): at most kBinChunk entries per unit
     int32_t *unit_total;                            // [1]
+    int32_t *bin_unit;                              // [nbins + 1]  first unit of every bin
+    float *slab;                                    // [unit_cap][81][48]  the units' texel sums (train_bin_gather_kernel adds them up)
     int32_t bin_base[3], bin_nbx[3], nbins, bin_cap;
+    int32_t bin_accumulate;                         // train_bin_gather_kernel adds to the planes' gradients (chunks after the first) instead of writing them
     double *loss;            // [2]: sum of squared residuals, (unused)
     int32_t chunk_base, chunk_n;      // the slice of the active list this launch works on
     const int32_t *n_active_dev;      // non-NULL: the active count lives on the device (offset[n]); chunk_n is then only the capacity and
@@ -865,6 +868,7 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
 // lane per channel) and sends every touched texel once: ~9x fewer transactions.
 constexpr int kBinChunk = 256;                     // pairs per unit
 constexpr int kBinTile = 81 * 48;                  // floats of a unit's LDS tile
+constexpr int kBinDummy = 10 * 48 + 16;            // ... and of the stretch behind it that lanes 48..63 add into
 
 // exclusive prefix of bin_count -> bin_off, and the unit list; one workgroup
 __global__ void __launch_bounds__(1024) train_bin_prefix_kernel(const TrainArgs T)
@@ -891,6 +895,7 @@ __global__ void __launch_bounds__(1024) train_bin_prefix_kernel(const TrainArgs 
     for (int b = b0; b < b1; ++b) {
         const int k = T.bin_count[b];
         T.bin_off[b] = rc;
+        T.bin_unit[b] = ru;
         for (int j = 0; j < k; j += kBinChunk) {
             int32_t *un = T.units + (size_t)ru * 3;
             un[0] = b; un[1] = rc + j; un[2] = min(kBinChunk, k - j);
@@ -898,7 +903,7 @@ __global__ void __launch_bounds__(1024) train_bin_prefix_kernel(const TrainArgs 
         }
         rc += k;
     }
-    if (t == 1023) { T.bin_off[T.nbins] = sc[1023]; *T.unit_total = su[1023]; }
+    if (t == 1023) { T.bin_off[T.nbins] = sc[1023]; T.bin_unit[T.nbins] = su[1023]; *T.unit_total = su[1023]; }
 }
 
 // perm[bin_off[bin] + rank] = sample row, for every pair that has a weight
@@ -920,17 +925,14 @@ __global__ void __launch_bounds__(256) train_bin_perm_kernel(const TrainArgs T)
 // one wave per unit
 __global__ void __launch_bounds__(256) train_bin_scatter_kernel(const TrainArgs T)
 {
-    __shared__ __attribute__((aligned(16))) float s_tile[4][kBinTile];
+    __shared__ __attribute__((aligned(16))) float s_tile[4][kBinTile + kBinDummy];
     const RenderArgs &A = T.R;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *tile = s_tile[wave];
     const int nunits = *T.unit_total;
-    const bool count_lines = (A.ablate & (1 << 21)) != 0;      // profiling: atomic line transactions -> T.prof[9]
-    unsigned long long n_lines = 0;
     const bool prof = (A.ablate & (1 << 20)) != 0;             // section clocks -> T.prof[11..15] (profiles/exp_train_sections.py)
     unsigned long long pc[4] = {0, 0, 0, 0}, t0 = 0, n_units = 0;
 #define NGF_SEC(k) if (prof) { const unsigned long long t1 = __builtin_readcyclecounter(); pc[k] += t1 - t0; t0 = t1; }
-    const int ch = lane < 48 ? lane : 47;
     for (int u = blockIdx.x * 4 + wave; u < nunits; u += gridDim.x * 4) {
         if (prof) { t0 = __builtin_readcyclecounter(); ++n_units; }
         const int bin = __builtin_amdgcn_readfirstlane(T.units[3 * u]), first = __builtin_amdgcn_readfirstlane(T.units[3 * u + 1]),
@@ -942,79 +944,81 @@ __global__ void __launch_bounds__(256) train_bin_scatter_kernel(const TrainArgs 
         for (int e = lane * 4; e < kBinTile; e += 256) *reinterpret_cast<f32x4 *>(tile + e) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         const int32_t *cellp = T.pair_cell + (size_t)p * T.bin_cap;
         const float *wp = T.pair_w + (size_t)p * T.bin_cap * 4;
-        const float *df = T.DF + p * 48 + ch;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // lane l holds the records of pairs l, 64 + l, 128 + l, 192 + l (row, tile offset of the cell, weights): two rounds of loads for the
-        // whole unit; the rows' gradients then arrive 16 at a time, the next 16 requested before the current 16 are added
+        // whole unit; the rows' gradients then arrive 32 at a time, the next 32 requested before the current 32 are added.  The kernel is
+        // bound by the instructions it issues per pair (profiles/exp_train_sections.py), so the inner loops carry no branch: entries past
+        // the unit's end have zero weights and the tile's first cell, lanes 48..63 (no channel) add into a dummy stretch
         int rowr[4], offr[4];
         f32x4 wr[4];
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) rowr[jb] = (jb * 64 + lane < len) ? T.perm[first + jb * 64 + lane] : 0;
+#ifdef NGF_EXP_SEQ_ROWS
+        for (int jb = 0; jb < 4; ++jb) rowr[jb] = (jb * 64 + lane < len) ? (first + jb * 64 + lane) / 3 : 0;      // timing experiment: rows in storage order
+#endif
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) {
             const bool have = jb * 64 + lane < len;
             const int cell = have ? cellp[rowr[jb]] : 0;
             wr[jb] = have ? *reinterpret_cast<const f32x4 *>(wp + (size_t)rowr[jb] * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            offr[jb] = (((cell >> 16) - y0) * 9 + ((cell & 0xffff) - x0)) * 48;
+            offr[jb] = have ? (((cell >> 16) - y0) * 9 + ((cell & 0xffff) - x0)) * (48 * 4) : 0;       // bytes
         }
         NGF_SEC(0)
         constexpr int SB = 32;                              // pairs per request group: two groups = 64 rows in flight per wave
         const int nsb = (len + SB - 1) / SB;
-        auto pick = [&](const int (&v)[4], int jb) { return jb == 0 ? v[0] : (jb == 1 ? v[1] : (jb == 2 ? v[2] : v[3])); };
-        auto load_sb = [&](int sb, float (&g)[SB]) {
-            const int rsel = pick(rowr, sb >> 1), l0 = (sb & 1) * SB;
+        {
+            // lanes 48..63: every lane stays active (the record picks below are per-lane selects that lanes 48..63 are read from), they add
+            // channel 47's values into a dummy stretch behind the tile (offset multiplier 0)
+            const char *dfl = reinterpret_cast<const char *>(T.DF + p * 48 + (lane < 48 ? lane : 47));
+            char *tl = reinterpret_cast<char *>(lane < 48 ? tile + lane : tile + kBinTile + (lane - 48));
+            const unsigned om = lane < 48 ? 1u : 0u;
+            auto pick = [&](const int (&v)[4], int jb) { return jb == 0 ? v[0] : (jb == 1 ? v[1] : (jb == 2 ? v[2] : v[3])); };
+            auto load_sb = [&](int sb, float (&g)[SB]) {
+                const int rsel = pick(rowr, sb >> 1), l0 = (sb & 1) * SB;
 #pragma unroll
-            for (int k = 0; k < SB; ++k) g[k] = df[(size_t)__builtin_amdgcn_readlane(rsel, l0 + k) * kFeat];
-        };
-        auto add_sb = [&](int sb, const float (&g)[SB]) {
-            const int jb = sb >> 1, l0 = (sb & 1) * SB;
-            const int osel = pick(offr, jb);
-            const f32x4 wsel = jb == 0 ? wr[0] : (jb == 1 ? wr[1] : (jb == 2 ? wr[2] : wr[3]));
+                for (int k = 0; k < SB; ++k)
+                    g[k] = *reinterpret_cast<const float *>(dfl + (size_t)(unsigned)__builtin_amdgcn_readlane(rsel, l0 + k) * (kFeat * 4));
+            };
+            auto add_sb = [&](int sb, const float (&g)[SB]) {
+                const int jb = sb >> 1, l0 = (sb & 1) * SB;
+                const int osel = pick(offr, jb);
+                const f32x4 wsel = jb == 0 ? wr[0] : (jb == 1 ? wr[1] : (jb == 2 ? wr[2] : wr[3]));
 #pragma unroll
-            for (int k = 0; k < SB; ++k) {
-                if (sb * SB + k >= len) break;                  // wave-uniform
-                float *t00 = tile + __builtin_amdgcn_readlane(osel, l0 + k) + lane;
-                const float w00 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsel[0]), l0 + k));
-                const float w10 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsel[1]), l0 + k));
-                const float w01 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsel[2]), l0 + k));
-                const float w11 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsel[3]), l0 + k));
-                if (lane < 48) {
+                for (int k = 0; k < SB; ++k) {
+                    float *t00 = reinterpret_cast<float *>(tl + __umul24((unsigned)__builtin_amdgcn_readlane(osel, l0 + k), om));
+                    const float w00 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsel[0]), l0 + k));
+                    const float w10 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsel[1]), l0 + k));
+                    const float w01 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsel[2]), l0 + k));
+                    const float w11 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wsel[3]), l0 + k));
                     const float a = t00[0], b = t00[48], c = t00[9 * 48], d = t00[10 * 48];
                     t00[0] = a + w00 * g[k];
                     t00[48] = b + w10 * g[k];
                     t00[9 * 48] = c + w01 * g[k];
                     t00[10 * 48] = d + w11 * g[k];
                 }
-            }
-        };
-        float ga[SB], gb[SB];
-        load_sb(0, ga);
+            };
+            // the requests are UNCONDITIONAL (past the unit's end they re-read its last group): a request behind a branch makes the compiler's
+            // s_waitcnt for the group being added cover the path on which nothing else is in flight -- i.e. wait for the group just requested
+            float ga[SB], gb[SB];
+            load_sb(0, ga);
 #pragma unroll 1
-        for (int sb = 0; sb < nsb; sb += 2) {
-            if (sb + 1 < nsb) load_sb(sb + 1, gb);
-            __builtin_amdgcn_sched_barrier(0);
-            add_sb(sb, ga);
-            __builtin_amdgcn_sched_barrier(0);
-            if (sb + 2 < nsb) load_sb(sb + 2, ga);
-            __builtin_amdgcn_sched_barrier(0);
-            if (sb + 1 < nsb) add_sb(sb + 1, gb);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int sb = 0; sb < nsb; sb += 2) {
+                load_sb(min(sb + 1, nsb - 1), gb);
+                __builtin_amdgcn_sched_barrier(0);
+                add_sb(sb, ga);
+                __builtin_amdgcn_sched_barrier(0);
+                load_sb(min(sb + 2, nsb - 1), ga);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sb + 1 < nsb) add_sb(sb + 1, gb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         NGF_SEC(1)
-        // every touched texel of the 9x9 tile once (texels past the padded plane cannot have been touched)
-        const Tex &tx = A.app[p];
-        float *gp = T.g_app[p];
-        for (int ty = 0; ty < 9; ++ty) {
-#pragma unroll
-            for (int tx_ = 0; tx_ < 9; ++tx_) {
-                const float v = lane < 48 ? tile[(ty * 9 + tx_) * 48 + lane] : 0.0f;
-                if (v != 0.0f) atomicAdd(gp + ((size_t)(y0 + ty) * tx.stride + (x0 + tx_)) * 48 + lane, v);
-                if (count_lines) {
-                    const unsigned long long mk = __ballot(v != 0.0f);
-                    n_lines += ((mk & 0xffffull) ? 1 : 0) + ((mk & 0xffff0000ull) ? 1 : 0) + ((mk & 0xffff00000000ull) ? 1 : 0);
-                }
-            }
+        // the tile leaves as it is (15.5 KB of plain, contiguous stores): train_bin_gather_kernel adds up the units that hold a texel
+        {
+            float *slab = T.slab + (size_t)u * kBinTile;
+            for (int e = lane * 4; e < kBinTile; e += 256) *reinterpret_cast<f32x4 *>(slab + e) = *reinterpret_cast<const f32x4 *>(tile + e);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         NGF_SEC(2)
@@ -1024,7 +1028,39 @@ __global__ void __launch_bounds__(256) train_bin_scatter_kernel(const TrainArgs 
         for (int k = 0; k < 3; ++k) atomicAdd(T.prof + 11 + k, pc[k]);
         atomicAdd(T.prof + 15, n_units);
     }
-    if (count_lines && lane == 0) atomicAdd(T.prof + 9, n_lines);
+}
+
+// d loss / d colour plane: every texel of the padded planes adds up the tiles that hold it -- the tile of the bin of its own block and,
+// on a block's first column / row, of the neighbours before it (a cell's second taps) -- over the units of those bins.  No atomics, and
+// every texel is written: the planes' gradients need no zero fill.  One thread per (texel, channel).
+__global__ void __launch_bounds__(256) train_bin_gather_kernel(const TrainArgs T)
+{
+    const RenderArgs &A = T.R;
+    const int p = blockIdx.y;
+    const Tex &tx = A.app[p];
+    const int W2 = tx.stride, H2 = tx.H + 2, nbx = T.bin_nbx[p];
+    const int nby = (H2 + 7) >> 3;
+    const int64_t total = (int64_t)W2 * H2 * 48;
+    float *gp = T.g_app[p];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / 48), c = (int)(i - (int64_t)t * 48);
+        const int y = t / W2, x = t - y * W2;
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // k & 1: the block to the left (tile column 8), k & 2: the block above (tile row 8)
+            if ((k & 1) && (x & 7)) continue;
+            if ((k & 2) && (y & 7)) continue;
+            const int bx = (x >> 3) - (k & 1), by = (y >> 3) - (k >> 1);
+            if (bx < 0 || by < 0 || bx >= nbx || by >= nby) continue;
+            const int bin = T.bin_base[p] + by * nbx + bx;
+            const int tcol = (k & 1) ? 8 : (x & 7), trow = (k & 2) ? 8 : (y & 7);
+            const float *src = T.slab + (size_t)(trow * 9 + tcol) * 48 + c;
+            const int u1 = T.bin_unit[bin + 1];
+            for (int u = T.bin_unit[bin]; u < u1; ++u) s += src[(size_t)u * kBinTile];
+        }
+        gp[i] = T.bin_accumulate ? gp[i] + s : s;
+    }
 }
 
 // ---- 6. weight gradients: out[M][N] += X^T . Y over `rows` samples (sample-major X [rows, ldx], Y [rows, ldy]) ------------------

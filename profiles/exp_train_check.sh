@@ -1,7 +1,7 @@
 # Training step: parity tests, then the per-kernel times of 20 iterations under rocprofv3 (gpurun -- bash profiles/exp_train_check.sh [tag])
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-cur}
-timeout 900 python -m pytest tests/test_gpu_train.py -x -q 2>&1 | tail -4
+timeout 240 python -m pytest tests/test_gpu_train.py -x -q 2>&1 | tail -4
 rm -rf gpurun_out/ktt && mkdir -p gpurun_out/ktt
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/ktt -o kt -- python profiles/workload.py train_R1 20 > gpurun_out/train_${TAG}.txt 2>/dev/null
 python profiles/summarize_rocpd.py $(find gpurun_out/ktt -name "*.db" | head -1) >> gpurun_out/train_${TAG}.txt

@@ -12,6 +12,8 @@ import torch
 import ngf_amd  # noqa: F401
 from ngf_amd import _lib, cases, synth, train
 
+if os.environ.get("NGF_LIB"):          # an experiment build (make -C neural-gauge-fields_amd/csrc exp NAME=... DEFS=...)
+    _lib.SO_PATH = os.path.abspath(os.environ["NGF_LIB"])
 L = _lib.lib()
 L.ngf_train_debug_sections.argtypes = [C.c_void_p, C.c_void_p]
 g, params, step = cases.big_case("triplane", "R1")
@@ -26,7 +28,7 @@ for it in range(3):
     tr.step(rays, tgt, it, N_samples=S)
 names = ["rows -> tiles (H1, H2), d3", "d2 + layer-2 backward (MFMA)", "D3/D2/D1 rows out, bias sums", "df = W1'^T d1 (MFMA)", "coords, taps, d loss / d t",
          "DF rows out, places in the bins"]
-with _lib.knobs(ablate=(1 << 20) | (1 << 21)):
+with _lib.knobs(ablate=(1 << 20) | (1 << 21) | int(os.environ.get('EXTRA_ABLATE', '0'))):
     out = (C.c_uint64 * 16)()
     _lib.check(L.ngf_train_debug_sections(tr._h, out))
     n = 5
