@@ -1035,6 +1035,12 @@ struct ngf_trainer {
     int64_t chunk = 0;
     int64_t bytes = 0;
     int num_cus = 256;
+    // after the colour backward the step forks: weight-gradient GEMMs | colour-plane scatter | density / gauge backward are independent
+    // chains of kernels none of which fills the device on its own (row transposes, LDS latency, the atomic unit); ngf_train_adam_all
+    // updates the three planes side by side
+    static constexpr int kAux = 2;
+    hipStream_t aux[kAux] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr};
 };
 
 template <typename T>
@@ -1052,6 +1058,11 @@ extern "C" int ngf_trainer_destroy(ngf_trainer *t)
 {
     if (!t) return NGF_OK;
     for (void *q : t->allocs) (void)hipFree(q);
+    for (int k = 0; k < ngf_trainer::kAux; ++k) {
+        if (t->aux[k]) { (void)hipStreamSynchronize(t->aux[k]); (void)hipStreamDestroy(t->aux[k]); }
+        if (t->ev_join[k]) (void)hipEventDestroy(t->ev_join[k]);
+    }
+    if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     delete t;
     return NGF_OK;
 }
@@ -1080,6 +1091,10 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) t->num_cus = prop.multiProcessorCount;
     int rc;
+    for (int k = 0; k < ngf_trainer::kAux; ++k)
+        if (hipStreamCreateWithFlags(&t->aux[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t->ev_join[k], hipEventDisableTiming) != hipSuccess)
+            return bail(fail(NGF_E_HIP, "trainer: stream / event creation failed"));
+    if (hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming) != hipSuccess) return bail(fail(NGF_E_HIP, "trainer: event creation failed"));
     TrainArgs &T = t->proto;
     memset(&T, 0, sizeof(T));
     RenderArgs &A = T.R;
@@ -1285,10 +1300,28 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         hipLaunchKernelGGL(train_color_fwd_kernel, dim3(tr_grid(t, (T.chunk_n + 15) / 16, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_f, st, T);
     }
     hipLaunchKernelGGL(train_composite_bwd_kernel, dim3(ray_blocks), dim3(64), 0, st, T);
+    // After the colour backward of a chunk the step forks: the weight-gradient GEMMs (sx) and the colour-plane scatter (sb) leave the
+    // caller's stream, which goes on with the density / gauge backward and waits for both before it returns to the caller's order.  None of
+    // these chains fills the device alone (LDS transposes, LDS latency, the atomic unit).  (Tried: the density / gauge backward beside the
+    // colour backward, with the colour path's d loss / d t scattered into the gauge planes by a kernel of its own -- the active entries of a
+    // ray span the whole plane, their scatter cannot be merged in LDS, and the step got 0.17 ms slower.)
+    // ngf_debug_set("ablate", 1 << 19) keeps everything on one stream.
+    const bool fork = !(A.ablate & (1 << 19));
+    hipStream_t sx = fork ? t->aux[0] : st, sb = fork ? t->aux[1] : st;
+    bool forked = false;
+    auto join = [&]() -> int {
+        if (fork && forked) {
+            HIP_TRY(hipStreamWaitEvent(st, t->ev_join[0], 0));
+            HIP_TRY(hipStreamWaitEvent(st, t->ev_join[1], 0));
+        }
+        forked = false;
+        return NGF_OK;
+    };
     for (int64_t base = 0; base < list_len; base += t->chunk) {
         T.chunk_base = (int32_t)base;
         T.chunk_n = (int32_t)std::min<int64_t>(t->chunk, list_len - base);
         const int passes = (T.chunk_n + 15) / 16;
+        if (int jrc = join()) return jrc;              // the previous chunk's chains read the rows this chunk overwrites
         if (!single) {
             T.store = 1;
             hipLaunchKernelGGL(train_color_fwd_kernel, dim3(tr_grid(t, passes, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_f, st, T);
@@ -1296,23 +1329,38 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         T.bin_accumulate = base > 0 ? 1 : 0;
         if (base > 0) HIP_TRY(hipMemsetAsync(T.bin_count, 0, ((size_t)T.nbins + 1) * sizeof(int32_t), st));      // the first chunk's counters: the zero arena
         hipLaunchKernelGGL(train_color_bwd_kernel, dim3(tr_grid(t, passes, kTrainWavesBwd, 1)), dim3(kTrainWavesBwd * 64), lds_b, st, T);
+        if (fork) {
+            HIP_TRY(hipEventRecord(t->ev_fork, st));
+            HIP_TRY(hipStreamWaitEvent(sb, t->ev_fork, 0));
+            HIP_TRY(hipStreamWaitEvent(sx, t->ev_fork, 0));
+        }
         // colour-plane scatter: order the chunk's (plane, sample) pairs by bin, then one wave per unit (ngf_train.hpp section 5b)
-        hipLaunchKernelGGL(train_bin_prefix_kernel, dim3(1), dim3(1024), 0, st, T);
-        hipLaunchKernelGGL(train_bin_perm_kernel, dim3(tr_grid(t, 3 * (int64_t)T.chunk_n, 256)), dim3(256), 0, st, T);
-        hipLaunchKernelGGL(train_bin_scatter_kernel, dim3(2 * t->num_cus), dim3(256), 0, st, T);
-        hipLaunchKernelGGL(train_bin_gather_kernel, dim3(4 * t->num_cus, 3), dim3(256), 0, st, T);
+        hipLaunchKernelGGL(train_bin_prefix_kernel, dim3(1), dim3(1024), 0, sb, T);
+        hipLaunchKernelGGL(train_bin_perm_kernel, dim3(tr_grid(t, 3 * (int64_t)T.chunk_n, 256)), dim3(256), 0, sb, T);
+        hipLaunchKernelGGL(train_bin_scatter_kernel, dim3(2 * t->num_cus), dim3(256), 0, sb, T);
+        hipLaunchKernelGGL(train_bin_gather_kernel, dim3(4 * t->num_cus, 3), dim3(256), 0, sb, T);
         const int rows = T.chunk_n;
         int xg = (rows + 31) / 32;                      // 32-sample chunks; at most two workgroups per CU walk them
         if (xg > 2 * t->num_cus) xg = 2 * t->num_cus;
-        hipLaunchKernelGGL((xty_block_kernel<1, 4>), dim3(xg), dim3(256), 0, st, (const float *)T.D3, 16, (const float *)T.H2, 64, rows, 3, 64, t->g_dense[TP_W3], 64, cnt);
-        hipLaunchKernelGGL((xty_block_kernel<4, 4>), dim3(xg), dim3(256), 0, st, (const float *)T.D2, 64, (const float *)T.H1, 64, rows, 64, 64, t->g_dense[TP_W2], 64, cnt);
-        // the 15 view columns of layer 1 directly, the 144 feature columns through M = Delta1^T F (train_unfold_kernel)
-        hipLaunchKernelGGL((xty_block_kernel<4, 1>), dim3(xg), dim3(256), 0, st, (const float *)T.D1, 64, (const float *)T.V, 16, rows, 64, 15, t->g_dense[TP_W1] + 144, 159, cnt);
-        hipLaunchKernelGGL((xty_block_kernel<4, 9>), dim3(xg), dim3(256), 0, st, (const float *)T.D1, 64, (const float *)T.F, 144, rows, 64, 144, T.M, 144, cnt);
+        // heaviest first: M = Delta1^T F (train_unfold_kernel turns it into d W1[:, :144] and d basis), d W2, the 15 view columns of d W1, d W3
+        XtyAll G;
+        G.X[0] = T.D1; G.ldx[0] = 64; G.Y[0] = T.F;  G.ldy[0] = 144; G.mvalid[0] = 64; G.nvalid[0] = 144; G.out[0] = T.M; G.ldo[0] = 144;
+        G.X[1] = T.D2; G.ldx[1] = 64; G.Y[1] = T.H1; G.ldy[1] = 64;  G.mvalid[1] = 64; G.nvalid[1] = 64;  G.out[1] = t->g_dense[TP_W2]; G.ldo[1] = 64;
+        G.X[2] = T.D1; G.ldx[2] = 64; G.Y[2] = T.V;  G.ldy[2] = 16;  G.mvalid[2] = 64; G.nvalid[2] = 15;  G.out[2] = t->g_dense[TP_W1] + 144; G.ldo[2] = 159;
+        G.X[3] = T.D3; G.ldx[3] = 16; G.Y[3] = T.H2; G.ldy[3] = 64;  G.mvalid[3] = 3;  G.nvalid[3] = 64;  G.out[3] = t->g_dense[TP_W3]; G.ldo[3] = 64;
+        G.rows = rows; G.rows_dev = cnt;
+        hipLaunchKernelGGL(xty_all_kernel, dim3(xg, 4), dim3(256), 0, sx, G);
+        if (base + t->chunk >= list_len) hipLaunchKernelGGL(train_unfold_kernel, dim3(96), dim3(256), 0, sx, T, t->g_dense[TP_W1], t->g_dense[TP_BASIS]);
+        if (fork) {
+            HIP_TRY(hipEventRecord(t->ev_join[0], sx));
+            HIP_TRY(hipEventRecord(t->ev_join[1], sb));
+        }
+        forked = true;
     }
-    if (list_len <= 0)          // no active sample and the host knows it: nothing wrote the colour planes' gradients
+    if (list_len <= 0) {        // no active sample and the host knows it: nothing wrote the colour planes' gradients
         for (int p = 0; p < 3; ++p) HIP_TRY(hipMemsetAsync(t->g_a[p], 0, (size_t)(d.plane_h[p] + 2) * (d.plane_w[p] + 2) * 48 * sizeof(float), st));
-    hipLaunchKernelGGL(train_unfold_kernel, dim3(96), dim3(256), 0, st, T, t->g_dense[TP_W1], t->g_dense[TP_BASIS]);
+        hipLaunchKernelGGL(train_unfold_kernel, dim3(96), dim3(256), 0, st, T, t->g_dense[TP_W1], t->g_dense[TP_BASIS]);
+    }
     hipLaunchKernelGGL(train_density_bwd_kernel, dim3(tr_grid(t, n * ((n_samples + 63) / 64), 4, 5)), dim3(256), 0, st, T);     // 33 KB of LDS: 4 workgroups per CU
     UnblockArgs U;
     for (int p = 0; p < 3; ++p) {
@@ -1322,6 +1370,7 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         U.src[p] = t->g_gb[p]; U.dst[p] = t->g_g[p]; U.w2[p] = d.gauge_w[p] + 2; U.h2[p] = d.gauge_h[p] + 2; U.bw[p] = T.g_bw[p];
     }
     hipLaunchKernelGGL(train_unblock_gauge_kernel, dim3(128, 3), dim3(256), 0, st, U);
+    if (int jrc = join()) return jrc;
     HIP_TRY(hipMemcpyAsync(rgb_loss, T.loss, sizeof(double), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipGetLastError());
     return NGF_OK;
@@ -1406,11 +1455,28 @@ extern "C" int ngf_train_adam_all(ngf_trainer *t, const int32_t *step_count, con
 {
     if (!t || !step_count || !lr) return fail(NGF_E_ARG, "ngf_train_adam_all: null argument");
     const ngf_train_desc &d = t->d;
+    // the three (plane, gauge plane) pairs are independent streams of reads and writes, none of which reaches the HBM rate alone: planes 1
+    // and 2 go to the trainer's own streams (ablate bit 1 << 19: all on the caller's)
+    hipStream_t st = (hipStream_t)hip_stream;
+    const bool fork = !(knob(KNOB_ABLATE) > 0 && (knob(KNOB_ABLATE) & (1 << 19)));
+    if (fork) {
+        HIP_TRY(hipEventRecord(t->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(t->aux[0], t->ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(t->aux[1], t->ev_fork, 0));
+    }
     for (int k = 0; k < 6; ++k)
         if (step_count[k] > 0) {
-            const int rc = ngf_train_adam(t, k, step_count[k], lr[k], beta1, beta2, eps, l1_weight, hip_stream);
+            const int p = k % 3;
+            hipStream_t sk = (fork && p > 0) ? t->aux[p - 1] : st;
+            const int rc = ngf_train_adam(t, k, step_count[k], lr[k], beta1, beta2, eps, l1_weight, (void *)sk);
             if (rc != NGF_OK) return rc;
         }
+    if (fork) {
+        for (int j = 0; j < 2; ++j) {
+            HIP_TRY(hipEventRecord(t->ev_join[j], t->aux[j]));
+            HIP_TRY(hipStreamWaitEvent(st, t->ev_join[j], 0));
+        }
+    }
     float *params[TP_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d.dens_w, d.dens_b, d.basis, d.w1, d.b1, d.w2, d.b2, d.w3, d.b3};
     AdamDenseAll D;
     int32_t at = 0;

@@ -16,7 +16,7 @@
 //                              the closed form of the cumprod backward (two sequential sweeps, no gathers)
 //   train_color_bwd_kernel     the data gradients of the colour MLP with the TRANSPOSED weights on the matrix pipe, the
 //                              feature gradients scattered into the packed colour planes (float atomics) and d loss / d t
-//   xty_block_kernel           weight gradients as sample-reduction GEMMs  dW = Delta^T . In  (MFMA, operand slabs through LDS);
+//   xty_all_kernel             weight gradients as sample-reduction GEMMs  dW = Delta^T . In  (MFMA, operand slabs through LDS);
 //   train_unfold_kernel        M -> d W1[:, :144], d basis
 //   train_density_bwd_kernel   every valid sample: ONE scalar per tap into the density-gradient images (the decoder is linear:
 //                              rank-one gradient, expanded by train_density_finish_kernel), d loss / d t -> gauge planes
@@ -37,7 +37,10 @@
 namespace ngf {
 
 constexpr int kTrainWaves = 6;                 // waves per workgroup in the colour forward kernel (H2 overwrites the dead feature tile)
-constexpr int kTrainWavesBwd = 6;              // ... and in the colour backward kernel (its tiles alias, see kBwdTileFloats)
+#ifndef NGF_TRAIN_WAVES_BWD
+#define NGF_TRAIN_WAVES_BWD 7
+#endif
+constexpr int kTrainWavesBwd = NGF_TRAIN_WAVES_BWD;              // ... and in the colour backward kernel (its tiles alias, see kBwdTileFloats)
 constexpr int kFeat = 144;                     // colour features (3 planes x 48)
 constexpr int kIn1 = 159, kIn1Pad = 160;       // [g(144), view(15)] (+1 zero pad)
 constexpr int kTs = 17;                        // row stride of the wave tiles [k][kTs]: odd, so that BOTH the MFMA operand reads (16 samples of a row) and the
@@ -1068,37 +1071,53 @@ __global__ void __launch_bounds__(256) train_bin_gather_kernel(const TrainArgs T
 // a tile-per-wave version re-read X and Y once per output tile, 0.94 GB for the 64 x 144 reduction), its four waves own the
 // MT x NT output tiles in registers for the whole walk and add them to `out` (the reference-layout gradient tensor
 // [Mvalid][ldo]) at the end.
+// The next chunk's rows are requested (into registers) before the current chunk's MFMAs are issued: as load -> store -> sync -> MFMA -> sync
+// the kernel read its 137 MB at 1.5 TB/s.  The four GEMMs of a step are ONE launch (blockIdx.y): each alone is a few hundred workgroups.
 template <int MT, int NT>
-__global__ void __launch_bounds__(256) xty_block_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ Y, int ldy, int rows,
-                                                        int Mvalid, int Nvalid, float *out, int ldo, const int32_t *rows_dev)
+__device__ __forceinline__ void xty_block(const float *__restrict__ X, int ldx, const float *__restrict__ Y, int ldy, int rows, int Mvalid, int Nvalid,
+                                          float *out, int ldo, float *sx, float *sy)
 {
-    if (rows_dev) rows = min(rows, *rows_dev);              // the row count lives on the device (no host sync on the active count)
     constexpr int CH = 32;                                              // samples per chunk = 8 MFMA k-steps
     constexpr int LX = 16 * MT + ((MT & 1) ? 0 : 16), LY = 16 * NT + ((NT & 1) ? 0 : 16);   // row strides == 16 (mod 32): 2 lanes per bank
     constexpr int TILES = MT * NT, PER_WAVE = (TILES + 3) / 4;
-    __shared__ __attribute__((aligned(16))) float sx[CH * LX], sy[CH * LY];
+    constexpr int EX = CH * 4 * MT, EY = CH * 4 * NT, NX = (EX + 255) / 256, NY = (EY + 255) / 256;      // float4 elements of a slab / per thread
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
     f32x4 acc[PER_WAVE];
 #pragma unroll
     for (int t = 0; t < PER_WAVE; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const int nchunks = (rows + CH - 1) / CH;
-    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    f32x4 px[NX], py[NY];
+    auto request = [&](int c) {                 // coalesced float4 loads of chunk c's rows, zeros past the end
         const int r0 = c * CH;
-        // cooperative, coalesced slab loads (float4 per thread), zero rows past the end
-        for (int e = threadIdx.x; e < CH * (4 * MT); e += 256) {
-            const int r = e / (4 * MT), q = e - r * (4 * MT);
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (r0 + r < rows) v = *reinterpret_cast<const f32x4 *>(X + (size_t)(r0 + r) * ldx + 4 * q);
-            *reinterpret_cast<f32x4 *>(sx + r * LX + 4 * q) = v;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = threadIdx.x + 256 * i, r = e / (4 * MT), q = e - r * (4 * MT);
+            px[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (e < EX && r0 + r < rows) px[i] = *reinterpret_cast<const f32x4 *>(X + (size_t)(r0 + r) * ldx + 4 * q);
         }
-        for (int e = threadIdx.x; e < CH * (4 * NT); e += 256) {
-            const int r = e / (4 * NT), q = e - r * (4 * NT);
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (r0 + r < rows) v = *reinterpret_cast<const f32x4 *>(Y + (size_t)(r0 + r) * ldy + 4 * q);
-            *reinterpret_cast<f32x4 *>(sy + r * LY + 4 * q) = v;
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int e = threadIdx.x + 256 * i, r = e / (4 * NT), q = e - r * (4 * NT);
+            py[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (e < EY && r0 + r < rows) py[i] = *reinterpret_cast<const f32x4 *>(Y + (size_t)(r0 + r) * ldy + 4 * q);
+        }
+    };
+    int c = blockIdx.x;
+    if (c < nchunks) request(c);
+    for (; c < nchunks; c += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int e = threadIdx.x + 256 * i, r = e / (4 * MT), q = e - r * (4 * MT);
+            if (e < EX) *reinterpret_cast<f32x4 *>(sx + r * LX + 4 * q) = px[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int e = threadIdx.x + 256 * i, r = e / (4 * NT), q = e - r * (4 * NT);
+            if (e < EY) *reinterpret_cast<f32x4 *>(sy + r * LY + 4 * q) = py[i];
         }
         __syncthreads();
+        request(min(c + (int)gridDim.x, nchunks));            // unconditional (past the end: zeros, no loads): see train_bin_scatter_kernel
 #pragma unroll
         for (int t = 0; t < PER_WAVE; ++t) {
             const int tile = wave + 4 * t;
@@ -1123,6 +1142,26 @@ __global__ void __launch_bounds__(256) xty_block_kernel(const float *__restrict_
             }
         }
     }
+}
+
+struct XtyAll {                                  // the four weight-gradient GEMMs of a chunk
+    const float *X[4], *Y[4];
+    float *out[4];
+    int32_t ldx[4], ldy[4], ldo[4], mvalid[4], nvalid[4];
+    int32_t rows;
+    const int32_t *rows_dev;                    // non-NULL: the row count lives on the device (no host sync on the active count)
+};
+
+__global__ void __launch_bounds__(256) xty_all_kernel(const XtyAll G)
+{
+    __shared__ __attribute__((aligned(16))) float sx[32 * 80], sy[32 * 144];
+    const int rows = G.rows_dev ? min(G.rows, *G.rows_dev) : G.rows;
+    const int g = blockIdx.y;
+    // heaviest first: D1^T F (64 x 144), D2^T H1 (64 x 64), D1^T V (64 x 16), D3^T H2 (16 x 64)
+    if (g == 0) xty_block<4, 9>(G.X[0], G.ldx[0], G.Y[0], G.ldy[0], rows, G.mvalid[0], G.nvalid[0], G.out[0], G.ldo[0], sx, sy);
+    else if (g == 1) xty_block<4, 4>(G.X[1], G.ldx[1], G.Y[1], G.ldy[1], rows, G.mvalid[1], G.nvalid[1], G.out[1], G.ldo[1], sx, sy);
+    else if (g == 2) xty_block<4, 1>(G.X[2], G.ldx[2], G.Y[2], G.ldy[2], rows, G.mvalid[2], G.nvalid[2], G.out[2], G.ldo[2], sx, sy);
+    else xty_block<1, 4>(G.X[3], G.ldx[3], G.Y[3], G.ldy[3], rows, G.mvalid[3], G.nvalid[3], G.out[3], G.ldo[3], sx, sy);
 }
 
 // ---- 7. density / gauge backward for every valid sample -----------------------------------------------------------------------

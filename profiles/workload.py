@@ -18,6 +18,8 @@ from ngf_amd import _lib, cases, rays as nrays, synth
 
 name = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+if os.environ.get("NGF_LIB"):          # an experiment build (make -C neural-gauge-fields_amd/csrc exp NAME=... DEFS=...)
+    _lib.SO_PATH = os.path.abspath(os.environ["NGF_LIB"])
 _lib.knobs_from_env()
 dev = "cuda"
 
