@@ -1245,6 +1245,11 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
     T.inv_count = 1.0f / (3.0f * (float)n);
     A.ablate = knob(KNOB_ABLATE) > 0 ? knob(KNOB_ABLATE) : 0;      // timing experiments only (profiles/exp_train_ablate.sh)
     if (int prc = poison_lds(st)) return prc;
+    // ngf_debug_set("ablate", 1 << 19) keeps the whole step on the caller's stream (see the forks below)
+    const bool fork = !(A.ablate & (1 << 19));
+    hipStream_t sx = fork ? t->aux[0] : st, sb = fork ? t->aux[1] : st;
+    ProjectArgs PJ;
+    PJ.wd = d.dens_w;
     // parameters -> packed textures where the trainer's copy is not current (ngf_train_adam writes the copy along with the parameter;
     // ngf_train_params_changed marks every copy stale); gradient buffers -> 0
     for (int p = 0; p < 3; ++p) {
@@ -1259,11 +1264,18 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
             pack_plane_kernel<<<256, 256, 0, st>>>(d.gauge[p], gh, gw, 0, 2, t->tex_g[p]);
             t->tex_fresh[3 + p] = true;
         }
-        hipLaunchKernelGGL(train_project_density_kernel, dim3(256), dim3(256), 0, st, (const float *)t->tex_d[p], d.dens_w + 16 * p, (int64_t)tex, t->q_d[p]);
+        PJ.tex16[p] = t->tex_d[p]; PJ.texels[p] = (int64_t)tex; PJ.q[p] = t->q_d[p];
     }
+    hipLaunchKernelGGL(train_project_density_kernel, dim3(128, 3), dim3(256), 0, st, PJ);
     HIP_TRY(hipMemsetAsync(t->zero_arena, 0, t->zero_bytes, st));
+    // the LDS images of the colour MLP are first read by the colour forward: built beside the density kernel and the scan
     T.fwd_image = t->fwd_image; T.bwd_image = t->bwd_image;
-    hipLaunchKernelGGL(train_fold_kernel, dim3(48), dim3(256), 0, st, T, t->fwd_image, t->bwd_image);
+    if (fork) {
+        HIP_TRY(hipEventRecord(t->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(sx, t->ev_fork, 0));
+    }
+    hipLaunchKernelGGL(train_fold_kernel, dim3(48), dim3(256), 0, sx, T, t->fwd_image, t->bwd_image);
+    if (fork) HIP_TRY(hipEventRecord(t->ev_join[0], sx));
 
     const int64_t pairs = n * n_samples;
     hipLaunchKernelGGL(train_density_kernel, dim3(tr_grid(t, pairs, 256)), dim3(256), 0, st, T);
@@ -1288,6 +1300,7 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
     static_assert((((kBwdImage + 3) & ~3) + kTrainWavesBwd * kBwdTileFloats) * 4 <= 160 * 1024, "colour backward LDS");
     HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(train_color_fwd_kernel), lds_f));
     HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(train_color_bwd_kernel), lds_b));
+    if (fork) HIP_TRY(hipStreamWaitEvent(st, t->ev_join[0], 0));          // the images
     const int32_t *cnt = no_sync ? T.offset + n : nullptr;
     T.n_active_dev = cnt;
     const int64_t list_len = no_sync ? pairs : n_active;          // upper bound of the list length the loops below are sized for
@@ -1299,15 +1312,13 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         T.store = single ? 1 : 0;
         hipLaunchKernelGGL(train_color_fwd_kernel, dim3(tr_grid(t, (T.chunk_n + 15) / 16, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_f, st, T);
     }
-    hipLaunchKernelGGL(train_composite_bwd_kernel, dim3(ray_blocks), dim3(64), 0, st, T);
+    hipLaunchKernelGGL(train_composite_bwd_kernel, dim3((unsigned)((n + 64 / kCompLanes - 1) / (64 / kCompLanes))), dim3(64), 0, st, T);
+    const dim3 dgrid(tr_grid(t, n * ((n_samples + 63) / 64), 4, kDensBwdGroupsPerCu + 1));
     // After the colour backward of a chunk the step forks: the weight-gradient GEMMs (sx) and the colour-plane scatter (sb) leave the
     // caller's stream, which goes on with the density / gauge backward and waits for both before it returns to the caller's order.  None of
     // these chains fills the device alone (LDS transposes, LDS latency, the atomic unit).  (Tried: the density / gauge backward beside the
     // colour backward, with the colour path's d loss / d t scattered into the gauge planes by a kernel of its own -- the active entries of a
     // ray span the whole plane, their scatter cannot be merged in LDS, and the step got 0.17 ms slower.)
-    // ngf_debug_set("ablate", 1 << 19) keeps everything on one stream.
-    const bool fork = !(A.ablate & (1 << 19));
-    hipStream_t sx = fork ? t->aux[0] : st, sb = fork ? t->aux[1] : st;
     bool forked = false;
     auto join = [&]() -> int {
         if (fork && forked) {
@@ -1329,13 +1340,14 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         T.bin_accumulate = base > 0 ? 1 : 0;
         if (base > 0) HIP_TRY(hipMemsetAsync(T.bin_count, 0, ((size_t)T.nbins + 1) * sizeof(int32_t), st));      // the first chunk's counters: the zero arena
         hipLaunchKernelGGL(train_color_bwd_kernel, dim3(tr_grid(t, passes, kTrainWavesBwd, 1)), dim3(kTrainWavesBwd * 64), lds_b, st, T);
+        // colour-plane scatter: order the chunk's (plane, sample) pairs by bin, then one wave per unit (ngf_train.hpp section 5b); the
+        // single-workgroup prefix stays on this stream, ahead of the fork (beside three full-device kernels it took 0.13 ms instead of 0.01)
+        hipLaunchKernelGGL(train_bin_prefix_kernel, dim3(1), dim3(1024), 0, st, T);
         if (fork) {
             HIP_TRY(hipEventRecord(t->ev_fork, st));
             HIP_TRY(hipStreamWaitEvent(sb, t->ev_fork, 0));
             HIP_TRY(hipStreamWaitEvent(sx, t->ev_fork, 0));
         }
-        // colour-plane scatter: order the chunk's (plane, sample) pairs by bin, then one wave per unit (ngf_train.hpp section 5b)
-        hipLaunchKernelGGL(train_bin_prefix_kernel, dim3(1), dim3(1024), 0, sb, T);
         hipLaunchKernelGGL(train_bin_perm_kernel, dim3(tr_grid(t, 3 * (int64_t)T.chunk_n, 256)), dim3(256), 0, sb, T);
         hipLaunchKernelGGL(train_bin_scatter_kernel, dim3(2 * t->num_cus), dim3(256), 0, sb, T);
         hipLaunchKernelGGL(train_bin_gather_kernel, dim3(4 * t->num_cus, 3), dim3(256), 0, sb, T);
@@ -1361,17 +1373,21 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         for (int p = 0; p < 3; ++p) HIP_TRY(hipMemsetAsync(t->g_a[p], 0, (size_t)(d.plane_h[p] + 2) * (d.plane_w[p] + 2) * 48 * sizeof(float), st));
         hipLaunchKernelGGL(train_unfold_kernel, dim3(96), dim3(256), 0, st, T, t->g_dense[TP_W1], t->g_dense[TP_BASIS]);
     }
-    hipLaunchKernelGGL(train_density_bwd_kernel, dim3(tr_grid(t, n * ((n_samples + 63) / 64), 4, 5)), dim3(256), 0, st, T);     // 33 KB of LDS: 4 workgroups per CU
+    // (Tried: the D_p share <true, false> beside the colour backward and the gauge share <false, true> after it -- each half takes as long
+    // as the whole, 0.31 ms: the kernel is bound by the dependent chain of an item, not by what it scatters.)
+    hipLaunchKernelGGL((train_density_bwd_kernel<true, true>), dgrid, dim3(256), 0, st, T);
     UnblockArgs U;
+    FinishArgs FA;
+    FA.wd = d.dens_w; FA.g_wd = t->g_dense[TP_DENS_W];
     for (int p = 0; p < 3; ++p) {
-        const int64_t tex = (int64_t)(d.plane_h[p] + 2) * (d.plane_w[p] + 2);
-        hipLaunchKernelGGL(train_density_finish_kernel, dim3(256), dim3(256), 0, st, (const float *)t->d_d[p], d.plane_w[p] + 2, T.d_bw[p], (const float *)t->tex_d[p],
-                           d.dens_w + 16 * p, tex, t->g_d[p], t->g_dense[TP_DENS_W] + 16 * p);
+        FA.D[p] = t->d_d[p]; FA.tex16[p] = t->tex_d[p]; FA.w2[p] = d.plane_w[p] + 2; FA.bw[p] = T.d_bw[p];
+        FA.texels[p] = (int64_t)(d.plane_h[p] + 2) * (d.plane_w[p] + 2); FA.g_dens[p] = t->g_d[p];
         U.src[p] = t->g_gb[p]; U.dst[p] = t->g_g[p]; U.w2[p] = d.gauge_w[p] + 2; U.h2[p] = d.gauge_h[p] + 2; U.bw[p] = T.g_bw[p];
     }
+    U.loss_src = T.loss; U.loss_dst = rgb_loss;        // the loss travels with the last kernel of the caller's stream (a copy of 8 bytes is a launch of its own)
+    hipLaunchKernelGGL(train_density_finish_kernel, dim3(128, 3), dim3(256), 0, st, FA);
     hipLaunchKernelGGL(train_unblock_gauge_kernel, dim3(128, 3), dim3(256), 0, st, U);
     if (int jrc = join()) return jrc;
-    HIP_TRY(hipMemcpyAsync(rgb_loss, T.loss, sizeof(double), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipGetLastError());
     return NGF_OK;
 }

@@ -579,26 +579,27 @@ __global__ void __launch_bounds__(kTrainWaves * 64) __attribute__((amdgpu_waves_
 }
 
 // ---- 4. compositing forward tail + backward to the pre-softplus density of every sample ------------------------------------
-// Sixteen lanes per ray as in the scan.  d loss / d alpha_i = dL/dw_i T_i - (sum_{j>i} w_j dL/dw_j) / (1 - alpha_i + 1e-10) with
+// kCompLanes lanes per ray.  d loss / d alpha_i = dL/dw_i T_i - (sum_{j>i} w_j dL/dw_j) / (1 - alpha_i + 1e-10) with
 // dL/dw_j = G . (c_j [active] - bg) is the cumprod backward; the suffix sum is accumulated from the END of the ray in float64
 // (what ATen's reverse cumsum does on the CPU), T_i was parked in dx by the scan.
 constexpr int kCompAhead = 4;
+constexpr int kCompLanes = 16;                   // lanes per ray (eight -- two waves per SIMD for a 4096-ray batch -- measured slower: 71 vs 64 us)
 __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs T)
 {
     const RenderArgs &A = T.R;
-    const int lane = threadIdx.x & 63, seg = lane & 15, rl = lane >> 4;
-    const int64_t r0 = (int64_t)blockIdx.x * 4 + rl;
+    const int lane = threadIdx.x & 63, seg = lane & (kCompLanes - 1), rl = lane / kCompLanes;
+    const int64_t r0 = (int64_t)blockIdx.x * (64 / kCompLanes) + rl;
     const bool live = r0 < A.n;
     const int64_t r = live ? r0 : A.n - 1;
     const float bg = A.white_bg ? 1.0f : 0.0f;
     float acc = 0.0f, rgb[3] = {0.0f, 0.0f, 0.0f};
     // one wave per SIMD: the loads of kCompAhead blocks are requested together (as in the scan); the colours are read whether the
     // sample is active or not (inactive entries are never written: whatever they hold is dropped by the select below)
-    for (int i0 = seg; i0 < A.S; i0 += 16 * kCompAhead) {
+    for (int i0 = seg; i0 < A.S; i0 += kCompLanes * kCompAhead) {
         float wv[kCompAhead], cv[kCompAhead][3];
 #pragma unroll
         for (int u = 0; u < kCompAhead; ++u) {
-            const int i = i0 + 16 * u;
+            const int i = i0 + kCompLanes * u;
             const int64_t idx = r * A.S + (i < A.S ? i : 0);
             wv[u] = i < A.S ? T.w[idx] : 0.0f;
 #pragma unroll
@@ -606,7 +607,7 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
         }
 #pragma unroll
         for (int u = 0; u < kCompAhead; ++u) {
-            if (i0 + 16 * u >= A.S) continue;
+            if (i0 + kCompLanes * u >= A.S) continue;
             acc += wv[u];
             if (wv[u] > A.thr) {
 #pragma unroll
@@ -615,7 +616,7 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
         }
     }
 #pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
+    for (int d = 1; d < kCompLanes; d <<= 1) {
         acc += __shfl_xor(acc, d);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) rgb[ch] += __shfl_xor(rgb[ch], d);
@@ -636,12 +637,12 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
     const float tmin = ray_tmin(A, r);
     const float jit = A.jitter ? A.jitter[r] : 0.0f;
     double carry = 0.0;                                       // sum of the terms of all steps above the current block
-    for (int j0 = ((A.S - 1) / 16) * 16; j0 >= 0; j0 -= 16 * kCompAhead) {
+    for (int j0 = ((A.S - 1) / kCompLanes) * kCompLanes; j0 >= 0; j0 -= kCompLanes * kCompAhead) {
         float xv[kCompAhead], sv[kCompAhead], tv[kCompAhead], wv[kCompAhead], cv[kCompAhead][3];
 #pragma unroll
         for (int u = 0; u < kCompAhead; ++u) {
-            const int i = j0 - 16 * u + seg;
-            const bool inb = (j0 - 16 * u >= 0) && (i < A.S);
+            const int i = j0 - kCompLanes * u + seg;
+            const bool inb = (j0 - kCompLanes * u >= 0) && (i < A.S);
             const int64_t idx = r * A.S + (inb ? i : 0);
             xv[u] = inb ? T.et[idx] : 1.0f;
             sv[u] = inb ? T.sg[idx] : 0.0f;
@@ -652,7 +653,7 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
         }
 #pragma unroll
         for (int u = 0; u < kCompAhead; ++u) {
-            const int i0 = j0 - 16 * u;
+            const int i0 = j0 - kCompLanes * u;
             if (i0 < 0) break;                                           // wave-uniform
             const int i = i0 + seg;
             const bool inb = i < A.S;
@@ -669,9 +670,9 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
             const double term = inb ? (double)((dw * alpha) * Ti) : 0.0;     // autograd's order: dL/dT_j = dL/dw_j alpha_j, then times T_j
             double incl = term;                                              // inclusive suffix sum over the row: steps >= seg
 #pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                const double o = __shfl_down(incl, d, 16);
-                incl += (seg + d < 16) ? o : 0.0;
+            for (int d = 1; d < kCompLanes; d <<= 1) {
+                const double o = __shfl_down(incl, d, kCompLanes);
+                incl += (seg + d < kCompLanes) ? o : 0.0;
             }
             const double suffix = carry + (incl - term);
             const float keep = (1.0f - alpha) + 1e-10f;
@@ -679,7 +680,7 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
             const float dsigma = dalpha * delta * e;                        // d alpha / d sigma = delta exp(-sigma delta)
             const float sig = sv[u];                                         // softplus'; 0 where the sample is invalid
             if (live && inb) T.dx[idx] = (sig == 0.0f) ? 0.0f : dsigma * sig;
-            carry += __shfl(incl, rl * 16);
+            carry += __shfl(incl, rl * kCompLanes);
         }
     }
     // one double atomic per wave for the loss
@@ -1170,9 +1171,14 @@ __global__ void __launch_bounds__(256) xty_all_kernel(const XtyAll G)
 // and d loss / d wd[16p+c] = sum over texels of D_p[texel] * plane_p[c][texel].  The per-sample kernel therefore scatters ONE
 // float per tap (12 atomics instead of 192) and takes the spatial derivative from the wd-projected 1-channel planes Q_p;
 // train_density_finish_kernel expands D_p afterwards.
-__global__ void __launch_bounds__(256) train_project_density_kernel(const float *__restrict__ tex16, const float *__restrict__ wd, int64_t texels,
-                                                                    float *__restrict__ q)
+struct ProjectArgs { const float *tex16[3]; const float *wd; int64_t texels[3]; float *q[3]; };      // blockIdx.y = plane
+__global__ void __launch_bounds__(256) train_project_density_kernel(const ProjectArgs P)
 {
+    const int p = blockIdx.y;
+    const float *__restrict__ tex16 = P.tex16[p];
+    const float *__restrict__ wd = P.wd + 16 * p;
+    float *__restrict__ q = P.q[p];
+    const int64_t texels = P.texels[p];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < texels; i += stride) {
         const f32x4 *v = reinterpret_cast<const f32x4 *>(tex16 + i * 16);
@@ -1198,7 +1204,12 @@ __global__ void __launch_bounds__(256) train_project_density_kernel(const float 
 // every touched block as ONE whole-line atomic.  The LDS sums are plain read-add-writes made collision-free: runs of consecutive lanes
 // in the SAME cell are added up in registers (segmented scan over the 16-lane DPP rows), and of the run leaders only those that win a
 // last-writer-wins election on their cell write in a round (distinct cells => distinct texels for every tap index; normally one round).
-constexpr int kScatCap = 128;                   // blocks of a wave tile (8 KB); a bounding box beyond it takes the per-tap path
+#ifndef NGF_SCAT_CAP
+#define NGF_SCAT_CAP 64
+#endif
+constexpr int kScatCap = NGF_SCAT_CAP;          // blocks of a wave tile (4 KB: seven workgroups per CU); a bounding box beyond it is taken in halves
+                                                // (128 with the per-tap path as the only fallback was round 2's choice; 32 / 48 / 192 / 256 measured slower)
+constexpr int kDensBwdGroupsPerCu = (160 * 1024) / ((NGF_SCAT_CAP * 16 + 256) * 4 * 4 + 64);      // workgroups (4 waves) of train_density_bwd_kernel an LDS holds
 constexpr int kScatOwn = 256;                   // election slots per wave
 constexpr int kScatWaveFloats = kScatCap * 16 + kScatOwn;
 
@@ -1222,14 +1233,25 @@ __device__ __forceinline__ int blocked_offset(int X, int Y, int bw)
 
 // (X, Y) = padded (column, row) of the cell's first tap, val[tap][channel] the contributions (tap = 2 * dy + dx), bw = blocks per row;
 // tile: kScatWaveFloats floats of wave-private LDS.  Every lane of the wave must call it (wave-uniform control flow inside).
-template <int BYS, int CH, int N = 4 * CH>
+template <int BYS, int CH, int N = 4 * CH, int DEPTH = 0>
 __device__ __forceinline__ void scatter_blocked(float *tile, int lane, bool work, int X, int Y, float (&val)[N], float *gbuf, int bw, unsigned *lines = nullptr)        // lines: profiling counters {whole-line atomics, per-tap fallbacks}
 {
     const int big = 1 << 20;
     const int bx0 = wave_min_i(work ? X >> 2 : big), bx1 = wave_max_i(work ? (X + 1) >> 2 : -big);
     const int by0 = wave_min_i(work ? Y >> BYS : big), by1 = wave_max_i(work ? (Y + 1) >> BYS : -big);
     const int nbx = bx1 - bx0 + 1, nb = nbx * (by1 - by0 + 1);
-    if (nb > kScatCap) {                        // wave-uniform; rare (a gauge field that tears the ray apart)
+    if (nb > kScatCap) {                        // wave-uniform
+        // a box beyond the tile: the two halves of the lanes in turn (half the steps of a ray: a quarter of the box), twice at most;
+        // then the per-tap path (a gauge field that tears the ray apart)
+        if constexpr (DEPTH < 2) {
+            constexpr int H = 32 >> DEPTH;
+            float v0[N], v1[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) v0[j] = v1[j] = val[j];
+            scatter_blocked<BYS, CH, N, DEPTH + 1>(tile, lane, work && !(lane & H), X, Y, v0, gbuf, bw, lines);
+            scatter_blocked<BYS, CH, N, DEPTH + 1>(tile, lane, work && (lane & H), X, Y, v1, gbuf, bw, lines);
+            return;
+        }
         if (lines) lines[1] += 1;
         if (work) {
 #pragma unroll
@@ -1309,6 +1331,10 @@ __device__ __forceinline__ void scatter_blocked(float *tile, int lane, bool work
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// DENS: the D_p images and d loss / d density bias -- needs d loss / d sigma only, so it runs beside the colour backward.  GAUGE: d loss / d t
+// of both paths (the density path's recomputed from the projected planes, the colour path's from T.dt) -> gauge planes, after the colour
+// backward.  <true, true> is the whole backward in one pass (single-stream mode).
+template <bool DENS, bool GAUGE>
 __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs T)
 {
     const RenderArgs &A = T.R;
@@ -1331,13 +1357,13 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
         const int i = inr ? i0 : A.S - 1;
         const int64_t idx = r * A.S + i;
         const float dx = inr ? T.dx[idx] : 0.0f;
-        const bool active = inr && (T.w[idx] > A.thr);
+        const bool active = GAUGE && inr && (T.w[idx] > A.thr);
         const bool work = (dx != 0.0f) | active;
         if (!__any(work)) continue;
         float t[6], xn[3];
         list_sample_coords(A, r, i, t, xn);
         float dt[6];
-        bsum += dx;
+        if (DENS) bsum += dx;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const Tex &tx = A.dens[p];
@@ -1346,12 +1372,12 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
             const float v00 = q[0], v10 = q[1], v01 = q[tx.stride], v11 = q[tx.stride + 1];
             dt[2 * p] = dx * (b.wy0 * (v10 - v00) + b.wy1 * (v11 - v01)) * b.sx;
             dt[2 * p + 1] = dx * (b.wx0 * (v01 - v00) + b.wx1 * (v11 - v10)) * b.sy;
-            if (!(A.ablate & 256)) {
+            if (DENS && !(A.ablate & 256)) {
                 float dw[4] = {b.w00 * dx, b.w10 * dx, b.w01 * dx, b.w11 * dx};
                 scatter_blocked<2, 1>(tile, lane, work, b.cx, b.cy, dw, T.d_dens[p], T.d_bw[p], count_lines ? n_lines : nullptr);
             }
         }
-        if (A.mode) {
+        if (GAUGE && A.mode) {
             if (active) {
                 const float *dc = T.dt + idx * 6;
 #pragma unroll
@@ -1378,15 +1404,16 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
     for (int s = 32; s > 0; s >>= 1) bsum += __shfl_xor(bsum, s);
     if (lane == 0) atomicAdd(&s_bd, bsum);
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(T.g_bd, s_bd);
+    if (DENS && threadIdx.x == 0) atomicAdd(T.g_bd, s_bd);
 }
 
 // blocked gauge-gradient plane -> [texel][2] (what the Adam kernel and ngf_train_get_grad read); blockIdx.y = plane
-struct UnblockArgs { const float *src[3]; float *dst[3]; int32_t w2[3], h2[3], bw[3]; };
+struct UnblockArgs { const float *src[3]; float *dst[3]; int32_t w2[3], h2[3], bw[3]; const double *loss_src; double *loss_dst; };   // + the step's loss to the caller's buffer
 __global__ void __launch_bounds__(256) train_unblock_gauge_kernel(const UnblockArgs U)
 {
     const int p = blockIdx.y;
     const int total = U.w2[p] * U.h2[p];
+    if (U.loss_dst && blockIdx.x == 0 && p == 0 && threadIdx.x == 0) *U.loss_dst = *U.loss_src;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int y = i / U.w2[p], x = i - y * U.w2[p];
         const f32x2 v = *reinterpret_cast<const f32x2 *>(U.src[p] + blocked_offset<1, 2>(x, y, U.bw[p]));
@@ -1395,9 +1422,15 @@ __global__ void __launch_bounds__(256) train_unblock_gauge_kernel(const UnblockA
 }
 
 // expand the scalar gradient image of plane p: g_dens[texel][c] = wd[c] * D[texel]; g_wd[c] += sum_texels D[texel] * tex16[texel][c]
-__global__ void __launch_bounds__(256) train_density_finish_kernel(const float *__restrict__ D, int w2, int bw, const float *__restrict__ tex16,
-                                                                   const float *__restrict__ wd, int64_t texels, float *__restrict__ g_dens, float *g_wd)
+struct FinishArgs { const float *D[3], *tex16[3]; const float *wd; int32_t w2[3], bw[3]; int64_t texels[3]; float *g_dens[3]; float *g_wd; };   // blockIdx.y = plane
+__global__ void __launch_bounds__(256) train_density_finish_kernel(const FinishArgs F)
 {
+    const int p = blockIdx.y;
+    const float *__restrict__ D = F.D[p], *__restrict__ tex16 = F.tex16[p], *__restrict__ wd = F.wd + 16 * p;
+    float *__restrict__ g_dens = F.g_dens[p];
+    float *g_wd = F.g_wd + 16 * p;
+    const int w2 = F.w2[p], bw = F.bw[p];
+    const int64_t texels = F.texels[p];
     __shared__ float sh[16];
     if (threadIdx.x < 16) sh[threadIdx.x] = 0.0f;
     __syncthreads();

@@ -176,7 +176,14 @@ class Trainer:
 
     @property
     def last_active(self) -> int:
-        """Active (weight > thr) samples of the last backward; reading it synchronises with the device."""
+        """Active (weight > thr) samples of the last backward; reading it copies the count from the trainer and synchronises with the
+        device (the copy is a launch of its own: it is not part of the step)."""
+        n = getattr(self, "_last_n", 0)
+        if n <= 0:
+            return 0
+        with torch.cuda.device(self.dev):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(self.L.ngf_train_get_active(self._h, n, self._active.data_ptr(), st))
         return int(self._active.item())
 
     # ---------------------------------------------------------------------------------------------------------------------
@@ -203,12 +210,12 @@ class Trainer:
             white_bg = c < 0.5
         gauge_on = int(iteration >= self.field.gauge_start)
         # no host pointer for the active count: the call stays asynchronous (the colour kernels read the count on the device);
-        # ``last_active`` fetches it lazily from a device int
+        # ``last_active`` fetches it lazily
         with torch.cuda.device(self.dev):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             _lib.check(self.L.ngf_train_backward(self._h, rays.data_ptr(), tgt.data_ptr(), jitter.data_ptr(), n, S, int(bool(white_bg)), gauge_on,
                                                  self._loss.data_ptr(), None, st))
-            _lib.check(self.L.ngf_train_get_active(self._h, n, self._active.data_ptr(), st))
+        self._last_n = n
         self._gauge_on = gauge_on
         return self._loss[0] / (3.0 * n)
 
