@@ -1350,7 +1350,13 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         }
         hipLaunchKernelGGL(train_bin_perm_kernel, dim3(tr_grid(t, 3 * (int64_t)T.chunk_n, 256)), dim3(256), 0, sb, T);
         hipLaunchKernelGGL(train_bin_scatter_kernel, dim3(2 * t->num_cus), dim3(256), 0, sb, T);
-        hipLaunchKernelGGL(train_bin_gather_kernel, dim3(4 * t->num_cus, 3), dim3(256), 0, sb, T);
+        {   // one (texel, channel) per thread and two dependent loads each: as many workgroups as the largest plane has items (a few per thread
+            // left the kernel waiting on memory latency: 40 us -> see profiles/r03_train_R1_kernel_stats.txt)
+            int64_t items = 0;
+            for (int p = 0; p < 3; ++p) items = std::max<int64_t>(items, (int64_t)(d.plane_h[p] + 2) * (d.plane_w[p] + 2) * 48);
+            const int gx = (int)std::min<int64_t>((items + 255) / 256, (int64_t)64 * t->num_cus);
+            hipLaunchKernelGGL(train_bin_gather_kernel, dim3(gx, 3), dim3(256), 0, sb, T);
+        }
         const int rows = T.chunk_n;
         int xg = (rows + 31) / 32;                      // 32-sample chunks; at most two workgroups per CU walk them
         if (xg > 2 * t->num_cus) xg = 2 * t->num_cus;
@@ -1480,19 +1486,13 @@ extern "C" int ngf_train_adam_all(ngf_trainer *t, const int32_t *step_count, con
         HIP_TRY(hipStreamWaitEvent(t->aux[0], t->ev_fork, 0));
         HIP_TRY(hipStreamWaitEvent(t->aux[1], t->ev_fork, 0));
     }
-    for (int k = 0; k < 6; ++k)
+    // planes 1 and 2 leave first; the caller's stream takes the small updates (gauge planes, the MLP parameters below) and plane 0
+    for (int k : {1, 2, 3, 4, 5})
         if (step_count[k] > 0) {
-            const int p = k % 3;
-            hipStream_t sk = (fork && p > 0) ? t->aux[p - 1] : st;
+            hipStream_t sk = (fork && (k == 1 || k == 2)) ? t->aux[k - 1] : st;
             const int rc = ngf_train_adam(t, k, step_count[k], lr[k], beta1, beta2, eps, l1_weight, (void *)sk);
             if (rc != NGF_OK) return rc;
         }
-    if (fork) {
-        for (int j = 0; j < 2; ++j) {
-            HIP_TRY(hipEventRecord(t->ev_join[j], t->aux[j]));
-            HIP_TRY(hipStreamWaitEvent(st, t->ev_join[j], 0));
-        }
-    }
     float *params[TP_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d.dens_w, d.dens_b, d.basis, d.w1, d.b1, d.w2, d.b2, d.w3, d.b3};
     AdamDenseAll D;
     int32_t at = 0;
@@ -1510,6 +1510,16 @@ extern "C" int ngf_train_adam_all(ngf_trainer *t, const int32_t *step_count, con
     }
     D.begin[kDenseParams] = at;
     if (at > 0) hipLaunchKernelGGL(adam_dense_all_kernel, dim3((at + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, D);
+    if (step_count[0] > 0) {
+        const int rc = ngf_train_adam(t, 0, step_count[0], lr[0], beta1, beta2, eps, l1_weight, hip_stream);
+        if (rc != NGF_OK) return rc;
+    }
+    if (fork) {
+        for (int j = 0; j < 2; ++j) {
+            HIP_TRY(hipEventRecord(t->ev_join[j], t->aux[j]));
+            HIP_TRY(hipStreamWaitEvent(st, t->ev_join[j], 0));
+        }
+    }
     HIP_TRY(hipGetLastError());
     return NGF_OK;
 }
