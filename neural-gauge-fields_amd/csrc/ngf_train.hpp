@@ -6,21 +6,26 @@
 // per-sample activations of a 4096-ray batch are simply kept, 1.7 KB per active sample):
 //
 //   train_density_kernel       every (step, ray) pair in parallel: sample_ray + normalize + compute_gauge + the 48-feature
-//                              density fetch -> xs = Linear(48,1) - 10 (pre-softplus), -inf where the sample is invalid
-//   train_scan_kernel          one lane per ray, sequential raw2alpha (FieldBase.py:12-19) over the stored xs: weights,
+//                              density fetch -> xs = Linear(48,1) - 10 (pre-softplus); stores exp(-softplus(xs) dist) and softplus'(xs)
+//                              (every per-sample transcendental of the step is taken here, 3.6 M samples in parallel)
+//   train_scan_kernel          sixteen lanes per ray, sequential raw2alpha (FieldBase.py:12-19) over the stored factors: weights,
 //                              active counts (pass 0) and the (ray, step)-ordered active list (pass 1): deterministic
 //   train_fold_kernel          W1' = W1[:, :144] . basis and the padded / transposed LDS images of the colour MLP
 //   train_color_fwd_kernel     16 active samples per wave pass on v_mfma_f32_16x16x4_f32: [144 colour features, view] -> 64 ->
 //                              64 -> 3 sigmoid; colours to the dense buffer, activations to HBM rows
-//   train_composite_bwd_kernel one lane per ray: rgb_map, clamp, residual, loss; then d loss / d xs for every sample from
+//   train_composite_bwd_kernel sixteen lanes per ray: rgb_map, clamp, residual, loss; then d loss / d xs for every sample from
 //                              the closed form of the cumprod backward (two sequential sweeps, no gathers)
-//   train_color_bwd_kernel     the data gradients of the colour MLP with the TRANSPOSED weights on the matrix pipe, the
-//                              feature gradients scattered into the packed colour planes (float atomics) and d loss / d t
-//   xty_all_kernel             weight gradients as sample-reduction GEMMs  dW = Delta^T . In  (MFMA, operand slabs through LDS);
+//   train_color_bwd_kernel     the data gradients of the colour MLP with the TRANSPOSED weights on the matrix pipe, d loss / d t, the
+//                              feature-gradient rows and every (plane, sample) pair's cell, weights and place in its bin
+//   train_bin_*_kernel         d loss / d colour planes without atomics: pairs ordered by 8x8-cell bins (prefix, perm), summed per unit
+//                              in an LDS tile (scatter), the units' tiles added up per texel (gather)            -- section 5b
+//   xty_all_kernel             weight gradients as sample-reduction GEMMs  dW = Delta^T . In  (MFMA, operand slabs through LDS, one launch);
 //   train_unfold_kernel        M -> d W1[:, :144], d basis
 //   train_density_bwd_kernel   every valid sample: ONE scalar per tap into the density-gradient images (the decoder is linear:
 //                              rank-one gradient, expanded by train_density_finish_kernel), d loss / d t -> gauge planes
 //   adam_*_kernel              torch.optim.Adam's update; planes read their gradient from the packed layout and add the L1 term
+// ngf_train_backward (ngf_field.hip) runs the weight-gradient GEMMs, the colour-plane scatter and the density backward side by side on
+// three streams after the colour backward (event fork / join; the caller's stream order is kept).
 //
 // basis has neither bias nor activation (networks.py:17,26), so layer 1 acts on the features through W1' = W1[:, :144] . basis
 // (64 x 144).  train_fold_kernel rebuilds W1' from the current weights every step (float64 accumulate); forward and data

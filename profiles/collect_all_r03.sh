@@ -3,7 +3,7 @@
 #   1. kernel-trace stats + PMC passes per workload (profiles/collect.sh) -> gpurun_out/r03_<workload>_{kernel_stats.txt,pmc.txt,pmc.json}
 #   2. the default bench line (compact) + its side file                 -> gpurun_out/r03_bench.json, r03_bench_extras.json
 #   3. the SAME command under rocprofv3 --kernel-trace --stats          -> gpurun_out/r03_kernel_stats_headline.txt
-#   4. the training iteration per kernel                                -> gpurun_out/r03_train_R1_kernel_stats.txt
+#   4. the training iteration per kernel, its timeline, one-stream A/B   -> gpurun_out/r03_train_R1_{kernel_stats,timeline,one_stream_kernel_stats,streams}.txt, r03_train_sections.txt
 # Copy gpurun_out/r03_* into profiles/ afterwards (tracked).  Workload names: profiles/workload.py (`_bd` = level 2, the module default).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
@@ -25,9 +25,17 @@ timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/kt -o kt -- python be
 python profiles/summarize_rocpd.py $(find gpurun_out/kt -name "*.db" | head -1) > gpurun_out/r03_kernel_stats_headline.txt
 rm -rf gpurun_out/kt
 if [ "$1" != quick ]; then
+  # the training iteration: per-kernel times and the timeline of one iteration (the step's three streams), then the same on ONE stream
+  # (ngf_debug_set("ablate", 1 << 19): kernel times then add up to the iteration) and the colour backward's / scatter's section clocks
   rm -rf gpurun_out/ktt && mkdir -p gpurun_out/ktt
   timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/ktt -o kt -- python profiles/workload.py train_R1 20 > gpurun_out/r03_train_R1_kernel_stats.txt 2>/dev/null
   python profiles/summarize_rocpd.py $(find gpurun_out/ktt -name "*.db" | head -1) >> gpurun_out/r03_train_R1_kernel_stats.txt
+  python profiles/timeline_rocpd.py $(find gpurun_out/ktt -name "*.db" | head -1) > gpurun_out/r03_train_R1_timeline.txt 2>&1
+  rm -rf gpurun_out/ktt && mkdir -p gpurun_out/ktt
+  NGF_ABLATE=524288 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/ktt -o kt -- python profiles/workload.py train_R1 20 > gpurun_out/r03_train_R1_one_stream_kernel_stats.txt 2>/dev/null
+  python profiles/summarize_rocpd.py $(find gpurun_out/ktt -name "*.db" | head -1) >> gpurun_out/r03_train_R1_one_stream_kernel_stats.txt
   rm -rf gpurun_out/ktt
+  for a in 0 524288; do NGF_ABLATE=$a timeout 120 python profiles/workload.py train_R1 20 2>&1 | grep train_R1; done > gpurun_out/r03_train_R1_streams.txt
+  timeout 120 python profiles/exp_train_sections.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_train_sections.txt
 fi
 ls gpurun_out | grep r03_ | head -80

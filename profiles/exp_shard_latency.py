@@ -24,9 +24,15 @@ for rows in ((350, 450), (0, 100), (0, 800)):
     ms = np.median([a.elapsed_time(b) for a, b in ev])
     print(f"  rows {rows}: {ms:.3f} ms  ({rays.shape[0] / ms / 1e3:.1f} Mray/s)")
 ''' % (ROOT, ROOT)
+if os.environ.get("ONLY_DEFAULT"):          # the product library's only configuration: level 2, 12 waves, one step per lane
+    env = dict(os.environ, BD="1")
+    print("bake_density=1 (level 2, the module default), product library")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    print(r.stdout, r.stderr[-300:] if r.returncode else "")
+    sys.exit(0)
 for bd in ("0", "1"):
     for w, ns in (("12", "1"), ("8", "1"), ("8", "2")):
-        env = dict(os.environ, NGF_WAVES=w, NGF_NSTEP=ns, BD=bd)
+        env = dict(os.environ, NGF_WAVES=w, NGF_NSTEP=ns, BD=bd)      # these knobs select the experiment library (libngf_hip_exp.so)
         print(f"bake_density={bd} waves={w} nstep={ns}")
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
         print(r.stdout, r.stderr[-300:] if r.returncode else "")
