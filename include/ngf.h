@@ -206,7 +206,7 @@ typedef struct ngf_train_desc {
     float mask_aabb[6];
     int64_t max_rays;              /* largest batch (args.batch_size) */
     int32_t max_samples;           /* largest N_samples */
-    int64_t chunk_samples;         /* active samples whose activation rows (1.7 KB each) are kept at once; 0 = the whole batch (up to 9 Mi samples) */
+    int64_t chunk_samples;         /* active samples whose activation rows (2.4 KB each) are kept at once; 0 = the whole batch (up to 9 Mi samples) */
 } ngf_train_desc;
 typedef struct ngf_trainer ngf_trainer;
 int ngf_trainer_create(const ngf_train_desc *desc, ngf_trainer **out, void *hip_stream);
@@ -220,7 +220,13 @@ int32_t ngf_sizeof_train_desc(void);
  * Asynchronous on the stream when n_active_host is NULL and one chunk holds every sample of the batch (chunk_samples = 0: the
  * default): the colour kernels then read the active count on the device.  Passing n_active_host, or a chunk smaller than
  * n * n_samples, costs one stream synchronisation per call.  ngf_train_get_active copies the count of the last backward of an
- * n-ray batch into a DEVICE int32 without synchronising. */
+ * n-ray batch into a DEVICE int32 without synchronising.
+ * Streams: the trainer owns two non-blocking HIP streams.  After the colour backward the weight-gradient GEMMs and the colour-plane
+ * scatter run on them beside the density backward on hip_stream, forked and joined with events -- everything the call enqueues is
+ * ordered after what hip_stream held before the call and before what is enqueued on it afterwards, exactly as if it had run on
+ * hip_stream alone (ngf_debug_set("ablate", 1 << 19) makes it so, for A/B timing).  ngf_train_adam_all does the same for the planes.
+ * A trainer must not be used from two streams at once.  (1.7 KB per sample in the line above: 2.3 KB + 0.1 KB of scatter pairs since
+ * round 3 -- the feature-gradient rows are kept as well.) */
 int ngf_train_backward(ngf_trainer *t, const float *rays, const float *rgb_train, const float *jitter, int64_t n,
                        int32_t n_samples, int32_t white_bg, int32_t gauge_on, double *rgb_loss, int64_t *n_active_host,
                        void *hip_stream);

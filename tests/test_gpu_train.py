@@ -360,3 +360,48 @@ def test_single_parameter_adam_entry_point():
     for name in ("plane_yz", "plane_xy", "rgb_decoder.mlp.0.weight"):
         a, b = tr.gradient(name).cpu().numpy(), fresh.gradient(name).cpu().numpy()
         assert rel(a, b) < GRAD_TOL, (name, rel(a, b))
+
+
+def test_forked_and_one_stream_steps_agree_and_keep_the_callers_stream_order():
+    """ngf_train_backward / ngf_train_adam_all run three chains of kernels on the trainer's own streams (event fork / join).  The same three
+    iterations on ONE stream (ngf_debug_set("ablate", 1 << 19)) must give the same gradients and parameters up to the order of the float
+    sums, and work the caller enqueues on its stream right after a step must see the step's results (no host synchronisation in between,
+    a side stream as the caller's stream)."""
+    import copy
+    from helpers import big_case
+    from ngf_amd import _lib, synth
+    g, params, step = big_case("triplane", "R1")
+    frame = synth.lookat_rays(800, 800)
+    n = 1024
+    pick = (synth.hash_uniform(19, 1, (n,)) * np.float32(frame.shape[0])).astype(np.int64)
+    rays = torch.from_numpy(frame[pick]).cuda()
+    tgt = torch.from_numpy(synth.hash_uniform(19, 2, (n, 3))).cuda()
+    jit = torch.from_numpy(synth.hash_uniform(19, 3, (n,))).cuda()
+    out = {}
+    for mode in ("fork", "one"):
+        f = field_for_case(g, copy.deepcopy(params), None)
+        S = int(f.nSamples)
+        tr = train.Trainer(f, batch_size=n, max_samples=S)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        snaps = []
+        with _lib.knobs(ablate=(1 << 19) if mode == "one" else 0), torch.cuda.stream(side):
+            for it in range(3):
+                tr.step(rays, tgt, it + 7, N_samples=S, jitter=jit)
+                # enqueued right behind the step on the caller's stream: must read the updated parameter
+                snaps.append(tr.params[0].detach().clone())
+                if it == 0:          # the first step starts from identical parameters: its gradients and its update are what is compared
+                    grads1 = [tr.gradient(k) for k in range(len(train.PARAM_NAMES))]
+                    params1 = [p.detach().clone() for p in tr.params]
+        side.synchronize()
+        torch.cuda.synchronize()
+        out[mode] = ([g_.cpu().numpy() for g_ in grads1], [p.cpu().numpy() for p in params1], [s_.cpu().numpy() for s_ in snaps])
+        assert not np.array_equal(out[mode][2][0], out[mode][2][2])          # the snapshots differ: every step had landed when its clone ran
+        assert np.array_equal(out[mode][2][2], tr.params[0].detach().cpu().numpy())      # ... and the last one is the final parameter
+    for k, name in enumerate(train.PARAM_NAMES):
+        assert rel(out["fork"][0][k], out["one"][0][k]) < GRAD_TOL, (name, "gradient")
+        # Adam's first steps move an entry by +-lr whatever the size of its gradient: an entry whose gradient is a cancelling sum may flip with
+        # the order of the float sums, so the parameters are compared by the share of entries that moved apart, not by the worst entry
+        a, b = out["fork"][1][k], out["one"][1][k]
+        far = np.abs(a - b) > 1e-3 * max(float(np.abs(b).max()), 1e-30)
+        assert far.mean() < 1e-3, (name, "parameter", float(far.mean()))
