@@ -1349,6 +1349,10 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
             HIP_TRY(hipStreamWaitEvent(sx, t->ev_fork, 0));
         }
         hipLaunchKernelGGL(train_bin_perm_kernel, dim3(tr_grid(t, 3 * (int64_t)T.chunk_n, 256)), dim3(256), 0, sb, T);
+#ifdef NGF_EXPERIMENTS
+        if (A.ablate & (1 << 18)) hipLaunchKernelGGL(train_bin_scatter_mfma_kernel, dim3(3 * t->num_cus), dim3(256), 0, sb, T);      // the matrix-pipe version (slower)
+        else
+#endif
         hipLaunchKernelGGL(train_bin_scatter_kernel, dim3(2 * t->num_cus), dim3(256), 0, sb, T);
         {   // one (texel, channel) per thread and two dependent loads each: as many workgroups as the largest plane has items (a few per thread
             // left the kernel waiting on memory latency: 40 us -> see profiles/r03_train_R1_kernel_stats.txt)

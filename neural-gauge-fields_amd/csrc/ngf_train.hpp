@@ -1039,6 +1039,111 @@ __global__ void __launch_bounds__(256) train_bin_scatter_kernel(const TrainArgs 
     }
 }
 
+#ifdef NGF_EXPERIMENTS
+// The same sums on the matrix pipe, the tile in registers: tile[81 texels][48 channels] += Wm[81][pairs] . G[pairs][48], where column k of
+// Wm holds pair k's four tap weights at its four texels and zeros elsewhere.  v_mfma_f32_16x16x4_f32 takes four pairs per instruction
+// (6 texel tiles x 3 channel tiles = 18 instructions per four pairs, 72 accumulator registers); lane (kq, j) builds its A operands --
+// the weight of pair 4g + kq at texel 16 mt + j -- with four compares per texel tile and loads its B operands straight from the
+// gradient rows.  No LDS -- built to get away from the LDS version's ~500-cycle read-add-write chain per pair and from sharing the LDS with
+// the density backward's tiles.  MEASURED SLOWER (experiment library only, ablate bit 1 << 18): 111 k cycles per unit against 62 k, the step
+// 1.28 ms against 1.24 ms -- four groups of rows in flight at two waves per SIMD (204 registers) do not cover the memory latency, and the
+// matrix work itself (18 MFMAs per four pairs) is what the LDS version's chain costs.
+__global__ void __launch_bounds__(256) train_bin_scatter_mfma_kernel(const TrainArgs T)
+{
+    const RenderArgs &A = T.R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int nunits = *T.unit_total;
+    const bool prof = (A.ablate & (1 << 20)) != 0;             // section clocks -> T.prof[11..15] (profiles/exp_train_sections.py)
+    unsigned long long pc[4] = {0, 0, 0, 0}, t0 = 0, n_units = 0;
+#define NGF_SEC(k) if (prof) { const unsigned long long t1 = __builtin_readcyclecounter(); pc[k] += t1 - t0; t0 = t1; }
+    for (int u = blockIdx.x * 4 + wave; u < nunits; u += gridDim.x * 4) {
+        if (prof) { t0 = __builtin_readcyclecounter(); ++n_units; }
+        const int bin = __builtin_amdgcn_readfirstlane(T.units[3 * u]), first = __builtin_amdgcn_readfirstlane(T.units[3 * u + 1]),
+                  len = __builtin_amdgcn_readfirstlane(T.units[3 * u + 2]);
+        const int p = bin >= T.bin_base[2] ? 2 : (bin >= T.bin_base[1] ? 1 : 0);
+        const int bl = bin - T.bin_base[p];
+        const int by = bl / T.bin_nbx[p], bx = bl - by * T.bin_nbx[p];
+        const int x0 = bx * 8, y0 = by * 8;
+        const int32_t *cellp = T.pair_cell + (size_t)p * T.bin_cap;
+        const float *wp = T.pair_w + (size_t)p * T.bin_cap * 4;
+        const float *dfl = T.DF + p * 48 + j;
+        f32x4 acc[6][3];
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j0 = 0; j0 < len; j0 += 64) {
+            // lane l: the record of pair j0 + l.  Entries past the unit's end: weights 0 at the tile's first texel, gradient row 0 (a row
+            // that exists whenever a unit does) -- they add 0 . g, and no loop below needs a branch
+            const bool have = j0 + lane < len;
+            const int row = have ? T.perm[first + j0 + lane] : 0;
+            const int cell = have ? cellp[row] : 0;
+            const f32x4 w = have ? *reinterpret_cast<const f32x4 *>(wp + (size_t)row * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const int c = have ? ((cell >> 16) - y0) * 9 + ((cell & 0xffff) - x0) : 0;
+            const int ng = ((min(64, len - j0) + 15) >> 4) << 2;         // groups of four pairs, in fours
+            auto fetch = [&](int g, float (&b)[3]) {
+                const int r = __shfl(row, 4 * g + kq);
+                const float *src = dfl + (size_t)(unsigned)r * kFeat;
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) b[nt] = src[16 * nt];
+            };
+            auto mma = [&](int g, const float (&b)[3]) {
+                const int sl = 4 * g + kq;
+                const int cc = __shfl(c, sl);
+                const float w00 = __shfl(w[0], sl), w10 = __shfl(w[1], sl), w01 = __shfl(w[2], sl), w11 = __shfl(w[3], sl);
+#pragma unroll
+                for (int mt = 0; mt < 6; ++mt) {
+                    const int d = 16 * mt + j - cc;
+                    float a = 0.0f;                  // four independent selects (a nested conditional compiles to divergent branches here)
+                    a = d == 0 ? w00 : a;
+                    a = d == 1 ? w10 : a;
+                    a = d == 9 ? w01 : a;
+                    a = d == 10 ? w11 : a;
+#pragma unroll
+                    for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[mt][nt], 0, 0, 0);
+                }
+            };
+            // four groups of rows in flight; every request is unconditional (past the batch's end: its last group again)
+            float b0[3], b1[3], b2[3], b3[3];
+            fetch(0, b0); fetch(1, b1); fetch(2, b2); fetch(3, b3);
+#pragma unroll 1
+            for (int g = 0; g < ng; g += 4) {
+                mma(g, b0);
+                fetch(min(g + 4, 15), b0);
+                mma(g + 1, b1);
+                fetch(min(g + 5, 15), b1);
+                mma(g + 2, b2);
+                fetch(min(g + 6, 15), b2);
+                mma(g + 3, b3);
+                fetch(min(g + 7, 15), b3);
+            }
+        }
+        NGF_SEC(1)
+        // accumulator (mt, nt)[r] = texel 16 mt + 4 kq + r, channel 16 nt + j
+        {
+            float *slab = T.slab + (size_t)u * kBinTile + j;
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * mt + 4 * kq + r;
+                    if (i < 81) {
+#pragma unroll
+                        for (int nt = 0; nt < 3; ++nt) slab[i * 48 + 16 * nt] = acc[mt][nt][r];
+                    }
+                }
+        }
+        NGF_SEC(2)
+    }
+#undef NGF_SEC
+    if (prof && lane == 0) {
+        for (int k = 0; k < 3; ++k) atomicAdd(T.prof + 11 + k, pc[k]);
+        atomicAdd(T.prof + 15, n_units);
+    }
+}
+#endif
+
 // d loss / d colour plane: every texel of the padded planes adds up the tiles that hold it -- the tile of the bin of its own block and,
 // on a block's first column / row, of the neighbours before it (a cell's second taps) -- over the units of those bins.  No atomics, and
 // every texel is written: the planes' gradients need no zero fill.  One thread per (texel, channel).
