@@ -549,6 +549,24 @@ def main():
                 it_ms = (time.perf_counter() - t0) / 10 * 1e3
                 tr_extra = {"ms_per_iteration": it_ms, "iterations_per_s": 1e3 / it_ms, "batch_rays": 4096, "samples_per_ray": Str,
                             "active_samples": trn.last_active, "scratch_GiB": trn.scratch_bytes() / 2 ** 30}
+                # A/B of the trainer's streams (it forks onto two streams of its own after the colour backward: DESIGN.md section 8 N3): ten
+                # more iterations, alternately forked and with the whole step on the caller's stream -- the active count falls as the field
+                # trains, so the two are interleaved; every step is synchronised here, which the headline figure above is not
+                try:
+                    from ngf_amd import _lib as _lb
+                    ab = {0: [], 1: []}
+                    for it in range(20):
+                        one = it & 1
+                        with _lb.knobs(ablate=(1 << 19) if one else 0):
+                            torch.cuda.synchronize(device)
+                            t0 = time.perf_counter()
+                            trn.step(tr_rays, tr_rgb, 13 + it, N_samples=Str)
+                            torch.cuda.synchronize(device)
+                            ab[one].append((time.perf_counter() - t0) * 1e3)
+                    tr_extra["streams_ab"] = {"forked_ms": float(np.median(ab[0])), "one_stream_ms": float(np.median(ab[1])),
+                                              "note": "interleaved, synchronised per step; active samples at the end: %d" % trn.last_active}
+                except Exception as ex:
+                    tr_extra["streams_ab"] = repr(ex)
                 # what bounds the backward: global float atomics cost one transaction per (instruction, 64-byte line), 21 G/s for the whole
                 # device (profiles/micro/atomic_cost.hip -> profiles/r02_micro_atomic_cost.txt); one more iteration counts them
                 try:
@@ -559,7 +577,7 @@ def main():
                     cnt = (C.c_uint64 * 16)()
                     with _lib.knobs(ablate=1 << 21):
                         _lib.check(Lb.ngf_train_debug_sections(trn._h, cnt))
-                        trn.step(tr_rays, tr_rgb, 13, N_samples=Str)
+                        trn.step(tr_rays, tr_rgb, 34, N_samples=Str)
                         _lib.check(Lb.ngf_train_debug_sections(trn._h, cnt))
                     n_d, n_c = int(cnt[8]), int(cnt[9])
                     floor_ms = (n_d + n_c) / 21.0e9 * 1e3
