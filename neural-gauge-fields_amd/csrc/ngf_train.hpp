@@ -515,14 +515,34 @@ __global__ void __launch_bounds__(kTrainWaves * 64) __attribute__((amdgpu_waves_
     float *Ft = smem + ((kFwdImage + 3) & ~3) + wave * kFwdTileFloats, *H1t = Ft + kIn1Pad * kTs, *H2t = Ft;
     const int chunk_n = chunk_rows(T);
     const int passes = (chunk_n + 15) / 16;
-    for (int pass = blockIdx.x * kTrainWaves + wave; pass < passes; pass += gridDim.x * kTrainWaves) {
+    // The list entries of a pass and what hangs on them -- ray, gauge-shifted coordinates: three dependent global reads before the first
+    // feature tap can be requested -- are fetched during the wave's PREVIOUS pass (requests unconditional: past the last pass, that pass again).
+    const int stride = gridDim.x * kTrainWaves;
+    auto want_list = [&](int ps, int &r_, int &i_) {
+        const int lc = ps * 16 + n;
+        const int64_t sl = T.chunk_base + (lc < chunk_n ? lc : 0);
+        r_ = T.list[2 * sl]; i_ = T.list[2 * sl + 1];
+    };
+    auto want_coords = [&](int r_, int i_, float (&t_)[6], float (&d_)[3]) {
+        float xn_[3];
+        list_sample_coords(A, r_, i_, t_, xn_);
+        d_[0] = A.rays[(int64_t)r_ * 6 + 3]; d_[1] = A.rays[(int64_t)r_ * 6 + 4]; d_[2] = A.rays[(int64_t)r_ * 6 + 5];
+    };
+    int pass = blockIdx.x * kTrainWaves + wave;
+    int r_cur = 0, i_cur = 0;
+    float t[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, dcur[3] = {0.0f, 0.0f, 1.0f};
+    if (pass < passes) {
+        want_list(pass, r_cur, i_cur);
+        want_coords(r_cur, i_cur, t, dcur);
+    }
+    for (; pass < passes; pass += stride) {
         const int local = pass * 16 + n;
         const bool live = local < chunk_n;
-        const int64_t slot = T.chunk_base + (live ? local : 0);
-        const int64_t r = T.list[2 * slot];
-        const int i = T.list[2 * slot + 1];
-        float t[6], xn[3];
-        list_sample_coords(A, r, i, t, xn);
+        const int64_t r = r_cur;
+        const int i = i_cur;
+        const int next = pass + stride < passes ? pass + stride : pass;
+        int r_nx, i_nx;
+        want_list(next, r_nx, i_nx);
         // compute_rgb's fetch (Field.py:93-103): lane (q, n) interpolates channels 12q .. 12q+11 of every plane for sample n
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -539,7 +559,7 @@ __global__ void __launch_bounds__(kTrainWaves * 64) __attribute__((amdgpu_waves_
         }
         // the view inputs of layer 1 (networks.py:27-29): rows 144..159 of the input tile
         {
-            float d[3] = {A.rays[r * 6 + 3], A.rays[r * 6 + 4], A.rays[r * 6 + 5]}, v[16];
+            float d[3] = {dcur[0], dcur[1], dcur[2]}, v[16];
             view_inputs(d, v);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {          // v[4q + j] by selects: a q-indexed read would put v into scratch memory
@@ -556,6 +576,8 @@ __global__ void __launch_bounds__(kTrainWaves * 64) __attribute__((amdgpu_waves_
             tile_to_rows(Ft + kFeat * kTs, 16, T.V, 16, row, live, lane);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
+        float t_nx[6], d_nx[3];
+        want_coords(r_nx, i_nx, t_nx, d_nx);
         dense16<false, 1, 64, 64, 64>(img + kFwdW2, kLd2, 64, img + kFwdB2, H1t, H2t, nullptr, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // layer 3 + sigmoid on the VALU: lane (q, n) sums its 16 hidden units, then the four quarters meet
@@ -580,6 +602,11 @@ __global__ void __launch_bounds__(kTrainWaves * 64) __attribute__((amdgpu_waves_
             tile_to_rows(H2t, 64, T.H2, 64, row, live, lane);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        r_cur = r_nx; i_cur = i_nx;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[k] = t_nx[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dcur[k] = d_nx[k];
     }
 }
 
@@ -712,29 +739,67 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
     const bool prof = (A.ablate & (1 << 20)) != 0;
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
 #define NGF_SEC(k) if (prof) { const unsigned long long t1 = __builtin_readcyclecounter(); pc[k] += t1 - t0; t0 = t1; }
-    for (int pass = blockIdx.x * kTrainWavesBwd + wave; pass < passes; pass += gridDim.x * kTrainWavesBwd) {
+    // A pass's inputs -- its list entries, its 32 activation rows, the colours and ray gradients behind the list entries -- are requested
+    // during the PREVIOUS pass of the wave (1.75 waves per SIMD hide little: as plain loads at the head of the pass they were a quarter of
+    // the kernel, profiles/exp_train_sections.py).  Every request is unconditional (past the wave's last pass: that pass again).
+    const int stride = gridDim.x * kTrainWavesBwd;
+    auto want_list = [&](int ps, int &r_, int &i_, float &w_) {
+        const int lc = ps * 16 + n;
+        const int64_t sl = T.chunk_base + (lc < chunk_n ? lc : 0);
+        r_ = T.list[2 * sl]; i_ = T.list[2 * sl + 1]; w_ = T.list_w[sl];
+    };
+    auto want_rows = [&](int ps, float (&va)[16], float (&vb)[16]) {          // rows ps * 16 + s, 64 lanes on the 64 units of a row
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+            const int rw = ps * 16 + s_;
+            const size_t o = (size_t)(rw < chunk_n ? rw : 0) * 64 + lane;
+            va[s_] = T.H1[o]; vb[s_] = T.H2[o];
+        }
+    };
+    auto want_cg = [&](int r_, int i_, float (&c_)[3], float (&g_)[3]) {
+        const float *cc = T.c + ((int64_t)r_ * A.S + i_) * 3;
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) { c_[jj] = cc[jj]; g_[jj] = T.G[(int64_t)r_ * 3 + jj]; }
+    };
+    int pass = blockIdx.x * kTrainWavesBwd + wave;
+    int r_cur = 0, i_cur = 0;
+    float w_cur = 0.0f, va[16], vb[16], c_cur[3] = {0.0f, 0.0f, 0.0f}, g_cur[3] = {0.0f, 0.0f, 0.0f};
+    if (pass < passes) {
+        want_list(pass, r_cur, i_cur, w_cur);
+        want_rows(pass, va, vb);
+        want_cg(r_cur, i_cur, c_cur, g_cur);
+    }
+    for (; pass < passes; pass += stride) {
         const int local = pass * 16 + n;
         const bool live = local < chunk_n;
         const int64_t row = live ? local : 0;
-        const int64_t slot = T.chunk_base + row;
-        const int64_t r = T.list[2 * slot];
-        const int i = T.list[2 * slot + 1];
-        const float w = live ? T.list_w[slot] : 0.0f;
+        const int64_t r = r_cur;
+        const int i = i_cur;
+        const float w = live ? w_cur : 0.0f;
         if (prof) t0 = __builtin_readcyclecounter();
-        // the sample's coordinates (rays -> gauge planes: two dependent global reads) are requested first and travel with the tile loads
+        // the sample's coordinates (rays -> gauge planes: two dependent global reads) are requested first: they are not read before the
+        // d loss / d t section
         float t[6], xn[3];
         list_sample_coords(A, r, i, t, xn);
-        rows_to_tiles2<64>(T.H1, T.H2, 64, H1t, H2t, row, live, lane);
+        // the activation rows of this pass -> the wave's tiles (zeros for the entries past the chunk's end)
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+            const bool ok = pass * 16 + s_ < chunk_n;
+            H1t[lane * kTs + s_] = ok ? va[s_] : 0.0f;
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+            const bool ok = pass * 16 + s_ < chunk_n;
+            H2t[lane * kTs + s_] = ok ? vb[s_] : 0.0f;
+        }
         // d3 = dL/dc * sigmoid' ; dL/dc = G_ray * w
         float d3[3];
-        {
-            const float *cc = T.c + ((int64_t)r * A.S + i) * 3;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float c = cc[j];
-                d3[j] = live ? T.G[r * 3 + j] * w * (c * (1.0f - c)) : 0.0f;
-            }
-        }
+        for (int j = 0; j < 3; ++j) d3[j] = live ? g_cur[j] * w * (c_cur[j] * (1.0f - c_cur[j])) : 0.0f;
+        const int next = pass + stride < passes ? pass + stride : pass;
+        int r_nx, i_nx;
+        float w_nx;
+        want_list(next, r_nx, i_nx, w_nx);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         NGF_SEC(0)
         // d2 = (W3^T d3) * [h2 > 0] on the VALU (3 terms per hidden unit)
@@ -803,6 +868,9 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         NGF_SEC(4)
+        // the next pass of this wave: its rows now (the 32 row registers are free from here: requested earlier in the pass they spill), its
+        // colours / ray gradients at the end of the pass (the list entries they hang on were requested at its head)
+        want_rows(next, va, vb);
         // feature gradients: the rows leave for the bin-ordered scatter (train_bin_scatter_kernel) -- DF^T is sample-major, 64 lanes
         // write 64 consecutive floats of one row
         {
@@ -818,6 +886,7 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
         }
         // the pairs' places in their bins: the 16 samples of a pass mostly share a bin, so the first lane of every distinct bin asks for the
         // places of all its lanes with ONE returning atomic (one per pair made the hot bins' counters the bottleneck of the kernel)
+        // (reading the answers one pass later -- a returning atomic is a round trip past the L2 -- was tried: no gain, 16 bytes of spills)
         {
             int leader[3], before[3], base[3];
 #pragma unroll
@@ -850,6 +919,8 @@ __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_wav
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         NGF_SEC(5)
         if (prof) pc[7] += 1;
+        r_cur = r_nx; i_cur = i_nx; w_cur = w_nx;
+        want_cg(r_cur, i_cur, c_cur, g_cur);
     }
 #undef NGF_SEC
     if (prof && lane == 0)
