@@ -35,7 +35,7 @@ if [ "$1" != quick ]; then
   NGF_ABLATE=524288 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/ktt -o kt -- python profiles/workload.py train_R1 20 > gpurun_out/r03_train_R1_one_stream_kernel_stats.txt 2>/dev/null
   python profiles/summarize_rocpd.py $(find gpurun_out/ktt -name "*.db" | head -1) >> gpurun_out/r03_train_R1_one_stream_kernel_stats.txt
   rm -rf gpurun_out/ktt
-  for a in 0 524288; do NGF_ABLATE=$a timeout 120 python profiles/workload.py train_R1 20 2>&1 | grep train_R1; done > gpurun_out/r03_train_R1_streams.txt
+  for rep in 1 2 3; do for a in 0 524288; do echo -n "ablate=$a ($([ $a = 0 ] && echo 'three streams' || echo 'one stream')): "; NGF_ABLATE=$a timeout 120 python profiles/workload.py train_R1 20 2>&1 | grep '^train_R1'; done; done > gpurun_out/r03_train_R1_streams.txt
   timeout 120 python profiles/exp_train_sections.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_train_sections.txt
 fi
 ls gpurun_out | grep r03_ | head -80
