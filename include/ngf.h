@@ -215,8 +215,8 @@ int64_t ngf_trainer_bytes(const ngf_trainer *t);
 int32_t ngf_sizeof_train_desc(void);
 /* forward (training mode) + backward of  mean((rgb_map - rgb_train)^2): the gradients of all 15 parameters land in the
  * trainer's buffers (zeroed first).  jitter [n] = the per-ray U[0,1) of sample_ray (FieldBase.py:129-130; NULL = 0),
- * white_bg = `white_bg or coin` of FieldBase.py:299, gauge_on = (iteration >= gauge_start).  *rgb_loss (DEVICE double)
- * receives the SUM of squared residuals (divide by 3n); *n_active_host (HOST, nullable) the active-sample count.
+ * white_bg = `white_bg or coin` of FieldBase.py:299, gauge_on = (iteration >= gauge_start).  rgb_loss (DEVICE, TWO doubles since ABI 2)
+ * receives the SUM of squared residuals in [0] and the mean (sum / 3n = the reference's rgb loss) in [1]; *n_active_host (HOST, nullable) the active-sample count.
  * Asynchronous on the stream when n_active_host is NULL and one chunk holds every sample of the batch (chunk_samples = 0: the
  * default): the colour kernels then read the active count on the device.  Passing n_active_host, or a chunk smaller than
  * n * n_samples, costs one stream synchronisation per call.  ngf_train_get_active copies the count of the last backward of an

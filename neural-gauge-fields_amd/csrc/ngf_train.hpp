@@ -318,30 +318,30 @@ __global__ void __launch_bounds__(64) train_scan_kernel(const TrainArgs T, int p
     if (live && seg == 0) T.count[r] = cnt;
 }
 
-// exclusive prefix of count[0..n) -> offset[0..n]; one block, sequential over chunks of 1024
+// exclusive prefix of count[0..n) -> offset[0..n]; one block: every thread sums a run of consecutive counts, ONE scan over the 1024 run
+// sums, then the run is written (round 2 scanned chunk after chunk of 1024: 80 barriers for a 4096-ray batch, 10 us)
 __global__ void __launch_bounds__(1024) train_prefix_kernel(const int32_t *count, int64_t n, int32_t *offset)
 {
     __shared__ int sh[1024];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
+    const int t = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t b0 = t * per, b1 = b0 + per < n ? b0 + per : n;
+    int c = 0;
+    for (int64_t b = b0; b < b1; ++b) c += count[b];
+    sh[t] = c;
     __syncthreads();
-    for (int64_t b0 = 0; b0 < n; b0 += 1024) {
-        const int64_t i = b0 + threadIdx.x;
-        const int v = i < n ? count[i] : 0;
-        sh[threadIdx.x] = v;
+    for (int s = 1; s < 1024; s <<= 1) {
+        const int add = t >= s ? sh[t - s] : 0;
         __syncthreads();
-        for (int s = 1; s < 1024; s <<= 1) {
-            int add = (int)threadIdx.x >= s ? sh[threadIdx.x - s] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += add;
-            __syncthreads();
-        }
-        if (i < n) offset[i] = carry + sh[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += sh[1023];
+        sh[t] += add;
         __syncthreads();
     }
-    if (threadIdx.x == 0) offset[n] = carry;
+    int run = sh[t] - c;
+    for (int64_t b = b0; b < b1; ++b) {
+        offset[b] = run;
+        run += count[b];
+    }
+    if (t == 1023) offset[n] = sh[1023];
 }
 
 // ---- MFMA building block: out[M][16] = act( W . in[K][16] + bias ) with 16 samples as the N dimension -------------------
@@ -1589,12 +1589,12 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
 }
 
 // blocked gauge-gradient plane -> [texel][2] (what the Adam kernel and ngf_train_get_grad read); blockIdx.y = plane
-struct UnblockArgs { const float *src[3]; float *dst[3]; int32_t w2[3], h2[3], bw[3]; const double *loss_src; double *loss_dst; };   // + the step's loss to the caller's buffer
+struct UnblockArgs { const float *src[3]; float *dst[3]; int32_t w2[3], h2[3], bw[3]; const double *loss_src; double *loss_dst; double inv_count; };   // + the step's loss to the caller's buffer: [0] sum of squared residuals, [1] their mean
 __global__ void __launch_bounds__(256) train_unblock_gauge_kernel(const UnblockArgs U)
 {
     const int p = blockIdx.y;
     const int total = U.w2[p] * U.h2[p];
-    if (U.loss_dst && blockIdx.x == 0 && p == 0 && threadIdx.x == 0) *U.loss_dst = *U.loss_src;
+    if (U.loss_dst && blockIdx.x == 0 && p == 0 && threadIdx.x == 0) { U.loss_dst[0] = *U.loss_src; U.loss_dst[1] = *U.loss_src * U.inv_count; }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int y = i / U.w2[p], x = i - y * U.w2[p];
         const f32x2 v = *reinterpret_cast<const f32x2 *>(U.src[p] + blocked_offset<1, 2>(x, y, U.bw[p]));

@@ -104,7 +104,7 @@ class Trainer:
                     self.exp_avg_sq[k].copy_(state_from.exp_avg_sq[k])
                     self.steps[k] = state_from.steps[k]
             self.lr = list(state_from.lr)
-        self._loss = torch.zeros((1,), dtype=torch.float64, device=self.dev)
+        self._loss = torch.zeros((2,), dtype=torch.float64, device=self.dev)      # [sum of squared residuals, their mean]
         self._active = torch.zeros((1,), dtype=torch.int32, device=self.dev)
         self._gauge_on = True          # set by backward(); optimizer_step() before any backward() updates nothing but must not raise
         self._build()
@@ -217,7 +217,7 @@ class Trainer:
                                                  self._loss.data_ptr(), None, st))
         self._last_n = n
         self._gauge_on = gauge_on
-        return self._loss[0] / (3.0 * n)
+        return self._loss[1]          # a view: the division is done by the step's last kernel (a torch op here is one more launch per step)
 
     @torch.no_grad()
     def gradient(self, which) -> torch.Tensor:
