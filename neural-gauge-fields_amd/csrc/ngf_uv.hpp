@@ -398,19 +398,21 @@ __device__ __forceinline__ void dense_out(const float *w, const float *bias4, in
 }
 
 // positional-encoding inputs [x(D), sin(D*F), cos(D*F)] (util.py:427-438): lane-quarter kq supplies entry 4t + kq
+// (the three coordinates by value: as an array in memory the compiler turns the selects below into indexed loads and the array into
+// scratch -- 128 bytes per lane in rounds 1 and 2)
 template <int D, int F>
-__device__ __forceinline__ float pe_entry(const float x[3], int f)
+__device__ __forceinline__ float pe_entry(float x0, float x1, float x2, int f)
 {
     constexpr int N = D * F;
     if (f >= D + 2 * N) return 0.0f;
     const int g = f - D;
     const int gi = g < 0 ? 0 : (g >= N ? g - N : g);
     const int dim = gi / F, fr = gi - dim * F;
-    const float xd = dim == 0 ? x[0] : (dim == 1 ? x[1] : x[2]);
+    const float xd = dim == 0 ? x0 : (dim == 1 ? x1 : x2);
     const float arg = xd * (float)(1 << fr);
     float s, c;
     sincos_small(arg, s, c);
-    const float raw = f == 0 ? x[0] : (f == 1 ? x[1] : x[2]);
+    const float raw = f == 0 ? x0 : (f == 1 ? x1 : x2);
     return f < D ? raw : (g < N ? s : c);
 }
 
@@ -420,8 +422,9 @@ __device__ __forceinline__ void store_pe(float *act, int t0, int KT, int lane, c
     const int kq = lane >> 4;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
+        const float x0 = x[s][0], x1 = x[s][1], x2 = x[s][2];
 #pragma unroll 1
-        for (int t = 0; t < KT; ++t) act[s * kUvWaveLds + (t0 + t) * 64 + lane] = pe_entry<D, F>(x[s], 4 * t + kq);
+        for (int t = 0; t < KT; ++t) act[s * kUvWaveLds + (t0 + t) * 64 + lane] = pe_entry<D, F>(x0, x1, x2, 4 * t + kq);
     }
 }
 
@@ -615,12 +618,17 @@ __global__ void __launch_bounds__(512 / NS) uv_render_kernel(const UvArgs A)
                     const int owner = __ffsll((long long)m) - 1;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
+                        // (the directions through an opaque copy: a select between elements of d[][] becomes an indexed load of the array,
+                        // and the array then lives in scratch)
                         float pv = __shfl(p[0][k], owner), dv = d[0][k];
+                        asm volatile("" : "+v"(dv));
 #pragma unroll
                         for (int j = 1; j < NS; ++j) {
                             const float pj = __shfl(p[j][k], owner);
+                            float dj = d[j][k];
+                            asm volatile("" : "+v"(dj));
                             pv = jr == j ? pj : pv;
-                            dv = jr == j ? d[j][k] : dv;
+                            dv = jr == j ? dj : dv;
                         }
                         q[ts][k] = pv; vq[ts][k] = dv;
                     }
