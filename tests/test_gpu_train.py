@@ -405,3 +405,36 @@ def test_forked_and_one_stream_steps_agree_and_keep_the_callers_stream_order():
         a, b = out["fork"][1][k], out["one"][1][k]
         far = np.abs(a - b) > 1e-3 * max(float(np.abs(b).max()), 1e-30)
         assert far.mean() < 1e-3, (name, "parameter", float(far.mean()))
+
+
+def test_odd_plane_sizes_match_autograd_oracle():
+    """Planes whose padded sizes are not multiples of the scatter's blocks -- 37x53, 41x30, 64x17 colour / density planes (8x8-cell bins with
+    partial last rows and columns, bins that differ per plane), 19x23 gauge planes (4x2-texel blocks) -- and enough samples per bin for
+    multi-unit bins: every gradient against autograd of the eager port."""
+    from ngf_amd import geometry, synth
+    g = {"model": np.array("triplane"), "aabb": np.array([[-1.5] * 3, [1.5] * 3], np.float32), "grid": np.array([48] * 3),
+         "near_far": np.array([2.0, 6.0], np.float32), "step_ratio": np.float32(0.5), "distance_scale": np.float32(25), "thr": np.float32(1e-4)}
+    params = synth.triplane_params(23, ((37, 53), (41, 30), (64, 17)), (19, 23), preset="R1")
+    step = geometry.step_size(g["aabb"], g["grid"], 0.5)
+    f = field_for_case(g, params, None)
+    frame = synth.lookat_rays(96, 96)
+    n, S = 2500, 96
+    rays_np = frame[(synth.hash_uniform(29, 1, (n,)) * np.float32(frame.shape[0])).astype(np.int64)]
+    tgt_np = synth.hash_uniform(29, 2, (n, 3))
+    jit_np = synth.hash_uniform(29, 3, (n,))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    orc = otrain.EagerTrainer(params, g["aabb"], step, g["near_far"], float(g["distance_scale"]), float(g["thr"]))
+    grads, rgb_loss, _, aux = orc.gradients(torch.from_numpy(rays_np), torch.from_numpy(tgt_np), S, torch.from_numpy(jit_np), True, 5)
+    tr = train.Trainer(f, batch_size=n, max_samples=S)
+    loss = tr.backward(torch.from_numpy(rays_np), torch.from_numpy(tgt_np), S, white_bg=True, iteration=5, jitter=torch.from_numpy(jit_np))
+    n_ref = int(aux["active"].sum())
+    assert n_ref > 20000 and abs(tr.last_active - n_ref) <= 1          # ~10 active samples per ray: bins of several hundred pairs
+    assert abs(loss.item() - rgb_loss) < 2e-6
+    for k, name in enumerate(train.PARAM_NAMES):
+        got = tr.gradient(k).cpu().numpy()
+        want = grads[name].numpy()
+        if k < 3:
+            want = want - l1_term(params[name])
+        assert rel(got, want) < GRAD_TOL, (name, rel(got, want))
+    tr.optimizer_step()
+    assert all(torch.isfinite(p).all() for p in tr.params)
