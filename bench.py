@@ -493,8 +493,13 @@ def main():
                 for split in (False, True):
                     net = uvmapping.NeuTex(primitive_type="sphere", sample_num=64, device=device, split_bf16=split)
                     net.load_params(up)
-                    net(cam_t, dirs_t, None, jitter_u=Uj)
-                    ms = kernel_ms(lambda: net(cam_t, dirs_t, None, jitter_u=Uj), 3, device)
+                    for _ in range(2):          # two warm calls (the first packs the weights), then the median of five launches of 40-70 ms
+                        net(cam_t, dirs_t, None, jitter_u=Uj)
+                    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+                    for ea, eb in ev:
+                        ea.record(); net(cam_t, dirs_t, None, jitter_u=Uj); eb.record()
+                    torch.cuda.synchronize(device)
+                    ms = float(np.median([ea.elapsed_time(eb) for ea, eb in ev]))
                     net(cam_t, dirs_t, None, jitter_u=Uj, collect_stats=True)
                     us = net.last_stats.cpu().numpy().astype(np.float64)
                     flops = us[1] * 16 * 2 * 1334592.0                                    # passes x 16 samples x 2 x MAC/sample
