@@ -216,6 +216,31 @@ __device__ __forceinline__ void kmma(const KStepA<NT, NS> &k, f32x4 acc[NS][NT])
             for (int s = 0; s < NS; ++s) acc[s][4 * g + e] = NGF_UV_MFMA(k.a[g][e], k.b[s], acc[s][4 * g + e]);
 }
 
+#ifdef NGF_EXP_UV_FUSED
+// EXPERIMENT (measured slower): one k-step consumed and another one requested piece by piece -- the 8 MFMAs of a 4-tile
+// group, then ONE of the requested k-step's four weight loads -- instead of 16 loads in front of 128 MFMAs.
+template <int NT, int NS>
+__device__ __forceinline__ void kstep_fused(const KStepA<NT, NS> &k, f32x4 acc[NS][NT], const float *w, const float *act, int t, int lane,
+                                            KStepA<NT, NS> &kn)
+{
+    const f32x4 *wp = reinterpret_cast<const f32x4 *>(w) + ((size_t)t * (NT / 4)) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < NT / 4; ++g) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s][4 * g + e] = NGF_UV_MFMA(k.a[g][e], k.b[s], acc[s][4 * g + e]);
+        __builtin_amdgcn_sched_barrier(0);
+        kn.a[g] = wp[g * 64];
+        if (g == 0) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) kn.b[s] = act[s * kUvWaveLds + t * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+#endif
+
 // Dense layer, KT4 k-steps (multiple of 4; padded steps have zero weights and zero inputs).  Software pipeline with
 // two k-steps of weight loads in flight behind the MFMAs (the un-pipelined loop left the waves 67 % of their cycles
 // in s_waitcnt with the matrix pipe 31 % busy: latency-, not bandwidth-bound).
@@ -255,6 +280,16 @@ __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4
         for (int t = 0; t < KT4; t += 8) {
             const bool has_b = t + 4 < KT4;
             const int tb = has_b ? t + 4 : t;                    // harmless reload when the layer ends on the first half
+#ifdef NGF_EXP_UV_FUSED
+            kstep_fused<NT_OUT, NS>(a0, out, w, act, tb, lane, b0); kstep_fused<NT_OUT, NS>(a1, out, w, act, tb + 1, lane, b1);
+            kstep_fused<NT_OUT, NS>(a2, out, w, act, tb + 2, lane, b2); kstep_fused<NT_OUT, NS>(a3, out, w, act, tb + 3, lane, b3);
+            if (has_b) {
+                const int ta = t + 8 < KT4 ? t + 8 : t;
+                kstep_fused<NT_OUT, NS>(b0, out, w, act, ta, lane, a0); kstep_fused<NT_OUT, NS>(b1, out, w, act, ta + 1, lane, a1);
+                kstep_fused<NT_OUT, NS>(b2, out, w, act, ta + 2, lane, a2); kstep_fused<NT_OUT, NS>(b3, out, w, act, ta + 3, lane, a3);
+            }
+            continue;
+#endif
             kload<NT_OUT, NS>(w, act, tb, lane, b0); kload<NT_OUT, NS>(w, act, tb + 1, lane, b1);
             kload<NT_OUT, NS>(w, act, tb + 2, lane, b2); kload<NT_OUT, NS>(w, act, tb + 3, lane, b3);
             __builtin_amdgcn_sched_barrier(0);
