@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NGF_ABI_VERSION 2      /* 2: ngf_uv_desc.flags (was padding), ngf_uv_render_batch, ngf_debug_dirty_lds, trainer chunk_samples = 0 means the whole batch */
+#define NGF_ABI_VERSION 3      /* 3: ngf_train_backward2 (loss_len travels with the call; ngf_train_backward is back to its ABI-1 contract of ONE double); 2: ngf_uv_desc.flags (was padding), ngf_uv_render_batch, ngf_debug_dirty_lds, trainer chunk_samples = 0 means the whole batch */
 
 enum { NGF_OK = 0, NGF_E_ARG = 1, NGF_E_HIP = 2, NGF_E_UNSUPPORTED = 3 };
 enum { NGF_MODEL_TRIPLANE = 0, NGF_MODEL_INFOINV = 1 };
@@ -215,8 +215,10 @@ int64_t ngf_trainer_bytes(const ngf_trainer *t);
 int32_t ngf_sizeof_train_desc(void);
 /* forward (training mode) + backward of  mean((rgb_map - rgb_train)^2): the gradients of all 15 parameters land in the
  * trainer's buffers (zeroed first).  jitter [n] = the per-ray U[0,1) of sample_ray (FieldBase.py:129-130; NULL = 0),
- * white_bg = `white_bg or coin` of FieldBase.py:299, gauge_on = (iteration >= gauge_start).  rgb_loss (DEVICE, TWO doubles since ABI 2)
- * receives the SUM of squared residuals in [0] and the mean (sum / 3n = the reference's rgb loss) in [1]; *n_active_host (HOST, nullable) the active-sample count.
+ * white_bg = `white_bg or coin` of FieldBase.py:299, gauge_on = (iteration >= gauge_start).  rgb_loss (DEVICE, loss_len doubles, loss_len >= 1)
+ * receives the SUM of squared residuals in [0] and, when loss_len >= 2, the mean (sum / 3n = the reference's rgb loss, main.py:277) in [1]; *n_active_host
+ * (HOST, nullable) the active-sample count.  ngf_train_backward (no loss_len) is the ABI-1 entry point and writes ONE double, the sum.
+ * On an error return after the call has forked, the caller's stream has still been made to wait for the trainer's streams.
  * Asynchronous on the stream when n_active_host is NULL and one chunk holds every sample of the batch (chunk_samples = 0: the
  * default): the colour kernels then read the active count on the device.  Passing n_active_host, or a chunk smaller than
  * n * n_samples, costs one stream synchronisation per call.  ngf_train_get_active copies the count of the last backward of an
@@ -227,6 +229,9 @@ int32_t ngf_sizeof_train_desc(void);
  * hip_stream alone (ngf_debug_set("ablate", 1 << 19) makes it so, for A/B timing).  ngf_train_adam_all does the same for the planes.
  * A trainer must not be used from two streams at once.  (1.7 KB per sample in the line above: 2.3 KB + 0.1 KB of scatter pairs since
  * round 3 -- the feature-gradient rows are kept as well.) */
+int ngf_train_backward2(ngf_trainer *t, const float *rays, const float *rgb_train, const float *jitter, int64_t n,
+                        int32_t n_samples, int32_t white_bg, int32_t gauge_on, double *rgb_loss, int32_t loss_len,
+                        int64_t *n_active_host, void *hip_stream);
 int ngf_train_backward(ngf_trainer *t, const float *rays, const float *rgb_train, const float *jitter, int64_t n,
                        int32_t n_samples, int32_t white_bg, int32_t gauge_on, double *rgb_loss, int64_t *n_active_host,
                        void *hip_stream);

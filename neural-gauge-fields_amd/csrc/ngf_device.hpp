@@ -115,8 +115,9 @@ __device__ __forceinline__ Bil bil_setup(float u, float v, const Tex &t)
     // bitwise &, not &&: the short-circuit form compiles to branches, which splits every gather stage into basic
     // blocks and makes hipcc spill hundreds of VGPRs in the shade pipeline (measured: 139 spills -> 0)
     // (x0 in range <=> the clamp leaves it alone: two compares instead of four; a NaN coordinate clamps to -1 and compares unequal.  The
-    // 1-D weights of an out-of-range cell are zeroed BEFORE the four products -- two selects instead of four; the other axis' weights are
-    // finite whenever its coordinate is, so the products are exactly 0 as before)
+    // 1-D weights of an out-of-range cell are zeroed BEFORE the four products.  The y weights are zeroed too: with only the x weights at 0
+    // a NON-FINITE y coordinate (inf - floor(inf) = NaN, e.g. from a diverged gauge) would give 0 * NaN = NaN weights and poison sigma and
+    // the trainer's density fetch instead of the exact-zero out-of-range result of grid_sample.)
     float cx = fminf(fmaxf(fx, -1.0f), t.fw);
     float cy = fminf(fmaxf(fy, -1.0f), t.fh);
     bool in = (cx == fx) & (cy == fy);
@@ -124,6 +125,8 @@ __device__ __forceinline__ Bil bil_setup(float u, float v, const Tex &t)
     b.wx1 = wx1; b.wy1 = wy1; b.in = in ? 1 : 0;
     wx0 = in ? wx0 : 0.0f;
     wx1 = in ? wx1 : 0.0f;
+    wy0 = in ? wy0 : 0.0f;
+    wy1 = in ? wy1 : 0.0f;
     b.cx = (int)cx + 1;
     b.cy = (int)cy + 1;
     b.idx = (int)__umul24((unsigned)b.cy, (unsigned)t.stride) + b.cx;      // both factors < 2^24: the full-rate 24-bit multiply
@@ -150,9 +153,11 @@ __device__ __forceinline__ Bil bil_from_rec(int32_t idx, float wx1, float wy1, b
     Bil b;
     b.idx = idx; b.cx = 0; b.cy = 0; b.wx1 = wx1; b.wy1 = wy1; b.in = in ? 1 : 0;
     float wx0 = 1.0f - wx1;
-    const float wy0 = 1.0f - wy1;
+    float wy0 = 1.0f - wy1;
     wx0 = in ? wx0 : 0.0f;
     wx1 = in ? wx1 : 0.0f;
+    wy0 = in ? wy0 : 0.0f;
+    wy1 = in ? wy1 : 0.0f;
     b.w00 = wx0 * wy0;
     b.w10 = wx1 * wy0;
     b.w01 = wx0 * wy1;

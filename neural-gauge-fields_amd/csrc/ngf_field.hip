@@ -626,8 +626,10 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
         const int H = d->plane_h[p], W = d->plane_w[p];
         const size_t texels = (size_t)(H + 2) * (W + 2);
         const int dc = bake ? 1 : d->dens_dim;
-        if (texels * (size_t)(app_c > 96 ? app_c : 96) * sizeof(float) >= ((size_t)1 << 32))      // the kernels address a texture with 32-bit byte offsets (tex_at)
+        if (texels * (size_t)(app_c > 96 ? app_c : 96) * sizeof(float) >= ((size_t)1 << 32)) {     // the kernels address a texture with 32-bit byte offsets (tex_at)
+            if (wp_dev) (void)hipFree(wp_dev);
             return bail(fail(NGF_E_UNSUPPORTED, "plane %d: %d x %d texels do not fit a 4 GiB packed texture", p, H, W));
+        }
         if ((rc = alloc_f(&f->tex[p], texels * dc, f, st)) || (rc = alloc_f(&f->tex[3 + p], texels * app_c, f, st))) {
             if (wp_dev) (void)hipFree(wp_dev);
             return bail(rc);
@@ -1229,10 +1231,16 @@ static int tr_grid(const ngf_trainer *t, int64_t items, int per_block, int waves
     return g < 1 ? 1 : (int)g;
 }
 
-extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float *rgb_train, const float *jitter, int64_t n, int32_t n_samples,
-                                  int32_t white_bg, int32_t gauge_on, double *rgb_loss, int64_t *n_active_host, void *hip_stream)
+// What of the step's forks is still open on the aux streams: an error exit of the body must not leave them un-joined to the caller's stream
+// (the next call on that stream would otherwise run beside this one's aux-stream kernels).
+struct ForkState { bool fold = false, chains = false; };
+
+static int train_backward_body(ngf_trainer *t, const float *rays, const float *rgb_train, const float *jitter, int64_t n, int32_t n_samples,
+                               int32_t white_bg, int32_t gauge_on, double *rgb_loss, int32_t loss_len, int64_t *n_active_host, void *hip_stream,
+                               ForkState &fs)
 {
     if (!t || !rays || !rgb_train || !rgb_loss) return fail(NGF_E_ARG, "ngf_train_backward: null argument");
+    if (loss_len < 1) return fail(NGF_E_ARG, "ngf_train_backward2: loss_len=%d (1 = the sum of squared residuals, 2 = sum and mean)", loss_len);
     if (n <= 0 || n > t->d.max_rays || n_samples <= 0 || n_samples > t->d.max_samples)
         return fail(NGF_E_ARG, "ngf_train_backward: n=%lld (max %lld), n_samples=%d (max %d)", (long long)n, (long long)t->d.max_rays, n_samples,
                     t->d.max_samples);
@@ -1275,7 +1283,7 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         HIP_TRY(hipStreamWaitEvent(sx, t->ev_fork, 0));
     }
     hipLaunchKernelGGL(train_fold_kernel, dim3(48), dim3(256), 0, sx, T, t->fwd_image, t->bwd_image);
-    if (fork) HIP_TRY(hipEventRecord(t->ev_join[0], sx));
+    if (fork) { HIP_TRY(hipEventRecord(t->ev_join[0], sx)); fs.fold = true; }
 
     const int64_t pairs = n * n_samples;
     hipLaunchKernelGGL(train_density_kernel, dim3(tr_grid(t, pairs, 256)), dim3(256), 0, st, T);
@@ -1300,7 +1308,7 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
     static_assert((((kBwdImage + 3) & ~3) + kTrainWavesBwd * kBwdTileFloats) * 4 <= 160 * 1024, "colour backward LDS");
     HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(train_color_fwd_kernel), lds_f));
     HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(train_color_bwd_kernel), lds_b));
-    if (fork) HIP_TRY(hipStreamWaitEvent(st, t->ev_join[0], 0));          // the images
+    if (fork) { HIP_TRY(hipStreamWaitEvent(st, t->ev_join[0], 0)); fs.fold = false; }          // the images
     const int32_t *cnt = no_sync ? T.offset + n : nullptr;
     T.n_active_dev = cnt;
     const int64_t list_len = no_sync ? pairs : n_active;          // upper bound of the list length the loops below are sized for
@@ -1319,13 +1327,12 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
     // these chains fills the device alone (LDS transposes, LDS latency, the atomic unit).  (Tried: the density / gauge backward beside the
     // colour backward, with the colour path's d loss / d t scattered into the gauge planes by a kernel of its own -- the active entries of a
     // ray span the whole plane, their scatter cannot be merged in LDS, and the step got 0.17 ms slower.)
-    bool forked = false;
     auto join = [&]() -> int {
-        if (fork && forked) {
+        if (fork && fs.chains) {
             HIP_TRY(hipStreamWaitEvent(st, t->ev_join[0], 0));
             HIP_TRY(hipStreamWaitEvent(st, t->ev_join[1], 0));
         }
-        forked = false;
+        fs.chains = false;
         return NGF_OK;
     };
     for (int64_t base = 0; base < list_len; base += t->chunk) {
@@ -1374,10 +1381,12 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         hipLaunchKernelGGL(xty_all_kernel, dim3(xg, 4), dim3(256), 0, sx, G);
         if (base + t->chunk >= list_len) hipLaunchKernelGGL(train_unfold_kernel, dim3(96), dim3(256), 0, sx, T, t->g_dense[TP_W1], t->g_dense[TP_BASIS]);
         if (fork) {
-            HIP_TRY(hipEventRecord(t->ev_join[0], sx));
-            HIP_TRY(hipEventRecord(t->ev_join[1], sb));
+            // both events are recorded before an error can return: the wrapper's rescue join waits on events of THIS step
+            const hipError_t e0 = hipEventRecord(t->ev_join[0], sx), e1 = hipEventRecord(t->ev_join[1], sb);
+            fs.chains = true;
+            HIP_TRY(e0);
+            HIP_TRY(e1);
         }
-        forked = true;
     }
     if (list_len <= 0) {        // no active sample and the host knows it: nothing wrote the colour planes' gradients
         for (int p = 0; p < 3; ++p) HIP_TRY(hipMemsetAsync(t->g_a[p], 0, (size_t)(d.plane_h[p] + 2) * (d.plane_w[p] + 2) * 48 * sizeof(float), st));
@@ -1394,12 +1403,41 @@ extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float
         FA.texels[p] = (int64_t)(d.plane_h[p] + 2) * (d.plane_w[p] + 2); FA.g_dens[p] = t->g_d[p];
         U.src[p] = t->g_gb[p]; U.dst[p] = t->g_g[p]; U.w2[p] = d.gauge_w[p] + 2; U.h2[p] = d.gauge_h[p] + 2; U.bw[p] = T.g_bw[p];
     }
-    U.loss_src = T.loss; U.loss_dst = rgb_loss; U.inv_count = 1.0 / (3.0 * (double)n);        // the loss travels with the last kernel of the caller's stream (a copy of 8 bytes is a launch of its own)
+    U.loss_src = T.loss; U.loss_dst = rgb_loss; U.loss_len = loss_len; U.inv_count = 1.0 / (3.0 * (double)n);        // the loss travels with the last kernel of the caller's stream (a copy of 8 bytes is a launch of its own)
     hipLaunchKernelGGL(train_density_finish_kernel, dim3(128, 3), dim3(256), 0, st, FA);
     hipLaunchKernelGGL(train_unblock_gauge_kernel, dim3(128, 3), dim3(256), 0, st, U);
     if (int jrc = join()) return jrc;
     HIP_TRY(hipGetLastError());
     return NGF_OK;
+}
+
+static int train_backward_joined(ngf_trainer *t, const float *rays, const float *rgb_train, const float *jitter, int64_t n, int32_t n_samples,
+                                 int32_t white_bg, int32_t gauge_on, double *rgb_loss, int32_t loss_len, int64_t *n_active_host, void *hip_stream)
+{
+    ForkState fs;
+    const int rc = train_backward_body(t, rays, rgb_train, jitter, n, n_samples, white_bg, gauge_on, rgb_loss, loss_len, n_active_host, hip_stream, fs);
+    if (rc != NGF_OK && t && (fs.fold || fs.chains)) {
+        // error exit after a fork: the caller's stream still waits for what the aux streams hold (best effort: the error being reported stands)
+        hipStream_t st = (hipStream_t)hip_stream;
+        (void)hipStreamWaitEvent(st, t->ev_join[0], 0);
+        if (fs.chains) (void)hipStreamWaitEvent(st, t->ev_join[1], 0);
+    }
+    return rc;
+}
+
+// ABI 3: the loss buffer's length travels with the call (loss_len = 2: [0] the sum of squared residuals, [1] their mean)
+extern "C" int ngf_train_backward2(ngf_trainer *t, const float *rays, const float *rgb_train, const float *jitter, int64_t n, int32_t n_samples,
+                                   int32_t white_bg, int32_t gauge_on, double *rgb_loss, int32_t loss_len, int64_t *n_active_host, void *hip_stream)
+{
+    return train_backward_joined(t, rays, rgb_train, jitter, n, n_samples, white_bg, gauge_on, rgb_loss, loss_len, n_active_host, hip_stream);
+}
+
+// The ABI-1 entry point keeps the ABI-1 contract: rgb_loss is ONE double (the sum of squared residuals).  (ABI 2 wrote two doubles through
+// this symbol: a caller built against ABI 1 got an 8-byte out-of-bounds device write.)
+extern "C" int ngf_train_backward(ngf_trainer *t, const float *rays, const float *rgb_train, const float *jitter, int64_t n, int32_t n_samples,
+                                  int32_t white_bg, int32_t gauge_on, double *rgb_loss, int64_t *n_active_host, void *hip_stream)
+{
+    return train_backward_joined(t, rays, rgb_train, jitter, n, n_samples, white_bg, gauge_on, rgb_loss, 1, n_active_host, hip_stream);
 }
 
 extern "C" int ngf_train_get_active(ngf_trainer *t, int64_t n, int32_t *out, void *hip_stream)

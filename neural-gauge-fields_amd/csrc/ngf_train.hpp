@@ -1589,12 +1589,12 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
 }
 
 // blocked gauge-gradient plane -> [texel][2] (what the Adam kernel and ngf_train_get_grad read); blockIdx.y = plane
-struct UnblockArgs { const float *src[3]; float *dst[3]; int32_t w2[3], h2[3], bw[3]; const double *loss_src; double *loss_dst; double inv_count; };   // + the step's loss to the caller's buffer: [0] sum of squared residuals, [1] their mean
+struct UnblockArgs { const float *src[3]; float *dst[3]; int32_t w2[3], h2[3], bw[3]; const double *loss_src; double *loss_dst; int32_t loss_len; double inv_count; };   // + the step's loss to the caller's buffer: [0] sum of squared residuals, [1] their mean
 __global__ void __launch_bounds__(256) train_unblock_gauge_kernel(const UnblockArgs U)
 {
     const int p = blockIdx.y;
     const int total = U.w2[p] * U.h2[p];
-    if (U.loss_dst && blockIdx.x == 0 && p == 0 && threadIdx.x == 0) { U.loss_dst[0] = *U.loss_src; U.loss_dst[1] = *U.loss_src * U.inv_count; }
+    if (U.loss_dst && blockIdx.x == 0 && p == 0 && threadIdx.x == 0) { U.loss_dst[0] = *U.loss_src; if (U.loss_len >= 2) U.loss_dst[1] = *U.loss_src * U.inv_count; }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int y = i / U.w2[p], x = i - y * U.w2[p];
         const f32x2 v = *reinterpret_cast<const f32x2 *>(U.src[p] + blocked_offset<1, 2>(x, y, U.bw[p]));

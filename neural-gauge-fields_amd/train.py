@@ -47,8 +47,8 @@ def _bind(L):
     L.ngf_trainer_destroy.argtypes = [C.c_void_p]
     L.ngf_trainer_bytes.restype = C.c_int64
     L.ngf_trainer_bytes.argtypes = [C.c_void_p]
-    L.ngf_train_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
-                                     C.POINTER(C.c_int64), C.c_void_p]
+    L.ngf_train_backward2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                      C.POINTER(C.c_int64), C.c_void_p]
     L.ngf_train_get_grad.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.ngf_train_get_active.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.ngf_train_adam.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
@@ -188,9 +188,14 @@ class Trainer:
 
     # ---------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def backward(self, rays_train, rgb_train, N_samples=-1, white_bg=True, iteration=0, jitter=None, coin=None):
+    def backward(self, rays_train, rgb_train, N_samples=-1, white_bg=True, iteration=0, jitter=None, coin=None, keep_loss=False):
         """forward(is_train=True) + backward of the rgb MSE; returns the rgb loss as a 0-dim float64 device tensor.
-        ``jitter`` [n] and ``coin`` (a float in [0,1)) replace torch.rand_like / torch.rand((1,)) for parity tests."""
+        ``jitter`` [n] and ``coin`` (a float in [0,1)) replace torch.rand_like / torch.rand((1,)) for parity tests.
+
+        ALIASING: by default the returned tensor is a VIEW of the trainer's persistent loss buffer (the step's last kernel writes the mean
+        there; a torch op here would be one more launch per step) -- the next ``backward`` overwrites it in place.  Read it (``.item()``,
+        ``float()``) before the next step, or pass ``keep_loss=True`` to get a fresh tensor per step as the reference's loss is
+        (main.py:277), e.g. for a loss history or deferred ``.item()`` calls."""
         if self._key() != self._shape_key:
             raise RuntimeError("the field's parameters were re-allocated (up_sampling / shrink / load): build a new Trainer")
         if self._param_versions() != self._versions:      # an in-place write from outside: the packed copies are stale
@@ -213,11 +218,12 @@ class Trainer:
         # ``last_active`` fetches it lazily
         with torch.cuda.device(self.dev):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            _lib.check(self.L.ngf_train_backward(self._h, rays.data_ptr(), tgt.data_ptr(), jitter.data_ptr(), n, S, int(bool(white_bg)), gauge_on,
-                                                 self._loss.data_ptr(), None, st))
+            _lib.check(self.L.ngf_train_backward2(self._h, rays.data_ptr(), tgt.data_ptr(), jitter.data_ptr(), n, S, int(bool(white_bg)), gauge_on,
+                                                  self._loss.data_ptr(), int(self._loss.numel()), None, st))
         self._last_n = n
         self._gauge_on = gauge_on
-        return self._loss[1]          # a view: the division is done by the step's last kernel (a torch op here is one more launch per step)
+        # a view: the division is done by the step's last kernel (a torch op here is one more launch per step)
+        return self._loss[1].clone() if keep_loss else self._loss[1]
 
     @torch.no_grad()
     def gradient(self, which) -> torch.Tensor:
@@ -246,9 +252,10 @@ class Trainer:
         self.field.invalidate()      # parameters changed behind torch's back: the eval image is re-packed on the next render
         self.lr = [x * self.lr_factor for x in self.lr]
 
-    def step(self, rays_train, rgb_train, iteration, N_samples=-1, white_bg=True, jitter=None, coin=None):
-        """One iteration of main.py:264-299.  Returns the rgb loss (0-dim float64 device tensor; ``.item()`` for PSNR)."""
-        loss = self.backward(rays_train, rgb_train, N_samples, white_bg, iteration, jitter, coin)
+    def step(self, rays_train, rgb_train, iteration, N_samples=-1, white_bg=True, jitter=None, coin=None, keep_loss=False):
+        """One iteration of main.py:264-299.  Returns the rgb loss (0-dim float64 device tensor; ``.item()`` for PSNR) -- a view of the
+        trainer's loss buffer that the next step overwrites unless ``keep_loss=True`` (see ``backward``)."""
+        loss = self.backward(rays_train, rgb_train, N_samples, white_bg, iteration, jitter, coin, keep_loss=keep_loss)
         self.optimizer_step()
         return loss
 

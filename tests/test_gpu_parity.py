@@ -251,8 +251,20 @@ def test_no_fold_level0_matches_reference(name):
     dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
     got = f0.decode_rgb(torch.from_numpy(coords), torch.from_numpy(dirs), mode=1).cpu().numpy()
     assert np.abs(got - orc.color_at(coords, dirs)).max() < 5e-6
-    with pytest.raises(RuntimeError):
+    with pytest.raises((RuntimeError, ValueError)):                                      # level 0 excludes the bakes (constructor and ngf_field_create)
         field_for_case(g, params, mask, no_fold=True, bake=True).handle()
+    # the documented level-0 option through the PUBLIC constructor alone: bake_density's default resolves to "not no_fold"
+    from ngf_amd import triplane
+    fp = triplane.TriPlane(torch.tensor(np.asarray(g["aabb"], np.float32)), [int(v) for v in g["grid"]], "cuda", no_fold=True, gauge_start=0,
+                           near_far=[float(v) for v in g["near_far"]], distance_scale=float(g["distance_scale"]),
+                           rayMarch_weight_thres=float(g["thr"]), step_ratio=float(g["step_ratio"]))
+    assert fp.no_fold and not fp.bake_density
+    fp.load_params(params)
+    if mask is None:
+        c = fp(rays, N_samples=S, white_bg=white, **kw)
+        assert torch.equal(c["rgb_map"], a["rgb_map"]) and torch.equal(c["depth_map"], a["depth_map"])
+    else:
+        fp.handle()
 
 
 @pytest.mark.parametrize("name", ["triplane_r1_gauge", "triplane_r2_nogauge", "triplane_r1_mask"])

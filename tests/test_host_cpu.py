@@ -221,3 +221,22 @@ def test_ray_restatements_match_reference_fixtures():
         for k, r in enumerate(fd[f"v{v}_rows"]):
             mine = synth.dtu_rays_dir(600, 800, fd[f"v{v}_focal"], fd[f"v{v}_princpt"], fd[f"v{v}_rot"], rows=(int(r), int(r) + 1))
             assert np.array_equal(mine, fd[f"v{v}_raydir"][k])
+
+
+def test_optimisation_level_flags_resolve_in_the_constructor():
+    """bake_density=None (the default) means level 2 unless level 0 (no_fold) is asked for: TriPlane(..., no_fold=True) alone must not end in
+    ngf_field_create's NGF_E_ARG (NGF_F_NO_FOLD excludes the NGF_F_BAKE_* flags)."""
+    from ngf_amd import triplane
+    aabb = torch.tensor([[-1.5] * 3, [1.5] * 3])
+    mk = lambda **kw: triplane.TriPlane(aabb, [16, 16, 16], "cpu", **kw)
+    f = mk()
+    assert f.bake_density and not f.no_fold and not f.bake_color                 # level 2
+    f = mk(no_fold=True)
+    assert f.no_fold and not f.bake_density and not f.bake_color                 # level 0
+    f = mk(bake_density=False)
+    assert not f.bake_density and not f.no_fold                                  # level 1
+    f = mk(bake_color=True)
+    assert f.bake_density and f.bake_color                                       # level 3
+    for bad in (dict(no_fold=True, bake_density=True), dict(no_fold=True, bake_color=True)):
+        with pytest.raises(ValueError):
+            mk(**bad)
