@@ -301,7 +301,9 @@ int ngf_uv_render_batch(const ngf_uv *m, const float *campos_dev, const float *r
 
 /* Experiment / test knobs of the launch code (tile shapes, kernel variants, A/B ablations used by the bit-identity tests and the
  * scripts under profiles/).  Process-wide; value -1 restores the library default.  The library never reads the environment:
- * this explicit call is the only way to change what a launch does.  Names: "tile_w" (64/32/16/8/4), "split" (0/1), "waves",
+ * this explicit call is the only way to change what a launch does.  Names: "tile_w" (64/32/16/8/4/2/1: ONE tile width for the whole
+ * launch instead of the tile plan), "tail" (16 x the narrow tiles per resident wave and width at the end of a launch's tile plan; 0 = wide
+ * tiles only), "split" (0/1), "waves",
  * "nstep", "profile", "ablate" (bit mask, see ngf_device.hpp), "uv_tiles" (1/2), "kernel" (0 = fused march+shade waves, 1 =
  * specialised march / shade waves), "stage" (1 = LDS-staged density strips), "poison" (bit 0: before every kernel of the library
  * a launch fills the LDS of every CU with the quiet-NaN pattern 0x7FC0DEAD, so that a read of LDS the kernel did not write shows up
@@ -317,6 +319,12 @@ int ngf_debug_dirty_lds(void *hip_stream);
 /* out8[x] = number of workgroups of a `workgroups`-wide launch that ran on XCD x (HW_REG_XCC_ID): the render launches keep one tile
  * queue per XCD (knob "xcd": 1 / 0 forces it on / off) and rely on this id */
 int ngf_debug_xcd_histogram(unsigned *out8, int32_t workgroups, void *hip_stream);
+/* The tile plan a render launch of n rays would use (host arithmetic only, no GPU): widest tile `wide` (8 TriPlane, 16 InfoInv), `resident`
+ * waves in the persistent grid (CUs x waves per workgroup), tail16 as knob "tail" (-1 = the library default).  The ray list is cut into up
+ * to four contiguous segments of seg_rays[k] rays in tiles of 1 << seg_shift[k] rays, widest first; every segment but the last holds whole
+ * tiles.  Returns the number of segments (1..4); unused entries are zeroed.  (Why: a persistent grid ends when its last wave does -- narrow
+ * tiles for the last rays let the waves run dry together.) */
+int ngf_debug_tile_plan(int64_t n, int32_t wide, int64_t resident, int32_t tail16, int64_t *seg_rays, int32_t *seg_shift);
 
 const char *ngf_last_error(void);
 int ngf_abi_version(void);

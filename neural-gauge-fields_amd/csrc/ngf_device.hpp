@@ -47,11 +47,20 @@ struct RenderArgs {
     unsigned int *tile_counter; // queue heads, zeroed before the launch: [0] alone (one queue) or [0..7] (one queue per XCD, xcd_queues = 8)
     int64_t n;
     int32_t S, white_bg, mode, skip_rgb;
-    int32_t tile_w;        // rays per wave tile: 64, or 32 / 16 / 8 for small launches (more waves, shorter critical path)
+    int32_t tile_w;        // rays per wave tile of the launch's FIRST (widest) plan segment: 64 (unsplit kernel) or 32 .. 1
     int32_t tile_shift;    // log2(tile_w); the split march gives every ray 64 >> tile_shift lanes (consecutive steps)
+    // Tile plan (launch_render): the ray list is cut into up to four contiguous segments of tiles of decreasing width -- wide tiles first (the
+    // efficient ones: fewer partial shade passes, finer early termination), narrow tiles for the last rays, so that the waves of the persistent
+    // grid run dry together instead of one tile apart (a launch used to pay ~one tile duration, 0.17 ms, for its tail whatever its size).
+    // Tile t belongs to segment g = #{k : t >= seg_end[k]}; its rays are seg_ray0[g] + ((t - seg_end[g-1]) << seg_shift[g]) ...
+    uint32_t seg_end[3];   // exclusive tile-index ends of segments 0..2 (segment 3 ends at `tiles`)
+    int32_t seg_shift[4];  // log2(tile width) of each segment
+    int64_t seg_ray0[4];   // first ray of each segment
     int32_t xcd_queues;    // 8: the tile range is cut into 8 contiguous chunks, XCD x starts on chunk x and steals from the others when it is done
                            // (each XCD has its own 4 MiB L2: its concurrent tiles then cover ONE compact ray range instead of an eighth of everybody's);
                            // 0 / 1: one queue
+    int32_t waves_active;  // waves of a workgroup that take tiles (the others leave after the LDS image barrier): < WAVES for launches with fewer tiles than
+                           // resident waves, so that the working waves are spread over all CUs and SIMDs
     uint32_t tiles;        // number of tiles of the launch
     int32_t ablate;        // debug instantiations only (render_kernel<.., DBG = true>): 32 no early termination, 64 no empty-iteration skip -- both
                            // EXACT (A/B timing and the bit-identity tests).  Round 1-2's bits 1 / 2 / 4 / 16 (skip collect, skip layers 2-3, cached

@@ -31,7 +31,7 @@ int ngf::fail(int code, const char *fmt, ...)
 }
 
 static std::atomic<int> g_knob[ngf::KNOB_COUNT];
-static const char *const g_knob_name[ngf::KNOB_COUNT] = {"tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage", "poison", "grid", "xcd"};
+static const char *const g_knob_name[ngf::KNOB_COUNT] = {"tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage", "poison", "grid", "xcd", "tail"};
 static bool g_knob_init = [] { for (auto &k : g_knob) k.store(-1); return true; }();
 
 int ngf::knob(int id) { return g_knob[id].load(std::memory_order_relaxed); }
@@ -679,6 +679,44 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     return NGF_OK;
 }
 
+// The tile plan of a render launch (see launch_render): n rays, widest tile `wide`, `resident` waves in the persistent grid, tail16 / 16 narrow
+// tiles per resident wave of each narrower width.  Fills up to four (rays, log2 width) segments in ray order, returns their number.  Every
+// segment but the last holds whole tiles.  Pure host arithmetic (ngf_debug_tile_plan exposes it to the CPU tests).
+static constexpr int kTailDefault16 = 16;
+static int make_tile_plan(int64_t n, int wide, int64_t resident, int tail16, int64_t seg_rays[4], int seg_shift[4])
+{
+    auto shift_of = [](int w) { int sft = 0; while ((1 << sft) < w) ++sft; return sft; };
+    const int widths[4] = {wide, 4, 2, 1};
+    int64_t left = n, want[4] = {0, 0, 0, 0};
+    for (int k = 3; k >= 1; --k) {      // the narrow segments are sized from the END of the ray list
+        if (widths[k] >= wide) continue;
+        want[k] = std::min<int64_t>(left, (resident * tail16 / 16) * widths[k]);
+        left -= want[k];
+    }
+    want[0] = left;
+    int nseg = 0;
+    int64_t carry = 0;
+    for (int k = 0; k < 4; ++k) {       // what does not fill a tile moves to the next narrower segment
+        int64_t r = want[k] + carry;
+        carry = 0;
+        if (k < 3) { carry = r % widths[k]; r -= carry; }
+        if (r <= 0) continue;
+        if (nseg > 0 && seg_shift[nseg - 1] == shift_of(widths[k])) { seg_rays[nseg - 1] += r; continue; }
+        seg_rays[nseg] = r; seg_shift[nseg] = shift_of(widths[k]); ++nseg;
+    }
+    if (nseg == 0) { seg_rays[0] = n; seg_shift[0] = 0; nseg = 1; }
+    return nseg;
+}
+
+extern "C" int ngf_debug_tile_plan(int64_t n, int32_t wide, int64_t resident, int32_t tail16, int64_t *seg_rays, int32_t *seg_shift)
+{
+    int64_t r[4] = {0, 0, 0, 0};
+    int sh[4] = {0, 0, 0, 0};
+    const int nseg = make_tile_plan(n, wide, resident, tail16 >= 0 ? tail16 : kTailDefault16, r, sh);
+    for (int k = 0; k < 4; ++k) { seg_rays[k] = k < nseg ? r[k] : 0; seg_shift[k] = k < nseg ? sh[k] : 0; }
+    return nseg;
+}
+
 // ---- launches ------------------------------------------------------------------------------------
 // kernel / kernel_split: the DBG = true instantiations (every feature); kernel_prod: the split kernel's production instantiation (no debug
 // outputs, ablation bits, statistics: render_kernel<P, true, false>) or null when the policy has none
@@ -695,22 +733,53 @@ static int launch_render(K kernel, K kernel_split, K kernel_prod, const ngf_fiel
     // chunks) and still buys 5 % on a full frame.  Measured in profiles/r01_split_march.txt: tile_w = 8 is best from
     // 160 000 rays to the full frame, tile_w = 4 below (80 000 rays: 1.43-1.49 vs 1.51-1.53 ms; 4000 rays: 0.29 vs 0.51 ms).  ngf_debug_set("tile_w" / "split") override for experiments.
     const int waves = threads / kWave;
-    int tw = 64;
-    if (kernel_split) tw = A.n < 40 * (int64_t)f->num_cus * waves ? 4 : wide_tile;     // up to ~120 k rays (5 tiles of 8 per resident wave) 4-ray tiles balance better
-    if (knob(KNOB_TILE_W) >= 0) tw = knob(KNOB_TILE_W);
-    if (tw != 64 && tw != 32 && tw != 16 && tw != 8 && tw != 4) return fail(NGF_E_ARG, "knob tile_w must be 64, 32, 16, 8 or 4");
-    bool split = tw < 64 && kernel_split;
+    const int cus = knob(KNOB_GRID) > 0 && knob(KNOB_GRID) < f->num_cus ? knob(KNOB_GRID) : f->num_cus;      // knob grid (tests): fewer workgroups
+    const int64_t resident = (int64_t)cus * waves;      // waves of the persistent grid
+    // ---- tile plan -------------------------------------------------------------------------------------------------------------------
+    // Wide tiles are the efficient ones (fewer partial shade passes, finer early termination); but the grid is persistent and a launch ends
+    // when its LAST wave is done: with one tile width the waves ran dry one tile duration apart -- ~0.17 ms of every launch, 15 % of one
+    // rank's 80 000-ray shard (profiles/r04_timeline.txt).  So the ray list is cut into segments of decreasing width: the widest tiles for the
+    // bulk, then about `tail` tiles per resident wave of each narrower width down to one ray per tile (a 1-ray tile is ~1/8 of an 8-ray one).
+    // A launch with fewer rays than that starts further down the list: a 4096-ray chunk is all 2-ray tiles on 2048 waves.
+    // Knobs: tile_w forces ONE width (bit-identity tests, A/B timing); tail = 16 x the narrow tiles per wave and width (0: none).
+    int64_t seg_rays[4] = {0, 0, 0, 0};
+    int seg_shift[4] = {0, 0, 0, 0};
+    int nseg = 1;
+    bool split = kernel_split != nullptr;
     if (knob(KNOB_SPLIT) >= 0) split = knob(KNOB_SPLIT) != 0 && kernel_split;
-    A.tile_w = tw;
-    A.tile_shift = tw == 64 ? 6 : tw == 32 ? 5 : tw == 16 ? 4 : tw == 8 ? 3 : 2;
+    const int forced = knob(KNOB_TILE_W);
+    auto shift_of = [](int w) { int sft = 0; while ((1 << sft) < w) ++sft; return sft; };
+    if (forced >= 0 || !split) {
+        int tw = forced >= 0 ? forced : 64;
+        if (tw != 64 && tw != 32 && tw != 16 && tw != 8 && tw != 4 && tw != 2 && tw != 1) return fail(NGF_E_ARG, "knob tile_w must be 64, 32, 16, 8, 4, 2 or 1");
+        if (knob(KNOB_SPLIT) < 0) split = tw < 64 && kernel_split;
+        if (tw < 4 && !split) return fail(NGF_E_ARG, "tiles of 2 or 1 rays exist in the split kernel only");
+        seg_rays[0] = A.n; seg_shift[0] = shift_of(tw);
+    } else {
+        nseg = make_tile_plan(A.n, wide_tile, resident, knob(KNOB_TAIL) >= 0 ? knob(KNOB_TAIL) : kTailDefault16, seg_rays, seg_shift);
+    }
+    A.tile_shift = seg_shift[0];
+    A.tile_w = 1 << seg_shift[0];
+    int64_t tiles = 0, ray0 = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int sft = k < nseg ? seg_shift[k] : seg_shift[nseg - 1];
+        const int64_t r = k < nseg ? seg_rays[k] : 0;
+        A.seg_shift[k] = sft;
+        A.seg_ray0[k] = ray0;
+        tiles += (r + (1 << sft) - 1) >> sft;
+        ray0 += r;
+        if (k < 3) {
+            if (tiles >= ((int64_t)1 << 32)) return fail(NGF_E_ARG, "render launch of %lld tiles: split the ray list", (long long)tiles);
+            A.seg_end[k] = (uint32_t)tiles;
+        }
+    }
     K k = split ? kernel_split : kernel;
-#ifdef NGF_EXP_DUMP      // experiment build: `stats` is the dump buffer of the production kernel
+#if defined(NGF_EXP_DUMP) || defined(NGF_EXP_TIMELINE)      // experiment builds: `stats` is the dump / timeline buffer of the production kernel
     if (split && kernel_prod) k = kernel_prod;
 #else
     if (split && kernel_prod && !A.dbg_weight && !A.dbg_sigma && !A.stats && !A.skip_rgb && !A.ablate) k = kernel_prod;
 #endif
     HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(k), lds_bytes));
-    const int64_t tiles = (A.n + tw - 1) / tw;
     if (tiles >= ((int64_t)1 << 32)) return fail(NGF_E_ARG, "render launch of %lld tiles: split the ray list", (long long)tiles);
     A.tiles = (uint32_t)tiles;
     // One tile queue per XCD (knob "xcd" = 1) is built, bit-identical and OFF by default: it cuts the fabric traffic of the MLP-stress frame
@@ -718,10 +787,13 @@ static int launch_render(K kernel, K kernel_split, K kernel_prod, const ngf_fiel
     // cycles, not by L2 misses (R1 / R2 / InfoInv within +-0.2 %) -- and the march-only frame loses 8 % to the stealing tail
     // (profiles/r03_xcd_queues.txt).
     A.xcd_queues = knob(KNOB_XCD) > 0 ? 8 : 1;
-    int64_t grid = (tiles + waves - 1) / waves;
-    if (grid > f->num_cus) grid = f->num_cus;
+    // One workgroup per CU as long as there are tiles, and only as many working waves per workgroup as the tiles need: a 4096-ray chunk (1024
+    // tiles) used to fill 86 CUs with 12 waves each -- three per SIMD, sharing its matrix pipe -- while 170 CUs idled.
+    int64_t grid = tiles < f->num_cus ? tiles : f->num_cus;
     if (knob(KNOB_GRID) > 0 && grid > knob(KNOB_GRID)) grid = knob(KNOB_GRID);      // tests: fewer workgroups -> every wave takes many tiles
     if (grid < 1) grid = 1;
+    const int64_t per_wg = (tiles + grid - 1) / grid;
+    A.waves_active = per_wg < waves ? (int)per_wg : waves;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds_bytes, st, A);
     HIP_TRY(hipGetLastError());
     return NGF_OK;

@@ -84,6 +84,24 @@ __device__ __forceinline__ void view_inputs_tile(const float d[3], float *dst, i
     }
 }
 
+// Copy the MLP image into LDS (every workgroup, once): 16-byte loads, four per thread requested before the first is stored.  The plain
+// `smem[i] = blob[i]` loop compiled to load -> s_waitcnt vmcnt(0) -> ds_write per dword: 20 serial round trips to the L2 for the 58.6 KB TriPlane
+// image (3.3-6.3 us of every launch, profiles/r04_timeline.txt) -- nothing for a frame, 2 % of a 4096-ray chunk.  The caller's barrier follows.
+__device__ __forceinline__ void stage_blob(float *smem, const float *blob, int blob_floats)
+{
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(blob);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+    const int n4 = blob_floats >> 2, nt = (int)blockDim.x;
+    for (int i = threadIdx.x; i < n4; i += 4 * nt) {
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int j = i + k * nt; v[k] = src[j < n4 ? j : n4 - 1]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int j = i + k * nt; if (j < n4) dst[j] = v[k]; }
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < blob_floats; i += nt) smem[i] = blob[i];
+}
+
 // The MLP image in LDS is read-only after the initial barrier, so LICM would hoist every per-lane weight /
 // bias read (160+ values) out of the persistent loops and pin them in VGPRs for the whole kernel (they
 // then spill).  Adding an opaque zero to the pointer once per pass keeps those reads inside the pass.
@@ -280,12 +298,104 @@ struct TriPlaneNoFoldPolicy : TriPlanePolicy<false, false, 8, 1> {
     }
 };
 
+// ---- raw2alpha of a split tile (FieldBase.py:12-19): the sequential cumprod / running sums of a ray, chained lane to lane with DPP ------------
+// Lane layout of a split tile (tile_w = 4 M rays, M = 1, 2, 4, 8): every 16-lane ROW holds M rays, lane-in-row = seg * M + r, so the K = 16 / M
+// lanes of a ray (its K consecutive steps) are M lanes apart inside one row and "the previous step's lane" is DPP row_shr:M -- a lane whose source
+// would be outside the row (seg 0) is disabled by bound_ctrl:0 and KEEPS its value.  The chain  P[seg] = P[seg-1] * f[seg]  (P = transmittance after
+// the lane's step) is therefore ONE v_mul_f32_dpp per round, in place: seg 0 starts from the ray's incoming T and is final at once, round r
+// finalises seg r.  The same for acc and depth with v_add_f32_dpp.  Products and sums are taken in step order with the operations of the unsplit
+// march (w = alpha T, T *= (1 - alpha) + 1e-10, acc += w, dep += w z): the results are its bits for every tile shape.  Rounds 1-3 used K-1 rounds of
+// eight VALU instructions + three ds_bpermute each (lane - tile_w through the LDS crossbar): 165 issue slots and 15 LDS round trips per march
+// iteration of a 4-ray tile, now ~55 VALU slots and none.  (Inline assembly: the in-place form -- destination = DPP source, disabled lanes keep the
+// old value -- is not what hipcc makes of __builtin_amdgcn_update_dpp + a multiply; the s_nop are the VALU-write -> DPP-read wait states, which the
+// hazard recogniser does not insert inside inline assembly.)
+// In: T, acc, dep valid in the seg-0 lane of each ray.  Out: w of the lane's own step; T, acc, dep after the tile's K steps, again in the seg-0 lane
+// (row_ror:M brings seg K-1 -- lane-in-row 16 - M + r -- to lane r); the other lanes hold values of no meaning.
+#define NGF_STR2(x) #x
+#define NGF_STR(x) NGF_STR2(x)
+#define NGF_SPLIT_CHAIN(M)                                                                                                                        \
+    template <> __device__ __forceinline__ void split_chain<M>(float alpha, float z, float &T, float &acc, float &dep, float &w)                    \
+    {                                                                                                                                               \
+        constexpr int K = 16 / M;                                                                                                                   \
+        const float f = (1.0f - alpha) + 1e-10f;                                                                                                    \
+        float Pt = T * f;                                                                                                                           \
+        asm volatile("s_nop 4" ::: "memory");      /* an EXEC write right before the first DPP instruction needs 5 wait states */                   \
+        _Pragma("unroll") for (int r = 1; r < K; ++r)                                                                                               \
+            asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %1 row_shr:" NGF_STR(M) " row_mask:0xf bank_mask:0xf" : "+v"(Pt) : "v"(f));              \
+        float Tin = T;                             /* seg 0 keeps the incoming T, seg s takes P of seg s - 1 */                                      \
+        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:" NGF_STR(M) " row_mask:0xf bank_mask:0xf" : "+v"(Tin) : "v"(Pt));                    \
+        w = alpha * Tin;                                                                                                                            \
+        const float wz = w * z;                                                                                                                     \
+        float Pa = acc + w, Pd = dep + wz;                                                                                                          \
+        _Pragma("unroll") for (int r = 1; r < K; ++r)                                                                                               \
+            asm volatile("s_nop 0\n\tv_add_f32_dpp %0, %0, %2 row_shr:" NGF_STR(M) " row_mask:0xf bank_mask:0xf\n\t"                                \
+                         "v_add_f32_dpp %1, %1, %3 row_shr:" NGF_STR(M) " row_mask:0xf bank_mask:0xf" : "+v"(Pa), "+v"(Pd) : "v"(w), "v"(wz));      \
+        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %3 row_ror:" NGF_STR(M) " row_mask:0xf bank_mask:0xf\n\t"                                        \
+                     "v_mov_b32_dpp %1, %4 row_ror:" NGF_STR(M) " row_mask:0xf bank_mask:0xf\n\t"                                                   \
+                     "v_mov_b32_dpp %2, %5 row_ror:" NGF_STR(M) " row_mask:0xf bank_mask:0xf" : "=&v"(T), "=&v"(acc), "=&v"(dep) : "v"(Pt), "v"(Pa), "v"(Pd)); \
+    }
+template <int M> __device__ __forceinline__ void split_chain(float alpha, float z, float &T, float &acc, float &dep, float &w);
+NGF_SPLIT_CHAIN(1)
+NGF_SPLIT_CHAIN(2)
+NGF_SPLIT_CHAIN(4)
+NGF_SPLIT_CHAIN(8)
+#undef NGF_SPLIT_CHAIN
+
+// Tiles of 2 or 1 rays (the tail of a launch's tile plan): a ray takes R = 2 or 4 whole rows (K = 32 / 64 consecutive steps).  The in-row chain is
+// the one above with M = 1; the carry from a row's lane 15 into the next row's lane 0 is DPP row_bcast:15 (lane 15 of every row -> all lanes of
+// the next row, written only into the rows whose turn it is: row_mask).  Row j of a ray is final after j + 1 runs of 15 rounds -- still one
+// multiply / add per step in step order.  The rounds run in all rows at once; a row that is already final recomputes its own values, a row whose
+// turn has not come holds values of no meaning until its carry arrives.
+#define NGF_ROW_ROUNDS15(OP, ACC, X) \
+    _Pragma("unroll") for (int r = 1; r < 16; ++r) asm volatile("s_nop 1\n\t" OP " %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(ACC) : "v"(X))
+#define NGF_ROW_CARRY(OP, ACC, X, MASK) \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %1 row_bcast:15 row_mask:" MASK " bank_mask:0xf" : "+v"(ACC) : "v"(X))
+template <int R> __device__ __forceinline__ void split_chain_rows(float alpha, float z, float &T, float &acc, float &dep, float &w, int last)
+{
+    static_assert(R == 2 || R == 4, "a ray takes 2 or 4 rows");
+    const float f = (1.0f - alpha) + 1e-10f;
+    float Pt = T * f;                              // right in the ray's first lane; every other lane is rewritten by the rounds
+    asm volatile("s_nop 4" ::: "memory");
+    NGF_ROW_ROUNDS15("v_mul_f32_dpp", Pt, f);
+    if constexpr (R == 2) { NGF_ROW_CARRY("v_mul_f32_dpp", Pt, f, "0xa"); NGF_ROW_ROUNDS15("v_mul_f32_dpp", Pt, f); }
+    else {
+        NGF_ROW_CARRY("v_mul_f32_dpp", Pt, f, "0x2"); NGF_ROW_ROUNDS15("v_mul_f32_dpp", Pt, f);
+        NGF_ROW_CARRY("v_mul_f32_dpp", Pt, f, "0x4"); NGF_ROW_ROUNDS15("v_mul_f32_dpp", Pt, f);
+        NGF_ROW_CARRY("v_mul_f32_dpp", Pt, f, "0x8"); NGF_ROW_ROUNDS15("v_mul_f32_dpp", Pt, f);
+    }
+    // T before the lane's own step: the ray's first lane keeps the incoming T, lane 0 of a later row takes lane 15 of the row before, the others their left neighbour
+    float Tin = T;
+    if constexpr (R == 2) asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(Tin) : "v"(Pt));
+    else asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_bcast:15 row_mask:0xe bank_mask:0xf" : "+v"(Tin) : "v"(Pt));
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(Tin) : "v"(Pt));
+    w = alpha * Tin;
+    const float wz = w * z;
+    float Pa = acc + w, Pd = dep + wz;
+    asm volatile("s_nop 4" ::: "memory");
+    NGF_ROW_ROUNDS15("v_add_f32_dpp", Pa, w); NGF_ROW_ROUNDS15("v_add_f32_dpp", Pd, wz);
+    if constexpr (R == 2) {
+        NGF_ROW_CARRY("v_add_f32_dpp", Pa, w, "0xa"); NGF_ROW_CARRY("v_add_f32_dpp", Pd, wz, "0xa");
+        NGF_ROW_ROUNDS15("v_add_f32_dpp", Pa, w); NGF_ROW_ROUNDS15("v_add_f32_dpp", Pd, wz);
+    } else {
+        NGF_ROW_CARRY("v_add_f32_dpp", Pa, w, "0x2"); NGF_ROW_CARRY("v_add_f32_dpp", Pd, wz, "0x2");
+        NGF_ROW_ROUNDS15("v_add_f32_dpp", Pa, w); NGF_ROW_ROUNDS15("v_add_f32_dpp", Pd, wz);
+        NGF_ROW_CARRY("v_add_f32_dpp", Pa, w, "0x4"); NGF_ROW_CARRY("v_add_f32_dpp", Pd, wz, "0x4");
+        NGF_ROW_ROUNDS15("v_add_f32_dpp", Pa, w); NGF_ROW_ROUNDS15("v_add_f32_dpp", Pd, wz);
+        NGF_ROW_CARRY("v_add_f32_dpp", Pa, w, "0x8"); NGF_ROW_CARRY("v_add_f32_dpp", Pd, wz, "0x8");
+        NGF_ROW_ROUNDS15("v_add_f32_dpp", Pa, w); NGF_ROW_ROUNDS15("v_add_f32_dpp", Pd, wz);
+    }
+    asm volatile("s_nop 1" ::: "memory");
+    // the ray's last lane holds the sums after its K steps: back to (all lanes of) the ray, the first lane is the one that counts
+    T = __shfl(Pt, last); acc = __shfl(Pa, last); dep = __shfl(Pd, last);
+}
+#undef NGF_ROW_ROUNDS15
+#undef NGF_ROW_CARRY
+
 // ---- the fused kernel ---------------------------------------------------------------------------
-// SPLIT = false: one ray per lane, tile_w (<= 64) rays per tile.  SPLIT = true (small launches: one rank's shard of a frame,
-// the reference's 4096-ray chunks): a tile holds tile_w = 64 >> k rays and every ray is marched by K = 64 / tile_w lanes that
-// take K CONSECUTIVE steps per iteration; transmittance, acc and depth are then chained lane to lane in step order, so each
-// ray sees exactly the sequential arithmetic of the unsplit march (results are bit-identical) while a tile's critical path
-// is K times shorter and all 64 lanes gather.
+// SPLIT = false: one ray per lane, tile_w (<= 64) rays per tile.  SPLIT = true (the default of every render): a tile holds
+// tile_w = 64 >> k rays and every ray is marched by K = 64 / tile_w lanes that take K CONSECUTIVE steps per iteration; transmittance,
+// acc and depth are then chained lane to lane in step order (split_chain: DPP row shifts), so each ray sees exactly the sequential
+// arithmetic of the unsplit march (results are bit-identical) while a tile's critical path is K times shorter and all 64 lanes gather.
 // DBG = false is the production instantiation: the per-sample debug outputs (dbg_weight / dbg_sigma), the ablation bits, skip_rgb and
 // the statistics counters are compiled OUT (they cost scalar registers -- the kernel parks SGPRs in VGPR lanes -- and issue slots of a
 // kernel that is bound by its vector pipe); launch_render picks DBG = true whenever one of them is requested.
@@ -298,8 +408,18 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
     }
     static_assert(!SPLIT || P::NSTEP == 1, "the split march is written for one step per lane per iteration");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    for (int i = threadIdx.x; i < A.blob_floats; i += blockDim.x) smem[i] = A.blob[i];
+#ifdef NGF_EXP_TIMELINE     // experiment build (profiles/exp_timeline.py): per-wave wall-clock marks of the production kernel -> A.stats[16 + 8 * wave id ..]
+    const unsigned long long tl_t0 = wall_clock64();
+    unsigned long long tl_tiles = 0, tl_pass = 0, tl_iter = 0, tl_first = 0;
+#endif
+    stage_blob(smem, A.blob, A.blob_floats);
     __syncthreads();
+#ifdef NGF_EXP_TIMELINE
+    const unsigned long long tl_t1 = wall_clock64();
+#endif
+    // small launches: launch_render spreads the tiles over all CUs and lets only the first waves_active waves of a workgroup work (they are dealt
+    // round robin to the four SIMDs): 1024 tiles are 4 waves on each of 256 CUs -- one per SIMD -- instead of 12 waves on 86 CUs
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= A.waves_active) return;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -327,12 +447,29 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
     for (;;) {
         unsigned int tile = 0;
         if (!next_tile(A, xcd, lane, q_first, tile)) break;
-        const int64_t base = (int64_t)tile * A.tile_w;
-        const int seg = SPLIT ? (lane >> A.tile_shift) : 0;              // which of the K consecutive steps this lane takes
-        const int rl = SPLIT ? (lane & (A.tile_w - 1)) : lane;           // ray slot inside the tile (= owner id in the queues)
-        const int K = SPLIT ? (64 >> A.tile_shift) : 1;
+#ifdef NGF_EXP_TIMELINE
+        if (!tl_tiles) tl_first = wall_clock64();
+        ++tl_tiles;
+#endif
+        // the tile's place in the launch's plan (RenderArgs::seg_*): which segment, hence how wide, and its first ray (scalar selects -- indexing
+        // the kernel-argument arrays with a run-time index would move them to scratch)
+        int ts = A.seg_shift[0];
+        int64_t base = A.seg_ray0[0] + ((int64_t)tile << ts);
+        if constexpr (SPLIT) {
+            if (tile >= A.seg_end[0]) { ts = A.seg_shift[1]; base = A.seg_ray0[1] + ((int64_t)(tile - A.seg_end[0]) << ts); }
+            if (tile >= A.seg_end[1]) { ts = A.seg_shift[2]; base = A.seg_ray0[2] + ((int64_t)(tile - A.seg_end[1]) << ts); }
+            if (tile >= A.seg_end[2]) { ts = A.seg_shift[3]; base = A.seg_ray0[3] + ((int64_t)(tile - A.seg_end[2]) << ts); }
+        }
+        const int tile_w = 1 << ts;
+        // split tile of >= 4 rays: a 16-lane row holds M = tile_w / 4 rays, lane-in-row = seg * M + r (split_chain above), ray slot = row * M + r;
+        // of 2 / 1 rays: a ray takes R = 2 / 4 whole rows, seg = its lane index inside them (split_chain_rows)
+        const int mshift = SPLIT ? (ts >= 2 ? ts - 2 : 0) : 0;           // log2(M)
+        const int rshift = SPLIT ? (ts >= 2 ? 0 : 2 - ts) : 0;           // log2(R)
+        const int K = SPLIT ? (64 >> ts) : 1;
+        const int seg = SPLIT ? (ts >= 2 ? ((lane & 15) >> mshift) : (lane & (K - 1))) : 0;              // which of the K consecutive steps this lane takes
+        const int rl = SPLIT ? (ts >= 2 ? (((lane >> 4) << mshift) | (lane & ((1 << mshift) - 1))) : (lane >> (4 + rshift))) : lane;      // ray slot inside the tile (= owner id in the queues)
         const int64_t ray = base + rl;
-        const bool live = (rl < A.tile_w) && (ray < A.n);
+        const bool live = (rl < tile_w) && (ray < A.n);
         const int64_t rr = live ? ray : A.n - 1;
         float o[3], d[3];
 #pragma unroll
@@ -363,10 +500,10 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         // tiles of <= 8 rays: fold the view part of layer 1 into one 64-float vector per ray (behind the 8 x 16 view inputs)
         bool view_fold = false;
         if constexpr (SPLIT && P::VIEW_FOLD) {
-            view_fold = A.tile_w <= 8;
+            view_fold = tile_w <= 8;
             if (view_fold) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                P::fold_view(smem, vfeat, vfeat + 8 * kViewFeat, A.tile_w, lane);
+                P::fold_view(smem, vfeat, vfeat + 8 * kViewFeat, tile_w, lane);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
         }
@@ -378,6 +515,9 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
             [[maybe_unused]] unsigned long long t_sec = 0;
             if constexpr (P::PROFILE) t_sec = __builtin_readcyclecounter();
             if (count < BATCH && i < S) {
+#ifdef NGF_EXP_TIMELINE
+                ++tl_iter;
+#endif
                 // ---------------- march NSTEP steps (independent gathers, sequential transmittance) ----
                 float z[NSTEP], dist[NSTEP], sigma[NSTEP], t[NSTEP][6];
                 [[maybe_unused]] Bil cells[NSTEP][3];
@@ -426,23 +566,16 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     const float alpha = 1.0f - expf(-sigma[u] * (dist[u] * A.dscale));
                     float w;
                     if constexpr (SPLIT) {
-                        // lane (seg, ray) needs T, acc, dep as they stand after steps i .. i+seg-1 of its ray: K-1 rounds of
-                        // "take the previous step's outputs from lane - tile_w"; after round r segments <= r are final
-                        const float f = (1.0f - alpha) + 1e-10f;
-                        float Tin = T, ain = acc, din = dep;
-                        const int prev = (lane - A.tile_w) & 63;
-                        for (int r = 1; r < K; ++r) {
-                            const float wr = alpha * Tin;
-                            const float To = Tin * f, ao = ain + wr, dz = wr * z[u];
-                            const float dn = din + dz;
-                            const float Tp = __shfl(To, prev), ap = __shfl(ao, prev), dp = __shfl(dn, prev);
-                            if (seg > 0) { Tin = Tp; ain = ap; din = dp; }
+                        // the K lanes of a ray chain T, acc and depth in step order (split_chain): the sequential arithmetic of the unsplit march
+                        switch (ts) {
+                        case 0: split_chain_rows<4>(alpha, z[u], T, acc, dep, w, 63); break;
+                        case 1: split_chain_rows<2>(alpha, z[u], T, acc, dep, w, lane | 31); break;
+                        case 2: split_chain<1>(alpha, z[u], T, acc, dep, w); break;
+                        case 3: split_chain<2>(alpha, z[u], T, acc, dep, w); break;
+                        case 4: split_chain<4>(alpha, z[u], T, acc, dep, w); break;
+                        case 5: split_chain<8>(alpha, z[u], T, acc, dep, w); break;
+                        default: w = alpha * T; T = T * ((1.0f - alpha) + 1e-10f); acc += w; dep += w * z[u]; break;      // tile_w = 64 through the split kernel (knob): one lane per ray
                         }
-                        w = alpha * Tin;
-                        const float To = Tin * f, ao = ain + w, dz = w * z[u];
-                        const float dn = din + dz;
-                        const int last = 64 - A.tile_w + rl;            // the lane that took step i + K - 1 of this ray
-                        T = __shfl(To, last); acc = __shfl(ao, last); dep = __shfl(dn, last);
                     } else {
                         w = alpha * T;
                         T = T * ((1.0f - alpha) + 1e-10f);
@@ -478,7 +611,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 // skipped -- wave-uniformly, when all rays of the tile are there (8-ray tiles of adjacent pixels).  Rays behind an
                 // opaque surface stop right after it.  Off for the per-sample debug outputs and with NGF_ABLATE=32.
                 if (!dbg_samples && !(DBG && (A.ablate & 32))) {
-                    const bool done = !live || ((T < A.thr) & (zmax > 0.0f) & (T < 0x1p-26f * fminf(acc, dep / zmax)));
+                    const bool done = !live || seg != 0 || ((T < A.thr) & (zmax > 0.0f) & (T < 0x1p-26f * fminf(acc, dep / zmax)));      // T / acc / dep live in a ray's seg-0 lane
                     if (!__any(!done)) i = S;
                 }
                 if constexpr (P::PROFILE) prof[0] += __builtin_readcyclecounter() - t_sec;
@@ -492,8 +625,10 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 const f32x4 r0 = r[0], r1 = r[1];
                 const float rec[kRecFloats] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
                 const int owner = R12 ? (__float_as_int(r0[0]) & 0xff) : __float_as_int(r0[0]);
+                // the lane that owns the ray's sums (its seg-0 lane): row owner / M, lane-in-row owner % M
+                const int owner_lane = SPLIT ? (ts >= 2 ? (((owner >> mshift) << 4) | (owner & ((1 << mshift) - 1))) : (owner << (4 + rshift))) : owner;
                 float od[3] = {0.0f, 0.0f, 0.0f};
-                if constexpr (!P::VLDS) { od[0] = __shfl(d[0], owner); od[1] = __shfl(d[1], owner); od[2] = __shfl(d[2], owner); }
+                if constexpr (!P::VLDS) { od[0] = __shfl(d[0], owner_lane); od[1] = __shfl(d[1], owner_lane); od[2] = __shfl(d[2], owner_lane); }
                 float c[3];
                 [[maybe_unused]] const float *pre = view_fold ? vfeat + 8 * kViewFeat + owner * 64 : nullptr;
                 if constexpr (P::PROFILE) {
@@ -516,7 +651,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 // result list, structure-of-arrays: res[0..B) owner lane ids, then weighted r, g, b
                 // c[] holds the three logits in all four lanes of a sample: lane quarter kq applies the sigmoid to channel kq and writes that entry of
                 // the list (res[(1 + kq) * BATCH + s] is res[BATCH + lane]) -- one sigmoid per lane instead of three
-                if (lane < BATCH) res[lane] = lane < nb ? __int_as_float(owner) : __int_as_float(-1);
+                if (lane < BATCH) res[lane] = lane < nb ? __int_as_float(owner_lane) : __int_as_float(-1);
                 if (lane < 3 * BATCH) {
                     const int kq_ = lane >> 4;
                     const float logit = kq_ == 0 ? c[0] : (kq_ == 1 ? c[1] : c[2]);
@@ -546,6 +681,9 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 head = wrap(head + nb);
                 count -= nb;
+#ifdef NGF_EXP_TIMELINE
+                ++tl_pass;
+#endif
                 if constexpr (DBG) ++st_pass;
                 if constexpr (P::PROFILE) prof[5] += __builtin_readcyclecounter() - t_sec;     // result list + owner collect
             } else {
@@ -565,6 +703,12 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         }
         if constexpr (DBG) st_rays += __popcll(__ballot(live && seg == 0));
     }
+#ifdef NGF_EXP_TIMELINE
+    if (!DBG && A.stats && lane == 0) {
+        unsigned long long *row = A.stats + 16 + 8 * ((size_t)blockIdx.x * P::WAVES + wave);
+        row[0] = tl_t0; row[1] = tl_t1; row[2] = tl_first; row[3] = wall_clock64(); row[4] = tl_tiles; row[5] = tl_pass; row[6] = tl_iter; row[7] = (unsigned long long)xcd;
+    }
+#endif
     if (DBG && A.stats && lane == 0) {
         atomicAdd(A.stats + 0, st_valid);
         atomicAdd(A.stats + 1, st_active);
@@ -592,7 +736,7 @@ __global__ void __launch_bounds__(256) alpha_kernel(const RenderArgs A, const fl
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (karg_tex(offsetof(RenderArgs, dens)).p != A.dens[0].p) __builtin_trap();      // the RenderArgs must be the first kernel argument (karg_tex)
     if constexpr (P::INFOINV) {
-        for (int i = threadIdx.x; i < A.blob_floats; i += blockDim.x) smem[i] = A.blob[i];
+        stage_blob(smem, A.blob, A.blob_floats);
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
@@ -727,7 +871,7 @@ __global__ void __launch_bounds__(256) decode_rgb_kernel(const RenderArgs A, con
 {
     constexpr int BATCH = P::BATCH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    for (int i = threadIdx.x; i < A.blob_floats; i += blockDim.x) smem[i] = A.blob[i];
+    stage_blob(smem, A.blob, A.blob_floats);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;

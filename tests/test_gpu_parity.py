@@ -133,13 +133,21 @@ def test_split_march_is_bit_identical(name):
     from ngf_amd._lib import knobs
     with knobs(tile_w=64, split=0, kernel=0):
         ref = f(rays, N_samples=45, **kw)
-    for tw in (32, 16, 8, 4):
+    for tw in (32, 16, 8, 4, 2, 1):            # 2 / 1: a ray takes two / four 16-lane rows (split_chain_rows)
         with knobs(tile_w=tw, split=1, kernel=0):
             got = f(rays, N_samples=45, **kw)
         assert torch.equal(ref["rgb_map"], got["rgb_map"]), tw
         assert torch.equal(ref["depth_map"], got["depth_map"]), tw
-    got = f(rays, N_samples=45, **kw)          # the default choice
+    got = f(rays, N_samples=45, **kw)          # the default choice: 203 rays are all one-ray tiles
     assert torch.equal(ref["rgb_map"], got["rgb_map"]) and torch.equal(ref["depth_map"], got["depth_map"])
+    # mixed tile plans (wide tiles first, narrow tiles for the last rays): few workgroups and a small tail so that every width occurs
+    many = torch.from_numpy(np.concatenate([g["rays"]] * 8)).cuda()[:1999]
+    with knobs(tile_w=64, split=0, kernel=0):
+        ref = f(many, N_samples=45, **kw)
+    for grid, tail in ((2, 16), (3, 8), (1, 40), (2, 0)):
+        with knobs(grid=grid, tail=tail):
+            got = f(many, N_samples=45, **kw)
+        assert torch.equal(ref["rgb_map"], got["rgb_map"]) and torch.equal(ref["depth_map"], got["depth_map"]), (grid, tail)
 
 
 @pytest.mark.parametrize("name", INFOINV)
@@ -370,15 +378,19 @@ def test_early_termination_is_bit_identical(name, bias):
     kw = {"infoinv": True} if name.startswith("infoinv") else {"iteration": 30001}
     from ngf_amd._lib import knobs
     for white in (True, False):
-        with knobs(ablate=96):                               # 32: no early termination, 64: no empty-iteration skip
-            full = f(rays, N_samples=160, white_bg=white, collect_stats=True, **kw)
-        n_full = int(f.last_stats[0])
-        early = f(rays, N_samples=160, white_bg=white, collect_stats=True, **kw)
-        n_early = int(f.last_stats[0])
-        assert torch.equal(full["rgb_map"], early["rgb_map"]) and torch.equal(full["depth_map"], early["depth_map"])
-        assert n_early <= n_full
-        if bias is not None:
-            assert n_early < 0.5 * n_full              # the opaque scenes really stop early
+        # a launch this small is all one-ray tiles by default (64 steps per iteration: these rays cross the box in fewer): the 8-ray tiles of a
+        # frame's bulk (8 steps per iteration) are where the early stop shows; both are checked for identical bits
+        for tw in (8, -1):
+            with knobs(ablate=96, tile_w=tw):                    # 32: no early termination, 64: no empty-iteration skip
+                full = f(rays, N_samples=160, white_bg=white, collect_stats=True, **kw)
+            n_full = int(f.last_stats[0])
+            with knobs(tile_w=tw):
+                early = f(rays, N_samples=160, white_bg=white, collect_stats=True, **kw)
+            n_early = int(f.last_stats[0])
+            assert torch.equal(full["rgb_map"], early["rgb_map"]) and torch.equal(full["depth_map"], early["depth_map"])
+            assert n_early <= n_full
+            if bias is not None and tw == 8:
+                assert n_early < 0.5 * n_full              # the opaque scenes really stop early
         o_rgb, o_depth = orc.render(g["rays"], 160, white_bg=white)
         np.testing.assert_allclose(early["rgb_map"].cpu().numpy(), o_rgb, rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(early["depth_map"].cpu().numpy(), o_depth, rtol=1e-4, atol=1e-5)

@@ -240,3 +240,37 @@ def test_optimisation_level_flags_resolve_in_the_constructor():
     for bad in (dict(no_fold=True, bake_density=True), dict(no_fold=True, bake_color=True)):
         with pytest.raises(ValueError):
             mk(**bad)
+
+
+def test_tile_plan_covers_every_ray_once_with_whole_tiles():
+    """launch_render's tile plan (wide tiles first, narrow tiles for the last rays so that the persistent grid runs dry together): host
+    arithmetic, checked here for every launch size class -- segments in ray order, widths strictly decreasing, every segment but the last a
+    whole number of tiles, all rays covered exactly once; and the documented shapes (a frame keeps >= 95 % of its rays in the widest tiles,
+    a launch smaller than the resident grid is all one-ray tiles, tail = 0 is the widest tile only)."""
+    import ctypes as C
+    from ngf_amd import _lib
+    L = _lib.lib()
+
+    def plan(n, wide, resident, tail):
+        r, sh = (C.c_int64 * 4)(), (C.c_int32 * 4)()
+        k = L.ngf_debug_tile_plan(n, wide, resident, tail, r, sh)
+        assert 1 <= k <= 4
+        return [(int(r[i]), 1 << int(sh[i])) for i in range(k)]
+
+    rng = np.random.default_rng(5)
+    sizes = [1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 4096, 40000, 80000, 160000, 640000, 640001, 2 ** 31 + 11] + [int(v) for v in rng.integers(1, 3_000_000, 200)]
+    for wide in (8, 16):
+        for resident in (12, 24, 3072, 2048):
+            for tail in (-1, 0, 1, 8, 16, 40):
+                for n in sizes:
+                    p = plan(n, wide, resident, tail)
+                    assert sum(r for r, _ in p) == n, (n, wide, resident, tail, p)
+                    assert all(r > 0 for r, _ in p)
+                    assert all(a[1] > b[1] for a, b in zip(p, p[1:])), p              # widths strictly decreasing
+                    assert all(r % w == 0 for r, w in p[:-1]), p                      # whole tiles everywhere but at the end of the list
+                    assert all(w in (wide, 4, 2, 1) for _, w in p)
+    p = plan(640000, 8, 3072, -1)
+    assert p[0][1] == 8 and p[0][0] >= 0.95 * 640000 and p[-1] == (3072, 1)
+    assert plan(2000, 8, 3072, -1) == [(2000, 1)]
+    assert plan(640000, 8, 3072, 0) == [(640000, 8)]
+    assert plan(80000, 8, 3072, 16) == [(58496, 8), (12288, 4), (6144, 2), (3072, 1)]
