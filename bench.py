@@ -144,8 +144,8 @@ def compact_line(result: dict) -> str:
         out["cpu_baseline"] = {"value": _r(cb["value"], 5), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:160]}
     if "parity" in result:
         out["parity"] = _r(result["parity"], 4)
-    for k in ("gathered_frame_bit_identical_to_single_gpu_render", "all_gather_ms", "all_gather_bytes_per_rank", "shard_kernel_ms",
-              "speedup_vs_cpu_port"):
+    for k in ("ms_per_step_median", "launch_ms", "gathered_frame_bit_identical_to_single_gpu_render", "all_gather_ms", "all_gather_bytes_per_rank",
+              "shard_kernel_ms", "critical_path_ms", "speedup_vs_cpu_port"):
         if k in result:
             out[k] = _r(result[k], 5)
     if "extras" in result:      # headline numbers of the other configs only; the full entries are in the side file
@@ -178,6 +178,15 @@ def write_side_file(result: dict):
                 pass
 
 
+def plan_tiles(n, wide, resident):
+    """Number of tiles of a render launch of n rays (ngf_debug_tile_plan: the library's own host arithmetic)."""
+    import ctypes as C
+    from ngf_amd import _lib
+    r, sh = (C.c_int64 * 4)(), (C.c_int32 * 4)()
+    k = _lib.lib().ngf_debug_tile_plan(int(n), int(wide), int(resident), -1, r, sh)
+    return sum((int(r[i]) + (1 << int(sh[i])) - 1) >> int(sh[i]) for i in range(k))
+
+
 def build_field(model, preset, device, bake=False, bake_color=False, no_fold=False, split_bf16=False):
     from ngf_amd.cases import big_case, field_for_case
     g, params, step = big_case(model, preset)
@@ -186,17 +195,22 @@ def build_field(model, preset, device, bake=False, bake_color=False, no_fold=Fal
     return f, g, params, step
 
 
-def time_steps(fn, steps, warmup, device, dist_on, finish=lambda: None):
+def time_steps(fn, steps, warmup, device, dist_on, finish=lambda: None, marks=None):
+    """The timed region of the contract: W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over
+    ranks.  `marks` (a list) receives one (start, end) HIP-event pair per timed step, recorded by `fn(pair)` around its render launch on
+    the launch stream INSIDE the timed loop: their durations are the per-step launch times the line reports (median / min / max) and
+    what roofline.kernel_ms is taken from -- the same launches the wall clock saw, not a second loop."""
     import torch.distributed as dist
     for _ in range(warmup):
-        fn()
+        fn(None)
     finish()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize(device)
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
+    for k in range(steps):
+        fn(pairs[k])
     finish()                 # the last frame's exchange + reorder belong to the timed region
     torch.cuda.synchronize(device)
     if dist_on:
@@ -207,6 +221,8 @@ def time_steps(fn, steps, warmup, device, dist_on, finish=lambda: None):
         t = torch.tensor([el], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    if marks is not None:
+        marks.extend(pairs)
     return el
 
 
@@ -334,14 +350,20 @@ def main():
     def render_only():
         f(rays, N_samples=S, white_bg=True, out=(rgb_view, depth_view), **kw)
 
-    def step_fn():
+    def step_fn(pair):
+        # pair: (start, end) HIP events recorded around THIS step's render launch on the launch stream (None in the warm-up)
         if not dist_on:
+            if pair: pair[0].record()
             render_only()
+            if pair: pair[1].record()
             return
         # frame k: march into send buffer k%2, start its all-gather on RCCL's stream, hand out frame k-1 (whose
         # exchange overlapped this march) in image order.  Every frame is complete when the timed region ends.
         k = frame_no[0]
-        f(rays, N_samples=S, white_bg=True, out=pipe.buffers(k), **kw)
+        out_k = pipe.buffers(k)
+        if pair: pair[0].record()
+        f(rays, N_samples=S, white_bg=True, out=out_k, **kw)
+        if pair: pair[1].record()
         pipe.submit(k)
         if k > 0:
             last_frame[0] = ndist.deinterleave(*pipe.frame(k - 1), H, W, world, ROW_BLOCK)
@@ -351,12 +373,16 @@ def main():
         if dist_on and frame_no[0] > 0:
             last_frame[0] = ndist.deinterleave(*pipe.frame(frame_no[0] - 1), H, W, world, ROW_BLOCK)
 
-    elapsed = time_steps(step_fn, args.steps, args.warmup, device, dist_on, finish)
+    marks = []
+    elapsed = time_steps(step_fn, args.steps, args.warmup, device, dist_on, finish, marks)
     ms_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed / 1e6
+    # per-step launch durations of the TIMED loop (HIP events on the launch stream around every render launch)
+    launch_ms = np.array([a.elapsed_time(b) for a, b in marks], np.float64)
+    launch_stats = {"min": float(launch_ms.min()), "median": float(np.median(launch_ms)), "max": float(launch_ms.max())}
 
-    # dominant kernel: duration by HIP events on the launch stream; algorithmic bytes from the measured active count
-    k_ms = kernel_ms(render_only, max(5, args.steps), device)
+    # dominant kernel: its duration = the median of the timed loop's own launches; algorithmic bytes from the measured active count
+    k_ms = launch_stats["median"]
     f(rays, N_samples=S, white_bg=True, collect_stats=True, **kw)
     torch.cuda.synchronize(device)
     st = f.last_stats.cpu().numpy().astype(np.float64)
@@ -368,8 +394,8 @@ def main():
     # (144 feature + 64 layer-2 MFMAs per pass, or 64 with the baked colour planes; the 16 view-input MFMAs are spent once per
     # 8-ray tile since the per-ray view fold)
     mfma_per_pass = 64 if args.bake_color else 208
-    tile_w = 8 if n_local >= 40 * 256 * 12 else 4          # launch_render's choice (csrc/ngf_field.hip)
-    mfma_flops = (st[2] * mfma_per_pass + ((n_local + tile_w - 1) // tile_w) * 16) * 2048.0 if model == "triplane" else None
+    n_tiles = plan_tiles(n_local, 8, torch.cuda.get_device_properties(device).multi_processor_count * 12)      # launch_render's tile plan (csrc/ngf_field.hip)
+    mfma_flops = (st[2] * mfma_per_pass + n_tiles * 16) * 2048.0 if model == "triplane" else None
     # rocprofv3 --pmc summary of THIS workload (profiles/collect.sh -> profiles/r02_<workload>_pmc.json); flagged stale when the
     # library it was collected with is not the one loaded now
     tag = f"{model}_{args.preset}" + ("_bd" if args.bake_density and not args.bake_color else "") + ("_bdc" if args.bake_color else "")
@@ -406,6 +432,9 @@ def main():
                              "1-channel planes)" if args.bake_density else "1 (layer 1 o basis, per-ray view fold)") if model == "triplane" else "default",
                    "bake_density": int(args.bake_density), "bake_color": int(args.bake_color)},
         "roofline": roofline,
+        # per-step durations of the render launch inside the timed loop (HIP events): SURVEY 8 D1 asks for the median of >= 20 frames
+        "ms_per_step_median": launch_stats["median"], "launch_ms": launch_stats,
+        "value_from_median_launch": n_local / launch_stats["median"] / 1e3,
     }
     if args.knobs:
         result["config"]["knobs"] = args.knobs
@@ -428,7 +457,33 @@ def main():
         torch.cuda.synchronize(device)
         result["all_gather_ms"] = float(np.median([a.elapsed_time(b) for a, b in ev]))
         result["all_gather_bytes_per_rank"] = 4 * per * 4
-        result["shard_kernel_ms"] = k_ms
+        # every rank's shard launch (median of ITS timed steps): min / max over the ranks -- strong scaling pays for the slowest
+        mine = torch.tensor([k_ms], device=device, dtype=torch.float64)
+        allk = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allk, mine)
+        per_rank = [float(t.item()) for t in allk]
+        result["shard_kernel_ms"] = {"min": min(per_rank), "max": max(per_rank), "rank0": k_ms}
+        # untimed: one frame with nothing overlapped -- render, exchange, reorder one after the other on this rank -- so that a
+        # scaling curve can be read: the pipelined step costs max(render, exchange) + reorder in the steady state, this is their sum
+        cp = []
+        for _ in range(5):
+            e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            e0.record()
+            f(rays, N_samples=S, white_bg=True, out=(pipe.send[0][1], pipe.send[0][2]), **kw)
+            e1.record()
+            dist.all_gather_into_tensor(pipe.recv[0], pipe.send[0][0])
+            e2.record()
+            blocks = pipe.recv[0].view(world, 4 * per)
+            ndist.deinterleave(blocks[:, : 3 * per].reshape(world * per, 3), blocks[:, 3 * per:].reshape(world * per), H, W, world, ROW_BLOCK)
+            e3.record()
+            torch.cuda.synchronize(device)
+            cp.append((e0.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3)))
+        cpm = torch.tensor(np.median(np.array(cp), 0), device=device, dtype=torch.float64)
+        dist.all_reduce(cpm, op=dist.ReduceOp.MAX)
+        result["critical_path_ms"] = {"render": float(cpm[0]), "all_gather": float(cpm[1]), "reorder": float(cpm[2]),
+                                      "sum": float(cpm.sum()), "note": "unpipelined, max over ranks"}
 
     if world == 1 and rank == 0:
         if args.cpu_seconds > 0:
@@ -470,7 +525,7 @@ def main():
                     else:
                         if mdl == "triplane":
                             per_pass = 548 if flags.get("no_fold") else (64 if flags.get("bake_color") else 208)
-                            fl = sx[2] * per_pass * 2048.0 + (0 if flags.get("no_fold") else (n_total // 8) * 16 * 2048.0)
+                            fl = sx[2] * per_pass * 2048.0 + (0 if flags.get("no_fold") else plan_tiles(n_total, 8, torch.cuda.get_device_properties(device).multi_processor_count * 12) * 16 * 2048.0)
                         else:
                             fl = None if px is None else px.get("mfma_flops_per_dispatch")
                         entry.update({"executed_mfma_TFLOPs": None if fl is None else fl / (ms * 1e-3) / 1e12,

@@ -43,7 +43,10 @@ def _fat_result(monkeypatch):
         "parity": {"max_abs_err_vs_cpu_port": 1.1920928955078125e-06, "max_rel_err_vs_cpu_port": 2.337068735869252e-06,
                    "psnr_vs_cpu_port_db": 132.50515620545707, "cpu_active_fraction": 0.24215088836077986},
         "speedup_vs_cpu_port": 6682.07276634372, "gathered_frame_bit_identical_to_single_gpu_render": True, "all_gather_ms": 0.123456789,
-        "all_gather_bytes_per_rank": 1280000, "shard_kernel_ms": 1.456789, "extras": extras}
+        "all_gather_bytes_per_rank": 1280000, "shard_kernel_ms": {"min": 1.0456789, "max": 1.0656789, "rank0": 1.05123456},
+        "critical_path_ms": {"render": 1.0656789, "all_gather": 0.123456789, "reorder": 0.0456789, "sum": 1.234814589, "note": "unpipelined, max over ranks"},
+        "ms_per_step_median": 9.7912345678, "launch_ms": {"min": 9.7712345678, "median": 9.7912345678, "max": 9.9912345678},
+        "value_from_median_launch": 65.4, "extras": extras}
 
 
 def test_compact_line_fits_the_driver_tail(monkeypatch):
@@ -65,6 +68,8 @@ def test_compact_line_fits_the_driver_tail(monkeypatch):
     cb = d["cpu_baseline"]
     assert set(cb) == {"value", "unit", "cores", "kind", "sample"} and cb["kind"] in ("port", "reference")
     assert d["all_gather_ms"] > 0 and d["gathered_frame_bit_identical_to_single_gpu_render"] is True
+    assert set(d["launch_ms"]) == {"min", "median", "max"} and d["launch_ms"]["min"] <= d["ms_per_step_median"] <= d["launch_ms"]["max"]
+    assert d["shard_kernel_ms"]["min"] <= d["shard_kernel_ms"]["max"] and set(d["critical_path_ms"]) >= {"render", "all_gather", "reorder", "sum"}
     assert len(d["extras_Mray_s"]) == 24 and d["train_ms_per_iteration"] > 0
     assert "extras" not in d and "notes" not in d
 

@@ -522,7 +522,10 @@ def test_bench_rccl_path_single_gpu(tmp_path):
                       dict(NGF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"))
     assert d["n_gpus"] == 1 and d["value"] > 1 and d["scaling"] == "strong"
     assert d["gathered_frame_bit_identical_to_single_gpu_render"] is True
-    assert d["all_gather_ms"] > 0 and d["shard_kernel_ms"] > 0 and d["roofline"]["frac"] > 0
+    assert d["all_gather_ms"] > 0 and 0 < d["shard_kernel_ms"]["min"] <= d["shard_kernel_ms"]["max"] and d["roofline"]["frac"] > 0
+    cp = d["critical_path_ms"]          # one unpipelined frame: render -> all-gather -> reorder
+    assert cp["render"] > 0 and cp["all_gather"] > 0 and cp["reorder"] > 0 and abs(cp["sum"] - cp["render"] - cp["all_gather"] - cp["reorder"]) < 1e-3
+    assert d["launch_ms"]["min"] <= d["ms_per_step_median"] <= d["launch_ms"]["max"]
 
 
 def test_bench_default_line_is_parseable_with_extras():
@@ -534,6 +537,9 @@ def test_bench_default_line_is_parseable_with_extras():
     assert d["value"] > 1 and d["ms_per_step"] > 0 and d["unit"] == "Mray/s" and d["dtype"] == "f32"
     rf = d["roofline"]
     assert rf["bound"] in ("mfma", "hbm") and 0 < rf["frac"] <= 1.0 and rf["kernel_ms"] > 0
+    # the per-step launch times come from HIP events INSIDE the timed loop; roofline.kernel_ms is their median
+    assert d["launch_ms"]["min"] <= d["ms_per_step_median"] <= d["launch_ms"]["max"] and rf["kernel_ms"] == pytest.approx(d["ms_per_step_median"], rel=1e-3)
+    assert d["ms_per_step_median"] <= d["ms_per_step"] * 1.02           # the wall clock per step also holds the launch gaps
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["sample"]
