@@ -217,7 +217,9 @@ class Base(torch.nn.Module):
 
     # --- Base.forward (FieldBase.py:251-312) ---------------------------------------------------------
     @torch.no_grad()
-    def _render(self, rays_chunk, white_bg, is_train, N_samples, mode, collect_stats=False, out=None):
+    def _render(self, rays_chunk, white_bg, is_train, N_samples, mode, collect_stats=False, out=None, jitter=None, coin=None):
+        """``jitter`` [n] and ``coin`` (a float in [0,1)) replace the torch.rand_like of sample_ray (FieldBase.py:128-130) and the
+        torch.rand((1,)) of the random background (FieldBase.py:299) in training mode -- parity tests against captured reference forwards."""
         dev = torch.device(self.device)
         rays = rays_chunk.to(device=dev, dtype=torch.float32).contiguous()
         if rays.dim() != 2 or rays.shape[1] != 6:
@@ -233,8 +235,11 @@ class Base(torch.nn.Module):
             depth = torch.empty((n,), device=dev, dtype=torch.float32)
         if n == 0:
             return {'rgb_map': rgb, 'depth_map': depth}
-        jitter = torch.rand((n,), device=dev) if is_train else None
-        if not (white_bg or (is_train and torch.rand((1,)) < 0.5)):
+        if is_train:
+            jitter = torch.rand((n,), device=dev) if jitter is None else jitter.to(device=dev, dtype=torch.float32).reshape(n).contiguous()
+        else:
+            jitter = None
+        if not (white_bg or (is_train and (torch.rand((1,)) if coin is None else torch.tensor([float(coin)])) < 0.5)):
             white_bg = False
         else:
             white_bg = True

@@ -41,6 +41,6 @@ class TriPlane(Base):
         """compute_alpha / getDenseAlpha / updateAlphaMask(..., infoinv=True) of InfoInv/models/FieldBase.py:140,161,180."""
         return int(bool(infoinv))
 
-    def forward(self, rays_chunk, white_bg=True, is_train=False, N_samples=-1, infoinv=True, collect_stats=False, out=None):
+    def forward(self, rays_chunk, white_bg=True, is_train=False, N_samples=-1, infoinv=True, collect_stats=False, out=None, jitter=None, coin=None):
         """InfoInv/models/FieldBase.py:228."""
-        return self._render(rays_chunk, white_bg, is_train, N_samples, mode=int(bool(infoinv)), collect_stats=collect_stats, out=out)
+        return self._render(rays_chunk, white_bg, is_train, N_samples, mode=int(bool(infoinv)), collect_stats=collect_stats, out=out, jitter=jitter, coin=coin)

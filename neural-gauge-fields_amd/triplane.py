@@ -81,7 +81,7 @@ class TriPlane(Base):
             d.gauge_h[k], d.gauge_w[k] = g.shape[2], g.shape[3]
         d.dens_w1, d.dens_b1 = dp(self.density_decoder.weight), dp(self.density_decoder.bias)
 
-    def forward(self, rays_chunk, white_bg=True, is_train=False, N_samples=-1, iteration=0, collect_stats=False, out=None):
+    def forward(self, rays_chunk, white_bg=True, is_train=False, N_samples=-1, iteration=0, collect_stats=False, out=None, jitter=None, coin=None):
         """FieldBase.py:251: gauge is applied iff iteration >= gauge_start (Field.py:58)."""
         return self._render(rays_chunk, white_bg, is_train, N_samples, mode=int(iteration >= self.gauge_start),
-                            collect_stats=collect_stats, out=out)
+                            collect_stats=collect_stats, out=out, jitter=jitter, coin=coin)

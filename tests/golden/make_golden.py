@@ -66,7 +66,9 @@ def _rays_for_case(seed, n_frame=160, n_edge=64):
     return np.concatenate([frame[pick], synth.edge_rays(seed, n_edge)], 0)
 
 
-def capture_triplane(name, seed, preset, gauge_on, gauge_std, with_mask, S, white_bg=True):
+def capture_triplane(name, seed, preset, gauge_on, gauge_std, with_mask, S, white_bg=True, train=None):
+    """train = (coin,): forward(is_train=True) with the per-ray jitter of sample_ray (FieldBase.py:128-130) supplied through a patched
+    torch.rand_like and the background coin of FieldBase.py:299 through a patched torch.rand."""
     F = _import_ref("TriPlane")
     aabb = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
     grid = [24, 20, 18]
@@ -87,11 +89,27 @@ def capture_triplane(name, seed, preset, gauge_on, gauge_std, with_mask, S, whit
     rays = _rays_for_case(seed)
     iteration = 30001 if gauge_on else -1
     field.gauge_start = 0
+    is_train = train is not None
+    U = synth.hash_uniform(seed, 820, (rays.shape[0], 1))
+    real_like, real_rand = torch.rand_like, torch.rand
+    if is_train:
+        extra.update({"jitter": U[:, 0], "coin": np.float32(train[0]), "is_train": np.array(1)})
     with torch.no_grad():
-        out = field(torch.from_numpy(rays), white_bg=white_bg, is_train=False, N_samples=S, iteration=iteration)
+        if is_train:
+            torch.rand_like = lambda *a, **k: torch.from_numpy(U.copy())
+            torch.rand = lambda *a, **k: torch.tensor([float(train[0])])
+        try:
+            out = field(torch.from_numpy(rays), white_bg=white_bg, is_train=is_train, N_samples=S, iteration=iteration)
+        finally:
+            torch.rand_like, torch.rand = real_like, real_rand
         # intermediates of the first 8 rays through the reference's own sub-functions
         r8 = torch.from_numpy(rays[:8])
-        pts, z, valid = field.sample_ray(r8[:, :3], r8[:, 3:6], is_train=False, N_samples=S)
+        if is_train:
+            torch.rand_like = lambda *a, **k: torch.from_numpy(U[:8].copy())
+        try:
+            pts, z, valid = field.sample_ray(r8[:, :3], r8[:, 3:6], is_train=is_train, N_samples=S)
+        finally:
+            torch.rand_like = real_like
         if with_mask:
             a = field.alphaMask.sample_alpha(pts[valid])
             inv = ~valid
@@ -106,6 +124,13 @@ def capture_triplane(name, seed, preset, gauge_on, gauge_std, with_mask, S, whit
             coords[valid] = torch.cat([txy, tyz, txz], -1)
         dists = torch.cat((z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])), -1)
         alpha, weight, _ = F.raw2alpha(sigma, dists * field.distance_scale)
+        # per-sample colours of the active samples (FieldBase.py:289-294): rgb_mask and compute_rgb -> rgb_decoder, the reference's own calls
+        rgb_mask = weight > field.rayMarch_weight_thres
+        rgb = torch.zeros((*pts.shape[:2], 3))
+        vd = r8[:, 3:6].view(-1, 1, 3).expand(pts.shape)
+        if rgb_mask.any():
+            rgb[rgb_mask] = field.compute_rgb(coords[..., 0:2][rgb_mask], coords[..., 2:4][rgb_mask], coords[..., 4:6][rgb_mask], vd[rgb_mask])
+        extra.update({"i_rgb_mask": rgb_mask.numpy(), "i_rgb": rgb.numpy()})
     np.savez_compressed(
         os.path.join(HERE, name + ".npz"), model="triplane", seed=seed, preset=preset, gauge_on=int(gauge_on),
         gauge_std=np.float32(gauge_std), S=S, white_bg=int(white_bg), aabb=aabb.numpy(), grid=np.array(grid),
@@ -119,7 +144,7 @@ def capture_triplane(name, seed, preset, gauge_on, gauge_std, with_mask, S, whit
     print(f"{name}: rays {rays.shape[0]} S {S} mean rgb {out['rgb_map'].mean():.5f} active(first 8) {act:.3f}")
 
 
-def capture_infoinv(name, seed, preset, infoinv, S):
+def capture_infoinv(name, seed, preset, infoinv, S, with_mask=False, white_bg=True):
     F = _import_ref("InfoInv")
     aabb = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
     grid = [22, 22, 22]
@@ -129,27 +154,49 @@ def capture_infoinv(name, seed, preset, infoinv, S):
         field = F.TriPlane(aabb, grid, "cpu", near_far=[2.0, 6.0], alphaMask_thres=1e-4, distance_scale=25,
                            rayMarch_weight_thres=1e-4, step_ratio=0.5)
     _load_params(field, params)
+    extra = {}
+    if with_mask:      # the alpha-mask branch of the InfoInv forward (InfoInv/models/FieldBase.py:238-244)
+        dhw = (9, 11, 13)
+        vol, bits = synth.alpha_mask_bits(seed, dhw)
+        maabb = torch.tensor([[-1.45, -1.35, -1.4], [1.3, 1.5, 1.25]])
+        field.alphaMask = F.AlphaGridMask("cpu", maabb, torch.from_numpy(vol.astype(np.float32)))
+        extra = {"mask_bits": bits, "mask_dhw": np.array(dhw), "mask_aabb": maabb.numpy()}
     rays = _rays_for_case(seed, 96, 32)
     with torch.no_grad():
-        out = field(torch.from_numpy(rays), white_bg=True, is_train=False, N_samples=S, infoinv=infoinv)
+        out = field(torch.from_numpy(rays), white_bg=white_bg, is_train=False, N_samples=S, infoinv=infoinv)
         r8 = torch.from_numpy(rays[:8])
         pts, z, valid = field.sample_ray(r8[:, :3], r8[:, 3:6], is_train=False, N_samples=S)
+        if with_mask:
+            a = field.alphaMask.sample_alpha(pts[valid])
+            inv = ~valid
+            inv[valid] |= ~(a > 0)
+            valid = ~inv
         xyzn = field.normalize_coord(pts)
         sigma = torch.zeros(pts.shape[:-1])
+        coords = torch.zeros((*pts.shape[:2], 6))
         if valid.any():
             txy, tyz, txz = field.transform(xyzn[valid])
             sigma[valid] = field.compute_density(txy, tyz, txz, infoinv=infoinv)
+            coords[valid] = torch.cat([txy, tyz, txz], -1)
         dists = torch.cat((z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])), -1)
         alpha, weight, _ = F.raw2alpha(sigma, dists * field.distance_scale)
+        # per-sample colours of the active samples (InfoInv/models/FieldBase.py:262-266): the reference's own compute_rgb
+        rgb_mask = weight > field.rayMarch_weight_thres
+        rgb = torch.zeros((*pts.shape[:2], 3))
+        vd = r8[:, 3:6].view(-1, 1, 3).expand(pts.shape)
+        if rgb_mask.any():
+            rgb[rgb_mask] = field.compute_rgb(coords[..., 0:2][rgb_mask], coords[..., 2:4][rgb_mask], coords[..., 4:6][rgb_mask], vd[rgb_mask],
+                                              infoinv=infoinv)
+        extra.update({"i_rgb_mask": rgb_mask.numpy(), "i_rgb": rgb.numpy(), "i_coords": coords.numpy()})
     np.savez_compressed(
         os.path.join(HERE, name + ".npz"), model="infoinv", seed=seed, preset=preset, infoinv=int(infoinv), S=S,
-        white_bg=1, aabb=aabb.numpy(), grid=np.array(grid), plane_hw=np.array(plane_hw),
+        white_bg=int(white_bg), aabb=aabb.numpy(), grid=np.array(grid), plane_hw=np.array(plane_hw),
         near_far=np.array([2.0, 6.0], np.float32), step_ratio=np.float32(0.5), distance_scale=np.float32(25),
         thr=np.float32(1e-4), stepSize=field.stepSize.numpy(), nSamples=field.nSamples, rays=rays,
         rgb_map=out["rgb_map"].numpy(), depth_map=out["depth_map"].numpy(),
         i_z=z.numpy(), i_valid=valid.numpy(), i_sigma=sigma.numpy(), i_alpha=alpha.numpy(),
-        i_weight=weight.numpy(), **_checksums(params))
-    print(f"{name}: rays {rays.shape[0]} S {S} mean rgb {out['rgb_map'].mean():.5f}")
+        i_weight=weight.numpy(), **_checksums(params), **extra)
+    print(f"{name}: rays {rays.shape[0]} S {S} mean rgb {out['rgb_map'].mean():.5f} active(first 8) {float(rgb_mask.float().mean()):.3f}")
 
 
 def capture_ops(name="ops_grid_sample"):
@@ -579,6 +626,11 @@ if __name__ == "__main__":
     capture_triplane("triplane_r0", seed=14, preset="R0", gauge_on=True, gauge_std=0.01, with_mask=False, S=32)
     capture_infoinv("infoinv_r1_on", seed=21, preset="R1", infoinv=True, S=40)
     capture_infoinv("infoinv_r1_off", seed=22, preset="R1", infoinv=False, S=40)
+    # round 4 (SURVEY C2's remaining paths): InfoInv WITH an alpha mask on a black background; TriPlane training-mode forwards (supplied
+    # per-ray jitter; the background coin below / above 0.5: white / black background with white_bg=False)
+    capture_infoinv("infoinv_r1_mask", seed=23, preset="R1", infoinv=True, S=44, with_mask=True, white_bg=False)
+    capture_triplane("triplane_r1_train_white", seed=15, preset="R1", gauge_on=True, gauge_std=0.04, with_mask=False, S=44, white_bg=False, train=(0.3,))
+    capture_triplane("triplane_r1_train_black", seed=16, preset="R1", gauge_on=True, gauge_std=0.04, with_mask=True, S=44, white_bg=False, train=(0.7,))
     capture_alpha_mask()
     capture_infoinv_alpha()
     capture_uv("uv_sphere", seed=31, primitive_type="sphere")

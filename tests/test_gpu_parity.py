@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 
 RTOL, ATOL = 1e-4, 1e-5
 TRIPLANE = ["triplane_r1_gauge", "triplane_r2_nogauge", "triplane_r1_mask", "triplane_r0"]
-INFOINV = ["infoinv_r1_on", "infoinv_r1_off"]
+INFOINV = ["infoinv_r1_on", "infoinv_r1_off", "infoinv_r1_mask"]           # _mask: InfoInv WITH an alpha mask, black background (round 4)
+TRAIN = ["triplane_r1_train_white", "triplane_r1_train_black"]             # reference forwards with is_train=True: supplied jitter + background coin
 
 
 def _mode(g):
@@ -72,17 +73,23 @@ def test_march_matches_oracle(name, bake):
 
 
 @pytest.mark.parametrize("bake", [0, 1, 2, 3])
-@pytest.mark.parametrize("name", TRIPLANE + INFOINV)
+@pytest.mark.parametrize("name", TRIPLANE + INFOINV + TRAIN)
 def test_render_matches_oracle_and_reference(name, bake):
-    """bake: bit 0 = NGF_F_BAKE_DENSITY, bit 1 = NGF_F_BAKE_COLOR."""
+    """bake: bit 0 = NGF_F_BAKE_DENSITY, bit 1 = NGF_F_BAKE_COLOR.  The TRAIN cases are forwards of the reference with is_train=True
+    (FieldBase.py:128-130: per-ray jitter; :299: random background): the field gets the captured jitter and coin."""
     g, params, step, mask = load_case(name)
     if bake and str(g["model"]) != "triplane":
         pytest.skip("baked planes are a TriPlane option")
     orc = oracle_for_case(g, params, step, mask)
     S, wb = int(g["S"]), bool(int(g["white_bg"]))
-    o_rgb, o_depth = orc.render(g["rays"], S, white_bg=wb)
+    train_kw, jitter, eff_white = {}, None, wb
+    if "is_train" in g:
+        jitter = g["jitter"]
+        eff_white = wb or float(g["coin"]) < 0.5
+        train_kw = {"jitter": torch.from_numpy(jitter), "coin": float(g["coin"])}
+    o_rgb, o_depth = orc.render(g["rays"], S, white_bg=eff_white, jitter=jitter)
     f = field_for_case(g, params, mask, bake=bool(bake & 1), bake_color=bool(bake & 2))
-    out = f(torch.from_numpy(g["rays"]).cuda(), white_bg=wb, is_train=False, N_samples=S, collect_stats=True, **_mode(g))
+    out = f(torch.from_numpy(g["rays"]).cuda(), white_bg=wb, is_train="is_train" in g, N_samples=S, collect_stats=True, **_mode(g), **train_kw)
     rgb, depth = out["rgb_map"].cpu().numpy(), out["depth_map"].cpu().numpy()
     e1 = _close(rgb, o_rgb, "rgb vs oracle")
     _close(depth, o_depth, "depth vs oracle", atol=5e-5)
@@ -91,6 +98,39 @@ def test_render_matches_oracle_and_reference(name, bake):
     assert max(e1, e2) < 2e-5 and psnr(rgb, g["rgb_map"]) > 90
     st = f.last_stats.cpu().numpy()
     assert st[3] == g["rays"].shape[0] and st[1] <= st[0] <= g["rays"].shape[0] * S
+
+
+@pytest.mark.parametrize("level", ["level1", "level2", "no_fold", "split_bf16"])
+@pytest.mark.parametrize("name", TRIPLANE + INFOINV + TRAIN)
+def test_per_sample_colours_match_the_reference(name, level):
+    """SURVEY C2's last intermediates: the reference's own rgb_mask (weight > thr, FieldBase.py:289) and per-sample colours -- outputs of ITS
+    compute_rgb / rgb_decoder (Field.py:93-105, networks.py:25-32) at the active samples of the first 8 rays -- against the HIP march's weights
+    and the HIP colour stage (ngf_field_decode_rgb) at the reference's own gauge-shifted coordinates: compute_rgb is pinned to a
+    reference-held vector, not only through composited pixels."""
+    g, params, step, mask = load_case(name)
+    tri = str(g["model"]) == "triplane"
+    if level in ("level2", "no_fold") and not tri:
+        pytest.skip("TriPlane levels")
+    flags = {"level1": {}, "level2": {"bake": True}, "no_fold": {"no_fold": True}, "split_bf16": {"split_bf16": True}}[level]
+    f = field_for_case(g, params, mask, **flags)
+    mode = int(g["gauge_on"]) if "gauge_on" in g else int(g["infoinv"])
+    m = g["i_rgb_mask"]
+    S = int(g["S"])
+    # the march's weights of the same 8 rays (eval-mode cases: the debug march takes no jitter)
+    if "is_train" not in g:
+        _, weight = f.march(torch.from_numpy(g["rays"][:8]), S, mode=mode)
+        weight = weight.cpu().numpy()
+        near = np.abs(g["i_weight"] - np.float32(g["thr"])) < 2e-7              # within rounding of the threshold: either side is right
+        assert np.array_equal((weight > np.float32(g["thr"]))[~near], m[~near])
+        np.testing.assert_allclose(weight, g["i_weight"], rtol=1e-4, atol=2e-7)
+    if not m.any():
+        assert name == "triplane_r0" and not g["i_rgb"].any()               # the literal random-init preset has no active sample
+        return
+    dirs = np.ascontiguousarray(np.broadcast_to(g["rays"][:8, None, 3:6], (*m.shape, 3))[m])
+    coords = np.ascontiguousarray(g["i_coords"][m])
+    got = f.decode_rgb(torch.from_numpy(coords), torch.from_numpy(dirs), mode=mode).cpu().numpy()
+    assert np.abs(got - g["i_rgb"][m]).max() < 5e-6, np.abs(got - g["i_rgb"][m]).max()
+    assert int(m.sum()) >= 20
 
 
 def test_ragged_and_tiny_batches():
@@ -162,9 +202,10 @@ def test_infoinv_split_bf16_keeps_fp32_accuracy(name):
     rays = torch.from_numpy(g["rays"]).cuda()
     S = int(g["S"])
     kw = _mode(g)
-    a = fs(rays, N_samples=S, white_bg=True, **kw)
-    b = fd(rays, N_samples=S, white_bg=True, **kw)
-    o_rgb, o_depth = orc.render(g["rays"], S, white_bg=True)
+    wb = bool(int(g["white_bg"]))
+    a = fs(rays, N_samples=S, white_bg=wb, **kw)
+    b = fd(rays, N_samples=S, white_bg=wb, **kw)
+    o_rgb, o_depth = orc.render(g["rays"], S, white_bg=wb)
     ea = _close(a["rgb_map"].cpu().numpy(), o_rgb, "split-bf16 rgb vs oracle")
     _close(a["rgb_map"].cpu().numpy(), g["rgb_map"], "split-bf16 rgb vs reference golden")
     assert ea < 5e-6

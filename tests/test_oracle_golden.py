@@ -14,15 +14,26 @@ from helpers import load_case, oracle_for_case
 from oracle import oracle as O
 
 TRIPLANE = ["triplane_r1_gauge", "triplane_r2_nogauge", "triplane_r1_mask", "triplane_r0"]
-INFOINV = ["infoinv_r1_on", "infoinv_r1_off"]
+INFOINV = ["infoinv_r1_on", "infoinv_r1_off", "infoinv_r1_mask"]           # _mask: InfoInv WITH an alpha mask, black background (round 4)
+TRAIN = ["triplane_r1_train_white", "triplane_r1_train_black"]             # is_train=True forwards: supplied jitter, background coin (round 4)
 
 
-@pytest.mark.parametrize("name", TRIPLANE + INFOINV)
+def case_render_args(g):
+    """(white_bg, jitter) of a captured forward: a training-mode forward (FieldBase.py:128-130, 299) carries its per-ray jitter and the
+    background coin -- white_bg or coin < 0.5."""
+    white = bool(int(g["white_bg"]))
+    if "is_train" in g:
+        return white or float(g["coin"]) < 0.5, g["jitter"]
+    return white, None
+
+
+@pytest.mark.parametrize("name", TRIPLANE + INFOINV + TRAIN)
 def test_render_matches_reference(name):
     g, params, step, mask = load_case(name)
     assert np.float32(step) == np.float32(g["stepSize"]), "init_para stepSize restatement differs"
     orc = oracle_for_case(g, params, step, mask)
-    rgb, depth, dbg = orc.render(g["rays"], int(g["S"]), white_bg=bool(int(g["white_bg"])), debug_rays=8)
+    white, jitter = case_render_args(g)
+    rgb, depth, dbg = orc.render(g["rays"], int(g["S"]), white_bg=white, jitter=jitter, debug_rays=8)
     assert np.max(np.abs(rgb - g["rgb_map"])) <= 2e-6
     assert np.max(np.abs(depth - g["depth_map"])) <= 5e-6
     # intermediates of the first 8 rays: positions and masks are bit-exact, the rest to rounding
@@ -33,6 +44,15 @@ def test_render_matches_reference(name):
     np.testing.assert_allclose(dbg["weight"], g["i_weight"], rtol=1e-4, atol=2e-7)
     if "i_coords" in g:
         np.testing.assert_allclose(dbg["coords"], g["i_coords"], rtol=0, atol=5e-7)
+    # per-sample colours (FieldBase.py:289-294): the reference's rgb_mask and its own compute_rgb / rgb_decoder outputs on the first 8 rays
+    m = g["i_rgb_mask"]
+    near = np.abs(g["i_weight"] - np.float32(g["thr"])) < 1e-7
+    assert np.array_equal((dbg["weight"] > np.float32(g["thr"]))[~near], m[~near])
+    if m.any():
+        dirs = np.broadcast_to(g["rays"][:8, None, 3:6], (*m.shape, 3))[m]
+        col = orc.color_at(np.ascontiguousarray(g["i_coords"][m]), np.ascontiguousarray(dirs))
+        assert np.max(np.abs(col - g["i_rgb"][m])) <= 2e-6
+    assert not g["i_rgb"][~m].any()
 
 
 def test_nsamples_restatement():
