@@ -17,6 +17,10 @@
 namespace ngf {
 
 constexpr int kInfoInvWaves = 12;
+#ifndef NGF_II_TAP_PARTS
+#define NGF_II_TAP_PARTS 3        // density taps of the fp32 march: the 24 channels are fetched in this many parts (2: 48 tap registers in flight and 44 B of
+                                  // spills at the 168 registers of twelve waves per CU; 3: 32 and none -- same speed in an alternating A/B, profiles/r04_infoinv_tap_parts.txt)
+#endif
 constexpr int kInfoInvSplitWaves = 8;        // NGF_F_SPLIT_BF16: 102 KB of MLP images + 5.4 KB per wave
 
 struct InfoInvDensLayout {                  // floats, relative to MlpLayout16<72>::TOTAL inside the blob
@@ -616,16 +620,17 @@ struct InfoInvPolicyT {
                 const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + (size_t)b.idx * 24);
                 const f32x4 *q01 = q00 + (size_t)tx.stride * 6;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {      // twelve channels at a time: 48 instead of 96 registers of taps in flight (the fp32 kernel
-                                                            // runs at the 168 registers of twelve waves per CU; the wider form was what it spilled for)
-                    f32x4 v00[3], v10[3], v01[3], v11[3];
+                for (int part = 0; part < NGF_II_TAP_PARTS; ++part) {      // 24 / PARTS channels at a time: 96 / PARTS registers of taps in flight (the fp32 kernel
+                                                            // runs at the 168 registers of twelve waves per CU; all 24 at once was what it spilled for)
+                    constexpr int NQ = 6 / NGF_II_TAP_PARTS;
+                    f32x4 v00[NQ], v10[NQ], v01[NQ], v11[NQ];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) { const int q = 3 * half + j; v00[j] = q00[q]; v10[j] = q00[6 + q]; v01[j] = q01[q]; v11[j] = q01[6 + q]; }
+                    for (int j = 0; j < NQ; ++j) { const int q = NQ * part + j; v00[j] = q00[q]; v10[j] = q00[6 + q]; v01[j] = q01[q]; v11[j] = q01[6 + q]; }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
+                    for (int j = 0; j < NQ; ++j)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) feat[4 * (3 * half + j) + e] = bil_mix(b, v00[j][e], v10[j][e], v01[j][e], v11[j][e]);
+                        for (int e = 0; e < 4; ++e) feat[4 * (NQ * part + j) + e] = bil_mix(b, v00[j][e], v10[j][e], v01[j][e], v11[j][e]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (A.mode) {

@@ -463,11 +463,17 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         const int tile_w = 1 << ts;
         // split tile of >= 4 rays: a 16-lane row holds M = tile_w / 4 rays, lane-in-row = seg * M + r (split_chain above), ray slot = row * M + r;
         // of 2 / 1 rays: a ray takes R = 2 / 4 whole rows, seg = its lane index inside them (split_chain_rows)
+        // (per-tile copies of the lane id and of two uniform scalars behind an opaque asm: hipcc hoists the few cheap VALU results derived from
+        // them -- the lane's row, the clamp's canonicalised `far`, step * (S + 1) -- out of the persistent tile loop and then SPILLS them in the
+        // kernels that run at their register budget (InfoInv fp32: 3 of its 4 scratch dwords); recomputed per tile they cost three instructions)
+        int lane_t = lane, S_t = S;
+        float far_t = A.far_;
+        asm volatile("" : "+v"(lane_t), "+s"(S_t), "+s"(far_t));
         const int mshift = SPLIT ? (ts >= 2 ? ts - 2 : 0) : 0;           // log2(M)
         const int rshift = SPLIT ? (ts >= 2 ? 0 : 2 - ts) : 0;           // log2(R)
         const int K = SPLIT ? (64 >> ts) : 1;
-        const int seg = SPLIT ? (ts >= 2 ? ((lane & 15) >> mshift) : (lane & (K - 1))) : 0;              // which of the K consecutive steps this lane takes
-        const int rl = SPLIT ? (ts >= 2 ? (((lane >> 4) << mshift) | (lane & ((1 << mshift) - 1))) : (lane >> (4 + rshift))) : lane;      // ray slot inside the tile (= owner id in the queues)
+        const int seg = SPLIT ? (ts >= 2 ? ((lane_t & 15) >> mshift) : (lane_t & (K - 1))) : 0;              // which of the K consecutive steps this lane takes
+        const int rl = SPLIT ? (ts >= 2 ? (((lane_t >> 4) << mshift) | (lane_t & ((1 << mshift) - 1))) : (lane_t >> (4 + rshift))) : lane_t;      // ray slot inside the tile (= owner id in the queues)
         const int64_t ray = base + rl;
         const bool live = (rl < tile_w) && (ray < A.n);
         const int64_t rr = live ? ray : A.n - 1;
@@ -484,7 +490,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
             float ra = (A.a1[k] - o[k]) / vec, rb = (A.a0[k] - o[k]) / vec;
             tmin = fmaxf(tmin, fminf(ra, rb));
         }
-        tmin = fminf(fmaxf(tmin, A.near_), A.far_);
+        tmin = fminf(fmaxf(tmin, A.near_), far_t);
 
         if constexpr (P::VLDS) {   // view inputs of this lane's ray (networks.py:27-29), read back by the shade lanes
             if constexpr (SPLIT) {
@@ -509,7 +515,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         }
         float T = 1.0f, acc = 0.0f, dep = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
         int i = 0, head = 0, count = 0;
-        const float zmax = tmin + A.step * (float)(S + 1);      // bound of every z of the ray (exact early termination below)
+        const float zmax = tmin + A.step * (float)(S_t + 1);      // bound of every z of the ray (exact early termination below)
         const bool dbg_samples = DBG && A.dbg_weight;           // per-sample outputs requested (never in the production instantiation)
         for (;;) {
             [[maybe_unused]] unsigned long long t_sec = 0;
