@@ -46,7 +46,7 @@ def so_sha16():
     return hashlib.sha256(open(_lib.SO_PATH, "rb").read()).hexdigest()[:16]
 
 
-PMC_ROUNDS = ("r03", "r02")
+PMC_ROUNDS = ("r04", "r03", "r02")
 
 
 def load_pmc(tag):
