@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NGF_ABI_VERSION 3      /* 3: ngf_train_backward2 (loss_len travels with the call; ngf_train_backward is back to its ABI-1 contract of ONE double); 2: ngf_uv_desc.flags (was padding), ngf_uv_render_batch, ngf_debug_dirty_lds, trainer chunk_samples = 0 means the whole batch */
+#define NGF_ABI_VERSION 3      /* 3: ngf_train_overflow_count + speculative rows (ngf_train_desc.chunk_samples < 0), ngf_train_backward2 (loss_len travels with the call; ngf_train_backward is back to its ABI-1 contract of ONE double); 2: ngf_uv_desc.flags (was padding), ngf_uv_render_batch, ngf_debug_dirty_lds, trainer chunk_samples = 0 means the whole batch */
 
 enum { NGF_OK = 0, NGF_E_ARG = 1, NGF_E_HIP = 2, NGF_E_UNSUPPORTED = 3 };
 enum { NGF_MODEL_TRIPLANE = 0, NGF_MODEL_INFOINV = 1 };
@@ -206,7 +206,10 @@ typedef struct ngf_train_desc {
     float mask_aabb[6];
     int64_t max_rays;              /* largest batch (args.batch_size) */
     int32_t max_samples;           /* largest N_samples */
-    int64_t chunk_samples;         /* active samples whose activation rows (2.4 KB each) are kept at once; 0 = the whole batch (up to 9 Mi samples) */
+    int64_t chunk_samples;         /* active samples whose activation rows (2.4 KB each) are kept at once; 0 = the whole batch (up to 9 Mi samples: 9 GB for
+                                      4096 rays x 884 samples); > 0 = that many, the step then reads the active count on the host (one sync) to cut the list into
+                                      chunks; < 0 = SPECULATIVE: |chunk_samples| rows and never a host round trip -- a batch with more active samples than rows is
+                                      flagged on the device, its ngf_train_adam* updates leave parameters and moments untouched, ngf_train_overflow_count reports it */
 } ngf_train_desc;
 typedef struct ngf_trainer ngf_trainer;
 int ngf_trainer_create(const ngf_train_desc *desc, ngf_trainer **out, void *hip_stream);
@@ -236,6 +239,9 @@ int ngf_train_backward(ngf_trainer *t, const float *rays, const float *rgb_train
                        int32_t n_samples, int32_t white_bg, int32_t gauge_on, double *rgb_loss, int64_t *n_active_host,
                        void *hip_stream);
 int ngf_train_get_active(ngf_trainer *t, int64_t n, int32_t *out_device, void *hip_stream);
+/* speculative rows (chunk_samples < 0): *count_host = steps since the trainer was made whose batch had more active samples than the trainer keeps
+ * rows for (their updates were skipped), *rows_host (nullable) = the row count.  Synchronises hip_stream. */
+int ngf_train_overflow_count(ngf_trainer *t, int64_t *count_host, int64_t *rows_host, void *hip_stream);
 /* the gradient of parameter `which` in its reference layout -> out (device) */
 int ngf_train_get_grad(ngf_trainer *t, int32_t which, float *out, void *hip_stream);
 /* torch.optim.Adam's update of parameter `which` from the gradient held by the trainer; step_count >= 1 is that

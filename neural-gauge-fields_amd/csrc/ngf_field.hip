@@ -1107,6 +1107,8 @@ struct ngf_trainer {
     char *zero_arena = nullptr;             // every buffer a step accumulates into (gradients, M, loss): one memset per step
     size_t zero_bytes = 0;
     int64_t chunk = 0;
+    bool speculative = false;               // chunk_samples < 0: `chunk` rows, never a host round trip; a batch with more active samples is flagged on the device
+    int32_t *overflow = nullptr;            // device: [0] this step's batch had more active samples than rows (Adam then skips), [1] how often that happened
     int64_t bytes = 0;
     int num_cus = 256;
     // after the colour backward the step forks: weight-gradient GEMMs | colour-plane scatter | density / gauge backward are independent
@@ -1250,9 +1252,17 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
     const size_t cap = (size_t)d->max_rays * d->max_samples;
     // activation rows kept at once: by default the whole batch (1.7 KB per sample -- 6.2 GB for 4096 rays x 884 samples; the MI355X
     // has 288 GB), which also lets the step run without a host round trip; at most ~16 GB unless the caller asks otherwise
-    t->chunk = d->chunk_samples > 0 ? d->chunk_samples : (int64_t)std::min<size_t>(cap, (size_t)9 << 20);
+    // chunk_samples < 0 (speculative rows): |chunk_samples| rows, the step never waits for the host; a batch with more active samples than that
+    // is flagged by the device (Adam skips the step, ngf_train_overflow_count reports it) -- 4096 x 884 pairs with rows for a third of them
+    // are 3.4 GiB instead of 9.0
+    t->speculative = d->chunk_samples < 0;
+    const int64_t want = d->chunk_samples < 0 ? -d->chunk_samples : d->chunk_samples;
+    t->chunk = want > 0 ? want : (int64_t)std::min<size_t>(cap, (size_t)9 << 20);
     if ((size_t)t->chunk > cap) t->chunk = (int64_t)((cap + 15) & ~(size_t)15);
-    if (d->chunk_samples <= 0 && (size_t)t->chunk >= cap) t->chunk = (int64_t)((cap + 15) & ~(size_t)15);
+    if (want <= 0 && (size_t)t->chunk >= cap) t->chunk = (int64_t)((cap + 15) & ~(size_t)15);
+    if (t->speculative) t->chunk = (t->chunk + 15) & ~(int64_t)15;
+    if ((rc = tr_alloc(t, &t->overflow, 2))) return bail(rc);
+    if (hipMemsetAsync(t->overflow, 0, 2 * sizeof(int32_t), st) != hipSuccess) return bail(fail(NGF_E_HIP, "trainer setup failed"));
     if ((rc = tr_alloc(t, &T.et, cap)) || (rc = tr_alloc(t, &T.sg, cap)) || (rc = tr_alloc(t, &T.w, cap)) || (rc = tr_alloc(t, &T.dx, cap)) || (rc = tr_alloc(t, &T.c, cap * 3)) ||
         (rc = tr_alloc(t, &T.dt, cap * 6)) || (rc = tr_alloc(t, &T.G, (size_t)d->max_rays * 3)) || (rc = tr_alloc(t, &T.count, (size_t)d->max_rays)) ||
         (rc = tr_alloc(t, &T.offset, (size_t)d->max_rays + 1)) || (rc = tr_alloc(t, &T.list, cap * 2)) || (rc = tr_alloc(t, &T.list_w, cap)) ||
@@ -1276,7 +1286,7 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
         while (t->allocs.size() > mark) { (void)hipFree(t->allocs.back()); t->allocs.pop_back(); }
         t->bytes = bytes_mark;
         (void)hipGetLastError();
-        if (attempt > 0 || d->chunk_samples > 0 || ch <= ((size_t)1 << 18)) return bail(rc);
+        if (attempt > 0 || d->chunk_samples != 0 || ch <= ((size_t)1 << 18)) return bail(rc);
         t->chunk = (int64_t)1 << 18;
     }
     // the packed copies (their zero borders are written here and never again) and defined gradients before the first backward
@@ -1361,11 +1371,11 @@ static int train_backward_body(ngf_trainer *t, const float *rays, const float *r
     hipLaunchKernelGGL(train_density_kernel, dim3(tr_grid(t, pairs, 256)), dim3(256), 0, st, T);
     const int ray_blocks = (int)((n + 3) / 4);        // sixteen lanes per ray
     hipLaunchKernelGGL(train_scan_kernel, dim3(ray_blocks), dim3(64), 0, st, T, 0);
-    hipLaunchKernelGGL(train_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)T.count, n, T.offset);
+    hipLaunchKernelGGL(train_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)T.count, n, T.offset, t->speculative ? t->chunk : (int64_t)0, t->overflow);
     // The colour kernels walk the active list.  When one chunk of activation rows holds every sample of the batch (the default:
     // HBM is sized for it) they read the active count from the device and run with fixed grids -- the stream never waits for the
     // host.  With a smaller chunk (chunk_samples of the descriptor) the count comes to the host to cut the list into chunks.
-    const bool no_sync = t->chunk >= pairs && !n_active_host;
+    const bool no_sync = (t->chunk >= pairs || t->speculative) && !n_active_host;
     int32_t n_active = 0;
     if (!no_sync) {
         HIP_TRY(hipMemcpyAsync(&n_active, T.offset + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1383,7 +1393,9 @@ static int train_backward_body(ngf_trainer *t, const float *rays, const float *r
     if (fork) { HIP_TRY(hipStreamWaitEvent(st, t->ev_join[0], 0)); fs.fold = false; }          // the images
     const int32_t *cnt = no_sync ? T.offset + n : nullptr;
     T.n_active_dev = cnt;
-    const int64_t list_len = no_sync ? pairs : n_active;          // upper bound of the list length the loops below are sized for
+    // upper bound of the list length the loops below are sized for (speculative rows: what the trainer keeps rows for -- the kernels stop at
+    // min(that, the device's count); a longer list is flagged, train_prefix_kernel)
+    const int64_t list_len = no_sync ? std::min<int64_t>(pairs, t->chunk) : n_active;
     const bool single = list_len <= t->chunk;
     // colour forward over the whole list (activations kept when the list fits one chunk)
     for (int64_t base = 0; base < list_len; base += t->chunk) {
@@ -1554,18 +1566,31 @@ extern "C" int ngf_train_adam(ngf_trainer *t, int32_t which, int32_t step_count,
         a.l1 = l1_weight / (float)((int64_t)64 * H * W);             // d/dp of l1_weight * mean(|p|)
         if (!t->tex_fresh[p]) return fail(NGF_E_ARG, "ngf_train_adam: the planes changed (ngf_train_params_changed) and no backward has re-packed them");
         hipLaunchKernelGGL((adam_plane_kernel<64, 16>), dim3(H * ((W + 63) / 64)), dim3(256), 0, st, d.plane[p], d.exp_avg[which], d.exp_avg_sq[which], H, W,
-                           (const float *)t->g_d[p], (const float *)t->g_a[p], t->tex_d[p], t->tex_a[p], a);
+                           (const float *)t->g_d[p], (const float *)t->g_a[p], t->tex_d[p], t->tex_a[p], a, (const int32_t *)t->overflow);
     } else if (which < 6) {
         const int p = which - 3;
         if (!t->tex_fresh[which]) return fail(NGF_E_ARG, "ngf_train_adam: the planes changed (ngf_train_params_changed) and no backward has re-packed them");
         hipLaunchKernelGGL((adam_plane_kernel<2, 2>), dim3(d.gauge_h[p] * ((d.gauge_w[p] + 63) / 64)), dim3(256), 0, st, d.gauge[p], d.exp_avg[which],
-                           d.exp_avg_sq[which], d.gauge_h[p], d.gauge_w[p], (const float *)t->g_g[p], (const float *)nullptr, t->tex_g[p], (float *)nullptr, a);
+                           d.exp_avg_sq[which], d.gauge_h[p], d.gauge_w[p], (const float *)t->g_g[p], (const float *)nullptr, t->tex_g[p], (float *)nullptr, a, (const int32_t *)t->overflow);
     } else {
         float *params[TP_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d.dens_w, d.dens_b, d.basis, d.w1, d.b1, d.w2, d.b2, d.w3, d.b3};
         hipLaunchKernelGGL(adam_dense_kernel, dim3(64), dim3(256), 0, st, params[which], (const float *)t->g_dense[which], d.exp_avg[which],
-                           d.exp_avg_sq[which], t->dense_n[which], a);
+                           d.exp_avg_sq[which], t->dense_n[which], a, (const int32_t *)t->overflow);
     }
     HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+// Speculative rows (ngf_train_desc::chunk_samples < 0): how many steps since the trainer was made had more active samples than activation rows
+// (their Adam updates were skipped on the device) and the trainer's row count.  Synchronises the stream.
+extern "C" int ngf_train_overflow_count(ngf_trainer *t, int64_t *count_host, int64_t *rows_host, void *hip_stream)
+{
+    if (!t || !count_host) return fail(NGF_E_ARG, "ngf_train_overflow_count: null argument");
+    int32_t v[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(v, t->overflow, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+    *count_host = v[1];
+    if (rows_host) *rows_host = t->chunk;
     return NGF_OK;
 }
 
@@ -1623,6 +1648,7 @@ extern "C" int ngf_train_adam_all(ngf_trainer *t, const int32_t *step_count, con
         }
     }
     D.begin[kDenseParams] = at;
+    D.skip = t->overflow;
     if (at > 0) hipLaunchKernelGGL(adam_dense_all_kernel, dim3((at + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, D);
     if (step_count[0] > 0) {
         const int rc = ngf_train_adam(t, 0, step_count[0], lr[0], beta1, beta2, eps, l1_weight, hip_stream);

@@ -320,7 +320,10 @@ __global__ void __launch_bounds__(64) train_scan_kernel(const TrainArgs T, int p
 
 // exclusive prefix of count[0..n) -> offset[0..n]; one block: every thread sums a run of consecutive counts, ONE scan over the 1024 run
 // sums, then the run is written (round 2 scanned chunk after chunk of 1024: 80 barriers for a 4096-ray batch, 10 us)
-__global__ void __launch_bounds__(1024) train_prefix_kernel(const int32_t *count, int64_t n, int32_t *offset)
+// rows_cap / overflow (speculative rows, ngf_train_desc::chunk_samples < 0): when the batch has more active samples than the trainer keeps
+// activation rows for, overflow[0] = 1 for THIS step (the Adam kernels then leave parameters and moments alone: a truncated gradient is never
+// applied) and the sticky counter overflow[1] goes up (ngf_train_overflow_count); otherwise overflow[0] = 0.
+__global__ void __launch_bounds__(1024) train_prefix_kernel(const int32_t *count, int64_t n, int32_t *offset, int64_t rows_cap = 0, int32_t *overflow = nullptr)
 {
     __shared__ int sh[1024];
     const int t = threadIdx.x;
@@ -341,7 +344,14 @@ __global__ void __launch_bounds__(1024) train_prefix_kernel(const int32_t *count
         offset[b] = run;
         run += count[b];
     }
-    if (t == 1023) offset[n] = sh[1023];
+    if (t == 1023) {
+        offset[n] = sh[1023];
+        if (overflow) {
+            const int over = rows_cap > 0 && (int64_t)sh[1023] > rows_cap;
+            overflow[0] = over;
+            if (over) overflow[1] += 1;
+        }
+    }
 }
 
 // ---- MFMA building block: out[M][16] = act( W . in[K][16] + bias ) with 16 samples as the N dimension -------------------
@@ -1659,8 +1669,10 @@ __device__ __forceinline__ float adam_one(float p, float g, float &m, float &v, 
     return p - step * (m / denom);
 }
 
-__global__ void __launch_bounds__(256) adam_dense_kernel(float *p, const float *g, float *m, float *v, int64_t n, const AdamArgs a)
+// skip: device flag of the trainer (overflow[0], see train_prefix_kernel) -- non-zero: the step's gradient is incomplete, nothing is updated
+__global__ void __launch_bounds__(256) adam_dense_kernel(float *p, const float *g, float *m, float *v, int64_t n, const AdamArgs a, const int32_t *skip)
 {
+    if (skip && *skip) return;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float mi = m[i], vi = v[i];
@@ -1676,10 +1688,12 @@ struct AdamDenseAll {
     const float *g[kDenseParams];
     int32_t begin[kDenseParams + 1];           // begin[k+1] == begin[k] for a skipped parameter
     AdamArgs a[kDenseParams];
+    const int32_t *skip;
 };
 
 __global__ void __launch_bounds__(256) adam_dense_all_kernel(const AdamDenseAll D)
 {
+    if (D.skip && *D.skip) return;
     const int total = D.begin[kDenseParams];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         int k = 0;
@@ -1698,8 +1712,9 @@ __global__ void __launch_bounds__(256) adam_dense_all_kernel(const AdamDenseAll 
 // updated values leave the same way into the packed copy -- the next step's kernels read it without a re-pack.
 template <int C, int CS>
 __global__ void __launch_bounds__(256) adam_plane_kernel(float *p, float *m, float *v, int H, int W, const float *ga, const float *gb, float *ta, float *tb,
-                                                         const AdamArgs a)
+                                                         const AdamArgs a, const int32_t *skip)
 {
+    if (skip && *skip) return;
     constexpr int CB = C - CS;
     __shared__ float sg[64 * (C + 1)];
     const int tiles_x = (W + 63) / 64;

@@ -51,6 +51,7 @@ def _bind(L):
                                       C.POINTER(C.c_int64), C.c_void_p]
     L.ngf_train_get_grad.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.ngf_train_get_active.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.ngf_train_overflow_count.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]
     L.ngf_train_adam.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
     L.ngf_train_adam_all.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
     L.ngf_train_params_changed.argtypes = [C.c_void_p]
@@ -66,8 +67,14 @@ class Trainer:
     ``max_samples`` size the scratch buffers (args.batch_size and the largest N_samples that will be passed)."""
 
     def __init__(self, field, batch_size=4096, max_samples=None, lr_init=0.02, lr_basis=1e-3, lr_decay_iters=-1,
-                 lr_decay_target_ratio=0.1, n_iters=30000, L1_reg_weight=L1_REG_WEIGHT, betas=(0.9, 0.99), eps=1e-8, chunk_samples=0,
+                 lr_decay_target_ratio=0.1, n_iters=30000, L1_reg_weight=L1_REG_WEIGHT, betas=(0.9, 0.99), eps=1e-8, chunk_samples=None,
                  frozen=(), state_from=None):
+        """``chunk_samples`` sizes the activation rows (2.4 KB per active sample), ngf_train_desc.chunk_samples of include/ngf.h:
+        ``None`` (default) = SPECULATIVE rows for a third of the batch's (ray, sample) pairs, at least 262 144 -- 3.4 GiB for 4096 rays x 884
+        samples instead of the 9.0 GiB of rows for every pair -- with no host round trip; a batch with more active samples than rows is flagged
+        on the device, its optimizer_step leaves parameters and moments untouched, and ``check_rows()`` (called by ``fit`` at every progress
+        refresh) reports it and doubles the rows.  ``0`` = rows for every pair (never overflows); ``> 0`` = that many rows, the step reads the
+        active count on the host (one sync per step); ``< 0`` = speculative with that many rows."""
         self.field = field
         self.dev = torch.device(field.device)
         if self.dev.type != "cuda":
@@ -95,7 +102,12 @@ class Trainer:
         self.betas, self.eps, self.l1 = betas, eps, L1_reg_weight
         self.batch_size = int(batch_size)
         self.max_samples = int(max_samples if max_samples is not None else field.nSamples)
+        pairs = self.batch_size * self.max_samples
+        if chunk_samples is None:
+            rows = max(1 << 18, -(-pairs // 3))
+            chunk_samples = 0 if rows >= pairs else -((rows + 15) // 16 * 16)
         self.chunk_samples = int(chunk_samples)
+        self._overflows_seen = 0
         self._h = None
         if state_from is not None:                  # carry the optimiser state of parameters that kept their shape
             for k in range(15):
@@ -173,6 +185,32 @@ class Trainer:
 
     def scratch_bytes(self) -> int:
         return int(self.L.ngf_trainer_bytes(self._h))
+
+    def overflows(self):
+        """(steps whose batch had more active samples than the trainer keeps activation rows for -- their updates were skipped on the
+        device --, the row count).  Synchronises with the device."""
+        cnt, rows = C.c_int64(0), C.c_int64(0)
+        with torch.cuda.device(self.dev):
+            _lib.check(self.L.ngf_train_overflow_count(self._h, C.byref(cnt), C.byref(rows), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return int(cnt.value), int(rows.value)
+
+    def check_rows(self, grow=True) -> int:
+        """Speculative rows: report batches that did not fit since the last check (their steps changed nothing) and, with ``grow``, rebuild the
+        device trainer with twice the rows (the Adam state is the caller's tensors and stays).  Returns the number of new overflows."""
+        cnt, rows = self.overflows()
+        new = cnt - self._overflows_seen
+        self._overflows_seen = cnt
+        if new > 0 and grow and self.chunk_samples < 0:
+            import warnings
+            warnings.warn(f"ngf_amd.train.Trainer: {new} step(s) had more active samples than the {rows} activation rows and were skipped; "
+                          f"doubling the rows")
+            self.release()
+            self.chunk_samples = -min(self.batch_size * self.max_samples, 2 * rows)
+            if -self.chunk_samples >= self.batch_size * self.max_samples:
+                self.chunk_samples = 0
+            self._build()
+            self._overflows_seen = 0
+        return new
 
     @property
     def last_active(self) -> int:
@@ -309,6 +347,8 @@ def fit(field, allrays, allrgbs, args, white_bg=True, on_iteration=None):
         ids = sampler.nextids()
         rgb_loss = trainer.step(allrays[ids].to(dev), allrgbs[ids].to(dev), iteration, N_samples=nSamples, white_bg=white_bg).item()
         PSNRs.append(-10.0 * np.log(rgb_loss) / np.log(10.0))
+        if iteration % max(1, int(getattr(args, "progress_refresh_rate", 10))) == 0:
+            trainer.check_rows()                      # speculative activation rows: a batch that did not fit was skipped on the device
         if on_iteration is not None:
             on_iteration(iteration, rgb_loss)
         if iteration in mask_list:

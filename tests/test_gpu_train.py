@@ -75,10 +75,10 @@ def test_gradients_and_two_adam_steps_match_reference():
     assert torch.isfinite(out["rgb_map"]).all()
 
 
-@pytest.mark.parametrize("chunk", [0, 64])
+@pytest.mark.parametrize("chunk", [0, 64, -4096])
 def test_gradients_match_autograd_oracle(chunk):
     """triplane_r1_gauge geometry (24x20x18 planes, 224 rays incl. box misses and axis-aligned rays, S=48); chunk=64 forces
-    the multi-chunk path (colour forward recomputed per chunk)."""
+    the multi-chunk path (colour forward recomputed per chunk); chunk=-4096: speculative rows (no host round trip) that hold the batch."""
     g, params, step, mask = load_case("triplane_r1_gauge")
     f = field_for_case(g, params, None)
     rays_np = g["rays"]
@@ -99,6 +99,49 @@ def test_gradients_match_autograd_oracle(chunk):
         if k < 3:
             want = want - l1_term(params[name])
         assert rel(got, want) < GRAD_TOL, (name, rel(got, want))
+
+
+def test_speculative_rows_overflow_skips_the_step_and_is_reported():
+    """chunk_samples < 0: rows for fewer samples than a batch has active.  The device flags the batch, optimizer_step leaves parameters AND
+    moments untouched (a truncated gradient is never applied), overflows() counts it, check_rows() doubles the rows until the batch fits --
+    and then the step is the one a whole-batch trainer takes."""
+    g, params, step, mask = load_case("triplane_r1_gauge")
+    from ngf_amd import synth
+    rays = torch.from_numpy(g["rays"]).cuda()
+    n, S = rays.shape[0], 48
+    tgt = torch.from_numpy(synth.hash_uniform(78, 1, (n, 3))).cuda()
+    jit = torch.from_numpy(synth.hash_uniform(78, 2, (n,)))
+    fa, fb = field_for_case(g, params, None), field_for_case(g, params, None)
+    ref = train.Trainer(fb, batch_size=n, max_samples=S, chunk_samples=0)
+    ref.backward(rays, tgt, S, white_bg=True, iteration=5, jitter=jit)
+    n_active = ref.last_active
+    assert n_active > 200
+    tr = train.Trainer(fa, batch_size=n, max_samples=S, chunk_samples=-64)
+    before = [p.detach().clone() for p in tr.params]
+    tr.backward(rays, tgt, S, white_bg=True, iteration=5, jitter=jit)
+    tr.optimizer_step()
+    assert tr.overflows() == (1, 64)
+    for k in range(15):
+        assert torch.equal(tr.params[k].detach(), before[k]) and not tr.exp_avg[k].any() and not tr.exp_avg_sq[k].any(), train.PARAM_NAMES[k]
+    tr.steps = [0] * 15                               # the skipped step did not happen
+    with pytest.warns(UserWarning):
+        assert tr.check_rows() == 1
+    while -tr.chunk_samples < n_active and tr.chunk_samples != 0:      # 128, 256, ... rows: every attempt is flagged and skipped
+        tr.backward(rays, tgt, S, white_bg=True, iteration=5, jitter=jit)
+        tr.optimizer_step()
+        tr.steps = [0] * 15
+        with pytest.warns(UserWarning):
+            assert tr.check_rows() == 1
+    tr.backward(rays, tgt, S, white_bg=True, iteration=5, jitter=jit)
+    assert tr.last_active == n_active and tr.check_rows() == 0
+    for k, name in enumerate(train.PARAM_NAMES):
+        a, b = tr.gradient(k), ref.gradient(k)
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-30), name      # atomics: order-dependent last bits
+    tr.optimizer_step()
+    ref.optimizer_step()
+    for k, name in enumerate(train.PARAM_NAMES):
+        assert torch.allclose(tr.params[k], ref.params[k], rtol=0, atol=2e-3 * tr.lr[k] + 1e-7), name
+    tr.release(); ref.release()
 
 
 def test_gauge_off_before_gauge_start():
@@ -231,7 +274,10 @@ def test_full_size_batch_matches_autograd_oracle():
     orc = otrain.EagerTrainer(params, g["aabb"], step, g["near_far"], float(g["distance_scale"]), float(g["thr"]))
     grads, rgb_loss, _, aux = orc.gradients(torch.from_numpy(rays_np), torch.from_numpy(tgt_np), S, torch.from_numpy(jit_np), True, 7)
     tr = train.Trainer(f, batch_size=4096, max_samples=S)
+    # the default: speculative activation rows for a third of the 4096 x 884 pairs -- 3.4 GiB of scratch instead of 9.0 (<= 4 GiB)
+    assert tr.chunk_samples < 0 and tr.scratch_bytes() < 4 * 2 ** 30, (tr.chunk_samples, tr.scratch_bytes() / 2 ** 30)
     loss = tr.backward(torch.from_numpy(rays_np), torch.from_numpy(tgt_np), S, white_bg=True, iteration=7, jitter=torch.from_numpy(jit_np))
+    assert tr.overflows()[0] == 0
     n_ref = int(aux["active"].sum())
     assert abs(tr.last_active - n_ref) <= max(2, n_ref // 50000)          # a weight within 1 ulp of the threshold may flip
     assert abs(loss.item() - rgb_loss) < 1e-6
