@@ -402,47 +402,62 @@ __device__ __forceinline__ void baked16_consume(const BakedHalf &g, float sum[16
 // Two half-plane buffers (32 VGPRs each): stage s+1 is in flight while stage s is accumulated.  The interpolated
 // pre-activations are summed in plain VGPRs first and only then become the MFMA accumulator of the 16 view-input
 // MFMAs (updating MFMA accumulators with VALU adds in between made hipcc spill heavily).
+//
+// Round 4: the GATHER runs in another lane order than the matrix instructions.  The L1 (TCP) looks up one cache line per cycle and works
+// through a wave's load four consecutive lanes at a time; lane (s, kq) = kq * 16 + s of the matrix layout puts four DIFFERENT samples into every
+// such quad -- four lines per quad, 44.5 tag look-ups per load instruction measured (TCP_TOTAL_CACHE_ACCESSES, profiles/r04_triplane_R1_bdc_pmc.txt:
+// 2 138 per pass; the texture addresser 91 % busy was what bound level 3).  Here gather lane g = 4 s + kq fetches and interpolates what matrix
+// lane kq * 16 + s needs: the four lanes of a quad read ONE 64-byte line of a sample's 256-byte texel (16 look-ups per load), and the sixteen
+// sums reach their matrix lane through sixteen ds_bpermute_b32 (a lane permutation through the LDS crossbar: no LDS memory, no VALU slot).
 __device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v,
                                                  int lane, float rgb[3], const float *pre = nullptr)
 {
     using L = MlpLayout16Baked;
     blob = per_pass16(blob);
     const int kq = lane >> 4;
+    // gather role: sample lane >> 2 (its coordinates sit in the record of matrix lane (lane >> 2, 0)), channel quarter lane & 3
+    const int sg = lane >> 2, kqg = lane & 3;
+    float rg[kRecFloats];
+    rg[0] = rec[0]; rg[1] = rec[1];
+#pragma unroll
+    for (int k = 2; k < kRecFloats; ++k) rg[k] = __shfl(rec[k], sg);
     BakedHalf ga, gb;
-    baked16_issue<0>(A, rec, kq, ga);
+    baked16_issue<0>(A, rg, kqg, ga);
     __builtin_amdgcn_sched_barrier(0);
-    baked16_issue<1>(A, rec, kq, gb);
+    baked16_issue<1>(A, rg, kqg, gb);
     __builtin_amdgcn_sched_barrier(0);
     float sum[16];
-    {
-        const float *b0 = pre ? pre + kq * 16 : blob + L::B1 + kq * 16;      // per-ray view fold, or the bias
 #pragma unroll
-        for (int k = 0; k < 16; ++k) sum[k] = b0[k];
-    }
+    for (int k = 0; k < 16; ++k) sum[k] = 0.0f;
     __builtin_amdgcn_sched_barrier(0);
     baked16_consume<0>(ga, sum);
     __builtin_amdgcn_sched_barrier(0);
-    baked16_issue<2>(A, rec, kq, ga);
+    baked16_issue<2>(A, rg, kqg, ga);
     __builtin_amdgcn_sched_barrier(0);
     baked16_consume<1>(gb, sum);
     __builtin_amdgcn_sched_barrier(0);
-    baked16_issue<3>(A, rec, kq, gb);
+    baked16_issue<3>(A, rg, kqg, gb);
     __builtin_amdgcn_sched_barrier(0);
     baked16_consume<2>(ga, sum);
     __builtin_amdgcn_sched_barrier(0);
-    baked16_issue<4>(A, rec, kq, ga);
+    baked16_issue<4>(A, rg, kqg, ga);
     __builtin_amdgcn_sched_barrier(0);
     baked16_consume<3>(gb, sum);
     __builtin_amdgcn_sched_barrier(0);
-    baked16_issue<5>(A, rec, kq, gb);
+    baked16_issue<5>(A, rg, kqg, gb);
     __builtin_amdgcn_sched_barrier(0);
     baked16_consume<4>(ga, sum);
     __builtin_amdgcn_sched_barrier(0);
     baked16_consume<5>(gb, sum);
     __builtin_amdgcn_sched_barrier(0);
+    // gather lane 4 s + kq -> matrix lane kq * 16 + s, plus the per-ray view fold (or the bias) of the matrix lane's own sample
+    const int src = 4 * (lane & 15) + kq;
+    const float *b0 = pre ? pre + kq * 16 : blob + L::B1 + kq * 16;
     f32x4 acc[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{sum[4 * mt], sum[4 * mt + 1], sum[4 * mt + 2], sum[4 * mt + 3]};
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mt][e] = b0[4 * mt + e] + __shfl(sum[4 * mt + e], src);
     if (!pre) {
         const float *w1 = blob + L::W1V + lane;
 #pragma unroll
