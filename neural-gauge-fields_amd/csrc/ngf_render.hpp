@@ -223,7 +223,8 @@ struct TriPlanePolicy {
     // REC12 (split kernel of the default twelve-wave policies): a queue record carries the sample's three bilinear cells (texel index, fractional
     // parts, in-range bit) instead of its six coordinates, so a shade pass starts its gathers at once and spends 8 instead of ~28 instructions per
     // plane on the cell -- all 64 lanes of a pass used to redo the three setups of their 16 samples that the march had already done.
-    static constexpr bool REC12 = WAVES_ == 12 && NSTEP_ == 1 && !BAKE_C && !PROFILE_;
+    static constexpr bool REC12 = WAVES_ == 12 && NSTEP_ == 1 && !PROFILE_;
+    static constexpr bool GATHER_QUAD = BAKE_C;                 // the shade's gather lane 4 s + kq works for sample lane >> 2 (ngf_shade16.hpp mlp_pass16_baked): shade12 takes ITS cells
     __device__ static __forceinline__ float sigma(const RenderArgs &A, const float *, bool valid, const float x[3], int, float t[6], Bil *cells = nullptr)
     {
         // branch-free: out-of-box samples have out-of-range coordinates, for which bil_setup clamps the
@@ -264,7 +265,8 @@ struct TriPlanePolicy {
         const float rec[kRecFloats] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
         if (!pre) v = *reinterpret_cast<const f32x4 *>(vf + (lane >> 4) * 4);
-        if constexpr (!BAKE_C) mlp_pass16<48>(A, smem, rec, v, lane, c, nullptr, pre, &cells);
+        if constexpr (BAKE_C) mlp_pass16_baked(A, smem, rec, v, lane, c, pre, &cells);
+        else mlp_pass16<48>(A, smem, rec, v, lane, c, nullptr, pre, &cells);
     }
 };
 
@@ -647,8 +649,14 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     prof[6] += tk[3] - tk[4];      // layer 3 (VALU dot, 2 cross-lane adds, sigmoid)
                     t_sec = tk[3];
                 } else if constexpr (R12) {
-                    const f32x4 r2 = r[2];
-                    const RecCells cl = {{__float_as_int(r0[2]), __float_as_int(r0[3]), __float_as_int(r1[0])}, {r1[1], r1[3], r2[1]}, {r1[2], r2[0], r2[2]}, __float_as_int(r0[0])};
+                    // the cells of the sample the lane GATHERS for: its own (lane & 15), or -- baked colour planes, quad-coalesced gather -- sample lane >> 2
+                    f32x4 q0 = r0, q1 = r1, q2 = r[2];
+                    if constexpr (P::GATHER_QUAD) {
+                        const int sgq = lane >> 2;
+                        const f32x4 *rq = reinterpret_cast<const f32x4 *>(ring + wrap(head + (sgq < nb ? sgq : 0)) * RECF);
+                        q0 = rq[0]; q1 = rq[1]; q2 = rq[2];
+                    }
+                    const RecCells cl = {{__float_as_int(q0[2]), __float_as_int(q0[3]), __float_as_int(q1[0])}, {q1[1], q1[3], q2[1]}, {q1[2], q2[0], q2[2]}, __float_as_int(q0[0])};
                     P::shade12(A, smem, cl, vfeat + owner * kViewFeat, lane, c, pre);
                 } else {
                     if constexpr (P::VIEW_FOLD) P::shade(A, smem, rec, vfeat + owner * kViewFeat, od, lane, c, nullptr, pre);

@@ -370,12 +370,13 @@ struct BakedHalf {                // half a plane: 4 taps x 2 float4 = accumulat
     Bil b;
 };
 
-template <int ST>                 // stage = plane * 2 + half
-__device__ __forceinline__ void baked16_issue(const RenderArgs &A, const float rec[kRecFloats], int kq, BakedHalf &g)
+template <int ST>                 // stage = plane * 2 + half; cells: the sample's bilinear cells from a 12-float queue record (else from its coordinates)
+__device__ __forceinline__ void baked16_issue(const RenderArgs &A, const float rec[kRecFloats], int kq, BakedHalf &g, const RecCells *cells = nullptr)
 {
     constexpr int P = ST >> 1, H = ST & 1;
     const Tex &t = A.app[P];
-    g.b = bil_setup(rec[2 + 2 * P], rec[3 + 2 * P], t);
+    if (cells) g.b = bil_from_rec(cells->idx[P], cells->wx1[P], cells->wy1[P], (cells->bits >> (8 + P)) & 1);
+    else g.b = bil_setup(rec[2 + 2 * P], rec[3 + 2 * P], t);
     // channel 16*mt + 4*kq + r = hidden unit of accumulator (mt, r): natural order; 4 lanes read 64 contiguous bytes
     const f32x4 *t00 = tex_at<f32x4>(t.p, (uint32_t)g.b.idx * 64u + 4u * (kq + 8 * H));
     const f32x4 *t01 = tex_at<f32x4>(t.p, (uint32_t)(g.b.idx + t.stride) * 64u + 4u * (kq + 8 * H));
@@ -396,7 +397,10 @@ __device__ __forceinline__ void baked16_consume(const BakedHalf &g, float sum[16
     for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            sum[(2 * H + q) * 4 + e] += bil_mix(g.b, g.raw[0][q][e], g.raw[1][q][e], g.raw[2][q][e], g.raw[3][q][e]);
+        {       // four FMAs onto the running sum (bil_mix + add would be five; the sums are compared with the oracle at 1e-5, not bit for bit)
+            const int k = (2 * H + q) * 4 + e;
+            sum[k] = fmaf(g.b.w11, g.raw[3][q][e], fmaf(g.b.w01, g.raw[2][q][e], fmaf(g.b.w10, g.raw[1][q][e], fmaf(g.b.w00, g.raw[0][q][e], sum[k]))));
+        }
 }
 
 // Two half-plane buffers (32 VGPRs each): stage s+1 is in flight while stage s is accumulated.  The interpolated
@@ -409,22 +413,29 @@ __device__ __forceinline__ void baked16_consume(const BakedHalf &g, float sum[16
 // 2 138 per pass; the texture addresser 91 % busy was what bound level 3).  Here gather lane g = 4 s + kq fetches and interpolates what matrix
 // lane kq * 16 + s needs: the four lanes of a quad read ONE 64-byte line of a sample's 256-byte texel (16 look-ups per load), and the sixteen
 // sums reach their matrix lane through sixteen ds_bpermute_b32 (a lane permutation through the LDS crossbar: no LDS memory, no VALU slot).
+// gcells: the bilinear cells of the GATHER lane's sample (lane >> 2) from its 12-float queue record, or null: then its coordinates are
+// fetched from the record of matrix lane (lane >> 2, 0) with six lane permutations
 __device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v,
-                                                 int lane, float rgb[3], const float *pre = nullptr)
+                                                 int lane, float rgb[3], const float *pre = nullptr, const RecCells *gcells = nullptr)
 {
     using L = MlpLayout16Baked;
     blob = per_pass16(blob);
     const int kq = lane >> 4;
-    // gather role: sample lane >> 2 (its coordinates sit in the record of matrix lane (lane >> 2, 0)), channel quarter lane & 3
+    // gather role: sample lane >> 2, channel quarter lane & 3
     const int sg = lane >> 2, kqg = lane & 3;
     float rg[kRecFloats];
     rg[0] = rec[0]; rg[1] = rec[1];
+    if (!gcells) {
 #pragma unroll
-    for (int k = 2; k < kRecFloats; ++k) rg[k] = __shfl(rec[k], sg);
+        for (int k = 2; k < kRecFloats; ++k) rg[k] = __shfl(rec[k], sg);
+    } else {
+#pragma unroll
+        for (int k = 2; k < kRecFloats; ++k) rg[k] = 0.0f;
+    }
     BakedHalf ga, gb;
-    baked16_issue<0>(A, rg, kqg, ga);
+    baked16_issue<0>(A, rg, kqg, ga, gcells);
     __builtin_amdgcn_sched_barrier(0);
-    baked16_issue<1>(A, rg, kqg, gb);
+    baked16_issue<1>(A, rg, kqg, gb, gcells);
     __builtin_amdgcn_sched_barrier(0);
     float sum[16];
 #pragma unroll
@@ -432,19 +443,19 @@ __device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const floa
     __builtin_amdgcn_sched_barrier(0);
     baked16_consume<0>(ga, sum);
     __builtin_amdgcn_sched_barrier(0);
-    baked16_issue<2>(A, rg, kqg, ga);
+    baked16_issue<2>(A, rg, kqg, ga, gcells);
     __builtin_amdgcn_sched_barrier(0);
     baked16_consume<1>(gb, sum);
     __builtin_amdgcn_sched_barrier(0);
-    baked16_issue<3>(A, rg, kqg, gb);
+    baked16_issue<3>(A, rg, kqg, gb, gcells);
     __builtin_amdgcn_sched_barrier(0);
     baked16_consume<2>(ga, sum);
     __builtin_amdgcn_sched_barrier(0);
-    baked16_issue<4>(A, rg, kqg, ga);
+    baked16_issue<4>(A, rg, kqg, ga, gcells);
     __builtin_amdgcn_sched_barrier(0);
     baked16_consume<3>(gb, sum);
     __builtin_amdgcn_sched_barrier(0);
-    baked16_issue<5>(A, rg, kqg, gb);
+    baked16_issue<5>(A, rg, kqg, gb, gcells);
     __builtin_amdgcn_sched_barrier(0);
     baked16_consume<4>(ga, sum);
     __builtin_amdgcn_sched_barrier(0);
