@@ -132,7 +132,7 @@ def compact_line(result: dict) -> str:
     out["config"] = result["config"]
     rf = result.get("roofline") or {}
     keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "flops_per_launch", "active_samples_per_ray",
-            "evaluated_samples_per_ray")
+            "evaluated_samples_per_ray", "binding")
     crf = {k: _r(rf.get(k), 5) for k in keep if k in rf}
     ph = rf.get("physical")
     if ph:
@@ -297,7 +297,8 @@ def main():
     ap.add_argument("--model", default="triplane", choices=["triplane", "infoinv"])
     ap.add_argument("--bake-density", type=int, default=1, help="1 = NGF_F_BAKE_DENSITY (pre-composed density planes): optimisation level 2, the "
                     "default of ngf_amd.triplane.TriPlane since round 3; 0 = level 1")
-    ap.add_argument("--bake-color", type=int, default=0, help="1 = NGF_F_BAKE_COLOR (pre-composed layer-1 colour planes)")
+    ap.add_argument("--bake-color", type=int, default=1, help="1 = NGF_F_BAKE_COLOR (layer 1 pre-composed into 64-channel colour planes): optimisation level 3, the "
+                    "default of ngf_amd.triplane.TriPlane since round 4; 0 = level 2")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--extras", type=int, default=1, help="N=1 only: also time the other presets / variants (untimed region)")
     ap.add_argument("--knobs", default="", help="experiments only: comma-separated ngf_debug_set knobs, e.g. waves=12,tile_w=8,kernel=1")
@@ -417,6 +418,10 @@ def main():
         roofline = {"bound": "hbm", "achieved": None if hb is None else hb / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": None if hb is None else hb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": hb}
     roofline["physical"] = physical_roofs(pmc, k_ms, n_local / n_total)
+    if model == "triplane" and args.bake_color:
+        # level 3 trades 69 % of level 2's matrix flops for 64-channel gathers and FMA interpolation: the MFMA fraction falls by construction;
+        # what binds the launch is the SIMD's fp32 datapath, which matrix and vector instructions share (physical.simd_busy)
+        roofline["binding"] = "simd fp32 datapath: MFMA + VALU busy (physical.simd_busy); the MFMA fraction is 1/3 of level 2's by construction"
     roofline.update({"kernel": "ngf::render_kernel", "kernel_ms": k_ms, "active_samples_per_ray": s_active,
                      "evaluated_samples_per_ray": st[0] / n_local,      # in-box samples the march evaluated (exact early termination skips the rest)
                       "mlp_passes": st[2], "algorithmic_d3": alg})
@@ -428,7 +433,8 @@ def main():
         "config": {"workload": f"{'TriPlane' if model == 'triplane' else 'InfoInv'} 800x800 frame, S=192, preset {args.preset} "
                                f"(seeded random planes 256^2, dense density preset), gauge on, white_bg",
                    "rays_per_step": n_total, "samples_per_ray": S, "sharding": f"rays x{world} (10-row blocks, round robin) + double-buffered RCCL all_gather",
-                   "level": ("3 (bake density + colour)" if args.bake_color else "2 (module default: layer 1 o basis, per-ray view fold, density_decoder folded into "
+                   "level": ("3 (module default: SURVEY 7 folds (i)-(iii) -- layer 1 o basis folded into 64-channel pre-activation planes, density_decoder into "
+                             "1-channel planes, per-ray view fold)" if args.bake_color else "2 (layer 1 o basis, per-ray view fold, density_decoder folded into "
                              "1-channel planes)" if args.bake_density else "1 (layer 1 o basis, per-ray view fold)") if model == "triplane" else "default",
                    "bake_density": int(args.bake_density), "bake_color": int(args.bake_color)},
         "roofline": roofline,
@@ -494,16 +500,16 @@ def main():
         if args.extras:
             extras = {}
             # the other presets and the opt-in formulations: (model, preset, field flags, result tag, PMC tag)
-            BD = {"bake": True}        # level 2 = the module default
-            variants = (("triplane", "R0", BD, "", "_bd"), ("triplane", "R2", BD, "", "_bd"),
+            BD = {"bake": True, "bake_color": True}        # level 3 = the module default
+            variants = (("triplane", "R0", BD, "", "_bdc"), ("triplane", "R2", BD, "", "_bdc"),
+                        ("triplane", args.preset, {"bake": True}, "_level2", "_bd"),                        # level 2: layer 1 on the matrix pipe (round 3's default)
                         ("triplane", args.preset, {}, "_level1_no_bake", ""),                                # level 1: density_decoder on 16-channel taps
                         ("triplane", args.preset, {"no_fold": True}, "_level0_no_fold", "_nofold"),        # rgb_decoder as written: what the folds buy
-                        ("triplane", args.preset, {"bake": True, "bake_color": True}, "_level3_bake_color", "_bdc"),
-                        ("triplane", args.preset, {"bake": True, "split_bf16": True}, "_split_bf16", "_splitd"),   # colour MLP on bf16 MFMA, 3-term split operands
+                        ("triplane", args.preset, {"bake": True, "split_bf16": True}, "_level2_split_bf16", "_splitd"),   # colour MLP on bf16 MFMA, 3-term split operands
                         ("triplane", args.preset, {"split_bf16": True}, "_level1_split_bf16", "_split"),
-                        ("triplane", "R2", {"bake": True, "split_bf16": True}, "_split_bf16", "_splitd"),
+                        ("triplane", "R2", {"bake": True, "split_bf16": True}, "_level2_split_bf16", "_splitd"),
                         ("triplane", "R0", {}, "_level1_no_bake", ""),
-                        ("triplane", "R2", {"bake": True, "bake_color": True}, "_level3_bake_color", "_bdc"),
+                        ("triplane", "R2", {"bake": True}, "_level2", "_bd"),
                         ("infoinv", "R1", {}, "", ""),
                         ("infoinv", "R1", {"split_bf16": True}, "_split_bf16", "_split"))           # rgb_decoder + density MLP on bf16 MFMA, four lanes per sample
             for mdl, preset, flags, tag, ptag_sfx in variants:

@@ -51,7 +51,7 @@ class Base(torch.nn.Module):
 
     def __init__(self, aabb, gridSize, device, alphaMask=None, near_far=[2.0, 6.0], alphaMask_thres=0.001,
                  distance_scale=25, rayMarch_weight_thres=0.0001, step_ratio=2.0, gauge_start=0, bake_density=None,
-                 bake_color=False, no_fold=False, split_bf16=False):
+                 bake_color=None, no_fold=False, split_bf16=False):
         super().__init__()
         self.aabb = aabb if torch.is_tensor(aabb) else torch.tensor(aabb, dtype=torch.float32)
         self.alphaMask = alphaMask
@@ -62,17 +62,20 @@ class Base(torch.nn.Module):
         self.near_far = near_far
         self.step_ratio = step_ratio
         # Optimisation levels of the TriPlane render: 0 = no_fold (rgb_decoder as written), 1 = layer 1 pre-composed with
-        # `basis` + per-ray view fold, 2 = level 1 + density_decoder folded into 1-channel planes (bake_density, THE DEFAULT since round 3:
-        # Linear(48,1) commutes with bilinear interpolation, fp64 accumulate at pack time, |d sigma| <= 2e-6 relative -- the same kind of
-        # pre-composition as level 1's), 3 = level 2 + bake_color.  Every level is parity-tested against the oracle and the reference's
-        # golden pixels with the same tolerances; bake_density=False gives level 1.
+        # `basis` + per-ray view fold, 2 = level 1 + density_decoder folded into 1-channel planes (bake_density: Linear(48,1) commutes with
+        # bilinear interpolation, fp64 accumulate at pack time, |d sigma| <= 2e-6 relative), 3 = level 2 + layer 1 folded into 64-channel
+        # pre-activation planes (bake_color) -- both halves of SURVEY section 7's fold (iii).  LEVEL 3 IS THE DEFAULT since round 4 (its
+        # gather became quad-coalesced: 87 -> 142 Mray/s on the R1 frame, level 2: 83).  Every level is parity-tested against the oracle and
+        # the reference's golden pixels with the same tolerances; bake_color=False gives level 2, bake_density=False level 1.
         # bake_density=None (the default) resolves to level 2 unless the un-composed level 0 is asked for: NGF_F_NO_FOLD excludes the
         # NGF_F_BAKE_* flags (ngf_field_create rejects the combination), so TriPlane(..., no_fold=True) alone must give level 0.
         self.no_fold = bool(no_fold)                # NGF_F_NO_FOLD (TriPlane): rgb_decoder exactly as written, for measurements
         if self.no_fold and (bake_density or bake_color):
             raise ValueError("no_fold=True is the un-composed formulation (level 0): it excludes bake_density / bake_color")
         self.bake_density = (not self.no_fold) if bake_density is None else bool(bake_density)      # NGF_F_BAKE_DENSITY (TriPlane)
-        self.bake_color = bool(bake_color)          # NGF_F_BAKE_COLOR (TriPlane)
+        # NGF_F_BAKE_COLOR (TriPlane): on by default where it applies -- on top of the baked density, and not with the bf16 split (which works
+        # on the pre-composed layer 1, ngf_field_create rejects the combination)
+        self.bake_color = (self.bake_density and not self.no_fold and not bool(split_bf16)) if bake_color is None else bool(bake_color)
         self.split_bf16 = bool(split_bf16)          # NGF_F_SPLIT_BF16 (TriPlane): colour MLP on bf16 MFMA with 3-term split operands
         self._handle = None
         self._handle_key = None

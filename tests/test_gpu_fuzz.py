@@ -51,15 +51,18 @@ def _case(k):
     return g, params, mask, rays, S, bool(u[15] < 0.6)
 
 
-@pytest.mark.parametrize("split_bf16", [False, True])
+@pytest.mark.parametrize("variant", ["level1", "split_bf16", "level3"])
 @pytest.mark.parametrize("k", range(24))
-def test_random_configuration_matches_oracle(k, split_bf16):
-    """split_bf16 = True: the same sweep through NGF_F_SPLIT_BF16 (colour MLP on the bf16 matrix pipe with 3-term split operands,
-    csrc/ngf_shade_bf16.hpp / ngf_infoinv.hpp) -- same oracle, same tolerances, same threshold-adjacency rule."""
+def test_random_configuration_matches_oracle(k, variant):
+    """split_bf16: the same sweep through NGF_F_SPLIT_BF16 (colour MLP on the bf16 matrix pipe with 3-term split operands,
+    csrc/ngf_shade_bf16.hpp / ngf_infoinv.hpp); level3: through the module's default since round 4 (density_decoder and layer 1 folded into
+    the planes, quad-coalesced gather, 12-float queue records) -- same oracle, same tolerances, same threshold-adjacency rule."""
     g, params, mask, rays, S, white = _case(k)
     step = geometry.step_size(g["aabb"], [int(v) for v in g["grid"]], float(g["step_ratio"]))
     orc = oracle_for_case(g, params, step, mask)
-    f = field_for_case(g, params, mask, split_bf16=split_bf16)
+    if variant == "level3" and str(g["model"]) != "triplane":
+        pytest.skip("levels are a TriPlane option")
+    f = field_for_case(g, params, mask, split_bf16=variant == "split_bf16", bake=variant == "level3", bake_color=variant == "level3")
     kw = {"iteration": 30001 if int(g["gauge_on"]) else -1} if str(g["model"]) == "triplane" else {"infoinv": bool(int(g["infoinv"]))}
     if str(g["model"]) == "triplane":
         f.gauge_start = 0

@@ -593,14 +593,16 @@ def test_bench_default_line_is_parseable_with_extras():
     assert set(d["extras_Mray_s"]) <= set(side["extras"])
 
 
-def test_full_frame_properties():
-    """BASELINE config 2 at full size (800x800, S=192, R1): size-independent properties + a strided oracle check."""
+@pytest.mark.parametrize("level", [1, 3])
+def test_full_frame_properties(level):
+    """BASELINE config 2 at full size (800x800, S=192, R1): size-independent properties + a strided oracle check -- at level 1 and at level 3,
+    the module's default since round 4 (what bench.py's headline runs)."""
     from ngf_amd import synth
     g, params, step = big_case("triplane", "R1")
     g["gauge_on"] = np.array(1)
     rays_np = synth.lookat_rays(800, 800)
     rays = torch.from_numpy(rays_np).cuda()
-    f = field_for_case(g, params, None)
+    f = field_for_case(g, params, None, bake=level == 3, bake_color=level == 3)
     full = f(rays, N_samples=192, white_bg=True, iteration=30001, collect_stats=True)
     st = f.last_stats.cpu().numpy()
     assert st[3] == 640000 and 0.2 < st[1] / (640000 * 192) < 0.3          # active fraction of preset R1 (SURVEY 8 D2: 0.235)

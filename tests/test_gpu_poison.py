@@ -81,7 +81,10 @@ def test_fuzz_and_train_under_poison(poisoned):
     import test_gpu_fuzz as tf
     import test_gpu_train as tt
     for k in (1, 4, 9):
-        tf.test_random_configuration_matches_oracle(k, False)
-        tf.test_random_configuration_matches_oracle(k, True)
+        for variant in ("level1", "split_bf16", "level3"):
+            try:
+                tf.test_random_configuration_matches_oracle(k, variant)
+            except pytest.skip.Exception:
+                pass
     tt.test_gradients_match_autograd_oracle(0)
     tt.test_edge_batches_match_autograd_oracle("triplane_r1_mask", 203, 45)

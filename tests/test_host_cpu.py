@@ -230,11 +230,15 @@ def test_optimisation_level_flags_resolve_in_the_constructor():
     aabb = torch.tensor([[-1.5] * 3, [1.5] * 3])
     mk = lambda **kw: triplane.TriPlane(aabb, [16, 16, 16], "cpu", **kw)
     f = mk()
-    assert f.bake_density and not f.no_fold and not f.bake_color                 # level 2
+    assert f.bake_density and f.bake_color and not f.no_fold                     # level 3: the default since round 4
+    f = mk(bake_color=False)
+    assert f.bake_density and not f.bake_color                                   # level 2
     f = mk(no_fold=True)
     assert f.no_fold and not f.bake_density and not f.bake_color                 # level 0
     f = mk(bake_density=False)
-    assert not f.bake_density and not f.no_fold                                  # level 1
+    assert not f.bake_density and not f.bake_color and not f.no_fold             # level 1
+    f = mk(split_bf16=True)
+    assert f.bake_density and not f.bake_color and f.split_bf16                  # the bf16 split works on level 2
     f = mk(bake_color=True)
     assert f.bake_density and f.bake_color                                       # level 3
     for bad in (dict(no_fold=True, bake_density=True), dict(no_fold=True, bake_color=True)):
