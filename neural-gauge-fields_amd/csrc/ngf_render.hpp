@@ -685,10 +685,27 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                         const f32x4 vb = *reinterpret_cast<const f32x4 *>(res + 3 * BATCH + 4 * q);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
+#ifndef NGF_COLLECT_SELECT
+                            // the entry's owner lane alone adds it: v_cmpx narrows EXEC to that lane, three v_add_f32 run under it, EXEC comes back
+                            // (4 VALU instructions per entry; written in C++ -- `if (id == lane) cr += v` -- hipcc if-converts it into three adds +
+                            // three selects, and the select + FMA form below is a compare, a select, a packed FMA, an FMA and two moves).  Same sums:
+                            // `cr + v` in the owner lane, untouched elsewhere (the FMA form added 0 * v = +0 there).
+                            unsigned long long save;
+                            asm volatile("s_mov_b64 %3, exec\n\t"
+                                         "v_cmpx_eq_u32_e32 vcc, %4, %5\n\t"
+                                         "v_add_f32_e32 %0, %0, %6\n\t"
+                                         "v_add_f32_e32 %1, %1, %7\n\t"
+                                         "v_add_f32_e32 %2, %2, %8\n\t"
+                                         "s_mov_b64 exec, %3"
+                                         : "+v"(cr), "+v"(cg), "+v"(cb), "=&s"(save)
+                                         : "v"(id[e]), "v"(lane), "v"(vr[e]), "v"(vg[e]), "v"(vb[e])
+                                         : "vcc");
+#else
                             const float m = __float_as_int(id[e]) == lane ? 1.0f : 0.0f;
                             cr = fmaf(m, vr[e], cr);
                             cg = fmaf(m, vg[e], cg);
                             cb = fmaf(m, vb[e], cb);
+#endif
                         }
                     }
                 }
