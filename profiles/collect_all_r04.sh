@@ -40,5 +40,6 @@ if [ "$1" != quick ]; then
 fi
 # launch size vs time of the product library (level 2): the table VERDICT r3 asked for (4 096 / 40 000 / 80 000 / 160 000 / 640 000 rays), InfoInv beside it
 python profiles/exp_launch_size.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_shard_latency.txt
+LEVEL=2 python profiles/exp_launch_size.py 2>&1 | grep -v amdgpu.ids >> gpurun_out/r04_shard_latency.txt
 MODEL=infoinv python profiles/exp_launch_size.py 2>&1 | grep -v amdgpu.ids >> gpurun_out/r04_shard_latency.txt
 ls gpurun_out | grep r04_ | head -80

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Launch size vs time of the product library (level 2, the module default): contiguous row blocks of the 800x800 R1 frame, S = 192.
+"""Launch size vs time of the product library (LEVEL=3, the module default since round 4; LEVEL=2: round 3's): contiguous row blocks of the 800x800 R1 frame, S = 192.
 4 096 rays = the reference's chunk / training batch (TriPlane/main.py:94,272), 80 000 rays = one rank's shard of an 8-GPU frame.
 TILES="auto 4 8" sweeps the tile-width knob next to the library's own choice.  Output: profiles/r04_shard_latency.txt"""
 import os, sys
@@ -14,9 +14,10 @@ from ngf_amd.cases import big_case, field_for_case
 import hashlib
 model = os.environ.get("MODEL", "triplane")
 g, params, step = big_case(model, "R1")
-f = field_for_case(g, params, None, device="cuda", bake=True)
+LEVEL = int(os.environ.get("LEVEL", "3"))          # 3 = the module default since round 4; 2 = round 3's
+f = field_for_case(g, params, None, device="cuda", bake=True, bake_color=LEVEL >= 3)
 kw = dict(iteration=30001) if model == "triplane" else dict(infoinv=True)
-print(f"library sha256 {hashlib.sha256(open(_lib.SO_PATH,'rb').read()).hexdigest()[:16]}  model {model} level 2  S=192  {torch.cuda.get_device_name(0)}")
+print(f"library sha256 {hashlib.sha256(open(_lib.SO_PATH,'rb').read()).hexdigest()[:16]}  model {model} level {LEVEL if model == 'triplane' else '-'}  S=192  {torch.cuda.get_device_name(0)}")
 full = torch.from_numpy(synth.lookat_rays(800, 800)).cuda()
 ref = f(full, N_samples=192, **kw)
 if os.environ.get("TAIL"):          # narrow tiles per resident wave and width, x 16 (launch_render's tile plan); unset = the library's default
