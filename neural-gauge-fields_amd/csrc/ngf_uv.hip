@@ -44,6 +44,7 @@ struct UvPacker {
                     }
         return off;
     }
+    // output layer with <= 3 units: [KT / 4][64 lanes][4] -- a lane's A operands of four k-steps in one 16-byte load (dense_out)
     template <typename F>
     int out_layer(const std::vector<float> &W, int out_f, int in_f, int KT, F imap)
     {
@@ -52,7 +53,7 @@ struct UvPacker {
         for (int t = 0; t < KT; ++t)
             for (int l = 0; l < 64; ++l) {
                 const int o = l & 15, i = imap(t, l >> 4);
-                buf[off + (size_t)t * 64 + l] = (o < out_f && i >= 0 && i < in_f) ? W[(size_t)o * in_f + i] : 0.0f;
+                buf[off + ((size_t)(t >> 2) * 64 + l) * 4 + (t & 3)] = (o < out_f && i >= 0 && i < in_f) ? W[(size_t)o * in_f + i] : 0.0f;
             }
         return off;
     }

@@ -21,6 +21,22 @@ namespace ngf {
 
 #define NGF_UV_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// EXPERIMENT builds (make expuv; profiles/exp_uv_sections.py): -DNGF_EXP_UV_SECTIONS accumulates a wave's cycles per code section (s_memtime at the
+// section boundaries, never inside the k loop) into UvArgs::stats[2 + i]; -DNGF_EXP_UV_SAMEW lets every 256 -> 256 layer read the weights of geometry
+// layer 0 (wrong pixels, same instruction stream: what the launch costs when the weight set fits one XCD's L2).  Neither is in the product library.
+#ifdef NGF_EXP_UV_SECTIONS
+struct UvSec { unsigned long long t[8]; };
+#define NGF_UVSEC_PARAM , UvSec &uvsec
+#define NGF_UVSEC_ARG , uvsec
+#define NGF_UVSEC_T(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
+#define NGF_UVSEC_ADD(i, a, b) uvsec.t[i] += (b) - (a)
+#else
+#define NGF_UVSEC_PARAM
+#define NGF_UVSEC_ARG
+#define NGF_UVSEC_T(var)
+#define NGF_UVSEC_ADD(i, a, b)
+#endif
+
 struct UvArgs {
     const float *raydir;   // [R,3]
     const float *U;        // [R,S] jitter uniforms
@@ -245,8 +261,9 @@ __device__ __forceinline__ void kstep_fused(const KStepA<NT, NS> &k, f32x4 acc[N
 // two k-steps of weight loads in flight behind the MFMAs (the un-pipelined loop left the waves 67 % of their cycles
 // in s_waitcnt with the matrix pipe 31 % busy: latency-, not bandwidth-bound).
 template <int NT_OUT, int NS>
-__device__ __forceinline__ void dense(const float *w, const float *bias, int KT4, int lane, const float *act, f32x4 out[NS][NT_OUT])
+__device__ __forceinline__ void dense(const float *w, const float *bias, int KT4, int lane, const float *act, f32x4 out[NS][NT_OUT] NGF_UVSEC_PARAM)
 {
+    NGF_UVSEC_T(ts0);
     load_bias<NT_OUT, NS>(bias, lane >> 4, out);
     if constexpr (NS == 1) {
         KStepA<NT_OUT, NS> k0, k1, k2, k3;
@@ -276,6 +293,11 @@ __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4
         KStepA<NT_OUT, NS> a0, a1, a2, a3, b0, b1, b2, b3;
         kload<NT_OUT, NS>(w, act, 0, lane, a0); kload<NT_OUT, NS>(w, act, 1, lane, a1);
         kload<NT_OUT, NS>(w, act, 2, lane, a2); kload<NT_OUT, NS>(w, act, 3, lane, a3);
+#ifdef NGF_EXP_UV_SECTIONS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // section 0 = bias + the first four k-steps of weights ARRIVED (the layer's uncovered latency)
+#endif
+        NGF_UVSEC_T(ts1);
+        NGF_UVSEC_ADD(0, ts0, ts1);
 #pragma unroll 1
         for (int t = 0; t < KT4; t += 8) {
             const bool has_b = t + 4 < KT4;
@@ -304,6 +326,11 @@ __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        NGF_UVSEC_T(ts2);
+        NGF_UVSEC_ADD(1, ts1, ts2);          // section 1 = the k loop (KT4 / 4 x 128 MFMAs at NT_OUT = 16)
+#ifdef NGF_EXP_UV_SECTIONS
+        uvsec.t[6] += (unsigned long long)(KT4 * (NT_OUT * NS));     // MFMAs issued by the loops of section 1
+#endif
     }
 }
 
@@ -395,10 +422,10 @@ __device__ __forceinline__ void dense_bf16(const float *wq, const float *bias, i
 // a 256-unit layer on KT4 fp32 k-steps or (split mode) KT4 / 8 bf16 k-blocks; wq: the layer's packed bf16 weights (split mode)
 template <int NS, bool SPLIT>
 __device__ __forceinline__ void dense256(const UvArgs &A, const float *w, const float *wq, const float *bias, int KT4, int lane, const float *act,
-                                         f32x4 out[NS][16])
+                                         f32x4 out[NS][16] NGF_UVSEC_PARAM)
 {
     if constexpr (SPLIT) dense_bf16<NS>(wq, bias, (KT4 + 7) / 8, lane, act, out);
-    else dense<16, NS>(w, bias, KT4, lane, act, out);
+    else dense<16, NS>(w, bias, KT4, lane, act, out NGF_UVSEC_ARG);
 }
 
 template <int NT, int NS, int LEAKY>
@@ -412,55 +439,143 @@ __device__ __forceinline__ void store_act(float *act, int lane, const f32x4 acc[
             for (int r = 0; r < 4; ++r) act[s * kUvWaveLds + (mt * 4 + r) * 64 + lane] = act_fn<LEAKY>(acc[s][mt][r]);
 }
 
-// output layer with <= 3 units: packed [t][64 lanes] (rows >= n_out are zero); rows 0..3 land in lanes kq = 0
-template <int NS>
-__device__ __forceinline__ void dense_out(const float *w, const float *bias4, int KT, int lane, const float *act, f32x4 r[NS])
+// Output layer with <= 3 units on the matrix pipe (rows >= n_out of the 16-row tile are zero; rows 0..3 land in the lanes of quarter kq = 0).
+// Packed [KT / 4][64 lanes][4]: one 16-byte load per lane holds its A operands of four k-steps.  Round 4: the weights are requested BEFORE the
+// previous layer's activations are stored (out_prefetch: their L2 latency hides behind store_act) and the KT MFMAs of a tile run as two independent
+// chains over fully unrolled k-steps.  Rounds 1-3 ran `for t: load w[t]; MFMA` with one dependent chain per tile: a latency-bound loop of ~150 cycles
+// per MFMA, 4.6 % of a wave's life for 1 % of its matrix work (profiles/r04_uv_sections.txt).
+template <int KT>
+struct UvOutW { f32x4 w[KT / 4]; };
+
+template <int KT>
+__device__ __forceinline__ void out_prefetch(const float *w, int lane, UvOutW<KT> &o)
 {
-    f32x4 acc[NS];
+    const f32x4 *wp = reinterpret_cast<const f32x4 *>(w) + lane;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 4
-    for (int t = 0; t < KT; ++t) {
-        const float wv = w[t * 64 + lane];
+    for (int q = 0; q < KT / 4; ++q) o.w[q] = wp[q * 64];
+}
+
+template <int NS, int KT>
+__device__ __forceinline__ void dense_out(const UvOutW<KT> &o, const float *bias4, int lane, const float *act, f32x4 r[NS])
+{
+    f32x4 acc[NS][2];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) acc[s] = NGF_UV_MFMA(wv, act[s * kUvWaveLds + t * 64 + lane], acc[s]);
+    for (int s = 0; s < NS; ++s) acc[s][0] = acc[s][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // the B operands of four k-steps are read one group ahead of their MFMAs (sched_barrier pins it: left alone hipcc hoists all 2 KT LDS reads and spills)
+    float bq[2][NS][4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[0][s][e] = act[s * kUvWaveLds + e * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < KT / 4; ++q) {
+        if (q + 1 < KT / 4) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bq[(q + 1) & 1][s][e] = act[s * kUvWaveLds + (4 * (q + 1) + e) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s][e & 1] = NGF_UV_MFMA(o.w[q][e], bq[q & 1][s][e], acc[s][e & 1]);
+        __builtin_amdgcn_sched_barrier(0);
     }
     const int src = lane & 15;
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[s][e] = __shfl(acc[s][e], src) + bias4[e];
+        for (int e = 0; e < 4; ++e) r[s][e] = __shfl(acc[s][0][e] + acc[s][1][e], src) + bias4[e];
 }
 
-// positional-encoding inputs [x(D), sin(D*F), cos(D*F)] (util.py:427-438): lane-quarter kq supplies entry 4t + kq
+// Program-order point for the wave's LDS traffic: an IR-level fence (no instruction at wavefront scope), a compiler memory barrier and a
+// scheduling barrier for the machine scheduler.  The hardware needs nothing: a wave's LDS instructions execute in order.
+__device__ __forceinline__ void uv_lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Positional-encoding inputs [x(D), sin(x_d 2^f) (d-major: D*F values), cos(same)] (util.py:427-438) as B operands: entry f lives in row
+// t0 + (f >> 2) of the activation array, lane quarter f & 3 of its sample; entries past D + 2 D F up to the layer's 4 KT inputs are zero.
+// ONE sincos per (dimension, frequency) pair: lane (s, kq) takes the pairs g = kq, kq + 4, ... of its sample and writes the sine to entry D + g and
+// the cosine to entry D + D F + g -- slots of OTHER lane quarters of the same sample, read back after the wave-level fence below (the LDS queue of
+// a wave is in order).  Rounds 1-3: every lane evaluated a sincos for each of its own 16 entries and kept one of the two results (2.75 % of a wave's
+// life, profiles/r04_uv_sections.txt).  t0b >= 0: a second copy at rows t0b.. (the geometry and the gauge network both start from PE10(p): the
+// gauge's first layer reads the copy in rows 64..79, which the geometry network never touches).
 // (the three coordinates by value: as an array in memory the compiler turns the selects below into indexed loads and the array into
 // scratch -- 128 bytes per lane in rounds 1 and 2)
-template <int D, int F>
-__device__ __forceinline__ float pe_entry(float x0, float x1, float x2, int f)
+template <int D, int F, int NS>
+__device__ __forceinline__ void store_pe(float *act, int t0, int KT, int lane, const float x[NS][3], int t0b = -1)
 {
     constexpr int N = D * F;
-    if (f >= D + 2 * N) return 0.0f;
-    const int g = f - D;
-    const int gi = g < 0 ? 0 : (g >= N ? g - N : g);
-    const int dim = gi / F, fr = gi - dim * F;
-    const float xd = dim == 0 ? x0 : (dim == 1 ? x1 : x2);
-    const float arg = xd * (float)(1 << fr);
-    float s, c;
-    sincos_small(arg, s, c);
-    const float raw = f == 0 ? x0 : (f == 1 ? x1 : x2);
-    return f < D ? raw : (g < N ? s : c);
-}
-
-template <int D, int F, int NS>
-__device__ __forceinline__ void store_pe(float *act, int t0, int KT, int lane, const float x[NS][3])
-{
+    static_assert((2 * N) % 4 == 0, "the raw / padding entries are dealt out four at a time");
     const int kq = lane >> 4;
+    // The writes below land in slots that OTHER lanes read (before: the previous consumer of these rows; after: the next layer).  In one thread's
+    // view they alias none of its own reads, so these barriers are what keeps a wave-wide ds_write on its side of a wave-wide ds_read.
+    uv_lds_order();
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const float x0 = x[s][0], x1 = x[s][1], x2 = x[s][2];
+        float *a = act + s * kUvWaveLds + (lane & 15);
+        auto put = [&](int f, float v) {
+            a[(t0 + (f >> 2)) * 64 + (f & 3) * 16] = v;
+            if (t0b >= 0) a[(t0b + (f >> 2)) * 64 + (f & 3) * 16] = v;
+        };
+        // the entries that are neither sine nor cosine -- the D coordinates and the zero padding past D + 2 N -- are 4 KT - 2 N in number, a multiple
+        // of four: lane quarter kq takes the (kq + 4 i)-th of them
+        const int npad4 = KT - N / 2;
 #pragma unroll 1
-        for (int t = 0; t < KT; ++t) act[s * kUvWaveLds + (t0 + t) * 64 + lane] = pe_entry<D, F>(x0, x1, x2, 4 * t + kq);
+        for (int i = 0; i < npad4; ++i) {
+            const int j = kq + 4 * i;
+            const float raw = j == 0 ? x0 : (j == 1 ? x1 : x2);
+            put(j < D ? j : 2 * N + j, j < D ? raw : 0.0f);
+        }
+        // NO lane-dependent control flow in this function: uniform trip counts, and a lane quarter that runs out of pairs repeats its last one (same
+        // values to the same slots).  Round 4's first version looped `for (g = kq; g < N; g += 4)` -- EXEC-masked loops in a kernel that runs at 512
+        // registers with AGPR spill code around them -- and, TOGETHER with 64 more live registers elsewhere in the pass, gave wrong densities in 17 % of
+        // the samples of the split kernel (or in 8 samples of the fp32 kernel, depending on the build), deterministically, while each change alone
+        // passed every test.  The cause below the source was not found; the kernel keeps the property rounds 1-3 had by
+        // accident: no divergent control flow between the ray set-up and the compositing.
+#pragma unroll 1
+        for (int i = 0; i < (N + 3) / 4; ++i) {
+            int g = kq + 4 * i;
+            g = g < N ? g : g - 4;
+            const int dim = g / F, fr = g - dim * F;
+            const float xd = dim == 0 ? x0 : (dim == 1 ? x1 : x2);
+            float sn, cs;
+            sincos_small(xd * (float)(1 << fr), sn, cs);
+            put(D + g, sn);
+            put(D + N + g, cs);
+        }
     }
+    uv_lds_order();
+}
+
+// A run of n 256 -> 256 layers (weights w + l * 65536, split images wq + l * kUvQLayer, biases b + l * 256) followed by an output layer with <= 3
+// units, whose weights (w_out) are requested here.  (Requested one step earlier -- between the last layer's MFMAs and its activation store, a peeled
+// last iteration -- they would be covered by the store's ~1.8 k cycles; measured: 0.2 % SLOWER, 64 more live registers and 30 % more code.)
+#ifdef NGF_EXP_UV_SAMEW
+constexpr size_t kUvLayerStride = 0;          // every layer of a run reads the run's first weights (timing experiment, wrong pixels)
+#else
+constexpr size_t kUvLayerStride = 65536;
+#endif
+template <int NS, bool SPLIT, int LEAKY>
+__device__ __forceinline__ void hidden_run(const UvArgs &A, const float *w, const float *wq, const float *b, int n, int lane, float *act, f32x4 x[NS][16],
+                                           const float *w_out, UvOutW<64> &ow NGF_UVSEC_PARAM)
+{
+#pragma unroll 1
+    for (int l = 0; l < n; ++l) {
+        dense256<NS, SPLIT>(A, w + (size_t)l * kUvLayerStride, wq + (size_t)l * kUvQLayer, b + l * 256, 64, lane, act, x NGF_UVSEC_ARG);
+        NGF_UVSEC_T(u0);
+        store_act<16, NS, LEAKY>(act, lane, x);
+        NGF_UVSEC_T(u1);
+        NGF_UVSEC_ADD(2, u0, u1);
+    }
+    out_prefetch<64>(w_out, lane, ow);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---- the three networks for NS x 16 samples -----------------------------------------------------------------------------
@@ -468,40 +583,50 @@ __device__ __forceinline__ void store_pe(float *act, int t0, int KT, int lane, c
 // sample).
 template <int NS, bool SPLIT>
 __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lane, const float p[NS][3], const float v[NS][3], float sigma[NS],
-                                            float col[NS][3])
+                                            float col[NS][3] NGF_UVSEC_PARAM)
 {
-    const float *W = A.w;
+    // (the weight base plus an opaque zero and the lane id behind an opaque asm, once per pass: otherwise hipcc forms the ~60 per-layer weight / bias addresses of the
+    // lane ONCE, outside the persistent ray loop, and parks them in scratch -- 143 spilled dwords, reloaded in front of every layer)
+    // (an opaque ZERO OFFSET, not an opaque pointer: behind the asm a pointer loses its address space and every weight load becomes a flat_load,
+    // which counts on both memory counters -- the k loop then waits vmcnt(0) lgkmcnt(0) once per trip: 34.3 -> 37.2 cycles per MFMA, measured)
+    int wz = 0;
+    asm volatile("" : "+s"(wz), "+v"(lane));
+    const float *W = A.w + wz;
+#ifdef NGF_EXP_UV_SAMEW
+#define NGF_UV_SAME(x) A.geo_wh
+#else
+#define NGF_UV_SAME(x) (x)
+#endif
     f32x4 x[NS][16];
-    // geometry: 63 -> 256 -> (10x) 256 -> 1, ReLU
-    store_pe<3, 10, NS>(act, 0, 16, lane, p);
-    dense<16, NS>(W + A.geo_w0, W + A.geo_b0, 16, lane, act, x);
-    store_act<16, NS, 0>(act, lane, x);
-#pragma unroll 1
-    for (int l = 0; l < 10; ++l) {
-        dense256<NS, SPLIT>(A, W + A.geo_wh + (size_t)l * 65536, W + A.geo_qh + (size_t)l * kUvQLayer, W + A.geo_bh + l * 256, 64, lane, act, x);
-        store_act<16, NS, 0>(act, lane, x);
-    }
+    // geometry: 63 -> 256 -> (10x) 256 -> 1, ReLU.  PE10(p) goes to rows 0..15 AND to rows 64..79, where the gauge network finds it later
+    { NGF_UVSEC_T(u11a); store_pe<3, 10, NS>(act, 0, 16, lane, p, 64); NGF_UVSEC_T(u11b); NGF_UVSEC_ADD(3, u11a, u11b); }
+    dense<16, NS>(W + A.geo_w0, W + A.geo_b0, 16, lane, act, x NGF_UVSEC_ARG);
+    { NGF_UVSEC_T(u1a); store_act<16, NS, 0>(act, lane, x); NGF_UVSEC_T(u1b); NGF_UVSEC_ADD(2, u1a, u1b); }
     {
+        UvOutW<64> ow;
+        hidden_run<NS, SPLIT, 0>(A, W + A.geo_wh, W + A.geo_qh, W + A.geo_bh, 10, lane, act, x, W + A.geo_wo, ow NGF_UVSEC_ARG);
         f32x4 o[NS];
-        dense_out<NS>(W + A.geo_wo, W + A.geo_bo, 64, lane, act, o);
+        { NGF_UVSEC_T(u16a); dense_out<NS, 64>(ow, W + A.geo_bo, lane, act, o); NGF_UVSEC_T(u16b); NGF_UVSEC_ADD(4, u16a, u16b); }
 #pragma unroll
         for (int s = 0; s < NS; ++s) sigma[s] = o[s][0] > 20.0f ? o[s][0] : log1pf(expf(o[s][0]));
     }
-    // gauge: 63 -> 64 -> 128 -> 128 -> 128 -> 3|2, ReLU
+    // gauge: 63 -> 64 -> 128 -> 128 -> 128 -> 3|2, ReLU (first layer on the copy of PE10(p) in rows 64..79)
     float uv[NS][3];
     {
         f32x4 g4[NS][4], g[NS][8];
-        store_pe<3, 10, NS>(act, 0, 16, lane, p);
-        dense<4, NS>(W + A.ga_w0, W + A.ga_b0, 16, lane, act, g4);
-        store_act<4, NS, 0>(act, lane, g4);
-        dense<8, NS>(W + A.ga_w1, W + A.ga_b1, 16, lane, act, g);
-        store_act<8, NS, 0>(act, lane, g);
-        dense<8, NS>(W + A.ga_w2, W + A.ga_b2, 32, lane, act, g);
-        store_act<8, NS, 0>(act, lane, g);
-        dense<8, NS>(W + A.ga_w3, W + A.ga_b3, 32, lane, act, g);
-        store_act<8, NS, 0>(act, lane, g);
+        dense<4, NS>(W + A.ga_w0, W + A.ga_b0, 16, lane, act + 64 * 64, g4 NGF_UVSEC_ARG);
+        { NGF_UVSEC_T(u3a); store_act<4, NS, 0>(act, lane, g4); NGF_UVSEC_T(u3b); NGF_UVSEC_ADD(2, u3a, u3b); }
+        dense<8, NS>(W + A.ga_w1, W + A.ga_b1, 16, lane, act, g NGF_UVSEC_ARG);
+        { NGF_UVSEC_T(u4a); store_act<8, NS, 0>(act, lane, g); NGF_UVSEC_T(u4b); NGF_UVSEC_ADD(2, u4a, u4b); }
+        dense<8, NS>(W + A.ga_w2, W + A.ga_b2, 32, lane, act, g NGF_UVSEC_ARG);
+        { NGF_UVSEC_T(u5a); store_act<8, NS, 0>(act, lane, g); NGF_UVSEC_T(u5b); NGF_UVSEC_ADD(2, u5a, u5b); }
+        dense<8, NS>(W + A.ga_w3, W + A.ga_b3, 32, lane, act, g NGF_UVSEC_ARG);
+        { NGF_UVSEC_T(u6a); store_act<8, NS, 0>(act, lane, g); NGF_UVSEC_T(u6b); NGF_UVSEC_ADD(2, u6a, u6b); }
+        UvOutW<32> ow;
+        out_prefetch<32>(W + A.ga_wo, lane, ow);
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 q[NS];
-        dense_out<NS>(W + A.ga_wo, W + A.ga_bo, 32, lane, act, q);
+        { NGF_UVSEC_T(u17a); dense_out<NS, 32>(ow, W + A.ga_bo, lane, act, q); NGF_UVSEC_T(u17b); NGF_UVSEC_ADD(4, u17a, u17b); }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (A.sphere) {
@@ -515,31 +640,29 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     }
     // texture block1: (63|42) -> 256 -> (5x) 256, LeakyReLU(0.2)
     if (A.sphere) {
-        store_pe<3, 10, NS>(act, 0, 16, lane, uv);
-        dense<16, NS>(W + A.t1_w0, W + A.t1_b0, 16, lane, act, x);
+        { NGF_UVSEC_T(u13a); store_pe<3, 10, NS>(act, 0, 16, lane, uv); NGF_UVSEC_T(u13b); NGF_UVSEC_ADD(3, u13a, u13b); }
+        dense<16, NS>(W + A.t1_w0, W + A.t1_b0, 16, lane, act, x NGF_UVSEC_ARG);
     } else {
-        store_pe<2, 10, NS>(act, 0, 12, lane, uv);
-        dense<16, NS>(W + A.t1_w0, W + A.t1_b0, 12, lane, act, x);
+        { NGF_UVSEC_T(u14a); store_pe<2, 10, NS>(act, 0, 12, lane, uv); NGF_UVSEC_T(u14b); NGF_UVSEC_ADD(3, u14a, u14b); }
+        dense<16, NS>(W + A.t1_w0, W + A.t1_b0, 12, lane, act, x NGF_UVSEC_ARG);
     }
-    store_act<16, NS, 1>(act, lane, x);
-#pragma unroll 1
-    for (int l = 0; l < 5; ++l) {
-        dense256<NS, SPLIT>(A, W + A.t1_wh + (size_t)l * 65536, W + A.t1_qh + (size_t)l * kUvQLayer, W + A.t1_bh + l * 256, 64, lane, act, x);
-        store_act<16, NS, 1>(act, lane, x);
-    }
+    { NGF_UVSEC_T(u7a); store_act<16, NS, 1>(act, lane, x); NGF_UVSEC_T(u7b); NGF_UVSEC_ADD(2, u7a, u7b); }
     // act[0..63] = block1 output h; color1 and block2 both read it
     f32x4 c1[NS], c2[NS];
-    dense_out<NS>(W + A.c1_w, W + A.c1_b, 64, lane, act, c1);
-    // block2: [h(256), v(3), PE6(v)(36)] -> 256 -> (3x) 256 -> 3
-    store_pe<3, 6, NS>(act, 64, 12, lane, v);                 // 39 inputs + zero padding up to k-step 76
-    dense256<NS, SPLIT>(A, W + A.t2_w0, W + A.t2_q0, W + A.t2_b0, 76, lane, act, x);            // 76 k-steps -> 10 k-blocks in split mode (act rows 76..79 are zero)
-    store_act<16, NS, 1>(act, lane, x);
-#pragma unroll 1
-    for (int l = 0; l < 3; ++l) {
-        dense256<NS, SPLIT>(A, W + A.t2_wh + (size_t)l * 65536, W + A.t2_qh + (size_t)l * kUvQLayer, W + A.t2_bh + l * 256, 64, lane, act, x);
-        store_act<16, NS, 1>(act, lane, x);
+    {
+        UvOutW<64> ow;
+        hidden_run<NS, SPLIT, 1>(A, W + NGF_UV_SAME(A.t1_wh), W + A.t1_qh, W + A.t1_bh, 5, lane, act, x, W + A.c1_w, ow NGF_UVSEC_ARG);
+        { NGF_UVSEC_T(u18a); dense_out<NS, 64>(ow, W + A.c1_b, lane, act, c1); NGF_UVSEC_T(u18b); NGF_UVSEC_ADD(4, u18a, u18b); }
     }
-    dense_out<NS>(W + A.t2_wo, W + A.t2_bo, 64, lane, act, c2);
+    // block2: [h(256), v(3), PE6(v)(36)] -> 256 -> (3x) 256 -> 3
+    { NGF_UVSEC_T(u15a); store_pe<3, 6, NS>(act, 64, 12, lane, v); NGF_UVSEC_T(u15b); NGF_UVSEC_ADD(3, u15a, u15b); }                 // 39 inputs + zero padding up to k-step 76
+    dense256<NS, SPLIT>(A, W + A.t2_w0, W + A.t2_q0, W + A.t2_b0, 76, lane, act, x NGF_UVSEC_ARG);            // 76 k-steps -> 10 k-blocks in split mode (rows 76..79: zero weights on finite leftovers)
+    { NGF_UVSEC_T(u9a); store_act<16, NS, 1>(act, lane, x); NGF_UVSEC_T(u9b); NGF_UVSEC_ADD(2, u9a, u9b); }
+    {
+        UvOutW<64> ow;
+        hidden_run<NS, SPLIT, 1>(A, W + NGF_UV_SAME(A.t2_wh), W + A.t2_qh, W + A.t2_bh, 3, lane, act, x, W + A.t2_wo, ow NGF_UVSEC_ARG);
+        { NGF_UVSEC_T(u19a); dense_out<NS, 64>(ow, W + A.t2_bo, lane, act, c2); NGF_UVSEC_T(u19b); NGF_UVSEC_ADD(4, u19a, u19b); }
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         float orig[3];
@@ -572,6 +695,10 @@ __global__ void __launch_bounds__(512 / NS) uv_render_kernel(const UvArgs A)
             for (int t = 76; t < kUvActSteps; ++t) act[s * kUvWaveLds + t * 64 + lane] = 0.0f;
     }
     unsigned long long st_samples = 0, st_pass = 0;
+#ifdef NGF_EXP_UV_SECTIONS
+    UvSec uvsec = {{0, 0, 0, 0, 0, 0, 0, 0}};
+    const unsigned long long uv_t_begin = __builtin_readcyclecounter();
+#endif
     const float dt = (float)(2.0 / S), dtj = (float)((2.0 / S) * 0.05);     // renderer.py:107-117 (python floats)
     for (;;) {
         unsigned int ray0 = 0;
@@ -669,7 +796,10 @@ __global__ void __launch_bounds__(512 / NS) uv_render_kernel(const UvArgs A)
                     }
                 }
                 float sg[NS], cc[NS][3];
-                uv_networks<NS, SPLIT>(A, act, lane, q, vq, sg, cc);
+                NGF_UVSEC_T(un0);
+                uv_networks<NS, SPLIT>(A, act, lane, q, vq, sg, cc NGF_UVSEC_ARG);
+                NGF_UVSEC_T(un1);
+                NGF_UVSEC_ADD(5, un0, un1);          // section 5 = the three networks of a pass, everything included
                 // owners pull their result from lane slot (kq = 0 copy) of their tile
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
@@ -723,6 +853,10 @@ __global__ void __launch_bounds__(512 / NS) uv_render_kernel(const UvArgs A)
     if (A.stats && lane == 0) {
         atomicAdd(A.stats + 0, st_samples);
         atomicAdd(A.stats + 1, st_pass);
+#ifdef NGF_EXP_UV_SECTIONS
+        uvsec.t[7] = __builtin_readcyclecounter() - uv_t_begin;       // the wave's life
+        for (int k = 0; k < 8; ++k) atomicAdd(A.stats + 2 + k, uvsec.t[k]);
+#endif
     }
 }
 

@@ -190,7 +190,7 @@ class NeuTex(nn.Module):
         trans = torch.empty((N, R), device=dev)
         dbg_s = torch.zeros((N, R, S), device=dev) if debug else None
         dbg_c = torch.zeros((N, R, S, 3), device=dev) if debug else None
-        stats = torch.zeros(2, dtype=torch.int64, device=dev) if collect_stats else None
+        stats = torch.zeros(16, dtype=torch.int64, device=dev) if collect_stats else None
         h = self.handle()
         # camera positions / backgrounds travel as device tensors ([N,3] in HBM): no `.cpu()`, so a chunked caller (the reference
         # renders 1024 rays per call, UV-Mapping/test.py:108-114) never synchronises, and the N cameras of a batch are ONE launch
