@@ -38,6 +38,16 @@ namespace ngf {
 // segment): true for every kernel of this library (TrainArgs starts with its RenderArgs, static_assert in ngf_train.hpp), and CHECKED at
 // run time: alpha_kernel and the DBG instantiations of render_kernel (every test goes through them) trap when the descriptor read from the
 // kernarg segment is not the one in their `A`.
+// The compile-time half of that contract (round 4; the production instantiation of render_kernel carries no run-time check): every kernel whose
+// body reaches karg_tex asserts, through its OWN function type, that its first parameter is the RenderArgs (or a struct that starts with one).
+template <typename K> struct kernel_first_param;
+template <typename A0, typename... Rest> struct kernel_first_param<void (*)(A0, Rest...)> { typedef A0 type; };
+template <typename K, typename Args = RenderArgs>
+constexpr bool kernel_args_at_offset_0 = __is_same(typename kernel_first_param<K>::type, Args);
+#define NGF_KARG_CONTRACT(kernel_ptr_expr) NGF_KARG_CONTRACT_T(kernel_ptr_expr, RenderArgs)
+#define NGF_KARG_CONTRACT_T(kernel_ptr_expr, ArgsType) \
+    static_assert(kernel_args_at_offset_0<decltype(kernel_ptr_expr), ArgsType>, "karg_tex reads the RenderArgs at offset 0 of the kernel-argument segment: it must be this kernel's first parameter")
+
 __device__ __forceinline__ Tex karg_tex(size_t off)
 {
     typedef const __attribute__((address_space(4))) Tex *tptr_t;
@@ -405,6 +415,7 @@ template <typename P, bool SPLIT = false, bool DBG = true>
 __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs A)
 {
     static_assert(DBG || !P::PROFILE, "the section profile is a debug instantiation");
+    NGF_KARG_CONTRACT((&render_kernel<P, SPLIT, DBG>));
     if constexpr (DBG) {       // karg_tex reads offset 0 of the kernel-argument segment: trap if a future kernel passes its RenderArgs elsewhere
         if (karg_tex(offsetof(RenderArgs, dens)).p != A.dens[0].p) __builtin_trap();
     }
@@ -765,6 +776,7 @@ template <typename P>
 __global__ void __launch_bounds__(256) alpha_kernel(const RenderArgs A, const float *xyz, const Lattice L, int64_t n, float length, float *alpha)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    NGF_KARG_CONTRACT((&alpha_kernel<P>));
     if (karg_tex(offsetof(RenderArgs, dens)).p != A.dens[0].p) __builtin_trap();      // the RenderArgs must be the first kernel argument (karg_tex)
     if constexpr (P::INFOINV) {
         stage_blob(smem, A.blob, A.blob_floats);
@@ -901,6 +913,7 @@ __global__ void __launch_bounds__(256) decode_rgb_kernel(const RenderArgs A, con
                                                          int64_t n, float *out)
 {
     constexpr int BATCH = P::BATCH;
+    NGF_KARG_CONTRACT((&decode_rgb_kernel<P>));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     stage_blob(smem, A.blob, A.blob_floats);
     __syncthreads();

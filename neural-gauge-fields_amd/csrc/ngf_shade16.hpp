@@ -88,12 +88,27 @@ __device__ __forceinline__ void mlp_tail16(const float *blob, int oW2, int oB2, 
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) c[mt] = *reinterpret_cast<const f32x4 *>(blob + oB2 + kq * 16 + mt * 4);
     const float *w2 = blob + oW2 + lane;
+#ifndef NGF_EXP_RELU_INTERLEAVED
+    // all sixteen ReLUs first, then 64 matrix instructions in a row: hipcc's own order -- four MFMAs, the next input's v_max_i32, four MFMAs ... --
+    // switches the SIMD between its matrix and its vector pipe sixteen times per pass, and a switch costs the wave ~38 cycles
+    // (profiles/r02_micro_mfma_valu_overlap.txt: 32 x (MFMA + 2 FMA) take 71 cycles per MFMA instead of 33)
+    float h[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) h[t] = relu1(acc[t >> 2][t & 3]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) c[mt] = NGF_MFMA16(w2[(mt * 16 + t) * 64], h[t], c[mt]);
+    __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const float h = relu1(acc[t >> 2][t & 3]);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) c[mt] = NGF_MFMA16(w2[(mt * 16 + t) * 64], h, c[mt]);
     }
+#endif
     if (tk) { __builtin_amdgcn_sched_barrier(0); tk[4] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
     const float *w3 = blob + oW3 + kq * 16;
 #pragma unroll

@@ -183,6 +183,7 @@ __device__ __forceinline__ float softplus_pre(float u)          // F.softplus, t
 // ---- 1. density features of every (step, ray) pair ---------------------------------------------------------------------
 __global__ void __launch_bounds__(256) train_density_kernel(const TrainArgs T)
 {
+    NGF_KARG_CONTRACT_T(&train_density_kernel, TrainArgs);      // TrainArgs starts with its RenderArgs (static_assert above)
     const RenderArgs &A = T.R;
     const int64_t total = (int64_t)A.S * A.n;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -515,6 +516,7 @@ __global__ void __launch_bounds__(256) train_unfold_kernel(const TrainArgs T, fl
 // ---- 3. colour forward over the active list -------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kTrainWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) train_color_fwd_kernel(const TrainArgs T)
 {
+    NGF_KARG_CONTRACT_T(&train_color_fwd_kernel, TrainArgs);      // TrainArgs starts with its RenderArgs (static_assert above)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RenderArgs &A = T.R;
     for (int i = threadIdx.x; i < kFwdImage; i += blockDim.x) smem[i] = T.fwd_image[i];
@@ -734,6 +736,7 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
 // ---- 5. colour backward over the active list --------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kTrainWavesBwd * 64) __attribute__((amdgpu_waves_per_eu(1, 2))) train_color_bwd_kernel(const TrainArgs T)
 {
+    NGF_KARG_CONTRACT_T(&train_color_bwd_kernel, TrainArgs);      // TrainArgs starts with its RenderArgs (static_assert above)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const RenderArgs &A = T.R;
     for (int i = threadIdx.x; i < kBwdImage; i += blockDim.x) smem[i] = T.bwd_image[i];
@@ -1528,6 +1531,7 @@ __device__ __forceinline__ void scatter_blocked(float *tile, int lane, bool work
 template <bool DENS, bool GAUGE>
 __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs T)
 {
+    NGF_KARG_CONTRACT_T((&train_density_bwd_kernel<DENS, GAUGE>), TrainArgs);
     const RenderArgs &A = T.R;
     __shared__ __attribute__((aligned(16))) float s_tile[4][kScatWaveFloats];
     __shared__ float s_bd;
