@@ -260,12 +260,14 @@ __device__ __forceinline__ void kstep_fused(const KStepA<NT, NS> &k, f32x4 acc[N
 // Dense layer, KT4 k-steps (multiple of 4; padded steps have zero weights and zero inputs).  Software pipeline with
 // two k-steps of weight loads in flight behind the MFMAs (the un-pipelined loop left the waves 67 % of their cycles
 // in s_waitcnt with the matrix pipe 31 % busy: latency-, not bandwidth-bound).
-template <int NT_OUT, int NS>
+// DEEP: the four-k-steps-ahead pipeline of the one-wave-per-SIMD kernel also for a single tile (its last pass of a ray pair, below); without it
+// NS = 1 is the two-waves-per-SIMD kernel's shallower pipeline.
+template <int NT_OUT, int NS, bool DEEP = (NS > 1)>
 __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4, int lane, const float *act, f32x4 out[NS][NT_OUT] NGF_UVSEC_PARAM)
 {
     NGF_UVSEC_T(ts0);
     load_bias<NT_OUT, NS>(bias, lane >> 4, out);
-    if constexpr (NS == 1) {
+    if constexpr (!DEEP) {
         KStepA<NT_OUT, NS> k0, k1, k2, k3;
         kload<NT_OUT, NS>(w, act, 0, lane, k0);
         kload<NT_OUT, NS>(w, act, 1, lane, k1);
@@ -420,12 +422,12 @@ __device__ __forceinline__ void dense_bf16(const float *wq, const float *bias, i
 }
 
 // a 256-unit layer on KT4 fp32 k-steps or (split mode) KT4 / 8 bf16 k-blocks; wq: the layer's packed bf16 weights (split mode)
-template <int NS, bool SPLIT>
+template <int NS, bool SPLIT, bool DEEP = (NS > 1)>
 __device__ __forceinline__ void dense256(const UvArgs &A, const float *w, const float *wq, const float *bias, int KT4, int lane, const float *act,
                                          f32x4 out[NS][16] NGF_UVSEC_PARAM)
 {
     if constexpr (SPLIT) dense_bf16<NS>(wq, bias, (KT4 + 7) / 8, lane, act, out);
-    else dense<16, NS>(w, bias, KT4, lane, act, out NGF_UVSEC_ARG);
+    else dense<16, NS, DEEP>(w, bias, KT4, lane, act, out NGF_UVSEC_ARG);
 }
 
 template <int NT, int NS, int LEAKY>
@@ -562,13 +564,13 @@ constexpr size_t kUvLayerStride = 0;          // every layer of a run reads the 
 #else
 constexpr size_t kUvLayerStride = 65536;
 #endif
-template <int NS, bool SPLIT, int LEAKY>
+template <int NS, bool SPLIT, int LEAKY, bool DEEP = (NS > 1)>
 __device__ __forceinline__ void hidden_run(const UvArgs &A, const float *w, const float *wq, const float *b, int n, int lane, float *act, f32x4 x[NS][16],
                                            const float *w_out, UvOutW<64> &ow NGF_UVSEC_PARAM)
 {
 #pragma unroll 1
     for (int l = 0; l < n; ++l) {
-        dense256<NS, SPLIT>(A, w + (size_t)l * kUvLayerStride, wq + (size_t)l * kUvQLayer, b + l * 256, 64, lane, act, x NGF_UVSEC_ARG);
+        dense256<NS, SPLIT, DEEP>(A, w + (size_t)l * kUvLayerStride, wq + (size_t)l * kUvQLayer, b + l * 256, 64, lane, act, x NGF_UVSEC_ARG);
         NGF_UVSEC_T(u0);
         store_act<16, NS, LEAKY>(act, lane, x);
         NGF_UVSEC_T(u1);
@@ -581,7 +583,7 @@ __device__ __forceinline__ void hidden_run(const UvArgs &A, const float *w, cons
 // ---- the three networks for NS x 16 samples -----------------------------------------------------------------------------
 // p: position of the lane's sample in each tile, v: its ray direction.  Returns sigma and colour (identical in the 4 lanes of a
 // sample).
-template <int NS, bool SPLIT>
+template <int NS, bool SPLIT, bool DEEP = (NS > 1)>
 __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lane, const float p[NS][3], const float v[NS][3], float sigma[NS],
                                             float col[NS][3] NGF_UVSEC_PARAM)
 {
@@ -600,11 +602,11 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     f32x4 x[NS][16];
     // geometry: 63 -> 256 -> (10x) 256 -> 1, ReLU.  PE10(p) goes to rows 0..15 AND to rows 64..79, where the gauge network finds it later
     { NGF_UVSEC_T(u11a); store_pe<3, 10, NS>(act, 0, 16, lane, p, 64); NGF_UVSEC_T(u11b); NGF_UVSEC_ADD(3, u11a, u11b); }
-    dense<16, NS>(W + A.geo_w0, W + A.geo_b0, 16, lane, act, x NGF_UVSEC_ARG);
+    dense<16, NS, DEEP>(W + A.geo_w0, W + A.geo_b0, 16, lane, act, x NGF_UVSEC_ARG);
     { NGF_UVSEC_T(u1a); store_act<16, NS, 0>(act, lane, x); NGF_UVSEC_T(u1b); NGF_UVSEC_ADD(2, u1a, u1b); }
     {
         UvOutW<64> ow;
-        hidden_run<NS, SPLIT, 0>(A, W + A.geo_wh, W + A.geo_qh, W + A.geo_bh, 10, lane, act, x, W + A.geo_wo, ow NGF_UVSEC_ARG);
+        hidden_run<NS, SPLIT, 0, DEEP>(A, W + A.geo_wh, W + A.geo_qh, W + A.geo_bh, 10, lane, act, x, W + A.geo_wo, ow NGF_UVSEC_ARG);
         f32x4 o[NS];
         { NGF_UVSEC_T(u16a); dense_out<NS, 64>(ow, W + A.geo_bo, lane, act, o); NGF_UVSEC_T(u16b); NGF_UVSEC_ADD(4, u16a, u16b); }
 #pragma unroll
@@ -614,13 +616,13 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     float uv[NS][3];
     {
         f32x4 g4[NS][4], g[NS][8];
-        dense<4, NS>(W + A.ga_w0, W + A.ga_b0, 16, lane, act + 64 * 64, g4 NGF_UVSEC_ARG);
+        dense<4, NS, DEEP>(W + A.ga_w0, W + A.ga_b0, 16, lane, act + 64 * 64, g4 NGF_UVSEC_ARG);
         { NGF_UVSEC_T(u3a); store_act<4, NS, 0>(act, lane, g4); NGF_UVSEC_T(u3b); NGF_UVSEC_ADD(2, u3a, u3b); }
-        dense<8, NS>(W + A.ga_w1, W + A.ga_b1, 16, lane, act, g NGF_UVSEC_ARG);
+        dense<8, NS, DEEP>(W + A.ga_w1, W + A.ga_b1, 16, lane, act, g NGF_UVSEC_ARG);
         { NGF_UVSEC_T(u4a); store_act<8, NS, 0>(act, lane, g); NGF_UVSEC_T(u4b); NGF_UVSEC_ADD(2, u4a, u4b); }
-        dense<8, NS>(W + A.ga_w2, W + A.ga_b2, 32, lane, act, g NGF_UVSEC_ARG);
+        dense<8, NS, DEEP>(W + A.ga_w2, W + A.ga_b2, 32, lane, act, g NGF_UVSEC_ARG);
         { NGF_UVSEC_T(u5a); store_act<8, NS, 0>(act, lane, g); NGF_UVSEC_T(u5b); NGF_UVSEC_ADD(2, u5a, u5b); }
-        dense<8, NS>(W + A.ga_w3, W + A.ga_b3, 32, lane, act, g NGF_UVSEC_ARG);
+        dense<8, NS, DEEP>(W + A.ga_w3, W + A.ga_b3, 32, lane, act, g NGF_UVSEC_ARG);
         { NGF_UVSEC_T(u6a); store_act<8, NS, 0>(act, lane, g); NGF_UVSEC_T(u6b); NGF_UVSEC_ADD(2, u6a, u6b); }
         UvOutW<32> ow;
         out_prefetch<32>(W + A.ga_wo, lane, ow);
@@ -641,26 +643,26 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     // texture block1: (63|42) -> 256 -> (5x) 256, LeakyReLU(0.2)
     if (A.sphere) {
         { NGF_UVSEC_T(u13a); store_pe<3, 10, NS>(act, 0, 16, lane, uv); NGF_UVSEC_T(u13b); NGF_UVSEC_ADD(3, u13a, u13b); }
-        dense<16, NS>(W + A.t1_w0, W + A.t1_b0, 16, lane, act, x NGF_UVSEC_ARG);
+        dense<16, NS, DEEP>(W + A.t1_w0, W + A.t1_b0, 16, lane, act, x NGF_UVSEC_ARG);
     } else {
         { NGF_UVSEC_T(u14a); store_pe<2, 10, NS>(act, 0, 12, lane, uv); NGF_UVSEC_T(u14b); NGF_UVSEC_ADD(3, u14a, u14b); }
-        dense<16, NS>(W + A.t1_w0, W + A.t1_b0, 12, lane, act, x NGF_UVSEC_ARG);
+        dense<16, NS, DEEP>(W + A.t1_w0, W + A.t1_b0, 12, lane, act, x NGF_UVSEC_ARG);
     }
     { NGF_UVSEC_T(u7a); store_act<16, NS, 1>(act, lane, x); NGF_UVSEC_T(u7b); NGF_UVSEC_ADD(2, u7a, u7b); }
     // act[0..63] = block1 output h; color1 and block2 both read it
     f32x4 c1[NS], c2[NS];
     {
         UvOutW<64> ow;
-        hidden_run<NS, SPLIT, 1>(A, W + NGF_UV_SAME(A.t1_wh), W + A.t1_qh, W + A.t1_bh, 5, lane, act, x, W + A.c1_w, ow NGF_UVSEC_ARG);
+        hidden_run<NS, SPLIT, 1, DEEP>(A, W + NGF_UV_SAME(A.t1_wh), W + A.t1_qh, W + A.t1_bh, 5, lane, act, x, W + A.c1_w, ow NGF_UVSEC_ARG);
         { NGF_UVSEC_T(u18a); dense_out<NS, 64>(ow, W + A.c1_b, lane, act, c1); NGF_UVSEC_T(u18b); NGF_UVSEC_ADD(4, u18a, u18b); }
     }
     // block2: [h(256), v(3), PE6(v)(36)] -> 256 -> (3x) 256 -> 3
     { NGF_UVSEC_T(u15a); store_pe<3, 6, NS>(act, 64, 12, lane, v); NGF_UVSEC_T(u15b); NGF_UVSEC_ADD(3, u15a, u15b); }                 // 39 inputs + zero padding up to k-step 76
-    dense256<NS, SPLIT>(A, W + A.t2_w0, W + A.t2_q0, W + A.t2_b0, 76, lane, act, x NGF_UVSEC_ARG);            // 76 k-steps -> 10 k-blocks in split mode (rows 76..79: zero weights on finite leftovers)
+    dense256<NS, SPLIT, DEEP>(A, W + A.t2_w0, W + A.t2_q0, W + A.t2_b0, 76, lane, act, x NGF_UVSEC_ARG);            // 76 k-steps -> 10 k-blocks in split mode (rows 76..79: zero weights on finite leftovers)
     { NGF_UVSEC_T(u9a); store_act<16, NS, 1>(act, lane, x); NGF_UVSEC_T(u9b); NGF_UVSEC_ADD(2, u9a, u9b); }
     {
         UvOutW<64> ow;
-        hidden_run<NS, SPLIT, 1>(A, W + NGF_UV_SAME(A.t2_wh), W + A.t2_qh, W + A.t2_bh, 3, lane, act, x, W + A.t2_wo, ow NGF_UVSEC_ARG);
+        hidden_run<NS, SPLIT, 1, DEEP>(A, W + NGF_UV_SAME(A.t2_wh), W + A.t2_qh, W + A.t2_bh, 3, lane, act, x, W + A.t2_wo, ow NGF_UVSEC_ARG);
         { NGF_UVSEC_T(u19a); dense_out<NS, 64>(ow, W + A.t2_bo, lane, act, c2); NGF_UVSEC_T(u19b); NGF_UVSEC_ADD(4, u19a, u19b); }
     }
 #pragma unroll
@@ -797,6 +799,16 @@ __global__ void __launch_bounds__(512 / NS) uv_render_kernel(const UvArgs A)
                 }
                 float sg[NS], cc[NS][3];
                 NGF_UVSEC_T(un0);
+                // the pair's last pass may hold one tile only (6 % of the passes of the DTU frame): the single-tile networks cost about 0.6 of a
+                // two-tile pass (same weight stream, half the matrix instructions).  Same arithmetic per sample: a sample's result does not depend on
+                // which tile, or which instantiation, evaluates it (the k loops accumulate in the same order).
+                // (fp32 kernel only: the split kernel is bound by its weight stream, which a single tile does not shorten -- 41.1 -> 43.7 ms with it)
+                if (NS == 2 && !SPLIT && total - g0 <= 16) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) cc[NS - 1][k] = 0.0f;
+                    sg[NS - 1] = 0.0f;
+                    uv_networks<1, SPLIT, true>(A, act, lane, q, vq, sg, cc NGF_UVSEC_ARG);
+                } else
                 uv_networks<NS, SPLIT>(A, act, lane, q, vq, sg, cc NGF_UVSEC_ARG);
                 NGF_UVSEC_T(un1);
                 NGF_UVSEC_ADD(5, un0, un1);          // section 5 = the three networks of a pass, everything included
