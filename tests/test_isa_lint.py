@@ -48,3 +48,41 @@ def test_the_lint_flags_the_unstable_build(asm):
     hits = isa_hazards.lint(asm["field_packed"], "render_kernel.*InfoInvPolicyTILb1")
     forms = {f for _, f, _ in hits}
     assert any(op == "v_pk_mov_b32" for op, _ in forms) and any(op == "v_pk_mul_f32" for op, _ in forms) and any(op == "v_pk_add_f32" for op, _ in forms), hits
+
+
+def _kernel_blocks(path):
+    """{kernel symbol: (body lines, scratch bytes per lane)} of a -save-temps assembly file."""
+    import re
+    text = open(path).read()
+    out = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+        out[m.group(1)] = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2)).group(1))
+    return out
+
+
+def test_shipped_hot_kernels_use_no_scratch(asm):
+    """DESIGN.md quotes 0 B of scratch for the UV-Mapping kernels (round 4: the split kernel's 140 B were per-layer addresses hipcc had hoisted out of
+    the ray loop and spilled) and for the production render kernels of the default levels; held here so a source change that brings spills back fails
+    on the CPU."""
+    scratch = {**_kernel_blocks(asm["uv"]), **_kernel_blocks(asm["field"])}
+    want = ["uv_render_kernelILi2ELb0", "uv_render_kernelILi2ELb1", "uv_render_kernelILi1ELb0",
+            "render_kernelINS_14TriPlanePolicyILb1ELb1ELi12ELi1ELb0EEELb1ELb0E",      # level 3 (module default), production instantiation
+            "render_kernelINS_14TriPlanePolicyILb1ELb0ELi12ELi1ELb0EEELb1ELb0E",      # level 2
+            "render_kernelINS_14InfoInvPolicyTILb0ELb0EEELb1ELb0E",                   # InfoInv fp32
+            "render_kernelINS_14InfoInvPolicyTILb1ELb0EEELb1ELb0E"]                   # InfoInv split bf16
+    for needle in want:
+        hits = {k: v for k, v in scratch.items() if needle in k}
+        assert hits, f"no kernel matches {needle}"
+        assert all(v == 0 for v in hits.values()), hits
+
+
+def test_uv_weight_loads_are_global_loads(asm):
+    """Round 4 pitfall: an opaque POINTER as per-pass weight base loses its address space -- every 16-byte weight load of
+    uv_render_kernel became a flat_load, which counts on both memory counters, and the k loop waited vmcnt(0) lgkmcnt(0) once per trip (+9 % time).
+    The shipped kernels stream their weights with global_load_dwordx4; the only flat loads left are the 12-byte camera / background rows."""
+    import isa_hazards
+    for name, body in isa_hazards.kernels(asm["uv"]):
+        if "uv_render_kernel" not in name:
+            continue
+        assert not [l for l in body if "flat_load_dwordx4" in l], name
+        assert sum("global_load_dwordx4" in l for l in body) > 100, name
