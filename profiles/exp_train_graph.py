@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Would a HIP graph shorten the training iteration?  One Trainer.step captured with torch.cuda.graph (the library's launches, its two aux streams
-and their event forks / joins are all capturable: no allocation, no host sync inside a step) and replayed, next to the same step launched normally.
-The captured step has its iteration number (learning rate, Adam bias corrections) frozen: a timing experiment, not a training loop."""
+"""Would a HIP graph of the WHOLE training iteration (backward + Adam + the jitter draw, no Python in between) shorten it?  One Trainer.step
+captured with torch.cuda.graph and replayed, against the same step launched normally -- both from the SAME parameter / moment state and with the
+SAME frozen step counters (a captured step has its learning rates and Adam bias corrections baked in; left alone the two runs would train
+different fields and their active-sample counts, hence their times, drift apart).  A timing experiment, not a training loop."""
 import os
 import sys
 import time
@@ -25,9 +26,26 @@ tr = train.Trainer(f, batch_size=4096, max_samples=S)
 for it in range(3):
     tr.step(rays, tgt, it, N_samples=S)
 torch.cuda.synchronize()
+state = ([p.detach().clone() for p in tr.params], [m.clone() for m in tr.exp_avg], [v.clone() for v in tr.exp_avg_sq], list(tr.steps), list(tr.lr))
 
 
-def timed(fn, n):
+def restore():
+    with torch.no_grad():
+        for p, q in zip(tr.params, state[0]): p.copy_(q)
+        for p, q in zip(tr.exp_avg, state[1]): p.copy_(q)
+        for p, q in zip(tr.exp_avg_sq, state[2]): p.copy_(q)
+    tr.steps, tr.lr = list(state[3]), list(state[4])
+    tr.params_changed()
+    tr.backward(rays, tgt, S, iteration=3)          # re-packs the planes (a plain call); no optimizer step
+    torch.cuda.synchronize()
+
+
+def frozen_step():
+    tr.steps, tr.lr = list(state[3]), list(state[4])          # every step is "iteration 3" as in the captured graph
+    tr.step(rays, tgt, 3, N_samples=S)
+
+
+def timed(fn, n=20):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
@@ -36,27 +54,23 @@ def timed(fn, n):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-it = [3]
-
-
-def eager():
-    tr.step(rays, tgt, it[0], N_samples=S)
-    it[0] += 1
-
-
-print(f"eager launches : {timed(eager, 20):.3f} ms / iteration ({tr.last_active} active samples)")
-side = torch.cuda.Stream()
-side.wait_stream(torch.cuda.current_stream())
-try:
+for rep in range(2):
+    restore()
+    ms = timed(frozen_step)
+    print(f"launched from Python : {ms:.3f} ms / iteration, {tr.last_active} active samples after 20 iterations")
+    restore()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        tr.step(rays, tgt, it[0], N_samples=S)          # warm-up on the capture stream
+        frozen_step()
     torch.cuda.synchronize()
+    restore()
     graph = torch.cuda.CUDAGraph()
+    tr.steps, tr.lr = list(state[3]), list(state[4])
     with torch.cuda.graph(graph, stream=side):
-        tr.step(rays, tgt, it[0], N_samples=S)
+        tr.step(rays, tgt, 3, N_samples=S)
     torch.cuda.synchronize()
-    print(f"graph replay   : {timed(graph.replay, 20):.3f} ms / iteration")
-    print(f"eager again    : {timed(eager, 20):.3f} ms / iteration")
-    print(f"graph replay   : {timed(graph.replay, 20):.3f} ms / iteration")
-except Exception as e:      # noqa: BLE001
-    print("capture failed:", repr(e)[:400])
+    restore()
+    ms = timed(graph.replay)
+    print(f"one graph per step   : {ms:.3f} ms / iteration, {tr.last_active} active samples after 20 iterations")
+    del graph
