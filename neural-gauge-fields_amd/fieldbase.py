@@ -132,12 +132,24 @@ class Base(torch.nn.Module):
         self.load({'state_dict': sd})
 
     # --- the HIP handle ----------------------------------------------------------------------------
+    def _aabb_host(self):
+        """The six floats of ``self.aabb`` on the host, fetched once per (tensor, version).  The reference's drivers keep aabb on the GPU
+        (``scene_bbox.to(device)``, TriPlane/main.py:211): ``aabb.tolist()`` in the per-call handle key was then a device-to-host copy plus a
+        stream synchronisation in front of EVERY render call and every training step -- nothing could be enqueued behind a running launch."""
+        a = self.aabb
+        key = (id(a), a.data_ptr(), a._version)
+        c = getattr(self, '_aabb_cache', None)
+        if c is None or c[0] != key:
+            c = (key, tuple(float(v) for v in a.detach().reshape(-1).tolist()))
+            self._aabb_cache = c
+        return c[1]
+
     def _param_key(self):
         ps = [(n, p.data_ptr(), p._version, tuple(p.shape)) for n, p in self.named_parameters()]
         if getattr(self, 'check_params', False):
             ps.append(tuple(float(p.detach().double().sum()) + float(p.detach().double().abs().sum()) for p in self.parameters()))
         m = None if self.alphaMask is None else (self.alphaMask.alpha_volume.data_ptr(), self.alphaMask.alpha_volume._version)
-        return (tuple(ps), m, float(self.stepSize), tuple(self.aabb.reshape(-1).tolist()), self.bake_density, self.bake_color, self.no_fold, self.split_bf16,
+        return (tuple(ps), m, float(self.stepSize), self._aabb_host(), self.bake_density, self.bake_color, self.no_fold, self.split_bf16,
                 tuple(self.near_far), float(self.distance_scale), float(self.rayMarch_weight_thres))
 
     def invalidate(self):
@@ -195,7 +207,7 @@ class Base(torch.nn.Module):
         d.w1, d.b1 = dp(rd.mlp[0].weight), dp(rd.mlp[0].bias)
         d.w2, d.b2 = dp(rd.mlp[2].weight), dp(rd.mlp[2].bias)
         d.w3, d.b3 = dp(rd.mlp[4].weight), dp(rd.mlp[4].bias)
-        d.aabb = (C.c_float * 6)(*self.aabb.reshape(-1).tolist())
+        d.aabb = (C.c_float * 6)(*self._aabb_host())
         d.near_, d.far_ = float(self.near_far[0]), float(self.near_far[1])
         d.step = float(self.stepSize)
         d.distance_scale = float(self.distance_scale)

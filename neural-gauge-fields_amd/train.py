@@ -124,7 +124,7 @@ class Trainer:
     def _build(self):
         f = self.field
         d = TrainDesc()
-        d.aabb = (C.c_float * 6)(*f.aabb.reshape(-1).tolist())
+        d.aabb = (C.c_float * 6)(*f._aabb_host())
         d.near_, d.far_ = float(f.near_far[0]), float(f.near_far[1])
         d.step = float(f.stepSize)
         d.distance_scale = float(f.distance_scale)
@@ -157,7 +157,7 @@ class Trainer:
 
     def _key(self):
         f = self.field
-        return (tuple((p.data_ptr(), tuple(p.shape)) for p in self.params), float(f.stepSize), tuple(f.aabb.reshape(-1).tolist()),
+        return (tuple((p.data_ptr(), tuple(p.shape)) for p in self.params), float(f.stepSize), f._aabb_host(),
                 None if f.alphaMask is None else f.alphaMask.alpha_volume.data_ptr())
 
     def _param_versions(self):

@@ -784,3 +784,36 @@ def test_renders_a_checkpoint_written_by_the_reference():
     out = f(torch.from_numpy(g["rays"]).cuda(), white_bg=True, is_train=False, N_samples=40, iteration=30001)
     np.testing.assert_allclose(out["rgb_map"].cpu().numpy(), g["rgb_map"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(out["depth_map"].cpu().numpy(), g["depth_map"], rtol=1e-4, atol=1e-5)
+
+
+def test_steady_state_calls_do_not_synchronise_with_the_host():
+    """The reference's drivers keep ``aabb`` on the GPU (TriPlane/main.py:211).  Round 4 found ``aabb.tolist()`` in the per-call handle key: a
+    device-to-host copy + stream synchronisation in front of every render call and training step of such a caller.  torch's sync debug mode
+    turns every synchronising torch call into an error: the second render of a field, and training steps after the first, must pass under it
+    (ctypes calls into the library are not seen by that mode; the library's own entry points do not synchronise on these paths by
+    construction -- include/ngf.h)."""
+    from ngf_amd import train, triplane
+    from helpers import big_case
+    from ngf_amd import synth
+    g, params, step = big_case("triplane", "R1")
+    aabb = torch.tensor(np.asarray(g["aabb"], np.float32)).cuda()                 # on the device, like scene_bbox.to(device)
+    f = triplane.TriPlane(aabb, [int(v) for v in g["grid"]], "cuda", gauge_start=0, near_far=[2.0, 6.0], alphaMask_thres=1e-4, distance_scale=25.0,
+                          rayMarch_weight_thres=1e-4, step_ratio=0.5)
+    f.load_params(params)
+    frame = torch.from_numpy(synth.lookat_rays(800, 800)[:8192]).cuda()
+    tgt = torch.from_numpy(synth.hash_uniform(5, 2, (4096, 3))).cuda()
+    jit = torch.from_numpy(synth.hash_uniform(5, 3, (4096,))).cuda()
+    ref = f(frame, N_samples=64, white_bg=True, iteration=30001)["rgb_map"].clone()
+    tr = train.Trainer(f, batch_size=4096, max_samples=64)
+    tr.step(frame[:4096], tgt, 0, N_samples=64, jitter=jit)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = f(frame, N_samples=64, white_bg=True, iteration=30001)["rgb_map"]      # parameters changed by the step: the handle is rebuilt here
+        out2 = f(frame, N_samples=64, white_bg=True, iteration=30001)["rgb_map"]
+        tr.step(frame[:4096], tgt, 1, N_samples=64, jitter=jit)
+        tr.step(frame[4096:], tgt, 2, N_samples=64, jitter=jit)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and not torch.equal(out, ref)
