@@ -24,6 +24,7 @@
 // Nothing of size [n,S,*] is ever materialised in HBM.
 #pragma once
 #include <cstddef>
+#include <type_traits>
 
 #include "ngf_device.hpp"
 #include "ngf_shade16.hpp"
@@ -57,6 +58,21 @@ __device__ __forceinline__ Tex karg_tex(size_t off)
     r.p = t->p; r.W = t->W; r.H = t->H; r.stride = t->stride; r.fw = t->fw; r.fh = t->fh;
     return r;
 }
+
+// A plain field of the RenderArgs re-read from the kernel-argument segment (same contract as karg_tex).  Round 4: the per-TILE fields -- the tile
+// plan's segments, the ray / output pointers, n, near / far -- are read this way at the tile's start and end: kept live across the march and shade
+// loops they were among the ~45 scalars hipcc parks in VGPR lanes (v_writelane at kernel entry, v_readlane at every use: 22 vector instructions per
+// march iteration of the level-3 kernel); a scalar load is latency the wave's neighbours cover, a v_readlane is an issue slot of the binding pipe.
+template <typename T>
+__device__ __forceinline__ T karg(size_t off)
+{
+    typedef const __attribute__((address_space(4))) T *ptr_t;
+    ptr_t q = (ptr_t)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + off);
+    asm volatile("" : "+s"(q));
+    return *q;
+}
+#define NGF_KARG(field) karg<decltype(RenderArgs::field)>(offsetof(RenderArgs, field))
+#define NGF_KARG_AT(field, k) karg<std::remove_extent_t<decltype(RenderArgs::field)>>(offsetof(RenderArgs, field) + (k) * sizeof(std::remove_extent_t<decltype(RenderArgs::field)>))
 
 // LDS carve (floats): [blob | per wave: ring of RING records, result list, view inputs of the 64 rays]
 template <typename P> constexpr int wave_lds_floats() { return P::RING * kRecFloats + P::BATCH * 4 + P::VFEAT_FLOATS + P::STAGE_FLOATS; }
@@ -466,12 +482,13 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
 #endif
         // the tile's place in the launch's plan (RenderArgs::seg_*): which segment, hence how wide, and its first ray (scalar selects -- indexing
         // the kernel-argument arrays with a run-time index would move them to scratch)
-        int ts = A.seg_shift[0];
-        int64_t base = A.seg_ray0[0] + ((int64_t)tile << ts);
+        int ts = NGF_KARG_AT(seg_shift, 0);
+        int64_t base = NGF_KARG_AT(seg_ray0, 0) + ((int64_t)tile << ts);
         if constexpr (SPLIT) {
-            if (tile >= A.seg_end[0]) { ts = A.seg_shift[1]; base = A.seg_ray0[1] + ((int64_t)(tile - A.seg_end[0]) << ts); }
-            if (tile >= A.seg_end[1]) { ts = A.seg_shift[2]; base = A.seg_ray0[2] + ((int64_t)(tile - A.seg_end[1]) << ts); }
-            if (tile >= A.seg_end[2]) { ts = A.seg_shift[3]; base = A.seg_ray0[3] + ((int64_t)(tile - A.seg_end[2]) << ts); }
+            const uint32_t e0 = NGF_KARG_AT(seg_end, 0), e1 = NGF_KARG_AT(seg_end, 1), e2 = NGF_KARG_AT(seg_end, 2);
+            if (tile >= e0) { ts = NGF_KARG_AT(seg_shift, 1); base = NGF_KARG_AT(seg_ray0, 1) + ((int64_t)(tile - e0) << ts); }
+            if (tile >= e1) { ts = NGF_KARG_AT(seg_shift, 2); base = NGF_KARG_AT(seg_ray0, 2) + ((int64_t)(tile - e1) << ts); }
+            if (tile >= e2) { ts = NGF_KARG_AT(seg_shift, 3); base = NGF_KARG_AT(seg_ray0, 3) + ((int64_t)(tile - e2) << ts); }
         }
         const int tile_w = 1 << ts;
         // split tile of >= 4 rays: a 16-lane row holds M = tile_w / 4 rays, lane-in-row = seg * M + r (split_chain above), ray slot = row * M + r;
@@ -480,7 +497,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         // them -- the lane's row, the clamp's canonicalised `far`, step * (S + 1) -- out of the persistent tile loop and then SPILLS them in the
         // kernels that run at their register budget (InfoInv fp32: 3 of its 4 scratch dwords); recomputed per tile they cost three instructions)
         int lane_t = lane, S_t = S;
-        float far_t = A.far_;
+        float far_t = NGF_KARG(far_), jit_t_ = 0.0f;
         asm volatile("" : "+v"(lane_t), "+s"(S_t), "+s"(far_t));
         const int mshift = SPLIT ? (ts >= 2 ? ts - 2 : 0) : 0;           // log2(M)
         const int rshift = SPLIT ? (ts >= 2 ? 0 : 2 - ts) : 0;           // log2(R)
@@ -488,12 +505,17 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         const int seg = SPLIT ? (ts >= 2 ? ((lane_t & 15) >> mshift) : (lane_t & (K - 1))) : 0;              // which of the K consecutive steps this lane takes
         const int rl = SPLIT ? (ts >= 2 ? (((lane_t >> 4) << mshift) | (lane_t & ((1 << mshift) - 1))) : (lane_t >> (4 + rshift))) : lane_t;      // ray slot inside the tile (= owner id in the queues)
         const int64_t ray = base + rl;
-        const bool live = (rl < tile_w) && (ray < A.n);
-        const int64_t rr = live ? ray : A.n - 1;
+        const int64_t n_rays = NGF_KARG(n);
+        const bool live = (rl < tile_w) && (ray < n_rays);
+        const int64_t rr = live ? ray : n_rays - 1;
         float o[3], d[3];
+        {
+            const float *rays_p = NGF_KARG(rays), *jit_p = NGF_KARG(jitter);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { o[k] = A.rays[rr * 6 + k]; d[k] = A.rays[rr * 6 + 3 + k]; }
-        const float jit = A.jitter ? A.jitter[rr] : 0.0f;
+            for (int k = 0; k < 3; ++k) { o[k] = rays_p[rr * 6 + k]; d[k] = rays_p[rr * 6 + 3 + k]; }
+            jit_t_ = jit_p ? jit_p[rr] : 0.0f;
+        }
+        const float jit = jit_t_;
 
         // sample_ray (FieldBase.py:122-125)
         float tmin = -INFINITY;
@@ -503,7 +525,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
             float ra = (A.a1[k] - o[k]) / vec, rb = (A.a0[k] - o[k]) / vec;
             tmin = fmaxf(tmin, fminf(ra, rb));
         }
-        tmin = fminf(fmaxf(tmin, A.near_), far_t);
+        tmin = fminf(fmaxf(tmin, NGF_KARG(near_)), far_t);
 
         if constexpr (P::VLDS) {   // view inputs of this lane's ray (networks.py:27-29), read back by the shade lanes
             if constexpr (SPLIT) {
@@ -735,13 +757,15 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         if (live && seg == 0) {
             // compositing tail (FieldBase.py:296-306)
             float out[3] = {cr, cg, cb};
+            float *rgb_p = NGF_KARG(rgb), *depth_p = NGF_KARG(depth);
+            const int32_t white = NGF_KARG(white_bg);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float v = out[c];
-                if (A.white_bg) v = v + (1.0f - acc);
-                A.rgb[ray * 3 + c] = fminf(fmaxf(v, 0.0f), 1.0f);
+                if (white) v = v + (1.0f - acc);
+                rgb_p[ray * 3 + c] = fminf(fmaxf(v, 0.0f), 1.0f);
             }
-            A.depth[ray] = dep + (1.0f - acc) * d[2];
+            depth_p[ray] = dep + (1.0f - acc) * d[2];
         }
         if constexpr (DBG) st_rays += __popcll(__ballot(live && seg == 0));
     }

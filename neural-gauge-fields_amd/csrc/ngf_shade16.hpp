@@ -110,12 +110,21 @@ __device__ __forceinline__ void mlp_tail16(const float *blob, int oW2, int oB2, 
     }
 #endif
     if (tk) { __builtin_amdgcn_sched_barrier(0); tk[4] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
-    const float *w3 = blob + oW3 + kq * 16;
+    // layer-3 weights as twelve 16-byte LDS reads with immediate offsets (left to itself hipcc pairs the scalar reads into ds_read2_b32, whose 8-bit
+    // offsets do not reach the image's offset: one v_add_u32 per pair, 24 vector instructions per pass)
+    const f32x4 *w3 = reinterpret_cast<const f32x4 *>(blob + oW3 + kq * 16);
+    float hr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hr[k] = relu1(c[k >> 2][k & 3]);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         float s = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s = fmaf(w3[ch * 64 + k], relu1(c[k >> 2][k & 3]), s);
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w = w3[ch * 16 + q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = fmaf(w[e], hr[4 * q + e], s);
+        }
         s = s + __shfl_xor(s, 16);
         s = s + __shfl_xor(s, 32);
         s = s + blob[oB3 + ch];

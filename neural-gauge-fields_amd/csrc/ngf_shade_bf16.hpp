@@ -106,12 +106,19 @@ __device__ __forceinline__ void kblock_bf16(const float *w, const Split8 &x, f32
 __device__ __forceinline__ void mlp_layer3_16(const float *blob, int oW3, int oB3, int lane, const f32x4 c[4], float rgb[3])
 {
     const int kq = lane >> 4;
-    const float *w3 = blob + oW3 + kq * 16;
+    const f32x4 *w3 = reinterpret_cast<const f32x4 *>(blob + oW3 + kq * 16);      // 16-byte LDS reads with immediate offsets (see mlp_tail16)
+    float hr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hr[k] = relu1(c[k >> 2][k & 3]);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         float s = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s = fmaf(w3[ch * 64 + k], relu1(c[k >> 2][k & 3]), s);
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w = w3[ch * 16 + q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = fmaf(w[e], hr[4 * q + e], s);
+        }
         s = s + __shfl_xor(s, 16);
         s = s + __shfl_xor(s, 32);
         s = s + blob[oB3 + ch];
