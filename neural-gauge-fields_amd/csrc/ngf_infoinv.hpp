@@ -222,8 +222,8 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
     constexpr int KB_STRIDE = 2 * 64 * 4;
     const float *w1 = blob + L::W1 + lane * 4;
     GatherRowII g;
-    Bil b = bil_setup(rec[2], rec[3], A.app[0]);
-    gather_row_ii(A.app[0].p + (size_t)b.idx * 72 + kq * 18, g);
+    Bil b = bil_setup(rec[2], rec[3], karg_tex(offsetof(RenderArgs, app) + (0) * sizeof(Tex)));
+    gather_row_ii(karg_tex(offsetof(RenderArgs, app) + (0) * sizeof(Tex)).p + (size_t)b.idx * 72 + kq * 18, g);
     LoFragII lo0, lo1;                         // k-blocks 2i / 2i+1: each is re-requested for block +2 as soon as it has been used
     lo_load_ii(A.basis_pack, 0, lane, lo0);
     lo_load_ii(A.basis_pack, 1, lane, lo1);
@@ -257,7 +257,7 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
 #pragma unroll
         for (int e = 0; e < 2; ++e) f[16 + e] = fmaf(b.w10, g.b[1][e], b.w00 * g.b[0][e]);
         __builtin_amdgcn_sched_barrier(0);
-        gather_row_ii(A.app[p].p + ((size_t)b.idx + A.app[p].stride) * 72 + kq * 18, g);
+        gather_row_ii(karg_tex(offsetof(RenderArgs, app) + (p) * sizeof(Tex)).p + ((size_t)b.idx + karg_tex(offsetof(RenderArgs, app) + (p) * sizeof(Tex)).stride) * 72 + kq * 18, g);
         __builtin_amdgcn_sched_barrier(0);
         // row 1: + w01 v01, + w11 v11 (bil_mix's order), then the positional factor
 #pragma unroll
@@ -268,8 +268,8 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
         for (int e = 0; e < 2; ++e) f[16 + e] = fmaf(b.w11, g.b[1][e], fmaf(b.w01, g.b[0][e], f[16 + e]));
         __builtin_amdgcn_sched_barrier(0);
         if (p < 2) {                           // the next plane's first row travels behind this plane's MFMAs
-            b = bil_setup(rec[4 + 2 * p], rec[5 + 2 * p], A.app[p + 1]);
-            gather_row_ii(A.app[p + 1].p + (size_t)b.idx * 72 + kq * 18, g);
+            b = bil_setup(rec[4 + 2 * p], rec[5 + 2 * p], karg_tex(offsetof(RenderArgs, app) + (p + 1) * sizeof(Tex)));
+            gather_row_ii(karg_tex(offsetof(RenderArgs, app) + (p + 1) * sizeof(Tex)).p + (size_t)b.idx * 72 + kq * 18, g);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (mode) {
@@ -379,8 +379,8 @@ __device__ __forceinline__ void mlp_pass16_ii(const RenderArgs &A, const float *
     const int kq = lane >> 4;
     const float *w1 = blob + L::W1 + lane;
     GatherRowII g;
-    Bil b = bil_setup(rec[2], rec[3], A.app[0]);
-    gather_row_ii(A.app[0].p + (size_t)b.idx * 72 + kq * 18, g);
+    Bil b = bil_setup(rec[2], rec[3], karg_tex(offsetof(RenderArgs, app) + (0) * sizeof(Tex)));
+    gather_row_ii(karg_tex(offsetof(RenderArgs, app) + (0) * sizeof(Tex)).p + (size_t)b.idx * 72 + kq * 18, g);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[4];
 #pragma unroll
@@ -408,7 +408,7 @@ __device__ __forceinline__ void mlp_pass16_ii(const RenderArgs &A, const float *
 #pragma unroll
         for (int e = 0; e < 2; ++e) f[16 + e] = fmaf(b.w10, g.b[1][e], b.w00 * g.b[0][e]);
         __builtin_amdgcn_sched_barrier(0);
-        gather_row_ii(A.app[p].p + ((size_t)b.idx + A.app[p].stride) * 72 + kq * 18, g);
+        gather_row_ii(karg_tex(offsetof(RenderArgs, app) + (p) * sizeof(Tex)).p + ((size_t)b.idx + karg_tex(offsetof(RenderArgs, app) + (p) * sizeof(Tex)).stride) * 72 + kq * 18, g);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -418,8 +418,8 @@ __device__ __forceinline__ void mlp_pass16_ii(const RenderArgs &A, const float *
         for (int e = 0; e < 2; ++e) f[16 + e] = fmaf(b.w11, g.b[1][e], fmaf(b.w01, g.b[0][e], f[16 + e]));
         __builtin_amdgcn_sched_barrier(0);
         if (p < 2) {                           // the next plane's first row travels behind this plane's 72 MFMAs
-            b = bil_setup(rec[4 + 2 * p], rec[5 + 2 * p], A.app[p + 1]);
-            gather_row_ii(A.app[p + 1].p + (size_t)b.idx * 72 + kq * 18, g);
+            b = bil_setup(rec[4 + 2 * p], rec[5 + 2 * p], karg_tex(offsetof(RenderArgs, app) + (p + 1) * sizeof(Tex)));
+            gather_row_ii(karg_tex(offsetof(RenderArgs, app) + (p + 1) * sizeof(Tex)).p + (size_t)b.idx * 72 + kq * 18, g);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (mode) {
@@ -498,7 +498,7 @@ __device__ __forceinline__ float infoinv_sigma_bf16(const RenderArgs &A, const f
     float carry[8];                                // the 8 inputs of a plane that wait for the next plane's first 8
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        const Tex &tx = A.dens[p];
+        const Tex tx = karg_tex(offsetof(RenderArgs, dens) + p * sizeof(Tex));
         float feat[24];
         if (valid) {
             Bil b = bil_setup(t[2 * p], t[2 * p + 1], tx);
@@ -613,7 +613,7 @@ struct InfoInvPolicyT {
         const float *d1 = img + D::D1 + lane;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            const Tex &tx = A.dens[p];
+            const Tex tx = karg_tex(offsetof(RenderArgs, dens) + p * sizeof(Tex));
             float feat[24];
             if (valid) {
                 Bil b = bil_setup(t[2 * p], t[2 * p + 1], tx);

@@ -32,47 +32,7 @@
 
 namespace ngf {
 
-// A Tex of the kernel's RenderArgs (byte offset `off` inside it), re-read from the kernel-argument segment on the scalar memory pipe at
-// the point of use.  RenderArgs holds nine Tex (63 dwords) next to 48 decoder weights: kept live across the march loop they overflow the
-// SGPR file and hipcc parks texture pointers in VGPR lanes -- ~38 v_readlane per march step on the vector pipe, which is the binding one
-// (measured: R1 frame 9.93 -> 9.82 ms, same bits).  REQUIRES the RenderArgs to be the kernel's first argument (offset 0 of the kernarg
-// segment): true for every kernel of this library (TrainArgs starts with its RenderArgs, static_assert in ngf_train.hpp), and CHECKED at
-// run time: alpha_kernel and the DBG instantiations of render_kernel (every test goes through them) trap when the descriptor read from the
-// kernarg segment is not the one in their `A`.
-// The compile-time half of that contract (round 4; the production instantiation of render_kernel carries no run-time check): every kernel whose
-// body reaches karg_tex asserts, through its OWN function type, that its first parameter is the RenderArgs (or a struct that starts with one).
-template <typename K> struct kernel_first_param;
-template <typename A0, typename... Rest> struct kernel_first_param<void (*)(A0, Rest...)> { typedef A0 type; };
-template <typename K, typename Args = RenderArgs>
-constexpr bool kernel_args_at_offset_0 = __is_same(typename kernel_first_param<K>::type, Args);
-#define NGF_KARG_CONTRACT(kernel_ptr_expr) NGF_KARG_CONTRACT_T(kernel_ptr_expr, RenderArgs)
-#define NGF_KARG_CONTRACT_T(kernel_ptr_expr, ArgsType) \
-    static_assert(kernel_args_at_offset_0<decltype(kernel_ptr_expr), ArgsType>, "karg_tex reads the RenderArgs at offset 0 of the kernel-argument segment: it must be this kernel's first parameter")
-
-__device__ __forceinline__ Tex karg_tex(size_t off)
-{
-    typedef const __attribute__((address_space(4))) Tex *tptr_t;
-    tptr_t t = (tptr_t)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + off);
-    asm volatile("" : "+s"(t));
-    Tex r;
-    r.p = t->p; r.W = t->W; r.H = t->H; r.stride = t->stride; r.fw = t->fw; r.fh = t->fh;
-    return r;
-}
-
-// A plain field of the RenderArgs re-read from the kernel-argument segment (same contract as karg_tex).  Round 4: the per-TILE fields -- the tile
-// plan's segments, the ray / output pointers, n, near / far -- are read this way at the tile's start and end: kept live across the march and shade
-// loops they were among the ~45 scalars hipcc parks in VGPR lanes (v_writelane at kernel entry, v_readlane at every use: 22 vector instructions per
-// march iteration of the level-3 kernel); a scalar load is latency the wave's neighbours cover, a v_readlane is an issue slot of the binding pipe.
-template <typename T>
-__device__ __forceinline__ T karg(size_t off)
-{
-    typedef const __attribute__((address_space(4))) T *ptr_t;
-    ptr_t q = (ptr_t)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + off);
-    asm volatile("" : "+s"(q));
-    return *q;
-}
-#define NGF_KARG(field) karg<decltype(RenderArgs::field)>(offsetof(RenderArgs, field))
-#define NGF_KARG_AT(field, k) karg<std::remove_extent_t<decltype(RenderArgs::field)>>(offsetof(RenderArgs, field) + (k) * sizeof(std::remove_extent_t<decltype(RenderArgs::field)>))
+// (karg_tex / karg / NGF_KARG_CONTRACT: ngf_device.hpp)
 
 // LDS carve (floats): [blob | per wave: ring of RING records, result list, view inputs of the 64 rays]
 template <typename P> constexpr int wave_lds_floats() { return P::RING * kRecFloats + P::BATCH * 4 + P::VFEAT_FLOATS + P::STAGE_FLOATS; }

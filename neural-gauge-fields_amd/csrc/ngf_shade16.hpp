@@ -144,7 +144,7 @@ template <int APP, int P>
 __device__ __forceinline__ void gather16_issue(const RenderArgs &A, const float rec[kRecFloats], int kq, Gather16<APP> &g, const RecCells *pre = nullptr)
 {
     constexpr int NQ = APP / 16;
-    const Tex &t = A.app[P];
+    const Tex t = karg_tex(offsetof(RenderArgs, app) + P * sizeof(Tex));
     if (pre) g.b = bil_from_rec(pre->idx[P], pre->wx1[P], pre->wy1[P], (pre->bits >> (8 + P)) & 1);
     else g.b = bil_setup(rec[2 + 2 * P], rec[3 + 2 * P], t);
     // lane-quarter kq owns channels [16q + 4kq, 16q + 4kq + 4), q = 0..NQ-1: the four lanes of a sample read one
@@ -398,7 +398,7 @@ template <int ST>                 // stage = plane * 2 + half; cells: the sample
 __device__ __forceinline__ void baked16_issue(const RenderArgs &A, const float rec[kRecFloats], int kq, BakedHalf &g, const RecCells *cells = nullptr)
 {
     constexpr int P = ST >> 1, H = ST & 1;
-    const Tex &t = A.app[P];
+    const Tex t = karg_tex(offsetof(RenderArgs, app) + P * sizeof(Tex));
     if (cells) g.b = bil_from_rec(cells->idx[P], cells->wx1[P], cells->wy1[P], (cells->bits >> (8 + P)) & 1);
     else g.b = bil_setup(rec[2 + 2 * P], rec[3 + 2 * P], t);
     // channel 16*mt + 4*kq + r = hidden unit of accumulator (mt, r): natural order; 4 lanes read 64 contiguous bytes

@@ -220,8 +220,8 @@ __device__ __forceinline__ void mlp_pass16_bf16_rows(const RenderArgs &A, const 
     constexpr int KB_STRIDE = 3 * 64 * 4, MT1 = L::KB1 * KB_STRIDE, MT2 = L::KB2 * KB_STRIDE;
     const float *w1 = blob + L::W1 + lane * 4, *w2 = blob + L::W2 + lane * 4;
     GatherRow16 g;
-    Bil b = bil_setup(rec[2], rec[3], A.app[0]);
-    gather_row16(A.app[0].p + (size_t)b.idx * 48 + 4 * kq, g);
+    Bil b = bil_setup(rec[2], rec[3], karg_tex(offsetof(RenderArgs, app) + (0) * sizeof(Tex)));
+    gather_row16(karg_tex(offsetof(RenderArgs, app) + (0) * sizeof(Tex)).p + (size_t)b.idx * 48 + 4 * kq, g);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[4];
 #pragma unroll
@@ -235,7 +235,7 @@ __device__ __forceinline__ void mlp_pass16_bf16_rows(const RenderArgs &A, const 
 #pragma unroll
             for (int e = 0; e < 4; ++e) f[4 * q + e] = fmaf(b.w10, g.a[1][q][e], b.w00 * g.a[0][q][e]);
         __builtin_amdgcn_sched_barrier(0);
-        gather_row16(A.app[p].p + ((size_t)b.idx + A.app[p].stride) * 48 + 4 * kq, g);
+        gather_row16(karg_tex(offsetof(RenderArgs, app) + (p) * sizeof(Tex)).p + ((size_t)b.idx + karg_tex(offsetof(RenderArgs, app) + (p) * sizeof(Tex)).stride) * 48 + 4 * kq, g);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 3; ++q)
@@ -243,8 +243,8 @@ __device__ __forceinline__ void mlp_pass16_bf16_rows(const RenderArgs &A, const 
             for (int e = 0; e < 4; ++e) f[4 * q + e] = fmaf(b.w11, g.a[1][q][e], fmaf(b.w01, g.a[0][q][e], f[4 * q + e]));
         __builtin_amdgcn_sched_barrier(0);
         if (p < 2) {                           // the next plane's first row travels behind this plane's MFMAs
-            b = bil_setup(rec[4 + 2 * p], rec[5 + 2 * p], A.app[p + 1]);
-            gather_row16(A.app[p + 1].p + (size_t)b.idx * 48 + 4 * kq, g);
+            b = bil_setup(rec[4 + 2 * p], rec[5 + 2 * p], karg_tex(offsetof(RenderArgs, app) + (p + 1) * sizeof(Tex)));
+            gather_row16(karg_tex(offsetof(RenderArgs, app) + (p + 1) * sizeof(Tex)).p + (size_t)b.idx * 48 + 4 * kq, g);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (p == 0) {                          // k-block 0: plane 0 [0..7]
