@@ -13,7 +13,9 @@ from ngf_amd.cases import big_case, field_for_case
 L = _lib.lib()
 model = os.environ.get("MODEL", "triplane")
 g, params, step = big_case(model, "R1")
-f = field_for_case(g, params, None, device="cuda", bake=True)
+LEVEL = int(os.environ.get("LEVEL", "3"))          # 3 = the module default since round 4 (baked colour planes), 2 = round 3's
+f = field_for_case(g, params, None, device="cuda", bake=True, bake_color=LEVEL >= 3)
+print("level", LEVEL)
 kw = dict(iteration=30001) if model == "triplane" else dict(infoinv=True)
 h = f.handle()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
