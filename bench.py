@@ -347,6 +347,8 @@ def main():
     send, rgb_view, depth_view = ndist.shard_buffers(per, device)
     frame_no = [0]
     last_frame = [None]
+    # the gathered frames in image order land in two alternating buffers (one strided copy per output and frame, no allocation in the loop)
+    frame_out = [(torch.empty((n_total, 3), device=device), torch.empty((n_total,), device=device)) for _ in range(2)] if dist_on else None
 
     def render_only():
         f(rays, N_samples=S, white_bg=True, out=(rgb_view, depth_view), **kw)
@@ -367,12 +369,12 @@ def main():
         if pair: pair[1].record()
         pipe.submit(k)
         if k > 0:
-            last_frame[0] = ndist.deinterleave(*pipe.frame(k - 1), H, W, world, ROW_BLOCK)
+            last_frame[0] = pipe.frame_in_image_order(k - 1, H, W, ROW_BLOCK, out=frame_out[(k - 1) % 2])
         frame_no[0] = k + 1
 
     def finish():
         if dist_on and frame_no[0] > 0:
-            last_frame[0] = ndist.deinterleave(*pipe.frame(frame_no[0] - 1), H, W, world, ROW_BLOCK)
+            last_frame[0] = pipe.frame_in_image_order(frame_no[0] - 1, H, W, ROW_BLOCK, out=frame_out[(frame_no[0] - 1) % 2])
 
     marks = []
     elapsed = time_steps(step_fn, args.steps, args.warmup, device, dist_on, finish, marks)
@@ -481,8 +483,7 @@ def main():
             e1.record()
             dist.all_gather_into_tensor(pipe.recv[0], pipe.send[0][0])
             e2.record()
-            blocks = pipe.recv[0].view(world, 4 * per)
-            ndist.deinterleave(blocks[:, : 3 * per].reshape(world * per, 3), blocks[:, 3 * per:].reshape(world * per), H, W, world, ROW_BLOCK)
+            pipe.frame_in_image_order(0, H, W, ROW_BLOCK, out=frame_out[0])
             e3.record()
             torch.cuda.synchronize(device)
             cp.append((e0.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3)))

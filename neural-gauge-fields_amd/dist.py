@@ -74,6 +74,26 @@ class PipelinedGather:
         blocks = self.recv[i].view(self.world, 4 * self.per)
         return blocks[:, : 3 * self.per].reshape(self.world * self.per, 3), blocks[:, 3 * self.per:].reshape(self.world * self.per)
 
+    def frame_in_image_order(self, k: int, H: int, W: int, block: int, out=None):
+        """Frame k in IMAGE order, straight from the receive buffer: ONE strided copy per output (rgb, depth).  ``frame(k)`` followed by
+        ``deinterleave`` is four -- slicing the rank-major [world, 4 per] buffer into rgb and depth makes a packed copy, the row permutation
+        another -- on the stream the next frame's render is waiting on; at eight ranks a 0.64 ms step has 0.08 ms to spare.
+        ``out`` = (rgb [H*W,3], depth [H*W]) to write into (else new tensors)."""
+        i = k % len(self.send)
+        if self.work[i] is not None:
+            self.work[i].wait()
+            self.work[i] = None
+        world, per = self.world, self.per
+        nblk = H // (world * block)
+        blocks = self.recv[i].view(world, 4 * per)
+        rgb_v = blocks[:, : 3 * per].view(world, nblk, block * W * 3).permute(1, 0, 2)           # [nblk, world, block*W*3]: image order, strided
+        dep_v = blocks[:, 3 * per:].view(world, nblk, block * W).permute(1, 0, 2)
+        if out is None:
+            out = (torch.empty((H * W, 3), device=blocks.device, dtype=blocks.dtype), torch.empty((H * W,), device=blocks.device, dtype=blocks.dtype))
+        out[0].view(nblk, world, block * W * 3).copy_(rgb_v)
+        out[1].view(nblk, world, block * W).copy_(dep_v)
+        return out
+
     def drain(self):
         for i, w in enumerate(self.work):
             if w is not None:

@@ -112,7 +112,7 @@ def _worker(rank, world, port, tmp):
         pipe.submit(k)
         if k > 0:
             got.append(ndist.deinterleave(*pipe.frame(k - 1), H, W, world, blk))
-    got.append(ndist.deinterleave(*pipe.frame(len(frames) - 1), H, W, world, blk))
+    got.append(pipe.frame_in_image_order(len(frames) - 1, H, W, blk))          # the fused form bench.py uses: one strided copy per output
     for (g_rgb, g_depth), (f_rgb, f_depth) in zip(got, full):
         ok = ok and np.array_equal(g_rgb.numpy(), f_rgb) and np.array_equal(g_depth.numpy(), f_depth)
     open(os.path.join(tmp, f"ok{rank}"), "w").write("1" if ok else "0")
@@ -158,8 +158,8 @@ def _worker_rows(rank, world, port, tmp):
         fill(k)
         pipe.submit(k)
         if k > 0:
-            got.append(ndist.deinterleave(*pipe.frame(k - 1), H, W, world, blk))
-    got.append(ndist.deinterleave(*pipe.frame(2), H, W, world, blk))
+            got.append(pipe.frame_in_image_order(k - 1, H, W, blk))          # what bench.py calls per step
+    got.append(ndist.deinterleave(*pipe.frame(2), H, W, world, blk))          # and the two-step form: the same frame
     pix = torch.arange(H * W, dtype=torch.float32)
     for k, (g_rgb, g_depth) in enumerate(got):
         ok = ok and torch.equal(g_rgb[:, 0], pix + 1000000.0 * k) and torch.equal(g_rgb[:, 2], pix + 0.5 + 1000000.0 * k)
