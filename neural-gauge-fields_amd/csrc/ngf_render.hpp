@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                         if (!dbg_samples && !(DBG && (A.ablate & 64)) && !__any(valid)) { empty_step = true; break; }
                     }
                     if constexpr (SPLIT && P::STAGED) {
-                        float *dscr = P::STAGE_FLOATS > 0 ? vfeat + kWave * kViewFeat : nullptr;
+                        float *dscr = P::STAGE_FLOATS > 0 ? vfeat + P::VFEAT_FLOATS : nullptr;
                         sigma[u] = P::sigma_staged(A, vfeat, dscr, valid, x, lane, t[u], (DBG && A.stats) ? &st_staged : nullptr);
                     } else if constexpr (R12) {
                         sigma[u] = P::sigma(A, smem, valid, x, lane, t[u], cells[u]);
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 float od[3] = {0.0f, 0.0f, 0.0f};
                 if constexpr (!P::VLDS) { od[0] = __shfl(d[0], owner_lane); od[1] = __shfl(d[1], owner_lane); od[2] = __shfl(d[2], owner_lane); }
                 float c[3];
-                [[maybe_unused]] const float *pre = view_fold ? vfeat + 8 * kViewFeat + owner * 64 : nullptr;
+                [[maybe_unused]] const float *pre = view_fold ? vfeat + 8 * kViewFeat + owner * kFoldStride : nullptr;
                 if constexpr (P::PROFILE) {
                     unsigned long long tk[5] = {0, 0, 0, 0, 0};
                     P::shade(A, smem, rec, vfeat + owner * kViewFeat, od, lane, c, tk, pre);

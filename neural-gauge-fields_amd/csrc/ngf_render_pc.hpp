@@ -30,8 +30,8 @@ constexpr unsigned kPcWatchdog = 1u << 24;  // consecutive s_sleep polls without
 template <int NM>
 struct PcLds {                              // floats after the MLP image
     static constexpr int RING = 0;                                  // [NM][kPcRing][kRecFloats]
-    static constexpr int VTAB = RING + NM * kPcRing * kRecFloats;   // [NM][2][8 rays][64]: b1 + W1[:, view] . view per ray, accumulator order
-    static constexpr int CTRL = VTAB + NM * 2 * 8 * 64;             // ints: tail[NM], head[NM], produced[NM], done[NM], finished[NM], info[NM][2][16], csum[NM][32]
+    static constexpr int VTAB = RING + NM * kPcRing * kRecFloats;   // [NM][2][8 rays][kFoldStride]: b1 + W1[:, view] . view per ray, accumulator order
+    static constexpr int CTRL = VTAB + NM * 2 * 8 * kFoldStride;             // ints: tail[NM], head[NM], produced[NM], done[NM], finished[NM], info[NM][2][16], csum[NM][32]
     static constexpr int CTRL_WORDS = 5 * NM + NM * 2 * kPcInfoWords + NM * 32;       // + per-ring colour sums [8 rays][3] (+ pad)
     static constexpr int TOTAL = CTRL + CTRL_WORDS;
 };
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__((NM + NS) * 64) render_pc_kernel(const RenderA
         // =========================================== MARCH =====================================================================
         const int m = wave;
         float *ring = base_f + L::RING + m * kPcRing * kRecFloats;
-        float *vtab = base_f + L::VTAB + m * 2 * 8 * 64;
+        float *vtab = base_f + L::VTAB + m * 2 * 8 * kFoldStride;
         lds_u32 *info = q_info + m * 2 * kPcInfoWords;
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
         const int seg = lane & (K - 1), rl = lane >> LOGK;
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__((NM + NS) * 64) render_pc_kernel(const RenderA
                 f32x4 v4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v4[e] = kq == 0 ? v[e] : (kq == 1 ? v[4 + e] : (kq == 2 ? v[8 + e] : v[12 + e]));
-                P::fold_view_regs(smem, v4, vtab + par * 8 * 64, TW, lane);
+                P::fold_view_regs(smem, v4, vtab + par * 8 * kFoldStride, TW, lane);
             }
             float T = 1.0f, acc = 0.0f, dep = 0.0f;
             int i = 0;
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__((NM + NS) * 64) render_pc_kernel(const RenderA
                 const f32x4 r0 = r[0], r1 = r[1];
                 const float rec[kRecFloats] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
                 const int owner = __float_as_int(r0[0]);
-                const float *pre = base_f + L::VTAB + ((m * 2 + par) * 8 + owner) * 64;
+                const float *pre = base_f + L::VTAB + ((m * 2 + par) * 8 + owner) * kFoldStride;
                 float c[3];
                 const float od[3] = {0.0f, 0.0f, 0.0f};
                 if constexpr (P::PROFILE) {

@@ -16,6 +16,11 @@
 namespace ngf {
 
 constexpr int kBatch16 = 16;
+// floats between the per-ray vectors of a tile's view-fold table (64 values each).  68, not 64: the lanes of a pass read the vector of THEIR sample's
+// ray, and with a stride of 64 floats every ray's vector starts in the same LDS bank -- eight rays, eight-way conflicts on each of the pass's reads
+// (19.6 % of the LDS-active cycles of the level-3 launch were bank conflicts, profiles/r04_triplane_R1_bdc_pmc.txt); a multiple of 4 keeps the
+// 16-byte reads of levels 1-2 aligned.
+constexpr int kFoldStride = 68;
 
 template <int APP>
 struct MlpLayout16 {                      // floats
@@ -204,7 +209,7 @@ __device__ __forceinline__ void view_fold16_regs(const float *blob, const f32x4 
         for (int mt = 0; mt < 4; ++mt) acc[mt] = NGF_MFMA16(w1[(mt * KSTRIDE + j) * 64], v[j], acc[mt]);
     if (s < n_rays) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4 *>(pre + s * 64 + kq * 16 + mt * 4) = acc[mt];
+        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4 *>(pre + s * kFoldStride + kq * 16 + mt * 4) = acc[mt];
     }
 }
 

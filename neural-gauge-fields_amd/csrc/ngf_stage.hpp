@@ -20,7 +20,7 @@ namespace ngf {
 constexpr int kStageGaugeCap = 64;          // texels per staged gauge strip (one per lane)
 constexpr int kStageDensCap = 48;           // texels per staged density strip: 48 x 20 floats = 3840 B per wave
 constexpr int kStageDensStride = 20;        // floats per staged density texel (16 + 4 pad: consecutive texels start 20 banks apart)
-constexpr int kStageGaugeOff = 640;         // gauge strips live in the unused tail of the wave's view-input block (3 x 64 x 2 floats)
+constexpr int kStageGaugeOff = 8 * kViewFeat + 8 * kFoldStride;      // gauge strips (3 x 64 x 2 floats) behind the view inputs and the fold table of an 8-ray tile
 
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float stage_dpp(float old, float v)
@@ -64,6 +64,8 @@ struct TriPlaneStagedPolicy : TriPlanePolicy<false, false, WAVES_, 1> {
     static constexpr bool REC12 = false;
     static constexpr bool STAGED = true;
     static constexpr int STAGE_FLOATS = WAVES_ <= 8 ? kStageDensCap * kStageDensStride : 0;      // density strip (8 waves per CU only: LDS)
+    static constexpr int VFEAT_FLOATS = kStageGaugeOff + 3 * kStageGaugeCap * 2;                  // view inputs + fold table + gauge strips (1056 floats)
+    static_assert(VFEAT_FLOATS >= kWave * kViewFeat, "the unsplit march keeps the view inputs of 64 rays here");
 
     // vscr: the wave's view-input block (gauge strips at +kStageGaugeOff); dscr: the wave's density strip or nullptr
     __device__ static __forceinline__ float sigma_staged(const RenderArgs &A, float *vscr, float *dscr, bool valid, const float x[3], int lane,
