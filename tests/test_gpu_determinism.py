@@ -65,7 +65,7 @@ def test_uv_render_repeats_bit_for_bit():
         args = (torch.from_numpy(g["campos"])[None].cuda(), torch.from_numpy(g["raydir"])[None].cuda(), torch.from_numpy(g["bg"])[None].cuda())
         U = torch.from_numpy(g["U"])[None].cuda()
         first = m(*args, jitter_u=U)["color"].clone()
-        n = LAUNCHES_BF16 if split else 2000
+        n = LAUNCHES_BF16 if split else 20000          # fp32: round 4 gave the kernel cross-lane LDS writes (positional encodings) and single-tile passes
         moved = torch.zeros((), dtype=torch.int64, device="cuda")
         for _ in range(n):
             moved += (m(*args, jitter_u=U)["color"] != first).any().to(torch.int64)
