@@ -36,7 +36,7 @@ def test_render_repeats_bit_for_bit(name, kw, flags):
     f = field_for_case(g, params, mask, **flags)
     first = f(rays, N_samples=S, white_bg=True, **kw)
     rgb0, d0 = first["rgb_map"].clone(), first["depth_map"].clone()
-    n = LAUNCHES_BF16 if flags.get("split_bf16") else LAUNCHES
+    n = LAUNCHES_BF16 if flags.get("split_bf16") else (20000 if flags.get("bake_color") else LAUNCHES)      # level 3 (the module default): EXEC-masked collect, lane-permuted gather
     from ngf_amd._lib import knobs
     # launch shapes: the library's own plan (a launch this small is all one-ray tiles, one wave per tile); 4-ray tiles with the waves of few
     # workgroups sharing their CU's matrix pipe -- the shape round 2's defect showed in; 8-ray tiles of a frame's bulk on two CUs
