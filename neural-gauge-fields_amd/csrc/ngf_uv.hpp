@@ -442,9 +442,9 @@ __device__ __forceinline__ void store_act(float *act, int lane, const f32x4 acc[
 }
 
 // Output layer with <= 3 units on the matrix pipe (rows >= n_out of the 16-row tile are zero; rows 0..3 land in the lanes of quarter kq = 0).
-// Packed [KT / 4][64 lanes][4]: one 16-byte load per lane holds its A operands of four k-steps.  Round 4: the weights are requested BEFORE the
-// previous layer's activations are stored (out_prefetch: their L2 latency hides behind store_act) and the KT MFMAs of a tile run as two independent
-// chains over fully unrolled k-steps.  Rounds 1-3 ran `for t: load w[t]; MFMA` with one dependent chain per tile: a latency-bound loop of ~150 cycles
+// Packed [KT / 4][64 lanes][4]: one 16-byte load per lane holds its A operands of four k-steps.  Round 4: all of a layer's weights are requested
+// in one go (out_prefetch, right behind the previous layer's activation store) and the KT MFMAs of a tile run as two independent chains over
+// fully unrolled k-steps.  Rounds 1-3 ran `for t: load w[t]; MFMA` with one dependent chain per tile: a latency-bound loop of ~150 cycles
 // per MFMA, 4.6 % of a wave's life for 1 % of its matrix work (profiles/r04_uv_sections.txt).
 template <int KT>
 struct UvOutW { f32x4 w[KT / 4]; };
