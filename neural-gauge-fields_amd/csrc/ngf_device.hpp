@@ -157,6 +157,9 @@ struct Bil {
     int32_t in;                  // carries per plane (bil_from_rec rebuilds the four weights with the same operations)
 };
 
+// MED3 = false: the two-instruction clamp of rounds 1-3.  Only the level-1 render kernel asks for it: with the one-instruction form its 16-channel
+// density taps spill 60 instead of 24 B per lane and the frame loses 0.9 % (the kernel sits at its 168-register budget; same values either way).
+template <bool MED3 = true>
 __device__ __forceinline__ Bil bil_setup(float u, float v, const Tex &t)
 {
     float px = ((u + 1.0f) / 2.0f) * t.fw;
@@ -174,8 +177,8 @@ __device__ __forceinline__ Bil bil_setup(float u, float v, const Tex &t)
     // (the clamp as ONE v_med3_f32: fminf(fmaxf(fx, -1), t.fw) compiles to v_max + v_min + a v_max_f32 s, s that canonicalises the scalar bound at
     // every use -- 36 instead of 12 instructions per march iteration.  Same value for every input: the median of (fx, -1, fw) is the clamp for
     // -1 <= fw, and a NaN fx gives min3 = -1 like fmaxf(NaN, -1) did.)
-    float cx = __builtin_amdgcn_fmed3f(fx, -1.0f, t.fw);
-    float cy = __builtin_amdgcn_fmed3f(fy, -1.0f, t.fh);
+    float cx = MED3 ? __builtin_amdgcn_fmed3f(fx, -1.0f, t.fw) : fminf(fmaxf(fx, -1.0f), t.fw);
+    float cy = MED3 ? __builtin_amdgcn_fmed3f(fy, -1.0f, t.fh) : fminf(fmaxf(fy, -1.0f), t.fh);
     bool in = (cx == fx) & (cy == fy);
     Bil b;
     b.wx1 = wx1; b.wy1 = wy1; b.in = in ? 1 : 0;

@@ -129,7 +129,7 @@ __device__ __forceinline__ float triplane_density_feature(const RenderArgs &A, c
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const Tex tx = karg_tex(offsetof(RenderArgs, dens) + p * sizeof(Tex));
-        Bil b = bil_setup(t[2 * p], t[2 * p + 1], tx);
+        Bil b = bil_setup<BAKED>(t[2 * p], t[2 * p + 1], tx);
         if (cells) cells[p] = b;
         if (BAKED) {
             const float *q = tex_at<float>(tx.p, (uint32_t)b.idx), *q1 = tex_at<float>(tx.p, (uint32_t)(b.idx + tx.stride));
@@ -163,6 +163,7 @@ __device__ __forceinline__ float triplane_density_feature(const RenderArgs &A, c
 }
 
 // compute_gauge (Field.py:53-75): three 2-channel bilinear fetches + the reference's add order
+template <bool MED3 = true>
 __device__ __forceinline__ void triplane_gauge(const RenderArgs &A, const float x[3], int gauge_on, float t[6])
 {
     const float u[3] = {x[0], x[1], x[0]}, v[3] = {x[1], x[2], x[2]};   // xy, yz, xz
@@ -171,7 +172,7 @@ __device__ __forceinline__ void triplane_gauge(const RenderArgs &A, const float 
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const Tex tx = karg_tex(offsetof(RenderArgs, gau) + p * sizeof(Tex));
-            Bil b = bil_setup(u[p], v[p], tx);
+            Bil b = bil_setup<MED3>(u[p], v[p], tx);
             const f32x2 *g = tex_at<f32x2>(tx.p, (uint32_t)b.idx * 2u), *g1 = tex_at<f32x2>(tx.p, (uint32_t)(b.idx + tx.stride) * 2u);
             f32x2 g00 = g[0], g10 = g[1], g01 = g1[0], g11 = g1[1];
             d[p][0] = bil_mix(b, g00[0], g10[0], g01[0], g11[0]);
@@ -217,7 +218,7 @@ struct TriPlanePolicy {
         // texel index and zeroes the weights, so their gathers are safe and their result is discarded.
         // Without the branch the NSTEP independent steps share one basic block and their gathers overlap.
         float tt[6];
-        triplane_gauge(A, x, A.mode, tt);
+        triplane_gauge<BAKE_D>(A, x, A.mode, tt);
         const float sg = softplus_shift(triplane_density_feature<BAKE_D>(A, tt, cells));
 #pragma unroll
         for (int k = 0; k < 6; ++k) t[k] = valid ? tt[k] : 0.0f;
