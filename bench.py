@@ -349,6 +349,8 @@ def main():
     last_frame = [None]
     # the gathered frames in image order land in two alternating buffers (one strided copy per output and frame, no allocation in the loop)
     frame_out = [(torch.empty((n_total, 3), device=device), torch.empty((n_total,), device=device)) for _ in range(2)] if dist_on else None
+    # ... copied there on a stream of their own: the render stream never waits for an exchange or a reorder (the timed region ends with a device-wide synchronise)
+    side = torch.cuda.Stream(device) if dist_on else None
 
     def render_only():
         f(rays, N_samples=S, white_bg=True, out=(rgb_view, depth_view), **kw)
@@ -369,12 +371,12 @@ def main():
         if pair: pair[1].record()
         pipe.submit(k)
         if k > 0:
-            last_frame[0] = pipe.frame_in_image_order(k - 1, H, W, ROW_BLOCK, out=frame_out[(k - 1) % 2])
+            last_frame[0] = pipe.frame_in_image_order(k - 1, H, W, ROW_BLOCK, out=frame_out[(k - 1) % 2], stream=side)
         frame_no[0] = k + 1
 
     def finish():
         if dist_on and frame_no[0] > 0:
-            last_frame[0] = pipe.frame_in_image_order(frame_no[0] - 1, H, W, ROW_BLOCK, out=frame_out[(frame_no[0] - 1) % 2])
+            last_frame[0] = pipe.frame_in_image_order(frame_no[0] - 1, H, W, ROW_BLOCK, out=frame_out[(frame_no[0] - 1) % 2], stream=side)
 
     marks = []
     elapsed = time_steps(step_fn, args.steps, args.warmup, device, dist_on, finish, marks)

@@ -53,17 +53,24 @@ class PipelinedGather:
         self.send = [shard_buffers(per, device) for _ in range(depth)]
         self.recv = [torch.empty((world * 4 * per,), device=device, dtype=torch.float32) for _ in range(depth)]
         self.work = [None] * depth
+        self.reorder_done = [None] * depth      # events: the side-stream copy that last READ receive buffer i (frame_in_image_order(stream=...))
 
     def buffers(self, k: int):
         i = k % len(self.send)
         if self.work[i] is not None:          # the exchange that last read this send buffer must be done
             self.work[i].wait()
             self.work[i] = None
+        if self.reorder_done[i] is not None:  # ... also when a side stream did the waiting (frame_in_image_order(stream=...)): its copy ran behind that exchange
+            torch.cuda.current_stream().wait_event(self.reorder_done[i])
+            self.reorder_done[i] = None       # everything enqueued on this stream from here on (the render, the exchange ``submit`` starts) is behind that copy
         _, rgb, depth = self.send[i]
         return rgb, depth
 
     def submit(self, k: int):
         i = k % len(self.send)
+        if self.reorder_done[i] is not None:      # the exchange overwrites receive buffer i: the side-stream copy of frame k - depth must have read it
+            torch.cuda.current_stream().wait_event(self.reorder_done[i])
+            self.reorder_done[i] = None
         self.work[i] = dist.all_gather_into_tensor(self.recv[i], self.send[i][0], group=self.group, async_op=True)
 
     def frame(self, k: int):
@@ -74,12 +81,22 @@ class PipelinedGather:
         blocks = self.recv[i].view(self.world, 4 * self.per)
         return blocks[:, : 3 * self.per].reshape(self.world * self.per, 3), blocks[:, 3 * self.per:].reshape(self.world * self.per)
 
-    def frame_in_image_order(self, k: int, H: int, W: int, block: int, out=None):
+    def frame_in_image_order(self, k: int, H: int, W: int, block: int, out=None, stream=None):
         """Frame k in IMAGE order, straight from the receive buffer: ONE strided copy per output (rgb, depth).  ``frame(k)`` followed by
         ``deinterleave`` is four -- slicing the rank-major [world, 4 per] buffer into rgb and depth makes a packed copy, the row permutation
         another -- on the stream the next frame's render is waiting on; at eight ranks a 0.64 ms step has 0.08 ms to spare.
-        ``out`` = (rgb [H*W,3], depth [H*W]) to write into (else new tensors)."""
+        ``out`` = (rgb [H*W,3], depth [H*W]) to write into (else new tensors).  ``stream`` (CUDA tensors): wait for the exchange and copy on THAT stream
+        instead of the caller's -- the next frame's render, enqueued on the caller's stream, then waits for neither; ``submit`` makes the exchange that
+        reuses the receive buffer wait for the copy.  The caller synchronises with ``stream`` before it reads ``out`` (bench.py: the device-wide
+        synchronise that ends the timed region)."""
         i = k % len(self.send)
+        if stream is not None and self.recv[i].is_cuda:
+            with torch.cuda.stream(stream):
+                res = self.frame_in_image_order(k, H, W, block, out=out)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            self.reorder_done[i] = ev
+            return res
         if self.work[i] is not None:
             self.work[i].wait()
             self.work[i] = None
