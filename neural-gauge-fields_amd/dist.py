@@ -6,10 +6,10 @@ replicated parameters and the only exchange is ONE all-gather of the composited 
 10 MB per 800x800 frame) -- RCCL over xGMI when the process group's backend is "nccl".  One process per GPU, launched by
 torch.distributed.run.  Two partitions:
   * `render_sharded` / `shard_bounds`: contiguous ray blocks [r*ceil(N/W), ...) -- the generic entry point for any ray list;
-  * `interleaved_rows` + `PipelinedGather` + `deinterleave` (what bench.py runs at N > 1): the frame's rows dealt out in 10-row
+  * `interleaved_rows` + `PipelinedGather` (`frame_in_image_order`; `frame` + `deinterleave` is the two-step form) -- what bench.py runs at N > 1: the frame's rows dealt out in 10-row
     blocks round robin.  BASELINE.json's north_star words the partition as contiguous row blocks; contiguous 100-row shards of the
     800x800 frame differ by 7 % in render time (background rows are cheap), and strong scaling pays for the slowest rank, so the
-    rows are interleaved and one strided device copy puts the gathered frame back in image order.
+    rows are interleaved and one strided device copy per output (rgb, depth), on a stream of its own, puts the gathered frame back in image order.
 """
 from __future__ import annotations
 
