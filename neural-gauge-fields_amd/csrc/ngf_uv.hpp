@@ -80,6 +80,17 @@ __device__ __forceinline__ float act_fn(float x)
     else return __int_as_float(max(__float_as_int(x), 0));
 }
 
+// fp32 kernels: a layer's outputs go to LDS RAW, straight from the accumulator registers (store_act), and the activation is applied where the next
+// layer READS its inputs.  ACT of a consumer = the activation of the layer that produced its inputs: kUvActNone (positional encodings, or a producer
+// that applied it at the store: the split-bf16 kernel, kUvRd / kUvSt below), 0 ReLU, 1 LeakyReLU.
+constexpr int kUvActNone = -1;
+template <int ACT>
+__device__ __forceinline__ float act_in(float x)
+{
+    if constexpr (ACT < 0) return x;
+    else return act_fn<ACT>(x);
+}
+
 // ---- texture editing: TextureMlpDecoder.forward with cubemap_ set (decoder.py:79-121) -------------------------------------
 // F.grid_sample(texture [H,W,C] as [1,C,H,W], (u,v), bilinear, padding_mode='border', align_corners=False) for one point
 __device__ __forceinline__ void tex_sample_border(const float *tex, int H, int W, int C, float u, float v, float out[4])
@@ -221,6 +232,17 @@ __device__ __forceinline__ void kload(const float *w, const float *act, int t, i
     for (int s = 0; s < NS; ++s) k.b[s] = act[s * kUvWaveLds + t * 64 + lane];
 }
 
+// the activation of the producing layer on a k-step's B operands (in place, once the LDS read has landed); k-steps from t_none on are inputs that
+// no layer produced (block2.0's view encodings behind the 64 k-steps of block 1's output)
+template <int ACT, int NT, int NS>
+__device__ __forceinline__ void kact(KStepA<NT, NS> &k, int t, int t_none)
+{
+    if constexpr (ACT >= 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) k.b[s] = t < t_none ? act_in<ACT>(k.b[s]) : k.b[s];
+    }
+}
+
 template <int NT, int NS>
 __device__ __forceinline__ void kmma(const KStepA<NT, NS> &k, f32x4 acc[NS][NT])
 {
@@ -262,8 +284,8 @@ __device__ __forceinline__ void kstep_fused(const KStepA<NT, NS> &k, f32x4 acc[N
 // in s_waitcnt with the matrix pipe 31 % busy: latency-, not bandwidth-bound).
 // DEEP: the four-k-steps-ahead pipeline of the one-wave-per-SIMD kernel also for a single tile (its last pass of a ray pair, below); without it
 // NS = 1 is the two-waves-per-SIMD kernel's shallower pipeline.
-template <int NT_OUT, int NS, bool DEEP = (NS > 1)>
-__device__ __forceinline__ void dense(const float *w, const float *bias, int KT4, int lane, const float *act, f32x4 out[NS][NT_OUT] NGF_UVSEC_PARAM)
+template <int NT_OUT, int NS, bool DEEP = (NS > 1), int ACT = kUvActNone>
+__device__ __forceinline__ void dense(const float *w, const float *bias, int KT4, int lane, const float *act, f32x4 out[NS][NT_OUT] NGF_UVSEC_PARAM, int t_none = 1 << 30)
 {
     NGF_UVSEC_T(ts0);
     load_bias<NT_OUT, NS>(bias, lane >> 4, out);
@@ -277,6 +299,7 @@ __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4
             // vmcnt(0) before each group of four MFMAs
             kload<NT_OUT, NS>(w, act, t + 2, lane, k2);
             kload<NT_OUT, NS>(w, act, t + 3, lane, k3);
+            kact<ACT>(k0, t, t_none); kact<ACT>(k1, t + 1, t_none);
             __builtin_amdgcn_sched_barrier(0);
             kmma<NT_OUT, NS>(k0, out);
             kmma<NT_OUT, NS>(k1, out);
@@ -284,6 +307,7 @@ __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4
             const int tn = t + 4 < KT4 ? t + 4 : t;          // last iteration: harmless reload instead of a branch
             kload<NT_OUT, NS>(w, act, tn, lane, k0);
             kload<NT_OUT, NS>(w, act, tn + 1, lane, k1);
+            kact<ACT>(k2, t + 2, t_none); kact<ACT>(k3, t + 3, t_none);
             __builtin_amdgcn_sched_barrier(0);
             kmma<NT_OUT, NS>(k2, out);
             kmma<NT_OUT, NS>(k3, out);
@@ -305,6 +329,7 @@ __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4
             const bool has_b = t + 4 < KT4;
             const int tb = has_b ? t + 4 : t;                    // harmless reload when the layer ends on the first half
 #ifdef NGF_EXP_UV_FUSED
+            static_assert(ACT < 0, "the fused k-step experiment predates the activation-on-read layout");
             kstep_fused<NT_OUT, NS>(a0, out, w, act, tb, lane, b0); kstep_fused<NT_OUT, NS>(a1, out, w, act, tb + 1, lane, b1);
             kstep_fused<NT_OUT, NS>(a2, out, w, act, tb + 2, lane, b2); kstep_fused<NT_OUT, NS>(a3, out, w, act, tb + 3, lane, b3);
             if (has_b) {
@@ -316,6 +341,9 @@ __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4
 #endif
             kload<NT_OUT, NS>(w, act, tb, lane, b0); kload<NT_OUT, NS>(w, act, tb + 1, lane, b1);
             kload<NT_OUT, NS>(w, act, tb + 2, lane, b2); kload<NT_OUT, NS>(w, act, tb + 3, lane, b3);
+            // (the activation of the four k-steps about to be consumed sits with the address arithmetic of the loads above: one cluster of vector
+            // instructions per 128 matrix instructions -- at one wave per SIMD every switch between the pipes costs the wave ~38 cycles)
+            kact<ACT>(a0, t, t_none); kact<ACT>(a1, t + 1, t_none); kact<ACT>(a2, t + 2, t_none); kact<ACT>(a3, t + 3, t_none);
             __builtin_amdgcn_sched_barrier(0);
             kmma<NT_OUT, NS>(a0, out); kmma<NT_OUT, NS>(a1, out); kmma<NT_OUT, NS>(a2, out); kmma<NT_OUT, NS>(a3, out);
             __builtin_amdgcn_sched_barrier(0);
@@ -323,6 +351,7 @@ __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4
                 const int ta = t + 8 < KT4 ? t + 8 : t;
                 kload<NT_OUT, NS>(w, act, ta, lane, a0); kload<NT_OUT, NS>(w, act, ta + 1, lane, a1);
                 kload<NT_OUT, NS>(w, act, ta + 2, lane, a2); kload<NT_OUT, NS>(w, act, ta + 3, lane, a3);
+                kact<ACT>(b0, t + 4, t_none); kact<ACT>(b1, t + 5, t_none); kact<ACT>(b2, t + 6, t_none); kact<ACT>(b3, t + 7, t_none);
                 __builtin_amdgcn_sched_barrier(0);
                 kmma<NT_OUT, NS>(b0, out); kmma<NT_OUT, NS>(b1, out); kmma<NT_OUT, NS>(b2, out); kmma<NT_OUT, NS>(b3, out);
                 __builtin_amdgcn_sched_barrier(0);
@@ -392,8 +421,8 @@ __device__ __forceinline__ void uv_gmma(const UvAPair &G, const UvSplit8 x[NS], 
 
 // KB k-blocks (8 inputs of every lane each; padded inputs have zero weights); act as in dense(): act[s][t][lane], t = the lane's input
 // index.  Four tile pairs (96 registers) are in flight: the pair consumed now was requested three pairs (72 x NS MFMAs) earlier.
-template <int NS>
-__device__ __forceinline__ void dense_bf16(const float *wq, const float *bias, int KB, int lane, const float *act, f32x4 out[NS][16])
+template <int NS, int ACT = kUvActNone>
+__device__ __forceinline__ void dense_bf16(const float *wq, const float *bias, int KB, int lane, const float *act, f32x4 out[NS][16], int t_none = 1 << 30)
 {
     load_bias<16, NS>(bias, lane >> 4, out);
     UvAPair A0, A1, A2, A3;
@@ -405,7 +434,10 @@ __device__ __forceinline__ void dense_bf16(const float *wq, const float *bias, i
         for (int s = 0; s < NS; ++s) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = act[s * kUvWaveLds + (kb * 8 + e) * 64 + lane];
+            for (int e = 0; e < 8; ++e) {
+                const float raw = act[s * kUvWaveLds + (kb * 8 + e) * 64 + lane];
+                v[e] = (ACT >= 0 && kb * 8 < t_none) ? act_in<ACT>(raw) : raw;          // a k-block lies wholly before or behind t_none (a multiple of 8)
+            }
             x[s] = uv_split8(v);
         }
         const int kn = kb + 1 < KB ? kb + 1 : kb;                // last k-block: harmless reload instead of a branch
@@ -422,24 +454,56 @@ __device__ __forceinline__ void dense_bf16(const float *wq, const float *bias, i
 }
 
 // a 256-unit layer on KT4 fp32 k-steps or (split mode) KT4 / 8 bf16 k-blocks; wq: the layer's packed bf16 weights (split mode)
-template <int NS, bool SPLIT, bool DEEP = (NS > 1)>
+template <int NS, bool SPLIT, bool DEEP = (NS > 1), int ACT = kUvActNone>
 __device__ __forceinline__ void dense256(const UvArgs &A, const float *w, const float *wq, const float *bias, int KT4, int lane, const float *act,
-                                         f32x4 out[NS][16] NGF_UVSEC_PARAM)
+                                         f32x4 out[NS][16] NGF_UVSEC_PARAM, int t_none = 1 << 30)
 {
-    if constexpr (SPLIT) dense_bf16<NS>(wq, bias, (KT4 + 7) / 8, lane, act, out);
-    else dense<16, NS, DEEP>(w, bias, KT4, lane, act, out NGF_UVSEC_ARG);
+    if constexpr (SPLIT) dense_bf16<NS, ACT>(wq, bias, (KT4 + 7) / 8, lane, act, out, t_none);
+    else dense<16, NS, DEEP, ACT>(w, bias, KT4, lane, act, out NGF_UVSEC_ARG, t_none);
 }
 
-template <int NT, int NS, int LEAKY>
+// A layer's NT x 16 outputs of every tile -> the wave's activation rows, RAW (the consumer applies the activation: act_in), straight from the
+// accumulator registers: `ds_write2st64_b32 addr, a[..], a[..]` with AGPR data operands.  In C++ (`act[...] = acc[s][mt][r]`) hipcc copies every
+// accumulator to a VGPR first (v_accvgpr_read_b32), and with the activation on this side the store was 128 x (copy + activation + half a write) per
+// lane: 3.2 % of a wave's life (profiles/r04_uv_sections.txt).  Row (mt * 4 + r) of tile s is 64-dword block s * kUvActSteps + mt * 4 + r behind the
+// lane's own slot.  The s_nop are the matrix-write -> LDS-read wait states of the layer's last MFMAs (the hazard recogniser does not look into
+// inline assembly); accumulators that live in VGPRs (the small gauge layers) are copied to AGPRs by the constraint -- no worse than before.
+template <int O>       // two consecutive rows (64-dword blocks O, O + 1 behind addr) from two accumulator registers
+__device__ __forceinline__ void ds_write2_rows_agpr(unsigned addr, float a0, float a1)
+{
+    asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "a"(a0), "a"(a1), "n"(O), "n"(O + 1) : "memory");
+}
+template <int NT, int NS, int I = 0>       // I enumerates (tile s, unit tile mt, register pair): the offsets are immediates, hence the recursion
+__device__ __forceinline__ void store_act_rows(unsigned addr, const f32x4 acc[NS][NT])
+{
+    if constexpr (I < NS * NT * 2) {
+        constexpr int s = I / (NT * 2), mt = (I / 2) % NT, r = (I % 2) * 2;
+        ds_write2_rows_agpr<s * kUvActSteps + mt * 4 + r>(addr, acc[s][mt][r], acc[s][mt][r + 1]);
+        store_act_rows<NT, NS, I + 1>(addr, acc);
+    }
+}
+// ACT = kUvActNone: raw rows for a consumer that applies the activation itself (the fp32 kernels); else the activation here (the split-bf16 kernel,
+// whose k loop is not the matrix pipe's but the vector pipe's: measured 0.6 % slower with the activation on its read side)
+template <int NT, int NS, int ACT = kUvActNone>
 __device__ __forceinline__ void store_act(float *act, int lane, const f32x4 acc[NS][NT])
 {
+    if constexpr (ACT < 0) {
+        static_assert(NS * kUvActSteps <= 256, "ds_write2st64 offsets are 8 bits");
+        const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(act + lane);
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        store_act_rows<NT, NS>(addr, acc);
+    } else {
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int mt = 0; mt < NT; ++mt)
+            for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) act[s * kUvWaveLds + (mt * 4 + r) * 64 + lane] = act_fn<LEAKY>(acc[s][mt][r]);
+                for (int r = 0; r < 4; ++r) act[s * kUvWaveLds + (mt * 4 + r) * 64 + lane] = act_fn<ACT>(acc[s][mt][r]);
+    }
 }
+// where a layer's activation ACT is applied: by its consumer (fp32 kernels) or at its store (split-bf16 kernel)
+template <bool SPLIT, int ACT> constexpr int kUvRd = SPLIT ? kUvActNone : ACT;
+template <bool SPLIT, int ACT> constexpr int kUvSt = SPLIT ? ACT : kUvActNone;
 
 // Output layer with <= 3 units on the matrix pipe (rows >= n_out of the 16-row tile are zero; rows 0..3 land in the lanes of quarter kq = 0).
 // Packed [KT / 4][64 lanes][4]: one 16-byte load per lane holds its A operands of four k-steps.  Round 4: all of a layer's weights are requested
@@ -457,7 +521,7 @@ __device__ __forceinline__ void out_prefetch(const float *w, int lane, UvOutW<KT
     for (int q = 0; q < KT / 4; ++q) o.w[q] = wp[q * 64];
 }
 
-template <int NS, int KT>
+template <int NS, int KT, int ACT>
 __device__ __forceinline__ void dense_out(const UvOutW<KT> &o, const float *bias4, int lane, const float *act, f32x4 r[NS])
 {
     f32x4 acc[NS][2];
@@ -477,6 +541,11 @@ __device__ __forceinline__ void dense_out(const UvOutW<KT> &o, const float *bias
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bq[(q + 1) & 1][s][e] = act[s * kUvWaveLds + (4 * (q + 1) + e) * 64 + lane];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) bq[q & 1][s][e] = act_in<ACT>(bq[q & 1][s][e]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -570,9 +639,9 @@ __device__ __forceinline__ void hidden_run(const UvArgs &A, const float *w, cons
 {
 #pragma unroll 1
     for (int l = 0; l < n; ++l) {
-        dense256<NS, SPLIT, DEEP>(A, w + (size_t)l * kUvLayerStride, wq + (size_t)l * kUvQLayer, b + l * 256, 64, lane, act, x NGF_UVSEC_ARG);
+        dense256<NS, SPLIT, DEEP, kUvRd<SPLIT, LEAKY>>(A, w + (size_t)l * kUvLayerStride, wq + (size_t)l * kUvQLayer, b + l * 256, 64, lane, act, x NGF_UVSEC_ARG);
         NGF_UVSEC_T(u0);
-        store_act<16, NS, LEAKY>(act, lane, x);
+        store_act<16, NS, kUvSt<SPLIT, LEAKY>>(act, lane, x);
         NGF_UVSEC_T(u1);
         NGF_UVSEC_ADD(2, u0, u1);
     }
@@ -603,12 +672,12 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     // geometry: 63 -> 256 -> (10x) 256 -> 1, ReLU.  PE10(p) goes to rows 0..15 AND to rows 64..79, where the gauge network finds it later
     { NGF_UVSEC_T(u11a); store_pe<3, 10, NS>(act, 0, 16, lane, p, 64); NGF_UVSEC_T(u11b); NGF_UVSEC_ADD(3, u11a, u11b); }
     dense<16, NS, DEEP>(W + A.geo_w0, W + A.geo_b0, 16, lane, act, x NGF_UVSEC_ARG);
-    { NGF_UVSEC_T(u1a); store_act<16, NS, 0>(act, lane, x); NGF_UVSEC_T(u1b); NGF_UVSEC_ADD(2, u1a, u1b); }
+    { NGF_UVSEC_T(u1a); store_act<16, NS, kUvSt<SPLIT, 0>>(act, lane, x); NGF_UVSEC_T(u1b); NGF_UVSEC_ADD(2, u1a, u1b); }
     {
         UvOutW<64> ow;
         hidden_run<NS, SPLIT, 0, DEEP>(A, W + A.geo_wh, W + A.geo_qh, W + A.geo_bh, 10, lane, act, x, W + A.geo_wo, ow NGF_UVSEC_ARG);
         f32x4 o[NS];
-        { NGF_UVSEC_T(u16a); dense_out<NS, 64>(ow, W + A.geo_bo, lane, act, o); NGF_UVSEC_T(u16b); NGF_UVSEC_ADD(4, u16a, u16b); }
+        { NGF_UVSEC_T(u16a); dense_out<NS, 64, kUvRd<SPLIT, 0>>(ow, W + A.geo_bo, lane, act, o); NGF_UVSEC_T(u16b); NGF_UVSEC_ADD(4, u16a, u16b); }
 #pragma unroll
         for (int s = 0; s < NS; ++s) sigma[s] = o[s][0] > 20.0f ? o[s][0] : log1pf(expf(o[s][0]));
     }
@@ -617,18 +686,18 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     {
         f32x4 g4[NS][4], g[NS][8];
         dense<4, NS, DEEP>(W + A.ga_w0, W + A.ga_b0, 16, lane, act + 64 * 64, g4 NGF_UVSEC_ARG);
-        { NGF_UVSEC_T(u3a); store_act<4, NS, 0>(act, lane, g4); NGF_UVSEC_T(u3b); NGF_UVSEC_ADD(2, u3a, u3b); }
-        dense<8, NS, DEEP>(W + A.ga_w1, W + A.ga_b1, 16, lane, act, g NGF_UVSEC_ARG);
-        { NGF_UVSEC_T(u4a); store_act<8, NS, 0>(act, lane, g); NGF_UVSEC_T(u4b); NGF_UVSEC_ADD(2, u4a, u4b); }
-        dense<8, NS, DEEP>(W + A.ga_w2, W + A.ga_b2, 32, lane, act, g NGF_UVSEC_ARG);
-        { NGF_UVSEC_T(u5a); store_act<8, NS, 0>(act, lane, g); NGF_UVSEC_T(u5b); NGF_UVSEC_ADD(2, u5a, u5b); }
-        dense<8, NS, DEEP>(W + A.ga_w3, W + A.ga_b3, 32, lane, act, g NGF_UVSEC_ARG);
-        { NGF_UVSEC_T(u6a); store_act<8, NS, 0>(act, lane, g); NGF_UVSEC_T(u6b); NGF_UVSEC_ADD(2, u6a, u6b); }
+        { NGF_UVSEC_T(u3a); store_act<4, NS, kUvSt<SPLIT, 0>>(act, lane, g4); NGF_UVSEC_T(u3b); NGF_UVSEC_ADD(2, u3a, u3b); }
+        dense<8, NS, DEEP, kUvRd<SPLIT, 0>>(W + A.ga_w1, W + A.ga_b1, 16, lane, act, g NGF_UVSEC_ARG);
+        { NGF_UVSEC_T(u4a); store_act<8, NS, kUvSt<SPLIT, 0>>(act, lane, g); NGF_UVSEC_T(u4b); NGF_UVSEC_ADD(2, u4a, u4b); }
+        dense<8, NS, DEEP, kUvRd<SPLIT, 0>>(W + A.ga_w2, W + A.ga_b2, 32, lane, act, g NGF_UVSEC_ARG);
+        { NGF_UVSEC_T(u5a); store_act<8, NS, kUvSt<SPLIT, 0>>(act, lane, g); NGF_UVSEC_T(u5b); NGF_UVSEC_ADD(2, u5a, u5b); }
+        dense<8, NS, DEEP, kUvRd<SPLIT, 0>>(W + A.ga_w3, W + A.ga_b3, 32, lane, act, g NGF_UVSEC_ARG);
+        { NGF_UVSEC_T(u6a); store_act<8, NS, kUvSt<SPLIT, 0>>(act, lane, g); NGF_UVSEC_T(u6b); NGF_UVSEC_ADD(2, u6a, u6b); }
         UvOutW<32> ow;
         out_prefetch<32>(W + A.ga_wo, lane, ow);
         __builtin_amdgcn_sched_barrier(0);
         f32x4 q[NS];
-        { NGF_UVSEC_T(u17a); dense_out<NS, 32>(ow, W + A.ga_bo, lane, act, q); NGF_UVSEC_T(u17b); NGF_UVSEC_ADD(4, u17a, u17b); }
+        { NGF_UVSEC_T(u17a); dense_out<NS, 32, kUvRd<SPLIT, 0>>(ow, W + A.ga_bo, lane, act, q); NGF_UVSEC_T(u17b); NGF_UVSEC_ADD(4, u17a, u17b); }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (A.sphere) {
@@ -648,22 +717,22 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
         { NGF_UVSEC_T(u14a); store_pe<2, 10, NS>(act, 0, 12, lane, uv); NGF_UVSEC_T(u14b); NGF_UVSEC_ADD(3, u14a, u14b); }
         dense<16, NS, DEEP>(W + A.t1_w0, W + A.t1_b0, 12, lane, act, x NGF_UVSEC_ARG);
     }
-    { NGF_UVSEC_T(u7a); store_act<16, NS, 1>(act, lane, x); NGF_UVSEC_T(u7b); NGF_UVSEC_ADD(2, u7a, u7b); }
+    { NGF_UVSEC_T(u7a); store_act<16, NS, kUvSt<SPLIT, 1>>(act, lane, x); NGF_UVSEC_T(u7b); NGF_UVSEC_ADD(2, u7a, u7b); }
     // act[0..63] = block1 output h; color1 and block2 both read it
     f32x4 c1[NS], c2[NS];
     {
         UvOutW<64> ow;
         hidden_run<NS, SPLIT, 1, DEEP>(A, W + NGF_UV_SAME(A.t1_wh), W + A.t1_qh, W + A.t1_bh, 5, lane, act, x, W + A.c1_w, ow NGF_UVSEC_ARG);
-        { NGF_UVSEC_T(u18a); dense_out<NS, 64>(ow, W + A.c1_b, lane, act, c1); NGF_UVSEC_T(u18b); NGF_UVSEC_ADD(4, u18a, u18b); }
+        { NGF_UVSEC_T(u18a); dense_out<NS, 64, kUvRd<SPLIT, 1>>(ow, W + A.c1_b, lane, act, c1); NGF_UVSEC_T(u18b); NGF_UVSEC_ADD(4, u18a, u18b); }
     }
     // block2: [h(256), v(3), PE6(v)(36)] -> 256 -> (3x) 256 -> 3
     { NGF_UVSEC_T(u15a); store_pe<3, 6, NS>(act, 64, 12, lane, v); NGF_UVSEC_T(u15b); NGF_UVSEC_ADD(3, u15a, u15b); }                 // 39 inputs + zero padding up to k-step 76
-    dense256<NS, SPLIT, DEEP>(A, W + A.t2_w0, W + A.t2_q0, W + A.t2_b0, 76, lane, act, x NGF_UVSEC_ARG);            // 76 k-steps -> 10 k-blocks in split mode (rows 76..79: zero weights on finite leftovers)
-    { NGF_UVSEC_T(u9a); store_act<16, NS, 1>(act, lane, x); NGF_UVSEC_T(u9b); NGF_UVSEC_ADD(2, u9a, u9b); }
+    dense256<NS, SPLIT, DEEP, kUvRd<SPLIT, 1>>(A, W + A.t2_w0, W + A.t2_q0, W + A.t2_b0, 76, lane, act, x NGF_UVSEC_ARG, 64);            // 76 k-steps -> 10 k-blocks in split mode (rows 76..79: zero weights on finite leftovers)
+    { NGF_UVSEC_T(u9a); store_act<16, NS, kUvSt<SPLIT, 1>>(act, lane, x); NGF_UVSEC_T(u9b); NGF_UVSEC_ADD(2, u9a, u9b); }
     {
         UvOutW<64> ow;
         hidden_run<NS, SPLIT, 1, DEEP>(A, W + NGF_UV_SAME(A.t2_wh), W + A.t2_qh, W + A.t2_bh, 3, lane, act, x, W + A.t2_wo, ow NGF_UVSEC_ARG);
-        { NGF_UVSEC_T(u19a); dense_out<NS, 64>(ow, W + A.t2_bo, lane, act, c2); NGF_UVSEC_T(u19b); NGF_UVSEC_ADD(4, u19a, u19b); }
+        { NGF_UVSEC_T(u19a); dense_out<NS, 64, kUvRd<SPLIT, 1>>(ow, W + A.t2_bo, lane, act, c2); NGF_UVSEC_T(u19b); NGF_UVSEC_ADD(4, u19a, u19b); }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
