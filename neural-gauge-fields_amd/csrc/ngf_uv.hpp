@@ -223,13 +223,34 @@ struct KStepA {
 };
 
 template <int NT, int NS>
-__device__ __forceinline__ void kload(const float *w, const float *act, int t, int lane, KStepA<NT, NS> &k)
+__device__ __forceinline__ void kload_w(const float *w, int t, int lane, KStepA<NT, NS> &k)
 {
+#ifndef NGF_EXP_UV_BUFFER_LOADS
     const f32x4 *wp = reinterpret_cast<const f32x4 *>(w) + ((size_t)t * (NT / 4)) * 64 + lane;
 #pragma unroll
     for (int g = 0; g < NT / 4; ++g) k.a[g] = wp[g * 64];
+#else
+    // EXPERIMENT (measured slower): buffer loads -- the k-step's offset in an SGPR (soffset), the lane's in a loop-invariant VGPR,
+    // the tile group's an immediate: no 64-bit vector add per k-step in the k loop, and still 0.8 % slower than global loads
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) k.b[s] = act[s * kUvWaveLds + t * 64 + lane];
+    for (int g = 0; g < NT / 4; ++g)
+        k.a[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16 + g * 1024, t * ((NT / 4) * 1024), 0));
+#endif
+}
+// B operands of k-step t0 + j; j: compile-time position in a group of k-steps that share t0 (one LDS address per group, j in the offset field)
+template <int NT, int NS>
+__device__ __forceinline__ void kload_b(const float *act, int t0, int lane, KStepA<NT, NS> &k, int j = 0)
+{
+    const float *ap = act + t0 * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) k.b[s] = ap[s * kUvWaveLds + j * 64];
+}
+template <int NT, int NS>
+__device__ __forceinline__ void kload(const float *w, const float *act, int t0, int lane, KStepA<NT, NS> &k, int j = 0)
+{
+    kload_w<NT, NS>(w, t0 + j, lane, k);
+    kload_b<NT, NS>(act, t0, lane, k, j);
 }
 
 // the activation of the producing layer on a k-step's B operands (in place, once the LDS read has landed); k-steps from t_none on are inputs that
@@ -317,8 +338,8 @@ __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4
         // one wave per SIMD: nobody else covers the L2 / Infinity-Cache latency, so FOUR k-steps of weights are in flight
         // behind four k-steps of MFMAs (4 x 32 x NS MFMAs = 4096 matrix-pipe cycles of cover at NS = 2)
         KStepA<NT_OUT, NS> a0, a1, a2, a3, b0, b1, b2, b3;
-        kload<NT_OUT, NS>(w, act, 0, lane, a0); kload<NT_OUT, NS>(w, act, 1, lane, a1);
-        kload<NT_OUT, NS>(w, act, 2, lane, a2); kload<NT_OUT, NS>(w, act, 3, lane, a3);
+        kload<NT_OUT, NS>(w, act, 0, lane, a0); kload<NT_OUT, NS>(w, act, 0, lane, a1, 1);
+        kload<NT_OUT, NS>(w, act, 0, lane, a2, 2); kload<NT_OUT, NS>(w, act, 0, lane, a3, 3);
 #ifdef NGF_EXP_UV_SECTIONS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // section 0 = bias + the first four k-steps of weights ARRIVED (the layer's uncovered latency)
 #endif
@@ -339,8 +360,8 @@ __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4
             }
             continue;
 #endif
-            kload<NT_OUT, NS>(w, act, tb, lane, b0); kload<NT_OUT, NS>(w, act, tb + 1, lane, b1);
-            kload<NT_OUT, NS>(w, act, tb + 2, lane, b2); kload<NT_OUT, NS>(w, act, tb + 3, lane, b3);
+            kload<NT_OUT, NS>(w, act, tb, lane, b0); kload<NT_OUT, NS>(w, act, tb, lane, b1, 1);
+            kload<NT_OUT, NS>(w, act, tb, lane, b2, 2); kload<NT_OUT, NS>(w, act, tb, lane, b3, 3);
             // (the activation of the four k-steps about to be consumed sits with the address arithmetic of the loads above: one cluster of vector
             // instructions per 128 matrix instructions -- at one wave per SIMD every switch between the pipes costs the wave ~38 cycles)
             kact<ACT>(a0, t, t_none); kact<ACT>(a1, t + 1, t_none); kact<ACT>(a2, t + 2, t_none); kact<ACT>(a3, t + 3, t_none);
@@ -349,8 +370,8 @@ __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4
             __builtin_amdgcn_sched_barrier(0);
             if (has_b) {
                 const int ta = t + 8 < KT4 ? t + 8 : t;
-                kload<NT_OUT, NS>(w, act, ta, lane, a0); kload<NT_OUT, NS>(w, act, ta + 1, lane, a1);
-                kload<NT_OUT, NS>(w, act, ta + 2, lane, a2); kload<NT_OUT, NS>(w, act, ta + 3, lane, a3);
+                kload<NT_OUT, NS>(w, act, ta, lane, a0); kload<NT_OUT, NS>(w, act, ta, lane, a1, 1);
+                kload<NT_OUT, NS>(w, act, ta, lane, a2, 2); kload<NT_OUT, NS>(w, act, ta, lane, a3, 3);
                 kact<ACT>(b0, t + 4, t_none); kact<ACT>(b1, t + 5, t_none); kact<ACT>(b2, t + 6, t_none); kact<ACT>(b3, t + 7, t_none);
                 __builtin_amdgcn_sched_barrier(0);
                 kmma<NT_OUT, NS>(b0, out); kmma<NT_OUT, NS>(b1, out); kmma<NT_OUT, NS>(b2, out); kmma<NT_OUT, NS>(b3, out);
@@ -505,6 +526,22 @@ __device__ __forceinline__ void store_act(float *act, int lane, const f32x4 acc[
 template <bool SPLIT, int ACT> constexpr int kUvRd = SPLIT ? kUvActNone : ACT;
 template <bool SPLIT, int ACT> constexpr int kUvSt = SPLIT ? ACT : kUvActNone;
 
+// store_act (raw rows) with the NEXT layer's bias loaded into each accumulator tile as soon as its rows are on their way: by the time the last tile is
+// stored the first biases have arrived, instead of a full L2 round trip between the store and the next layer's first MFMA
+template <int NT, int NS, int MT = 0>
+__device__ __forceinline__ void store_act_rows_next_bias(unsigned addr, f32x4 acc[NS][NT], const float *bias_lane)
+{
+    if constexpr (MT < NT) {
+        if constexpr (NS > 0) { ds_write2_rows_agpr<MT * 4>(addr, acc[0][MT][0], acc[0][MT][1]); ds_write2_rows_agpr<MT * 4 + 2>(addr, acc[0][MT][2], acc[0][MT][3]); }
+        if constexpr (NS > 1) { ds_write2_rows_agpr<kUvActSteps + MT * 4>(addr, acc[1][MT][0], acc[1][MT][1]); ds_write2_rows_agpr<kUvActSteps + MT * 4 + 2>(addr, acc[1][MT][2], acc[1][MT][3]); }
+        static_assert(NS <= 2, "tiles per pass");
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(bias_lane + MT * 4);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s][MT] = v;
+        store_act_rows_next_bias<NT, NS, MT + 1>(addr, acc, bias_lane);
+    }
+}
+
 // Output layer with <= 3 units on the matrix pipe (rows >= n_out of the 16-row tile are zero; rows 0..3 land in the lanes of quarter kq = 0).
 // Packed [KT / 4][64 lanes][4]: one 16-byte load per lane holds its A operands of four k-steps.  Round 4: all of a layer's weights are requested
 // in one go (out_prefetch, right behind the previous layer's activation store) and the KT MFMAs of a tile run as two independent chains over
@@ -633,10 +670,66 @@ constexpr size_t kUvLayerStride = 0;          // every layer of a run reads the 
 #else
 constexpr size_t kUvLayerStride = 65536;
 #endif
+// fp32, one wave per SIMD: ONE software pipeline across the run's layers.  The layers' weights are contiguous, so the load group that follows a layer's
+// last k-steps ("k-steps 64..67") IS the next layer's first four k-steps: they arrive behind the last MFMAs and the activation store instead of in front
+// of an idle matrix pipe (the per-layer prologue was 1.35 % of a wave's life, profiles/r04_uv_sections.txt); the B operands read with them (LDS rows
+// 64..67: they exist) are re-read once the layer's outputs are stored, and the next bias is loaded tile by tile inside the store.
+template <int NS, int ACT>
+__device__ __forceinline__ void hidden_run_deep(const float *w, const float *b, int n, int lane, float *act, f32x4 x[NS][16] NGF_UVSEC_PARAM)
+{
+    KStepA<16, NS> a0, a1, a2, a3, b0, b1, b2, b3;
+    const int kq = lane >> 4;
+    kload_w<16, NS>(w, 0, lane, a0); kload_w<16, NS>(w, 1, lane, a1); kload_w<16, NS>(w, 2, lane, a2); kload_w<16, NS>(w, 3, lane, a3);
+    load_bias<16, NS>(b, kq, x);
+#pragma unroll 1
+    for (int l = 0; l < n; ++l) {
+        const float *wl = w + (size_t)l * kUvLayerStride;
+        const bool more = kUvLayerStride != 0 && l + 1 < n;
+        NGF_UVSEC_T(ts0);
+        kload_b<16, NS>(act, 0, lane, a0); kload_b<16, NS>(act, 0, lane, a1, 1); kload_b<16, NS>(act, 0, lane, a2, 2); kload_b<16, NS>(act, 0, lane, a3, 3);
+#ifdef NGF_EXP_UV_SECTIONS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        NGF_UVSEC_T(ts1);
+        NGF_UVSEC_ADD(0, ts0, ts1);
+#pragma unroll 1
+        for (int t = 0; t < 64; t += 8) {
+            kload<16, NS>(wl, act, t + 4, lane, b0); kload<16, NS>(wl, act, t + 4, lane, b1, 1);
+            kload<16, NS>(wl, act, t + 4, lane, b2, 2); kload<16, NS>(wl, act, t + 4, lane, b3, 3);
+            kact<ACT>(a0, 0, 1); kact<ACT>(a1, 0, 1); kact<ACT>(a2, 0, 1); kact<ACT>(a3, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma<16, NS>(a0, x); kmma<16, NS>(a1, x); kmma<16, NS>(a2, x); kmma<16, NS>(a3, x);
+            __builtin_amdgcn_sched_barrier(0);
+            const int ta = (t + 8 < 64 || more) ? t + 8 : t;       // the run's last layer: harmless reload instead of reading behind the run
+            kload<16, NS>(wl, act, ta, lane, a0); kload<16, NS>(wl, act, ta, lane, a1, 1);
+            kload<16, NS>(wl, act, ta, lane, a2, 2); kload<16, NS>(wl, act, ta, lane, a3, 3);
+            kact<ACT>(b0, 0, 1); kact<ACT>(b1, 0, 1); kact<ACT>(b2, 0, 1); kact<ACT>(b3, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            kmma<16, NS>(b0, x); kmma<16, NS>(b1, x); kmma<16, NS>(b2, x); kmma<16, NS>(b3, x);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        NGF_UVSEC_T(ts2);
+        NGF_UVSEC_ADD(1, ts1, ts2);
+#ifdef NGF_EXP_UV_SECTIONS
+        uvsec.t[6] += (unsigned long long)(64 * 16 * NS);
+#endif
+        {
+            const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(act + lane);
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+            // (behind the run's last layer: the same bias again, unused)
+            store_act_rows_next_bias<16, NS>(addr, x, b + (more ? l + 1 : l) * 256 + kq * 64);
+        }
+        NGF_UVSEC_T(ts3);
+        NGF_UVSEC_ADD(2, ts2, ts3);
+    }
+}
+
 template <int NS, bool SPLIT, int LEAKY, bool DEEP = (NS > 1)>
 __device__ __forceinline__ void hidden_run(const UvArgs &A, const float *w, const float *wq, const float *b, int n, int lane, float *act, f32x4 x[NS][16],
                                            const float *w_out, UvOutW<64> &ow NGF_UVSEC_PARAM)
 {
+    if constexpr (!SPLIT && DEEP) hidden_run_deep<NS, LEAKY>(w, b, n, lane, act, x NGF_UVSEC_ARG);
+    else {
 #pragma unroll 1
     for (int l = 0; l < n; ++l) {
         dense256<NS, SPLIT, DEEP, kUvRd<SPLIT, LEAKY>>(A, w + (size_t)l * kUvLayerStride, wq + (size_t)l * kUvQLayer, b + l * 256, 64, lane, act, x NGF_UVSEC_ARG);
@@ -644,6 +737,7 @@ __device__ __forceinline__ void hidden_run(const UvArgs &A, const float *w, cons
         store_act<16, NS, kUvSt<SPLIT, LEAKY>>(act, lane, x);
         NGF_UVSEC_T(u1);
         NGF_UVSEC_ADD(2, u0, u1);
+    }
     }
     out_prefetch<64>(w_out, lane, ow);
     __builtin_amdgcn_sched_barrier(0);
