@@ -73,10 +73,18 @@ struct UvArgs {
 // pattern with 0 (ngf_shade16.hpp relu1); LeakyReLU(0.2) (texture, decoder.py:20-45) as max(x, 0.2 x): x for x >= 0, the single product
 // 0.2 x below -- the same bits as `x >= 0 ? x : 0.2 x`.  Round 2's generic `fmaxf(x,0) + slope * fminf(x,0)` cost five instructions per
 // value (640 per 256-unit layer and pass, ~4 % of the launch) because IEEE rules keep the compiler from folding the zero slope.
-template <int LEAKY>
+template <int LEAKY, bool ONE_OP = false>
 __device__ __forceinline__ float act_fn(float x)
 {
-    if constexpr (LEAKY) return fmaxf(x, 0.2f * x);
+    if constexpr (LEAKY && ONE_OP) {
+        // max(x, 0.2 x) as ONE v_max_f32 (the one-wave-per-SIMD k loops, where every vector instruction is the matrix pipe's time): fmaxf() puts a
+        // canonicalising `v_max_f32 x, x` in front (IEEE mode; x may be a signalling NaN for all hipcc knows), and so does fmed3(x, 0.2 x, inf), which
+        // it folds back to fmaxf.  Not everywhere: the inline assembly's VGPR operands cost the two-waves-per-SIMD kernel (uv_tiles = 1) 100 B of scratch
+        const float y = 0.2f * x;
+        float r;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+        return r;
+    } else if constexpr (LEAKY) return fmaxf(x, 0.2f * x);
     else return __int_as_float(max(__float_as_int(x), 0));
 }
 
@@ -84,11 +92,11 @@ __device__ __forceinline__ float act_fn(float x)
 // layer READS its inputs.  ACT of a consumer = the activation of the layer that produced its inputs: kUvActNone (positional encodings, or a producer
 // that applied it at the store: the split-bf16 kernel, kUvRd / kUvSt below), 0 ReLU, 1 LeakyReLU.
 constexpr int kUvActNone = -1;
-template <int ACT>
+template <int ACT, bool ONE_OP = false>
 __device__ __forceinline__ float act_in(float x)
 {
     if constexpr (ACT < 0) return x;
-    else return act_fn<ACT>(x);
+    else return act_fn<ACT, ONE_OP>(x);
 }
 
 // ---- texture editing: TextureMlpDecoder.forward with cubemap_ set (decoder.py:79-121) -------------------------------------
@@ -225,17 +233,21 @@ struct KStepA {
 template <int NT, int NS>
 __device__ __forceinline__ void kload_w(const float *w, int t, int lane, KStepA<NT, NS> &k)
 {
-#ifndef NGF_EXP_UV_BUFFER_LOADS
     const f32x4 *wp = reinterpret_cast<const f32x4 *>(w) + ((size_t)t * (NT / 4)) * 64 + lane;
 #pragma unroll
     for (int g = 0; g < NT / 4; ++g) k.a[g] = wp[g * 64];
+}
+// ONE of a k-step's NT / 4 weight loads (tile group g), as a buffer load: the k-step's offset is an SGPR (soffset), the lane's a loop-invariant VGPR,
+// the tile group's an immediate -- NO vector instruction per load, so it can sit between two MFMAs without a matrix -> vector -> matrix switch of
+// the SIMD's datapath (a global load there needs a 64-bit vector add for its address: that form measured 3 % SLOWER than the burst, this one 2 % faster)
+template <int NT, int NS>
+__device__ __forceinline__ void kload_wg(const float *w, int t, int g, int lane, KStepA<NT, NS> &k)
+{
+#ifdef NGF_EXP_UV_GLOBAL_LOADS
+    k.a[g] = (reinterpret_cast<const f32x4 *>(w) + ((size_t)t * (NT / 4)) * 64 + lane)[g * 64];
 #else
-    // EXPERIMENT (measured slower): buffer loads -- the k-step's offset in an SGPR (soffset), the lane's in a loop-invariant VGPR,
-    // the tile group's an immediate: no 64-bit vector add per k-step in the k loop, and still 0.8 % slower than global loads
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int g = 0; g < NT / 4; ++g)
-        k.a[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16 + g * 1024, t * ((NT / 4) * 1024), 0));
+    k.a[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16 + g * 1024, t * ((NT / 4) * 1024), 0));
 #endif
 }
 // B operands of k-step t0 + j; j: compile-time position in a group of k-steps that share t0 (one LDS address per group, j in the offset field)
@@ -255,12 +267,12 @@ __device__ __forceinline__ void kload(const float *w, const float *act, int t0, 
 
 // the activation of the producing layer on a k-step's B operands (in place, once the LDS read has landed); k-steps from t_none on are inputs that
 // no layer produced (block2.0's view encodings behind the 64 k-steps of block 1's output)
-template <int ACT, int NT, int NS>
+template <int ACT, bool ONE_OP = false, int NT, int NS>
 __device__ __forceinline__ void kact(KStepA<NT, NS> &k, int t, int t_none)
 {
     if constexpr (ACT >= 0) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) k.b[s] = t < t_none ? act_in<ACT>(k.b[s]) : k.b[s];
+        for (int s = 0; s < NS; ++s) k.b[s] = t < t_none ? act_in<ACT, ONE_OP>(k.b[s]) : k.b[s];
     }
 }
 
@@ -275,14 +287,15 @@ __device__ __forceinline__ void kmma(const KStepA<NT, NS> &k, f32x4 acc[NS][NT])
             for (int s = 0; s < NS; ++s) acc[s][4 * g + e] = NGF_UV_MFMA(k.a[g][e], k.b[s], acc[s][4 * g + e]);
 }
 
-#ifdef NGF_EXP_UV_FUSED
-// EXPERIMENT (measured slower): one k-step consumed and another one requested piece by piece -- the 8 MFMAs of a 4-tile
-// group, then ONE of the requested k-step's four weight loads -- instead of 16 loads in front of 128 MFMAs.
+// The one-wave-per-SIMD k loop: consume k-step k (B operands activated) and request k-step t's weights into kn, ONE load behind every 4 x NS MFMAs
+// (a tile group).  Sixteen loads in a burst in front of 128 MFMAs left the matrix pipe idle while they issued (~280 cycles per burst: 34.5 cycles per
+// MFMA against 32.8 for a pure MFMA loop).  NGF_EXP_UV_BURST: the burst form, for the A/B.
 template <int NT, int NS>
-__device__ __forceinline__ void kstep_fused(const KStepA<NT, NS> &k, f32x4 acc[NS][NT], const float *w, const float *act, int t, int lane,
-                                            KStepA<NT, NS> &kn)
+__device__ __forceinline__ void kstep(const KStepA<NT, NS> &k, f32x4 acc[NS][NT], const float *w, int t, int lane, KStepA<NT, NS> &kn)
 {
-    const f32x4 *wp = reinterpret_cast<const f32x4 *>(w) + ((size_t)t * (NT / 4)) * 64 + lane;
+#ifdef NGF_EXP_UV_BURST
+    kmma<NT, NS>(k, acc);
+#else
 #pragma unroll
     for (int g = 0; g < NT / 4; ++g) {
 #pragma unroll
@@ -290,15 +303,30 @@ __device__ __forceinline__ void kstep_fused(const KStepA<NT, NS> &k, f32x4 acc[N
 #pragma unroll
             for (int s = 0; s < NS; ++s) acc[s][4 * g + e] = NGF_UV_MFMA(k.a[g][e], k.b[s], acc[s][4 * g + e]);
         __builtin_amdgcn_sched_barrier(0);
-        kn.a[g] = wp[g * 64];
-        if (g == 0) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) kn.b[s] = act[s * kUvWaveLds + t * 64 + lane];
-        }
+        kload_wg<NT, NS>(w, t, g, lane, kn);
         __builtin_amdgcn_sched_barrier(0);
     }
-}
 #endif
+}
+// a group of four k-steps: B operands of the group requested (kb*: k-steps tn ..), the group consumed (ka*: k-steps t ..) activated, then the MFMAs with
+// the requested group's weight loads between them
+template <int ACT, int NT, int NS>
+__device__ __forceinline__ void kgroup(KStepA<NT, NS> &ka0, KStepA<NT, NS> &ka1, KStepA<NT, NS> &ka2, KStepA<NT, NS> &ka3, f32x4 acc[NS][NT], const float *w,
+                                       const float *act, int t, int t_none, int tn, int lane, KStepA<NT, NS> &kb0, KStepA<NT, NS> &kb1, KStepA<NT, NS> &kb2,
+                                       KStepA<NT, NS> &kb3)
+{
+#ifdef NGF_EXP_UV_BURST
+    kload_w<NT, NS>(w, tn, lane, kb0); kload_w<NT, NS>(w, tn + 1, lane, kb1); kload_w<NT, NS>(w, tn + 2, lane, kb2); kload_w<NT, NS>(w, tn + 3, lane, kb3);
+#endif
+    kload_b<NT, NS>(act, tn, lane, kb0); kload_b<NT, NS>(act, tn, lane, kb1, 1); kload_b<NT, NS>(act, tn, lane, kb2, 2); kload_b<NT, NS>(act, tn, lane, kb3, 3);
+    // (the activation of the four k-steps about to be consumed: one cluster of vector instructions per 128 matrix instructions -- at one wave per
+    // SIMD every switch between the pipes costs the wave ~38 cycles)
+    kact<ACT, true>(ka0, t, t_none); kact<ACT, true>(ka1, t + 1, t_none); kact<ACT, true>(ka2, t + 2, t_none); kact<ACT, true>(ka3, t + 3, t_none);
+    __builtin_amdgcn_sched_barrier(0);
+    kstep<NT, NS>(ka0, acc, w, tn, lane, kb0); kstep<NT, NS>(ka1, acc, w, tn + 1, lane, kb1);
+    kstep<NT, NS>(ka2, acc, w, tn + 2, lane, kb2); kstep<NT, NS>(ka3, acc, w, tn + 3, lane, kb3);
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 // Dense layer, KT4 k-steps (multiple of 4; padded steps have zero weights and zero inputs).  Software pipeline with
 // two k-steps of weight loads in flight behind the MFMAs (the un-pipelined loop left the waves 67 % of their cycles
@@ -349,33 +377,10 @@ __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4
         for (int t = 0; t < KT4; t += 8) {
             const bool has_b = t + 4 < KT4;
             const int tb = has_b ? t + 4 : t;                    // harmless reload when the layer ends on the first half
-#ifdef NGF_EXP_UV_FUSED
-            static_assert(ACT < 0, "the fused k-step experiment predates the activation-on-read layout");
-            kstep_fused<NT_OUT, NS>(a0, out, w, act, tb, lane, b0); kstep_fused<NT_OUT, NS>(a1, out, w, act, tb + 1, lane, b1);
-            kstep_fused<NT_OUT, NS>(a2, out, w, act, tb + 2, lane, b2); kstep_fused<NT_OUT, NS>(a3, out, w, act, tb + 3, lane, b3);
+            kgroup<ACT, NT_OUT, NS>(a0, a1, a2, a3, out, w, act, t, t_none, tb, lane, b0, b1, b2, b3);
             if (has_b) {
                 const int ta = t + 8 < KT4 ? t + 8 : t;
-                kstep_fused<NT_OUT, NS>(b0, out, w, act, ta, lane, a0); kstep_fused<NT_OUT, NS>(b1, out, w, act, ta + 1, lane, a1);
-                kstep_fused<NT_OUT, NS>(b2, out, w, act, ta + 2, lane, a2); kstep_fused<NT_OUT, NS>(b3, out, w, act, ta + 3, lane, a3);
-            }
-            continue;
-#endif
-            kload<NT_OUT, NS>(w, act, tb, lane, b0); kload<NT_OUT, NS>(w, act, tb, lane, b1, 1);
-            kload<NT_OUT, NS>(w, act, tb, lane, b2, 2); kload<NT_OUT, NS>(w, act, tb, lane, b3, 3);
-            // (the activation of the four k-steps about to be consumed sits with the address arithmetic of the loads above: one cluster of vector
-            // instructions per 128 matrix instructions -- at one wave per SIMD every switch between the pipes costs the wave ~38 cycles)
-            kact<ACT>(a0, t, t_none); kact<ACT>(a1, t + 1, t_none); kact<ACT>(a2, t + 2, t_none); kact<ACT>(a3, t + 3, t_none);
-            __builtin_amdgcn_sched_barrier(0);
-            kmma<NT_OUT, NS>(a0, out); kmma<NT_OUT, NS>(a1, out); kmma<NT_OUT, NS>(a2, out); kmma<NT_OUT, NS>(a3, out);
-            __builtin_amdgcn_sched_barrier(0);
-            if (has_b) {
-                const int ta = t + 8 < KT4 ? t + 8 : t;
-                kload<NT_OUT, NS>(w, act, ta, lane, a0); kload<NT_OUT, NS>(w, act, ta, lane, a1, 1);
-                kload<NT_OUT, NS>(w, act, ta, lane, a2, 2); kload<NT_OUT, NS>(w, act, ta, lane, a3, 3);
-                kact<ACT>(b0, t + 4, t_none); kact<ACT>(b1, t + 5, t_none); kact<ACT>(b2, t + 6, t_none); kact<ACT>(b3, t + 7, t_none);
-                __builtin_amdgcn_sched_barrier(0);
-                kmma<NT_OUT, NS>(b0, out); kmma<NT_OUT, NS>(b1, out); kmma<NT_OUT, NS>(b2, out); kmma<NT_OUT, NS>(b3, out);
-                __builtin_amdgcn_sched_barrier(0);
+                kgroup<ACT, NT_OUT, NS>(b0, b1, b2, b3, out, w, act, t + 4, t_none, ta, lane, a0, a1, a2, a3);
             }
         }
         NGF_UVSEC_T(ts2);
@@ -558,7 +563,7 @@ __device__ __forceinline__ void out_prefetch(const float *w, int lane, UvOutW<KT
     for (int q = 0; q < KT / 4; ++q) o.w[q] = wp[q * 64];
 }
 
-template <int NS, int KT, int ACT>
+template <int NS, int KT, int ACT, bool ONE_OP = false>
 __device__ __forceinline__ void dense_out(const UvOutW<KT> &o, const float *bias4, int lane, const float *act, f32x4 r[NS])
 {
     f32x4 acc[NS][2];
@@ -582,7 +587,7 @@ __device__ __forceinline__ void dense_out(const UvOutW<KT> &o, const float *bias
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) bq[q & 1][s][e] = act_in<ACT>(bq[q & 1][s][e]);
+            for (int s = 0; s < NS; ++s) bq[q & 1][s][e] = act_in<ACT, ONE_OP>(bq[q & 1][s][e]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -694,19 +699,9 @@ __device__ __forceinline__ void hidden_run_deep(const float *w, const float *b, 
         NGF_UVSEC_ADD(0, ts0, ts1);
 #pragma unroll 1
         for (int t = 0; t < 64; t += 8) {
-            kload<16, NS>(wl, act, t + 4, lane, b0); kload<16, NS>(wl, act, t + 4, lane, b1, 1);
-            kload<16, NS>(wl, act, t + 4, lane, b2, 2); kload<16, NS>(wl, act, t + 4, lane, b3, 3);
-            kact<ACT>(a0, 0, 1); kact<ACT>(a1, 0, 1); kact<ACT>(a2, 0, 1); kact<ACT>(a3, 0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            kmma<16, NS>(a0, x); kmma<16, NS>(a1, x); kmma<16, NS>(a2, x); kmma<16, NS>(a3, x);
-            __builtin_amdgcn_sched_barrier(0);
+            kgroup<ACT, 16, NS>(a0, a1, a2, a3, x, wl, act, 0, 1 << 30, t + 4, lane, b0, b1, b2, b3);
             const int ta = (t + 8 < 64 || more) ? t + 8 : t;       // the run's last layer: harmless reload instead of reading behind the run
-            kload<16, NS>(wl, act, ta, lane, a0); kload<16, NS>(wl, act, ta, lane, a1, 1);
-            kload<16, NS>(wl, act, ta, lane, a2, 2); kload<16, NS>(wl, act, ta, lane, a3, 3);
-            kact<ACT>(b0, 0, 1); kact<ACT>(b1, 0, 1); kact<ACT>(b2, 0, 1); kact<ACT>(b3, 0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            kmma<16, NS>(b0, x); kmma<16, NS>(b1, x); kmma<16, NS>(b2, x); kmma<16, NS>(b3, x);
-            __builtin_amdgcn_sched_barrier(0);
+            kgroup<ACT, 16, NS>(b0, b1, b2, b3, x, wl, act, 0, 1 << 30, ta, lane, a0, a1, a2, a3);
         }
         NGF_UVSEC_T(ts2);
         NGF_UVSEC_ADD(1, ts1, ts2);
@@ -771,7 +766,7 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
         UvOutW<64> ow;
         hidden_run<NS, SPLIT, 0, DEEP>(A, W + A.geo_wh, W + A.geo_qh, W + A.geo_bh, 10, lane, act, x, W + A.geo_wo, ow NGF_UVSEC_ARG);
         f32x4 o[NS];
-        { NGF_UVSEC_T(u16a); dense_out<NS, 64, kUvRd<SPLIT, 0>>(ow, W + A.geo_bo, lane, act, o); NGF_UVSEC_T(u16b); NGF_UVSEC_ADD(4, u16a, u16b); }
+        { NGF_UVSEC_T(u16a); dense_out<NS, 64, kUvRd<SPLIT, 0>, DEEP>(ow, W + A.geo_bo, lane, act, o); NGF_UVSEC_T(u16b); NGF_UVSEC_ADD(4, u16a, u16b); }
 #pragma unroll
         for (int s = 0; s < NS; ++s) sigma[s] = o[s][0] > 20.0f ? o[s][0] : log1pf(expf(o[s][0]));
     }
@@ -791,7 +786,7 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
         out_prefetch<32>(W + A.ga_wo, lane, ow);
         __builtin_amdgcn_sched_barrier(0);
         f32x4 q[NS];
-        { NGF_UVSEC_T(u17a); dense_out<NS, 32, kUvRd<SPLIT, 0>>(ow, W + A.ga_bo, lane, act, q); NGF_UVSEC_T(u17b); NGF_UVSEC_ADD(4, u17a, u17b); }
+        { NGF_UVSEC_T(u17a); dense_out<NS, 32, kUvRd<SPLIT, 0>, DEEP>(ow, W + A.ga_bo, lane, act, q); NGF_UVSEC_T(u17b); NGF_UVSEC_ADD(4, u17a, u17b); }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (A.sphere) {
@@ -817,7 +812,7 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     {
         UvOutW<64> ow;
         hidden_run<NS, SPLIT, 1, DEEP>(A, W + NGF_UV_SAME(A.t1_wh), W + A.t1_qh, W + A.t1_bh, 5, lane, act, x, W + A.c1_w, ow NGF_UVSEC_ARG);
-        { NGF_UVSEC_T(u18a); dense_out<NS, 64, kUvRd<SPLIT, 1>>(ow, W + A.c1_b, lane, act, c1); NGF_UVSEC_T(u18b); NGF_UVSEC_ADD(4, u18a, u18b); }
+        { NGF_UVSEC_T(u18a); dense_out<NS, 64, kUvRd<SPLIT, 1>, DEEP>(ow, W + A.c1_b, lane, act, c1); NGF_UVSEC_T(u18b); NGF_UVSEC_ADD(4, u18a, u18b); }
     }
     // block2: [h(256), v(3), PE6(v)(36)] -> 256 -> (3x) 256 -> 3
     { NGF_UVSEC_T(u15a); store_pe<3, 6, NS>(act, 64, 12, lane, v); NGF_UVSEC_T(u15b); NGF_UVSEC_ADD(3, u15a, u15b); }                 // 39 inputs + zero padding up to k-step 76
@@ -826,7 +821,7 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     {
         UvOutW<64> ow;
         hidden_run<NS, SPLIT, 1, DEEP>(A, W + NGF_UV_SAME(A.t2_wh), W + A.t2_qh, W + A.t2_bh, 3, lane, act, x, W + A.t2_wo, ow NGF_UVSEC_ARG);
-        { NGF_UVSEC_T(u19a); dense_out<NS, 64, kUvRd<SPLIT, 1>>(ow, W + A.t2_bo, lane, act, c2); NGF_UVSEC_T(u19b); NGF_UVSEC_ADD(4, u19a, u19b); }
+        { NGF_UVSEC_T(u19a); dense_out<NS, 64, kUvRd<SPLIT, 1>, DEEP>(ow, W + A.t2_bo, lane, act, c2); NGF_UVSEC_T(u19b); NGF_UVSEC_ADD(4, u19a, u19b); }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
