@@ -419,11 +419,18 @@ struct UvAPair { uv_bf16x8 a[3][2]; };            // [part hi / mid / lo][tile o
 // pair g2 (0..7) of k-block kb: tiles 2 g2, 2 g2 + 1
 __device__ __forceinline__ void uv_gload(const float *wq, int kb, int g2, int lane, UvAPair &G)
 {
+    // (global loads: as buffer loads -- kload_wg -- these measured 2.8 % SLOWER; a buffer load issues more slowly, and the bf16 loop has no
+    // matrix -> vector -> matrix switch to save: its address arithmetic hides among the split's vector instructions)
     const uv_bf16x8 *p = reinterpret_cast<const uv_bf16x8 *>(wq) + ((size_t)(kb * 4 + (g2 >> 1)) * 12 + (g2 & 1) * 2) * 64 + lane;
 #pragma unroll
     for (int part = 0; part < 3; ++part)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) G.a[part][e] = p[(part * 4 + e) * 64];
+        for (int e = 0; e < 2; ++e) {
+#ifdef NGF_EXP_UV_SPLIT_NOLO            // timing experiment (wrong pixels): a third of the weight bytes not loaded
+            if (part == 2) { G.a[2][e] = G.a[1][e]; continue; }
+#endif
+            G.a[part][e] = p[(part * 4 + e) * 64];
+        }
 }
 #define NGF_UV_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 // the six products for the two tiles of a pair, product-major so that consecutive MFMAs hit different accumulators
@@ -453,6 +460,13 @@ __device__ __forceinline__ void dense_bf16(const float *wq, const float *bias, i
     load_bias<16, NS>(bias, lane >> 4, out);
     UvAPair A0, A1, A2, A3;
     uv_gload(wq, 0, 0, lane, A0); uv_gload(wq, 0, 1, lane, A1); uv_gload(wq, 0, 2, lane, A2); uv_gload(wq, 0, 3, lane, A3);
+    // the lane's 8 raw inputs of a k-block are read from LDS one k-block ahead (behind the 96 x NS MFMAs of the previous one): read at the top of the
+    // k-block they are split in, each tile's LDS latency stood in front of an idle matrix pipe
+    float raw[NS][8];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) raw[s][e] = act[s * kUvWaveLds + e * 64 + lane];
 #pragma unroll 1
     for (int kb = 0; kb < KB; ++kb) {
         UvSplit8 x[NS];
@@ -460,13 +474,18 @@ __device__ __forceinline__ void dense_bf16(const float *wq, const float *bias, i
         for (int s = 0; s < NS; ++s) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float raw = act[s * kUvWaveLds + (kb * 8 + e) * 64 + lane];
-                v[e] = (ACT >= 0 && kb * 8 < t_none) ? act_in<ACT>(raw) : raw;          // a k-block lies wholly before or behind t_none (a multiple of 8)
-            }
+            for (int e = 0; e < 8; ++e) v[e] = (ACT >= 0 && kb * 8 < t_none) ? act_in<ACT>(raw[s][e]) : raw[s][e];          // a k-block lies wholly before or behind t_none (a multiple of 8)
             x[s] = uv_split8(v);
         }
         const int kn = kb + 1 < KB ? kb + 1 : kb;                // last k-block: harmless reload instead of a branch
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float *ap = act + kn * 8 * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) raw[s][e] = ap[s * kUvWaveLds + e * 64];
+        }
         __builtin_amdgcn_sched_barrier(0);
         uv_gmma<NS>(A0, x, out, 0);   __builtin_amdgcn_sched_barrier(0);  uv_gload(wq, kb, 4, lane, A0);  __builtin_amdgcn_sched_barrier(0);
         uv_gmma<NS>(A1, x, out, 2);   __builtin_amdgcn_sched_barrier(0);  uv_gload(wq, kb, 5, lane, A1);  __builtin_amdgcn_sched_barrier(0);
