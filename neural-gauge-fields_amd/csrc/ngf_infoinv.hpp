@@ -223,7 +223,7 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
     const float *w1 = blob + L::W1 + lane * 4;
     GatherRowII g;
     Bil b = bil_setup(rec[2], rec[3], karg_tex(offsetof(RenderArgs, app) + (0) * sizeof(Tex)));
-    gather_row_ii(karg_tex(offsetof(RenderArgs, app) + (0) * sizeof(Tex)).p + (size_t)b.idx * 72 + kq * 18, g);
+    gather_row_ii(tex_at<float>(karg_tex(offsetof(RenderArgs, app) + (0) * sizeof(Tex)).p, (uint32_t)b.idx * 72u + (uint32_t)kq * 18u), g);
     LoFragII lo0, lo1;                         // k-blocks 2i / 2i+1: each is re-requested for block +2 as soon as it has been used
     lo_load_ii(A.basis_pack, 0, lane, lo0);
     lo_load_ii(A.basis_pack, 1, lane, lo1);
@@ -257,7 +257,7 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
 #pragma unroll
         for (int e = 0; e < 2; ++e) f[16 + e] = fmaf(b.w10, g.b[1][e], b.w00 * g.b[0][e]);
         __builtin_amdgcn_sched_barrier(0);
-        gather_row_ii(karg_tex(offsetof(RenderArgs, app) + (p) * sizeof(Tex)).p + ((size_t)b.idx + karg_tex(offsetof(RenderArgs, app) + (p) * sizeof(Tex)).stride) * 72 + kq * 18, g);
+        gather_row_ii(tex_at<float>(karg_tex(offsetof(RenderArgs, app) + (p) * sizeof(Tex)).p, (uint32_t)(b.idx + karg_tex(offsetof(RenderArgs, app) + (p) * sizeof(Tex)).stride) * 72u + (uint32_t)kq * 18u), g);
         __builtin_amdgcn_sched_barrier(0);
         // row 1: + w01 v01, + w11 v11 (bil_mix's order), then the positional factor
 #pragma unroll
@@ -269,7 +269,7 @@ __device__ __forceinline__ void mlp_pass16_bf16_ii(const RenderArgs &A, const fl
         __builtin_amdgcn_sched_barrier(0);
         if (p < 2) {                           // the next plane's first row travels behind this plane's MFMAs
             b = bil_setup(rec[4 + 2 * p], rec[5 + 2 * p], karg_tex(offsetof(RenderArgs, app) + (p + 1) * sizeof(Tex)));
-            gather_row_ii(karg_tex(offsetof(RenderArgs, app) + (p + 1) * sizeof(Tex)).p + (size_t)b.idx * 72 + kq * 18, g);
+            gather_row_ii(tex_at<float>(karg_tex(offsetof(RenderArgs, app) + (p + 1) * sizeof(Tex)).p, (uint32_t)b.idx * 72u + (uint32_t)kq * 18u), g);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (mode) {
@@ -380,7 +380,7 @@ __device__ __forceinline__ void mlp_pass16_ii(const RenderArgs &A, const float *
     const float *w1 = blob + L::W1 + lane;
     GatherRowII g;
     Bil b = bil_setup(rec[2], rec[3], karg_tex(offsetof(RenderArgs, app) + (0) * sizeof(Tex)));
-    gather_row_ii(karg_tex(offsetof(RenderArgs, app) + (0) * sizeof(Tex)).p + (size_t)b.idx * 72 + kq * 18, g);
+    gather_row_ii(tex_at<float>(karg_tex(offsetof(RenderArgs, app) + (0) * sizeof(Tex)).p, (uint32_t)b.idx * 72u + (uint32_t)kq * 18u), g);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[4];
 #pragma unroll
@@ -408,7 +408,7 @@ __device__ __forceinline__ void mlp_pass16_ii(const RenderArgs &A, const float *
 #pragma unroll
         for (int e = 0; e < 2; ++e) f[16 + e] = fmaf(b.w10, g.b[1][e], b.w00 * g.b[0][e]);
         __builtin_amdgcn_sched_barrier(0);
-        gather_row_ii(karg_tex(offsetof(RenderArgs, app) + (p) * sizeof(Tex)).p + ((size_t)b.idx + karg_tex(offsetof(RenderArgs, app) + (p) * sizeof(Tex)).stride) * 72 + kq * 18, g);
+        gather_row_ii(tex_at<float>(karg_tex(offsetof(RenderArgs, app) + (p) * sizeof(Tex)).p, (uint32_t)(b.idx + karg_tex(offsetof(RenderArgs, app) + (p) * sizeof(Tex)).stride) * 72u + (uint32_t)kq * 18u), g);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -419,7 +419,7 @@ __device__ __forceinline__ void mlp_pass16_ii(const RenderArgs &A, const float *
         __builtin_amdgcn_sched_barrier(0);
         if (p < 2) {                           // the next plane's first row travels behind this plane's 72 MFMAs
             b = bil_setup(rec[4 + 2 * p], rec[5 + 2 * p], karg_tex(offsetof(RenderArgs, app) + (p + 1) * sizeof(Tex)));
-            gather_row_ii(karg_tex(offsetof(RenderArgs, app) + (p + 1) * sizeof(Tex)).p + (size_t)b.idx * 72 + kq * 18, g);
+            gather_row_ii(tex_at<float>(karg_tex(offsetof(RenderArgs, app) + (p + 1) * sizeof(Tex)).p, (uint32_t)b.idx * 72u + (uint32_t)kq * 18u), g);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (mode) {
@@ -502,8 +502,8 @@ __device__ __forceinline__ float infoinv_sigma_bf16(const RenderArgs &A, const f
         float feat[24];
         if (valid) {
             Bil b = bil_setup(t[2 * p], t[2 * p + 1], tx);
-            const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + (size_t)b.idx * 24);
-            const f32x4 *q01 = q00 + (size_t)tx.stride * 6;
+            const f32x4 *q00 = tex_at<f32x4>(tx.p, (uint32_t)b.idx * 24u);       // 32-bit byte offsets from a scalar base (ngf_device.hpp tex_at): +1.2 %; as 24-bit multiplies of byte offsets: 0.5 % slower than this
+            const f32x4 *q01 = tex_at<f32x4>(tx.p, (uint32_t)(b.idx + tx.stride) * 24u);
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
                 f32x4 v00 = q00[q], v10 = q00[6 + q], v01 = q01[q], v11 = q01[6 + q];
@@ -617,8 +617,8 @@ struct InfoInvPolicyT {
             float feat[24];
             if (valid) {
                 Bil b = bil_setup(t[2 * p], t[2 * p + 1], tx);
-                const f32x4 *q00 = reinterpret_cast<const f32x4 *>(tx.p + (size_t)b.idx * 24);
-                const f32x4 *q01 = q00 + (size_t)tx.stride * 6;
+                const f32x4 *q00 = tex_at<f32x4>(tx.p, (uint32_t)b.idx * 24u);       // 32-bit byte offsets from a scalar base (ngf_device.hpp tex_at)
+                const f32x4 *q01 = tex_at<f32x4>(tx.p, (uint32_t)(b.idx + tx.stride) * 24u);
 #pragma unroll
                 for (int part = 0; part < NGF_II_TAP_PARTS; ++part) {      // 24 / PARTS channels at a time: 96 / PARTS registers of taps in flight (the fp32 kernel
                                                             // runs at the 168 registers of twelve waves per CU; all 24 at once was what it spilled for)
