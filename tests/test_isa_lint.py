@@ -79,10 +79,47 @@ def test_shipped_hot_kernels_use_no_scratch(asm):
 def test_uv_weight_loads_are_global_loads(asm):
     """Round 4 pitfall: an opaque POINTER as per-pass weight base loses its address space -- every 16-byte weight load of
     uv_render_kernel became a flat_load, which counts on both memory counters, and the k loop waited vmcnt(0) lgkmcnt(0) once per trip (+9 % time).
-    The shipped kernels stream their weights with global_load_dwordx4; the only flat loads left are the 12-byte camera / background rows."""
+    The shipped kernels stream their weights with global_load_dwordx4 (the fp32 k loops, late in round 4, with buffer_load_dwordx4 -- next test; biases,
+    output layers, prologues and the split-bf16 fragments stay global loads); the only flat loads left are the 12-byte camera / background rows."""
     import isa_hazards
     for name, body in isa_hazards.kernels(asm["uv"]):
         if "uv_render_kernel" not in name:
             continue
         assert not [l for l in body if "flat_load_dwordx4" in l], name
         assert sum("global_load_dwordx4" in l for l in body) > 100, name
+
+
+def test_uv_fp32_k_loops_have_no_vector_instruction_between_the_mfmas_of_a_group(asm):
+    """DESIGN.md 4.2 (round 4, late): fp32 MFMA and VALU share the SIMD's datapath and a lone wave pays ~38 cycles for every matrix -> vector -> matrix
+    switch, so the one-wave-per-SIMD k loops of uv_render_kernel<2, false> are [B operands + activations of a group] then 16 x (8 MFMAs, one
+    BUFFER load whose k-step offset is an SGPR).  A weight load that needs vector address arithmetic again (a global load: 3 % slower than the burst it
+    replaced), or a scheduler that spreads the activations among the MFMAs, shows up here as more vector gaps than one per 128 MFMAs."""
+    import re
+    import isa_hazards
+    checked = 0
+    for name, body in isa_hazards.kernels(asm["uv"]):
+        if "uv_render_kernelILi2ELb0" not in name:
+            continue
+        blocks, cur, label = [], [], None          # loop bodies: from a label to the branch back to it
+        for l in body:
+            t = l.strip()
+            m = re.match(r"^(\.LBB\d+_\d+):", t)
+            if m:
+                label, cur = m.group(1), []
+            elif t and not t.startswith((";", ".")):
+                cur.append(t)
+                if label and re.match(r"^s_cbranch_\w+ " + re.escape(label) + r"$", t):
+                    blocks.append(cur)
+                    label, cur = None, []
+        for b in blocks:
+            idx = [i for i, t in enumerate(b) if t.startswith("v_mfma_f32_16x16x4_f32")]
+            if len(idx) < 256:
+                continue
+            gaps = [b[i + 1:j] for i, j in zip(idx, idx[1:])]
+            vector_gaps = sum(any(t.startswith("v_") for t in g) for g in gaps)
+            loads_between = sum(sum(t.startswith("buffer_load_dwordx4") for t in g) for g in gaps)
+            assert vector_gaps <= len(idx) // 128, (name, len(idx), vector_gaps)
+            assert loads_between >= len(idx) // 8 - 8, (name, len(idx), loads_between)
+            assert not any(t.startswith("global_load") for g in gaps for t in g if len(g) < 4), name
+            checked += 1
+    assert checked >= 4, checked          # the geometry / texture hidden runs and block2.0, at least
