@@ -588,30 +588,34 @@ __device__ __forceinline__ void dense_out(const UvOutW<KT> &o, const float *bias
     f32x4 acc[NS][2];
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc[s][0] = acc[s][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    // the B operands of four k-steps are read one group ahead of their MFMAs (sched_barrier pins it: left alone hipcc hoists all 2 KT LDS reads and spills)
-    float bq[2][NS][4];
+    // the B operands of a group of G k-steps are read one group ahead of their MFMAs (sched_barrier pins it: left alone hipcc hoists all 2 KT LDS reads
+    // and spills) and activated in one cluster of vector instructions per group.  (G = 16 -- four times fewer matrix <-> vector switches -- measured
+    // 0.2 % slower: the first group's 32 LDS reads stand in front of the layer)
+    constexpr int G = 4;
+    static_assert(KT % G == 0, "k-steps per group");
+    float bq[2][NS][G];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bq[0][s][e] = act[s * kUvWaveLds + e * 64 + lane];
+        for (int e = 0; e < G; ++e) bq[0][s][e] = act[s * kUvWaveLds + e * 64 + lane];
 #pragma unroll
-    for (int q = 0; q < KT / 4; ++q) {
-        if (q + 1 < KT / 4) {
+    for (int q = 0; q < KT / G; ++q) {
+        if (q + 1 < KT / G) {
 #pragma unroll
             for (int s = 0; s < NS; ++s)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bq[(q + 1) & 1][s][e] = act[s * kUvWaveLds + (4 * (q + 1) + e) * 64 + lane];
+                for (int e = 0; e < G; ++e) bq[(q + 1) & 1][s][e] = act[s * kUvWaveLds + (G * (q + 1) + e) * 64 + lane];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < G; ++e)
 #pragma unroll
             for (int s = 0; s < NS; ++s) bq[q & 1][s][e] = act_in<ACT, ONE_OP>(bq[q & 1][s][e]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < G; ++e)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) acc[s][e & 1] = NGF_UV_MFMA(o.w[q][e], bq[q & 1][s][e], acc[s][e & 1]);
+            for (int s = 0; s < NS; ++s) acc[s][e & 1] = NGF_UV_MFMA(o.w[q * (G / 4) + e / 4][e & 3], bq[q & 1][s][e], acc[s][e & 1]);
         __builtin_amdgcn_sched_barrier(0);
     }
     const int src = lane & 15;
@@ -716,12 +720,60 @@ __device__ __forceinline__ void hidden_run_deep(const float *w, const float *b, 
 #endif
         NGF_UVSEC_T(ts1);
         NGF_UVSEC_ADD(0, ts0, ts1);
+#ifndef NGF_EXP_UV_ACT_PER_GROUP
+        // ONE cluster of vector instructions per EIGHT k-steps (256 MFMAs at NS = 2): the activations of both groups at the top of the first, all LDS
+        // reads of the next eight k-steps at the top of the second (LDS reads are no vector instructions: no switch of the datapath).  The second
+        // group's operands wait in eight registers of their own (bn) while the current ones are in use.
+        float bn[4][NS];
+        {
+            const float *ap = act + 4 * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) bn[j][s] = ap[s * kUvWaveLds + j * 64];
+        }
+        // LDS byte address of the lane's slot in row t + 8, advanced in the activation cluster and kept opaque: formed where the reads are (from t),
+        // it is one more vector instruction in the middle of the 256 MFMAs -- one more switch
+        typedef __attribute__((address_space(3))) const float lds_cf;
+        unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(act + lane);
+#pragma unroll 1
+        for (int t = 0; t < 64; t += 8) {
+            la += 8 * 64 * 4;
+            asm volatile("" : "+v"(la));
+            const unsigned cur = la;
+            kact<ACT, true>(a0, 0, 1); kact<ACT, true>(a1, 0, 1); kact<ACT, true>(a2, 0, 1); kact<ACT, true>(a3, 0, 1);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                b0.b[s] = act_in<ACT, true>(bn[0][s]); b1.b[s] = act_in<ACT, true>(bn[1][s]);
+                b2.b[s] = act_in<ACT, true>(bn[2][s]); b3.b[s] = act_in<ACT, true>(bn[3][s]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            kstep<16, NS>(a0, x, wl, t + 4, lane, b0); kstep<16, NS>(a1, x, wl, t + 5, lane, b1);
+            kstep<16, NS>(a2, x, wl, t + 6, lane, b2); kstep<16, NS>(a3, x, wl, t + 7, lane, b3);
+            __builtin_amdgcn_sched_barrier(0);
+            const int ta = (t + 8 < 64 || more) ? t + 8 : t;       // the run's last layer: harmless reload instead of reading behind the run
+            {
+                lds_cf *ap = (lds_cf *)(size_t)cur;         // rows t + 8 .. t + 15 <= 71 (80 exist); behind a layer's last k-steps the values are re-read above
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    a0.b[s] = ap[s * kUvWaveLds]; a1.b[s] = ap[s * kUvWaveLds + 64]; a2.b[s] = ap[s * kUvWaveLds + 128]; a3.b[s] = ap[s * kUvWaveLds + 192];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bn[j][s] = ap[s * kUvWaveLds + (4 + j) * 64];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            kstep<16, NS>(b0, x, wl, ta, lane, a0); kstep<16, NS>(b1, x, wl, ta + 1, lane, a1);
+            kstep<16, NS>(b2, x, wl, ta + 2, lane, a2); kstep<16, NS>(b3, x, wl, ta + 3, lane, a3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll 1
         for (int t = 0; t < 64; t += 8) {
             kgroup<ACT, 16, NS>(a0, a1, a2, a3, x, wl, act, 0, 1 << 30, t + 4, lane, b0, b1, b2, b3);
             const int ta = (t + 8 < 64 || more) ? t + 8 : t;       // the run's last layer: harmless reload instead of reading behind the run
             kgroup<ACT, 16, NS>(b0, b1, b2, b3, x, wl, act, 0, 1 << 30, ta, lane, a0, a1, a2, a3);
         }
+#endif
         NGF_UVSEC_T(ts2);
         NGF_UVSEC_ADD(1, ts1, ts2);
 #ifdef NGF_EXP_UV_SECTIONS
