@@ -265,6 +265,15 @@ __device__ __forceinline__ void kload(const float *w, const float *act, int t0, 
     kload_b<NT, NS>(act, t0, lane, k, j);
 }
 
+// the weights of a layer's k-steps 0..3, requested ahead of the layer (one wave per SIMD: in front of the positional encodings or the activation store
+// that produce its inputs, instead of in front of an idle matrix pipe once they are stored)
+template <int NT, int NS>
+__device__ __forceinline__ void uv_wprefetch(const float *w, int lane, KStepA<NT, NS> pre[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kload_w<NT, NS>(w, j, lane, pre[j]);
+}
+
 // the activation of the producing layer on a k-step's B operands (in place, once the LDS read has landed); k-steps from t_none on are inputs that
 // no layer produced (block2.0's view encodings behind the 64 k-steps of block 1's output)
 template <int ACT, bool ONE_OP = false, int NT, int NS>
@@ -334,7 +343,8 @@ __device__ __forceinline__ void kgroup(KStepA<NT, NS> &ka0, KStepA<NT, NS> &ka1,
 // DEEP: the four-k-steps-ahead pipeline of the one-wave-per-SIMD kernel also for a single tile (its last pass of a ray pair, below); without it
 // NS = 1 is the two-waves-per-SIMD kernel's shallower pipeline.
 template <int NT_OUT, int NS, bool DEEP = (NS > 1), int ACT = kUvActNone>
-__device__ __forceinline__ void dense(const float *w, const float *bias, int KT4, int lane, const float *act, f32x4 out[NS][NT_OUT] NGF_UVSEC_PARAM, int t_none = 1 << 30)
+__device__ __forceinline__ void dense(const float *w, const float *bias, int KT4, int lane, const float *act, f32x4 out[NS][NT_OUT] NGF_UVSEC_PARAM, int t_none = 1 << 30,
+                                      const KStepA<NT_OUT, NS> *pre = nullptr, bool use_pre = false)        // pre: the weights of k-steps 0..3, requested by the caller (uv_wprefetch) before the layer's inputs were stored
 {
     NGF_UVSEC_T(ts0);
     load_bias<NT_OUT, NS>(bias, lane >> 4, out);
@@ -366,8 +376,13 @@ __device__ __forceinline__ void dense(const float *w, const float *bias, int KT4
         // one wave per SIMD: nobody else covers the L2 / Infinity-Cache latency, so FOUR k-steps of weights are in flight
         // behind four k-steps of MFMAs (4 x 32 x NS MFMAs = 4096 matrix-pipe cycles of cover at NS = 2)
         KStepA<NT_OUT, NS> a0, a1, a2, a3, b0, b1, b2, b3;
-        kload<NT_OUT, NS>(w, act, 0, lane, a0); kload<NT_OUT, NS>(w, act, 0, lane, a1, 1);
-        kload<NT_OUT, NS>(w, act, 0, lane, a2, 2); kload<NT_OUT, NS>(w, act, 0, lane, a3, 3);
+        if (use_pre) {
+            a0 = pre[0]; a1 = pre[1]; a2 = pre[2]; a3 = pre[3];
+            kload_b<NT_OUT, NS>(act, 0, lane, a0); kload_b<NT_OUT, NS>(act, 0, lane, a1, 1); kload_b<NT_OUT, NS>(act, 0, lane, a2, 2); kload_b<NT_OUT, NS>(act, 0, lane, a3, 3);
+        } else {
+            kload<NT_OUT, NS>(w, act, 0, lane, a0); kload<NT_OUT, NS>(w, act, 0, lane, a1, 1);
+            kload<NT_OUT, NS>(w, act, 0, lane, a2, 2); kload<NT_OUT, NS>(w, act, 0, lane, a3, 3);
+        }
 #ifdef NGF_EXP_UV_SECTIONS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // section 0 = bias + the first four k-steps of weights ARRIVED (the layer's uncovered latency)
 #endif
@@ -501,10 +516,10 @@ __device__ __forceinline__ void dense_bf16(const float *wq, const float *bias, i
 // a 256-unit layer on KT4 fp32 k-steps or (split mode) KT4 / 8 bf16 k-blocks; wq: the layer's packed bf16 weights (split mode)
 template <int NS, bool SPLIT, bool DEEP = (NS > 1), int ACT = kUvActNone>
 __device__ __forceinline__ void dense256(const UvArgs &A, const float *w, const float *wq, const float *bias, int KT4, int lane, const float *act,
-                                         f32x4 out[NS][16] NGF_UVSEC_PARAM, int t_none = 1 << 30)
+                                         f32x4 out[NS][16] NGF_UVSEC_PARAM, int t_none = 1 << 30, const KStepA<16, NS> *pre = nullptr, bool use_pre = false)
 {
     if constexpr (SPLIT) dense_bf16<NS, ACT>(wq, bias, (KT4 + 7) / 8, lane, act, out, t_none);
-    else dense<16, NS, DEEP, ACT>(w, bias, KT4, lane, act, out NGF_UVSEC_ARG, t_none);
+    else dense<16, NS, DEEP, ACT>(w, bias, KT4, lane, act, out NGF_UVSEC_ARG, t_none, pre, use_pre);
 }
 
 // A layer's NT x 16 outputs of every tile -> the wave's activation rows, RAW (the consumer applies the activation: act_in), straight from the
@@ -703,11 +718,12 @@ constexpr size_t kUvLayerStride = 65536;
 // of an idle matrix pipe (the per-layer prologue was 1.35 % of a wave's life, profiles/r04_uv_sections.txt); the B operands read with them (LDS rows
 // 64..67: they exist) are re-read once the layer's outputs are stored, and the next bias is loaded tile by tile inside the store.
 template <int NS, int ACT>
-__device__ __forceinline__ void hidden_run_deep(const float *w, const float *b, int n, int lane, float *act, f32x4 x[NS][16] NGF_UVSEC_PARAM)
+__device__ __forceinline__ void hidden_run_deep(const float *w, const float *b, int n, int lane, float *act, f32x4 x[NS][16], const KStepA<16, NS> *pre, bool use_pre NGF_UVSEC_PARAM)
 {
     KStepA<16, NS> a0, a1, a2, a3, b0, b1, b2, b3;
     const int kq = lane >> 4;
-    kload_w<16, NS>(w, 0, lane, a0); kload_w<16, NS>(w, 1, lane, a1); kload_w<16, NS>(w, 2, lane, a2); kload_w<16, NS>(w, 3, lane, a3);
+    if (use_pre) { a0 = pre[0]; a1 = pre[1]; a2 = pre[2]; a3 = pre[3]; }
+    else { kload_w<16, NS>(w, 0, lane, a0); kload_w<16, NS>(w, 1, lane, a1); kload_w<16, NS>(w, 2, lane, a2); kload_w<16, NS>(w, 3, lane, a3); }
     load_bias<16, NS>(b, kq, x);
 #pragma unroll 1
     for (int l = 0; l < n; ++l) {
@@ -792,9 +808,9 @@ __device__ __forceinline__ void hidden_run_deep(const float *w, const float *b, 
 
 template <int NS, bool SPLIT, int LEAKY, bool DEEP = (NS > 1)>
 __device__ __forceinline__ void hidden_run(const UvArgs &A, const float *w, const float *wq, const float *b, int n, int lane, float *act, f32x4 x[NS][16],
-                                           const float *w_out, UvOutW<64> &ow NGF_UVSEC_PARAM)
+                                           const float *w_out, UvOutW<64> &ow NGF_UVSEC_PARAM, const KStepA<16, NS> *pre = nullptr, bool use_pre = false)
 {
-    if constexpr (!SPLIT && DEEP) hidden_run_deep<NS, LEAKY>(w, b, n, lane, act, x NGF_UVSEC_ARG);
+    if constexpr (!SPLIT && DEEP) hidden_run_deep<NS, LEAKY>(w, b, n, lane, act, x, pre, use_pre NGF_UVSEC_ARG);
     else {
 #pragma unroll 1
     for (int l = 0; l < n; ++l) {
@@ -830,12 +846,17 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
 #endif
     f32x4 x[NS][16];
     // geometry: 63 -> 256 -> (10x) 256 -> 1, ReLU.  PE10(p) goes to rows 0..15 AND to rows 64..79, where the gauge network finds it later
+    // (one wave per SIMD: the first weights of a 256-wide layer are requested BEFORE the encodings / the store that produce its inputs)
+    KStepA<16, NS> pre[4];
+    constexpr bool PRE = DEEP && !SPLIT, PRE0 = PRE;         // the fp32 one-wave-per-SIMD kernel (the split-bf16 kernel measured 0.4 % slower with its fp32 layers 0 prefetched)
+    if constexpr (PRE0) uv_wprefetch<16, NS>(W + A.geo_w0, lane, pre);
     { NGF_UVSEC_T(u11a); store_pe<3, 10, NS>(act, 0, 16, lane, p, 64); NGF_UVSEC_T(u11b); NGF_UVSEC_ADD(3, u11a, u11b); }
-    dense<16, NS, DEEP>(W + A.geo_w0, W + A.geo_b0, 16, lane, act, x NGF_UVSEC_ARG);
+    dense<16, NS, DEEP>(W + A.geo_w0, W + A.geo_b0, 16, lane, act, x NGF_UVSEC_ARG, 1 << 30, pre, PRE0);
+    if constexpr (PRE) uv_wprefetch<16, NS>(W + A.geo_wh, lane, pre);
     { NGF_UVSEC_T(u1a); store_act<16, NS, kUvSt<SPLIT, 0>>(act, lane, x); NGF_UVSEC_T(u1b); NGF_UVSEC_ADD(2, u1a, u1b); }
     {
         UvOutW<64> ow;
-        hidden_run<NS, SPLIT, 0, DEEP>(A, W + A.geo_wh, W + A.geo_qh, W + A.geo_bh, 10, lane, act, x, W + A.geo_wo, ow NGF_UVSEC_ARG);
+        hidden_run<NS, SPLIT, 0, DEEP>(A, W + A.geo_wh, W + A.geo_qh, W + A.geo_bh, 10, lane, act, x, W + A.geo_wo, ow NGF_UVSEC_ARG, pre, PRE);
         f32x4 o[NS];
         { NGF_UVSEC_T(u16a); dense_out<NS, 64, kUvRd<SPLIT, 0>, DEEP>(ow, W + A.geo_bo, lane, act, o); NGF_UVSEC_T(u16b); NGF_UVSEC_ADD(4, u16a, u16b); }
 #pragma unroll
@@ -870,28 +891,32 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
         }
     }
     // texture block1: (63|42) -> 256 -> (5x) 256, LeakyReLU(0.2)
+    if constexpr (PRE0) uv_wprefetch<16, NS>(W + A.t1_w0, lane, pre);
     if (A.sphere) {
         { NGF_UVSEC_T(u13a); store_pe<3, 10, NS>(act, 0, 16, lane, uv); NGF_UVSEC_T(u13b); NGF_UVSEC_ADD(3, u13a, u13b); }
-        dense<16, NS, DEEP>(W + A.t1_w0, W + A.t1_b0, 16, lane, act, x NGF_UVSEC_ARG);
+        dense<16, NS, DEEP>(W + A.t1_w0, W + A.t1_b0, 16, lane, act, x NGF_UVSEC_ARG, 1 << 30, pre, PRE0);
     } else {
         { NGF_UVSEC_T(u14a); store_pe<2, 10, NS>(act, 0, 12, lane, uv); NGF_UVSEC_T(u14b); NGF_UVSEC_ADD(3, u14a, u14b); }
-        dense<16, NS, DEEP>(W + A.t1_w0, W + A.t1_b0, 12, lane, act, x NGF_UVSEC_ARG);
+        dense<16, NS, DEEP>(W + A.t1_w0, W + A.t1_b0, 12, lane, act, x NGF_UVSEC_ARG, 1 << 30, pre, PRE0);
     }
+    if constexpr (PRE) uv_wprefetch<16, NS>(W + NGF_UV_SAME(A.t1_wh), lane, pre);
     { NGF_UVSEC_T(u7a); store_act<16, NS, kUvSt<SPLIT, 1>>(act, lane, x); NGF_UVSEC_T(u7b); NGF_UVSEC_ADD(2, u7a, u7b); }
     // act[0..63] = block1 output h; color1 and block2 both read it
     f32x4 c1[NS], c2[NS];
     {
         UvOutW<64> ow;
-        hidden_run<NS, SPLIT, 1, DEEP>(A, W + NGF_UV_SAME(A.t1_wh), W + A.t1_qh, W + A.t1_bh, 5, lane, act, x, W + A.c1_w, ow NGF_UVSEC_ARG);
+        hidden_run<NS, SPLIT, 1, DEEP>(A, W + NGF_UV_SAME(A.t1_wh), W + A.t1_qh, W + A.t1_bh, 5, lane, act, x, W + A.c1_w, ow NGF_UVSEC_ARG, pre, PRE);
         { NGF_UVSEC_T(u18a); dense_out<NS, 64, kUvRd<SPLIT, 1>, DEEP>(ow, W + A.c1_b, lane, act, c1); NGF_UVSEC_T(u18b); NGF_UVSEC_ADD(4, u18a, u18b); }
     }
     // block2: [h(256), v(3), PE6(v)(36)] -> 256 -> (3x) 256 -> 3
+    if constexpr (PRE) uv_wprefetch<16, NS>(W + A.t2_w0, lane, pre);
     { NGF_UVSEC_T(u15a); store_pe<3, 6, NS>(act, 64, 12, lane, v); NGF_UVSEC_T(u15b); NGF_UVSEC_ADD(3, u15a, u15b); }                 // 39 inputs + zero padding up to k-step 76
-    dense256<NS, SPLIT, DEEP, kUvRd<SPLIT, 1>>(A, W + A.t2_w0, W + A.t2_q0, W + A.t2_b0, 76, lane, act, x NGF_UVSEC_ARG, 64);            // 76 k-steps -> 10 k-blocks in split mode (rows 76..79: zero weights on finite leftovers)
+    dense256<NS, SPLIT, DEEP, kUvRd<SPLIT, 1>>(A, W + A.t2_w0, W + A.t2_q0, W + A.t2_b0, 76, lane, act, x NGF_UVSEC_ARG, 64, pre, PRE);            // 76 k-steps -> 10 k-blocks in split mode (rows 76..79: zero weights on finite leftovers)
+    if constexpr (PRE) uv_wprefetch<16, NS>(W + NGF_UV_SAME(A.t2_wh), lane, pre);
     { NGF_UVSEC_T(u9a); store_act<16, NS, kUvSt<SPLIT, 1>>(act, lane, x); NGF_UVSEC_T(u9b); NGF_UVSEC_ADD(2, u9a, u9b); }
     {
         UvOutW<64> ow;
-        hidden_run<NS, SPLIT, 1, DEEP>(A, W + NGF_UV_SAME(A.t2_wh), W + A.t2_qh, W + A.t2_bh, 3, lane, act, x, W + A.t2_wo, ow NGF_UVSEC_ARG);
+        hidden_run<NS, SPLIT, 1, DEEP>(A, W + NGF_UV_SAME(A.t2_wh), W + A.t2_qh, W + A.t2_bh, 3, lane, act, x, W + A.t2_wo, ow NGF_UVSEC_ARG, pre, PRE);
         { NGF_UVSEC_T(u19a); dense_out<NS, 64, kUvRd<SPLIT, 1>, DEEP>(ow, W + A.t2_bo, lane, act, c2); NGF_UVSEC_T(u19b); NGF_UVSEC_ADD(4, u19a, u19b); }
     }
 #pragma unroll
