@@ -865,18 +865,14 @@ __device__ __forceinline__ void uv_networks(const UvArgs &A, float *act, int lan
     // gauge: 63 -> 64 -> 128 -> 128 -> 128 -> 3|2, ReLU (first layer on the copy of PE10(p) in rows 64..79)
     float uv[NS][3];
     {
-        f32x4 g4[NS][4], g[NS][8];
-        KStepA<8, NS> pg[4];         // the gauge layers' first weights, requested in front of the store that produces their inputs (PRE)
+        f32x4 g4[NS][4], g[NS][8];         // (the gauge layers' first weights requested ahead of their inputs, as for the 256-wide layers: measured neutral, not kept)
         dense<4, NS, DEEP>(W + A.ga_w0, W + A.ga_b0, 16, lane, act + 64 * 64, g4 NGF_UVSEC_ARG);
-        if constexpr (PRE) uv_wprefetch<8, NS>(W + A.ga_w1, lane, pg);
         { NGF_UVSEC_T(u3a); store_act<4, NS, kUvSt<SPLIT, 0>>(act, lane, g4); NGF_UVSEC_T(u3b); NGF_UVSEC_ADD(2, u3a, u3b); }
-        dense<8, NS, DEEP, kUvRd<SPLIT, 0>>(W + A.ga_w1, W + A.ga_b1, 16, lane, act, g NGF_UVSEC_ARG, 1 << 30, pg, PRE);
-        if constexpr (PRE) uv_wprefetch<8, NS>(W + A.ga_w2, lane, pg);
+        dense<8, NS, DEEP, kUvRd<SPLIT, 0>>(W + A.ga_w1, W + A.ga_b1, 16, lane, act, g NGF_UVSEC_ARG);
         { NGF_UVSEC_T(u4a); store_act<8, NS, kUvSt<SPLIT, 0>>(act, lane, g); NGF_UVSEC_T(u4b); NGF_UVSEC_ADD(2, u4a, u4b); }
-        dense<8, NS, DEEP, kUvRd<SPLIT, 0>>(W + A.ga_w2, W + A.ga_b2, 32, lane, act, g NGF_UVSEC_ARG, 1 << 30, pg, PRE);
-        if constexpr (PRE) uv_wprefetch<8, NS>(W + A.ga_w3, lane, pg);
+        dense<8, NS, DEEP, kUvRd<SPLIT, 0>>(W + A.ga_w2, W + A.ga_b2, 32, lane, act, g NGF_UVSEC_ARG);
         { NGF_UVSEC_T(u5a); store_act<8, NS, kUvSt<SPLIT, 0>>(act, lane, g); NGF_UVSEC_T(u5b); NGF_UVSEC_ADD(2, u5a, u5b); }
-        dense<8, NS, DEEP, kUvRd<SPLIT, 0>>(W + A.ga_w3, W + A.ga_b3, 32, lane, act, g NGF_UVSEC_ARG, 1 << 30, pg, PRE);
+        dense<8, NS, DEEP, kUvRd<SPLIT, 0>>(W + A.ga_w3, W + A.ga_b3, 32, lane, act, g NGF_UVSEC_ARG);
         { NGF_UVSEC_T(u6a); store_act<8, NS, kUvSt<SPLIT, 0>>(act, lane, g); NGF_UVSEC_T(u6b); NGF_UVSEC_ADD(2, u6a, u6b); }
         UvOutW<32> ow;
         out_prefetch<32>(W + A.ga_wo, lane, ow);
