@@ -641,6 +641,21 @@ struct InfoInvPolicyT {
 #pragma unroll
                 for (int c = 0; c < 24; ++c) feat[c] = 0.0f;
             }
+#ifndef NGF_EXP_II_DENS_INTERLEAVED
+            // all twelve operand exchanges first, then the plane's 24 matrix instructions in a row (LDS reads of the weights between them are no vector
+            // instructions): written `swap, 2 MFMAs, swap, 2 MFMAs ...` the SIMD switched between its vector and its matrix pipe 52 times per 64-sample
+            // pass, and a switch costs ~38 cycles.  Same operations on the same values in the same accumulation order.
+#pragma unroll
+            for (int j = 0; j < 12; ++j) swap32(feat[2 * j], feat[2 * j + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const float w = d1[(p * 12 + j) * 64];
+                h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, feat[2 * j], h0, 0, 0, 0);
+                h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, feat[2 * j + 1], h1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
             for (int j = 0; j < 12; ++j) {
                 float a = feat[2 * j], b = feat[2 * j + 1];
@@ -649,17 +664,36 @@ struct InfoInvPolicyT {
                 h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, a, h0, 0, 0, 0);
                 h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b, h1, 0, 0, 0);
             }
+#endif
         }
+#ifndef NGF_EXP_II_DENS_INTERLEAVED
+        asm volatile("" : "+v"(h0), "+v"(h1) :: "memory");         // (see below; "memory": the bias reads of layer 2 and their address arithmetic stay behind layer 1's MFMAs too)
+#endif
         f32x16 g0, g1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) g0[r] = g1[r] = img[D::B2 + hi * 16 + r];
         const float *d2 = img + D::D2 + lane;
+#ifndef NGF_EXP_II_DENS_INTERLEAVED
+        // (the accumulators behind an opaque asm: sched_barrier orders instructions with side effects; a ReLU is a pure value the instruction selector
+        // is free to emit in front of the barrier -- it put tile 1's sixteen among tile 0's last MFMAs)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { h0[k] = relu1(h0[k]); h1[k] = relu1(h1[k]); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float w = d2[k * 64];
+            g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, h0[k], g0, 0, 0, 0);
+            g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, h1[k], g1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const float w = d2[k * 64];
             g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, relu1(h0[k]), g0, 0, 0, 0);
             g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, relu1(h1[k]), g1, 0, 0, 0);
         }
+#endif
         float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
