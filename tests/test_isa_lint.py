@@ -123,3 +123,33 @@ def test_uv_fp32_k_loops_have_no_vector_instruction_between_the_mfmas_of_a_group
             assert not any(t.startswith("global_load") for g in gaps for t in g if len(g) < 4), name
             checked += 1
     assert checked >= 4, checked          # the geometry / texture hidden runs and block2.0, at least
+
+
+def test_infoinv_density_pass_keeps_its_matrix_instructions_in_runs(asm):
+    """DESIGN.md 9 (round 4, late): the fp32 InfoInv density pass issues a plane's twelve operand exchanges, then its 24 v_mfma_f32_32x32x2_f32 in a row, and
+    layer 2's 32 ReLUs, then its 32 MFMAs -- written `swap, 2 MFMAs, swap ...` it alternated between the vector and the matrix pipe 52 times per
+    64-sample pass.  Pure instructions are not ordered by sched_barrier (the instruction selector had emitted half the ReLUs among the last MFMAs of layer 1
+    until the accumulators went through an opaque asm), so the property is held here on the shipped ISA."""
+    import re
+    import isa_hazards
+    checked = 0
+    for name, body in isa_hazards.kernels(asm["field"]):
+        if "render_kernelINS_14InfoInvPolicyTILb0ELb0EEELb1ELb0E" not in name:
+            continue
+        blocks, cur = [], []
+        for l in body:
+            t = l.strip()
+            if re.match(r"^\.LBB\d+_\d+:", t):
+                blocks.append(cur)
+                cur = []
+            elif t and not t.startswith((";", ".")):
+                cur.append(t)
+        blocks.append(cur)
+        for b in blocks:
+            kinds = ["M" if t.startswith("v_mfma_f32_32x32x2") else "V" for t in b if t.startswith("v_")]
+            if "M" not in kinds:
+                continue
+            runs = sum(1 for i, k in enumerate(kinds) if k == "M" and (i == 0 or kinds[i - 1] != "M"))
+            assert runs <= 2, (name, runs, kinds.count("M"))
+            checked += kinds.count("M")
+    assert checked == 104, checked          # 3 planes x 24 + 32
