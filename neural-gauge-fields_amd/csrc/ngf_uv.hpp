@@ -562,8 +562,13 @@ __device__ __forceinline__ void store_act(float *act, int lane, const f32x4 acc[
     }
 }
 // where a layer's activation ACT is applied: by its consumer (fp32 kernels) or at its store (split-bf16 kernel)
+#ifdef NGF_EXP_UV_SPLIT_ACT_ON_READ      // EXPERIMENT: the split-bf16 kernel with raw stores and the activation on its read side too
+template <bool SPLIT, int ACT> constexpr int kUvRd = ACT;
+template <bool SPLIT, int ACT> constexpr int kUvSt = kUvActNone;
+#else
 template <bool SPLIT, int ACT> constexpr int kUvRd = SPLIT ? kUvActNone : ACT;
 template <bool SPLIT, int ACT> constexpr int kUvSt = SPLIT ? ACT : kUvActNone;
+#endif
 
 // store_act (raw rows) with the NEXT layer's bias loaded into each accumulator tile as soon as its rows are on their way: by the time the last tile is
 // stored the first biases have arrived, instead of a full L2 round trip between the store and the next layer's first MFMA
