@@ -420,6 +420,10 @@ __device__ __forceinline__ void mlp_pass16_ii(const RenderArgs &A, const float *
         if (p < 2) {                           // the next plane's first row travels behind this plane's 72 MFMAs
             b = bil_setup(rec[4 + 2 * p], rec[5 + 2 * p], karg_tex(offsetof(RenderArgs, app) + (p + 1) * sizeof(Tex)));
             gather_row_ii(tex_at<float>(karg_tex(offsetof(RenderArgs, app) + (p + 1) * sizeof(Tex)).p, (uint32_t)b.idx * 72u + (uint32_t)kq * 18u), g);
+#ifdef NGF_EXP_II_PIN_WEIGHTS
+            // (the four weights through an opaque asm: they are pure values, and the instruction selector sank their last ten instructions among this plane's MFMAs)
+            asm volatile("" : "+v"(b.w00), "+v"(b.w10), "+v"(b.w01), "+v"(b.w11));
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         if (mode) {
@@ -430,6 +434,10 @@ __device__ __forceinline__ void mlp_pass16_ii(const RenderArgs &A, const float *
                 for (int j = 0; j < 3; ++j) pe_octave(f[k * 3 + j], f[9 + k * 3 + j], sn, cs);
             }
         }
+#ifdef NGF_EXP_II_PIN_WEIGHTS
+        asm volatile("" : "+v"(f[0]), "+v"(f[17]));
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int i = 0; i < 18; ++i)
 #pragma unroll
