@@ -718,6 +718,41 @@ constexpr size_t kUvLayerStride = 0;          // every layer of a run reads the 
 #else
 constexpr size_t kUvLayerStride = 65536;
 #endif
+template <int NS, int MT, int END>
+__device__ __forceinline__ void store_act_rows_next_bias_range(unsigned addr, f32x4 acc[NS][16], const float *bias_lane)
+{
+    if constexpr (MT < END) {
+        if constexpr (NS > 0) { ds_write2_rows_agpr<MT * 4>(addr, acc[0][MT][0], acc[0][MT][1]); ds_write2_rows_agpr<MT * 4 + 2>(addr, acc[0][MT][2], acc[0][MT][3]); }
+        if constexpr (NS > 1) { ds_write2_rows_agpr<kUvActSteps + MT * 4>(addr, acc[1][MT][0], acc[1][MT][1]); ds_write2_rows_agpr<kUvActSteps + MT * 4 + 2>(addr, acc[1][MT][2], acc[1][MT][3]); }
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(bias_lane + MT * 4);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s][MT] = v;
+        store_act_rows_next_bias_range<NS, MT + 1, END>(addr, acc, bias_lane);
+    }
+}
+// EXPERIMENT NGF_EXP_UV_STORE_IN_LOOP: a layer's LAST k-step -- behind the MFMAs of tile group g the rows of group g - 1 (final by then, and 8 x NS / 2
+// MFMAs = 256 cycles behind their last write: the matrix-write -> LDS-read wait states are covered) are stored and take the next layer's bias
+template <int NS>
+__device__ __forceinline__ void kstep_last(const KStepA<16, NS> &k, f32x4 acc[NS][16], const float *w, int t, int lane, KStepA<16, NS> &kn, unsigned addr,
+                                           const float *bias_lane)
+{
+#define NGF_UV_LAST_GROUP(g)                                                                                                  \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                             \
+        _Pragma("unroll") for (int s = 0; s < NS; ++s) acc[s][4 * g + e] = NGF_UV_MFMA(k.a[g][e], k.b[s], acc[s][4 * g + e]);    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                        \
+    kload_wg<16, NS>(w, t, g, lane, kn);
+    // (the wait states in front of every group's stores as well: the MFMAs of group g normally stand between group g - 1's last write and its stores, but
+    // they are pure values the instruction selector may emit elsewhere, and the hazard recogniser does not look into inline assembly)
+#define NGF_UV_STORE_GROUP(g) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); store_act_rows_next_bias_range<NS, 4 * (g), 4 * (g) + 4>(addr, acc, bias_lane);
+    NGF_UV_LAST_GROUP(0) __builtin_amdgcn_sched_barrier(0);
+    NGF_UV_LAST_GROUP(1) NGF_UV_STORE_GROUP(0) __builtin_amdgcn_sched_barrier(0);
+    NGF_UV_LAST_GROUP(2) NGF_UV_STORE_GROUP(1) __builtin_amdgcn_sched_barrier(0);
+    NGF_UV_LAST_GROUP(3) NGF_UV_STORE_GROUP(2) __builtin_amdgcn_sched_barrier(0);
+    NGF_UV_STORE_GROUP(3)
+#undef NGF_UV_LAST_GROUP
+#undef NGF_UV_STORE_GROUP
+}
+
 // fp32, one wave per SIMD: ONE software pipeline across the run's layers.  The layers' weights are contiguous, so the load group that follows a layer's
 // last k-steps ("k-steps 64..67") IS the next layer's first four k-steps: they arrive behind the last MFMAs and the activation store instead of in front
 // of an idle matrix pipe (the per-layer prologue was 1.35 % of a wave's life, profiles/r04_uv_sections.txt); the B operands read with them (LDS rows
@@ -757,8 +792,13 @@ __device__ __forceinline__ void hidden_run_deep(const float *w, const float *b, 
         // it is one more vector instruction in the middle of the 256 MFMAs -- one more switch
         typedef __attribute__((address_space(3))) const float lds_cf;
         unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(act + lane);
+#ifdef NGF_EXP_UV_STORE_IN_LOOP
+        constexpr int T_LOOP = 56;          // the eighth iteration is peeled below: its last k-step stores the layer's outputs between its MFMAs
+#else
+        constexpr int T_LOOP = 64;
+#endif
 #pragma unroll 1
-        for (int t = 0; t < 64; t += 8) {
+        for (int t = 0; t < T_LOOP; t += 8) {
             la += 8 * 64 * 4;
             asm volatile("" : "+v"(la));
             const unsigned cur = la;
@@ -787,6 +827,26 @@ __device__ __forceinline__ void hidden_run_deep(const float *w, const float *b, 
             kstep<16, NS>(b2, x, wl, ta + 2, lane, a2); kstep<16, NS>(b3, x, wl, ta + 3, lane, a3);
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef NGF_EXP_UV_STORE_IN_LOOP
+        {
+            kact<ACT, true>(a0, 0, 1); kact<ACT, true>(a1, 0, 1); kact<ACT, true>(a2, 0, 1); kact<ACT, true>(a3, 0, 1);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                b0.b[s] = act_in<ACT, true>(bn[0][s]); b1.b[s] = act_in<ACT, true>(bn[1][s]);
+                b2.b[s] = act_in<ACT, true>(bn[2][s]); b3.b[s] = act_in<ACT, true>(bn[3][s]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            kstep<16, NS>(a0, x, wl, 60, lane, b0); kstep<16, NS>(a1, x, wl, 61, lane, b1);
+            kstep<16, NS>(a2, x, wl, 62, lane, b2); kstep<16, NS>(a3, x, wl, 63, lane, b3);
+            __builtin_amdgcn_sched_barrier(0);
+            const int ta = more ? 64 : 56;
+            const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(act + lane);
+            const float *bias_lane = b + (more ? l + 1 : l) * 256 + kq * 64;
+            kstep<16, NS>(b0, x, wl, ta, lane, a0); kstep<16, NS>(b1, x, wl, ta + 1, lane, a1); kstep<16, NS>(b2, x, wl, ta + 2, lane, a2);
+            kstep_last<NS>(b3, x, wl, ta + 3, lane, a3, addr, bias_lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
 #else
 #pragma unroll 1
         for (int t = 0; t < 64; t += 8) {
@@ -800,12 +860,14 @@ __device__ __forceinline__ void hidden_run_deep(const float *w, const float *b, 
 #ifdef NGF_EXP_UV_SECTIONS
         uvsec.t[6] += (unsigned long long)(64 * 16 * NS);
 #endif
+#if !(defined(NGF_EXP_UV_STORE_IN_LOOP) && !defined(NGF_EXP_UV_ACT_PER_GROUP))
         {
             const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(act + lane);
             asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
             // (behind the run's last layer: the same bias again, unused)
             store_act_rows_next_bias<16, NS>(addr, x, b + (more ? l + 1 : l) * 256 + kq * 64);
         }
+#endif
         NGF_UVSEC_T(ts3);
         NGF_UVSEC_ADD(2, ts2, ts3);
     }
