@@ -2,7 +2,9 @@
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, ngf_amd
-from ngf_amd import uvmapping
+from ngf_amd import uvmapping, _lib
+if os.environ.get("NGF_LIB"):          # an experiment build (make expuv) instead of the product library
+    _lib.SO_PATH = os.path.abspath(os.environ["NGF_LIB"])
 from helpers import load_uv_case
 for name in ("uv_sphere", "uv_square"):
     g, params = load_uv_case(name)
@@ -13,7 +15,7 @@ for name in ("uv_sphere", "uv_square"):
         U = torch.from_numpy(g["U"])[None].cuda()
         first = m(*args, jitter_u=U)["color"].clone()
         moved = torch.zeros((), dtype=torch.int64, device="cuda")
-        n = 150000
+        n = int(os.environ.get("N", "150000"))
         for _ in range(n):
             moved += (m(*args, jitter_u=U)["color"] != first).any().to(torch.int64)
         print(name, "split" if split else "fp32", n, "launches,", int(moved.item()), "differ", flush=True)
