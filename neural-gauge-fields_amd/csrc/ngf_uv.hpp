@@ -730,7 +730,7 @@ __device__ __forceinline__ void store_act_rows_next_bias_range(unsigned addr, f3
         store_act_rows_next_bias_range<NS, MT + 1, END>(addr, acc, bias_lane);
     }
 }
-// EXPERIMENT NGF_EXP_UV_STORE_IN_LOOP: a layer's LAST k-step -- behind the MFMAs of tile group g the rows of group g - 1 (final by then, and 8 x NS / 2
+// A hidden layer's LAST k-step (NGF_EXP_UV_STORE_AFTER_LOOP: the store behind the k loop, round 4's earlier form) -- behind the MFMAs of tile group g the rows of group g - 1 (final by then, and 8 x NS / 2
 // MFMAs = 256 cycles behind their last write: the matrix-write -> LDS-read wait states are covered) are stored and take the next layer's bias
 template <int NS>
 __device__ __forceinline__ void kstep_last(const KStepA<16, NS> &k, f32x4 acc[NS][16], const float *w, int t, int lane, KStepA<16, NS> &kn, unsigned addr,
@@ -792,7 +792,7 @@ __device__ __forceinline__ void hidden_run_deep(const float *w, const float *b, 
         // it is one more vector instruction in the middle of the 256 MFMAs -- one more switch
         typedef __attribute__((address_space(3))) const float lds_cf;
         unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(act + lane);
-#ifdef NGF_EXP_UV_STORE_IN_LOOP
+#ifndef NGF_EXP_UV_STORE_AFTER_LOOP
         constexpr int T_LOOP = 56;          // the eighth iteration is peeled below: its last k-step stores the layer's outputs between its MFMAs
 #else
         constexpr int T_LOOP = 64;
@@ -827,7 +827,7 @@ __device__ __forceinline__ void hidden_run_deep(const float *w, const float *b, 
             kstep<16, NS>(b2, x, wl, ta + 2, lane, a2); kstep<16, NS>(b3, x, wl, ta + 3, lane, a3);
             __builtin_amdgcn_sched_barrier(0);
         }
-#ifdef NGF_EXP_UV_STORE_IN_LOOP
+#ifndef NGF_EXP_UV_STORE_AFTER_LOOP
         {
             kact<ACT, true>(a0, 0, 1); kact<ACT, true>(a1, 0, 1); kact<ACT, true>(a2, 0, 1); kact<ACT, true>(a3, 0, 1);
 #pragma unroll
@@ -860,7 +860,7 @@ __device__ __forceinline__ void hidden_run_deep(const float *w, const float *b, 
 #ifdef NGF_EXP_UV_SECTIONS
         uvsec.t[6] += (unsigned long long)(64 * 16 * NS);
 #endif
-#if !(defined(NGF_EXP_UV_STORE_IN_LOOP) && !defined(NGF_EXP_UV_ACT_PER_GROUP))
+#if defined(NGF_EXP_UV_STORE_AFTER_LOOP) || defined(NGF_EXP_UV_ACT_PER_GROUP)
         {
             const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(act + lane);
             asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
