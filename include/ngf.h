@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NGF_ABI_VERSION 3      /* 3: ngf_train_overflow_count + speculative rows (ngf_train_desc.chunk_samples < 0), ngf_train_backward2 (loss_len travels with the call; ngf_train_backward is back to its ABI-1 contract of ONE double); 2: ngf_uv_desc.flags (was padding), ngf_uv_render_batch, ngf_debug_dirty_lds, trainer chunk_samples = 0 means the whole batch */
+#define NGF_ABI_VERSION 4      /* 4: ngf_train_forward / ngf_train_backward_grad (the step in two calls, d loss / d rgb_map handed in), trainers without Adam moments; 3: ngf_train_overflow_count + speculative rows (ngf_train_desc.chunk_samples < 0), ngf_train_backward2 (loss_len travels with the call; ngf_train_backward is back to its ABI-1 contract of ONE double); 2: ngf_uv_desc.flags (was padding), ngf_uv_render_batch, ngf_debug_dirty_lds, trainer chunk_samples = 0 means the whole batch */
 
 enum { NGF_OK = 0, NGF_E_ARG = 1, NGF_E_HIP = 2, NGF_E_UNSUPPORTED = 3 };
 enum { NGF_MODEL_TRIPLANE = 0, NGF_MODEL_INFOINV = 1 };
@@ -200,7 +200,7 @@ typedef struct ngf_train_desc {
     float *gauge[3];
     int32_t gauge_h[3], gauge_w[3];
     float *dens_w, *dens_b, *basis, *w1, *b1, *w2, *b2, *w3, *b3;
-    float *exp_avg[NGF_TRAIN_PARAMS], *exp_avg_sq[NGF_TRAIN_PARAMS]; /* Adam state, parameter layouts, zero-initialised by the caller */
+    float *exp_avg[NGF_TRAIN_PARAMS], *exp_avg_sq[NGF_TRAIN_PARAMS]; /* Adam state, parameter layouts, zero-initialised by the caller; ALL NULL = a trainer without optimiser (ngf_train_forward / ngf_train_backward_grad) */
     const uint8_t *mask_bits;      /* optional alpha mask as in ngf_field_desc; NULL = none */
     int32_t mask_d, mask_h, mask_w;
     float mask_aabb[6];
@@ -239,6 +239,22 @@ int ngf_train_backward(ngf_trainer *t, const float *rays, const float *rgb_train
                        int32_t n_samples, int32_t white_bg, int32_t gauge_on, double *rgb_loss, int64_t *n_active_host,
                        void *hip_stream);
 int ngf_train_get_active(ngf_trainer *t, int64_t n, int32_t *out_device, void *hip_stream);
+/* The step in TWO calls, for a caller that owns the loss and the optimiser -- the reference's loop as written (TriPlane/main.py:272-296):
+ *     output = field(rays_train, is_train=True, ...)                     -> ngf_train_forward      (FieldBase.py:251-312 with autograd recording)
+ *     total_loss = f(output['rgb_map'], ...); total_loss.backward()       -> ngf_train_backward_grad (autograd of that forward)
+ *     optimizer.step()                                                    -> the caller's optimiser on the gradients of ngf_train_get_grad
+ * ngf_train_forward renders the batch in training mode exactly as ngf_train_backward2 does (same kernels, same per-sample buffers) and writes
+ * rgb_map [n,3] (after the clamp of FieldBase.py:302) and depth_map [n] (the no_grad block of FieldBase.py:304-306); *ticket names this forward.
+ * ngf_train_backward_grad takes d loss / d rgb_map [n,3] (DEVICE) and leaves d loss / d parameter for all 15 parameters in the trainer's
+ * buffers (ngf_train_get_grad; planes WITHOUT any L1 term -- density_L1 is the caller's own graph here).  depth_map carries no gradient
+ * (the reference computes it under torch.no_grad()).  Between the two calls `rays`, `jitter` and the parameter tensors must stay alive and
+ * unchanged, and the trainer must not run another forward or fused step: its per-sample buffers hold THIS batch.  A ticket that is no longer
+ * the trainer's last forward is refused (NGF_E_ARG): run ngf_train_forward again on the same inputs, then the backward (ngf_amd does).
+ * A trainer used only this way may be created with every exp_avg / exp_avg_sq pointer NULL (ngf_train_adam* then refuse).
+ * n_active_host / synchronisation: as ngf_train_backward2 (the forward call is the one that may wait for the host). */
+int ngf_train_forward(ngf_trainer *t, const float *rays, const float *jitter, int64_t n, int32_t n_samples, int32_t white_bg, int32_t gauge_on,
+                      float *rgb_map, float *depth_map, int64_t *n_active_host, int64_t *ticket, void *hip_stream);
+int ngf_train_backward_grad(ngf_trainer *t, int64_t ticket, const float *d_rgb_map, void *hip_stream);
 /* speculative rows (chunk_samples < 0): *count_host = steps since the trainer was made whose batch had more active samples than the trainer keeps
  * rows for (their updates were skipped), *rows_host (nullable) = the row count.  Synchronises hip_stream. */
 int ngf_train_overflow_count(ngf_trainer *t, int64_t *count_host, int64_t *rows_host, void *hip_stream);

@@ -1117,6 +1117,17 @@ struct ngf_trainer {
     static constexpr int kAux = 2;
     hipStream_t aux[kAux] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kAux] = {nullptr, nullptr};
+    bool has_adam = true;                   // false: built without Adam moments (ngf_train_forward / ngf_train_backward_grad only; ngf_train_adam* refuse)
+    // what ngf_train_forward leaves for ngf_train_backward_grad (the two-call form of the step)
+    struct Pending {
+        bool valid = false;
+        TrainArgs T;
+        bool fork = false, no_sync = false, single = true;
+        int64_t n = 0, list_len = 0;
+        int32_t n_samples = 0;
+        int64_t ticket = 0;
+    } pending;
+    int64_t tickets = 0;
 };
 
 template <typename T>
@@ -1156,11 +1167,15 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
     }
     if (!d->dens_w || !d->dens_b || !d->basis || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->w3 || !d->b3)
         return fail(NGF_E_ARG, "ngf_trainer_create: missing MLP parameter");
-    for (int k = 0; k < TP_COUNT; ++k)
-        if (!d->exp_avg[k] || !d->exp_avg_sq[k]) return fail(NGF_E_ARG, "ngf_trainer_create: missing Adam state %d", k);
+    // Adam moments: all fifteen pairs, or none at all (a trainer that only serves ngf_train_forward / ngf_train_backward_grad -- the caller's
+    // own optimiser applies the gradients, e.g. torch.optim.Adam in the reference's loop, TriPlane/main.py:241,294-296)
+    int moments = 0;
+    for (int k = 0; k < TP_COUNT; ++k) moments += (d->exp_avg[k] ? 1 : 0) + (d->exp_avg_sq[k] ? 1 : 0);
+    if (moments != 0 && moments != 2 * TP_COUNT) return fail(NGF_E_ARG, "ngf_trainer_create: Adam state must be given for all %d parameters or for none", (int)TP_COUNT);
     ngf_trainer *t = new (std::nothrow) ngf_trainer();
     if (!t) return fail(NGF_E_HIP, "out of host memory");
     t->d = *d;
+    t->has_adam = moments != 0;
     auto bail = [&](int rc) { ngf_trainer_destroy(t); return rc; };
     hipStream_t st = (hipStream_t)hip_stream;
     int dev = 0;
@@ -1317,27 +1332,29 @@ static int tr_grid(const ngf_trainer *t, int64_t items, int per_block, int waves
 // (the next call on that stream would otherwise run beside this one's aux-stream kernels).
 struct ForkState { bool fold = false, chains = false; };
 
-static int train_backward_body(ngf_trainer *t, const float *rays, const float *rgb_train, const float *jitter, int64_t n, int32_t n_samples,
-                               int32_t white_bg, int32_t gauge_on, double *rgb_loss, int32_t loss_len, int64_t *n_active_host, void *hip_stream,
-                               ForkState &fs)
+// The step in two parts.  Part A (train_forward_part): everything up to and including the colour forward -- after it the per-sample weights and
+// colours of the batch are in the trainer's buffers.  Part B (train_backward_part): compositing backward, colour backward, the three forked
+// chains.  The fused entry points run A, the fused compositing kernel <0> and B in one call; ngf_train_forward runs A and the compositing
+// kernel <1> (rgb_map / depth_map out), ngf_train_backward_grad the compositing kernel <2> (d loss / d rgb_map in) and B.
+static int train_forward_part(ngf_trainer *t, const float *rays, const float *jitter, int64_t n, int32_t n_samples, int32_t white_bg, int32_t gauge_on,
+                              int64_t *n_active_host, void *hip_stream, ForkState &fs, ngf_trainer::Pending &P)
 {
-    if (!t || !rays || !rgb_train || !rgb_loss) return fail(NGF_E_ARG, "ngf_train_backward: null argument");
-    if (loss_len < 1) return fail(NGF_E_ARG, "ngf_train_backward2: loss_len=%d (1 = the sum of squared residuals, 2 = sum and mean)", loss_len);
     if (n <= 0 || n > t->d.max_rays || n_samples <= 0 || n_samples > t->d.max_samples)
         return fail(NGF_E_ARG, "ngf_train_backward: n=%lld (max %lld), n_samples=%d (max %d)", (long long)n, (long long)t->d.max_rays, n_samples,
                     t->d.max_samples);
     hipStream_t st = (hipStream_t)hip_stream;
     const ngf_train_desc &d = t->d;
-    TrainArgs T = t->proto;
+    P.valid = false;
+    P.T = t->proto;
+    TrainArgs &T = P.T;
     RenderArgs &A = T.R;
     A.rays = rays; A.jitter = jitter; A.n = n; A.S = n_samples; A.white_bg = white_bg ? 1 : 0; A.mode = gauge_on ? 1 : 0;
-    T.target = rgb_train;
     T.inv_count = 1.0f / (3.0f * (float)n);
     A.ablate = knob(KNOB_ABLATE) > 0 ? knob(KNOB_ABLATE) : 0;      // timing experiments only (profiles/exp_train_ablate.sh)
     if (int prc = poison_lds(st)) return prc;
     // ngf_debug_set("ablate", 1 << 19) keeps the whole step on the caller's stream (see the forks below)
     const bool fork = !(A.ablate & (1 << 19));
-    hipStream_t sx = fork ? t->aux[0] : st, sb = fork ? t->aux[1] : st;
+    hipStream_t sx = fork ? t->aux[0] : st;
     ProjectArgs PJ;
     PJ.wd = d.dens_w;
     // parameters -> packed textures where the trainer's copy is not current (ngf_train_adam writes the copy along with the parameter;
@@ -1371,7 +1388,10 @@ static int train_backward_body(ngf_trainer *t, const float *rays, const float *r
     hipLaunchKernelGGL(train_density_kernel, dim3(tr_grid(t, pairs, 256)), dim3(256), 0, st, T);
     const int ray_blocks = (int)((n + 3) / 4);        // sixteen lanes per ray
     hipLaunchKernelGGL(train_scan_kernel, dim3(ray_blocks), dim3(64), 0, st, T, 0);
-    hipLaunchKernelGGL(train_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)T.count, n, T.offset, t->speculative ? t->chunk : (int64_t)0, t->overflow);
+    // The overflow flag belongs to the path that cannot cut the list into chunks: speculative rows WITHOUT a host count.  A caller that passes
+    // n_active_host gets the chunked path and a complete gradient -- flagging that step would make Adam skip a valid update.
+    const bool spec_rows = t->speculative && !n_active_host;
+    hipLaunchKernelGGL(train_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int32_t *)T.count, n, T.offset, spec_rows ? t->chunk : (int64_t)0, t->overflow);
     // The colour kernels walk the active list.  When one chunk of activation rows holds every sample of the batch (the default:
     // HBM is sized for it) they read the active count from the device and run with fixed grids -- the stream never waits for the
     // host.  With a smaller chunk (chunk_samples of the descriptor) the count comes to the host to cut the list into chunks.
@@ -1404,7 +1424,29 @@ static int train_backward_body(ngf_trainer *t, const float *rays, const float *r
         T.store = single ? 1 : 0;
         hipLaunchKernelGGL(train_color_fwd_kernel, dim3(tr_grid(t, (T.chunk_n + 15) / 16, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_f, st, T);
     }
-    hipLaunchKernelGGL(train_composite_bwd_kernel, dim3((unsigned)((n + 64 / kCompLanes - 1) / (64 / kCompLanes))), dim3(64), 0, st, T);
+    P.fork = fork; P.no_sync = no_sync; P.single = single; P.n = n; P.n_samples = n_samples; P.list_len = list_len;
+    P.valid = true;
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+static inline dim3 comp_grid(int64_t n) { return dim3((unsigned)((n + 64 / kCompLanes - 1) / (64 / kCompLanes))); }
+
+// Part B; the compositing kernel of the calling form has run on hip_stream.  rgb_loss may be NULL (no loss is delivered).
+static int train_backward_part(ngf_trainer *t, ngf_trainer::Pending &P, double *rgb_loss, int32_t loss_len, void *hip_stream, ForkState &fs)
+{
+    hipStream_t st = (hipStream_t)hip_stream;
+    const ngf_train_desc &d = t->d;
+    TrainArgs &T = P.T;
+    RenderArgs &A = T.R;
+    (void)A;
+    const bool fork = P.fork, no_sync = P.no_sync, single = P.single;
+    const int64_t n = P.n, list_len = P.list_len;
+    const int32_t n_samples = P.n_samples;
+    hipStream_t sx = fork ? t->aux[0] : st, sb = fork ? t->aux[1] : st;
+    const size_t lds_f = (size_t)(((kFwdImage + 3) & ~3) + kTrainWaves * kFwdTileFloats) * sizeof(float),
+                 lds_b = (size_t)(((kBwdImage + 3) & ~3) + kTrainWavesBwd * kBwdTileFloats) * sizeof(float);
+    const int32_t *cnt = no_sync ? T.offset + n : nullptr;
     const dim3 dgrid(tr_grid(t, n * ((n_samples + 63) / 64), 4, kDensBwdGroupsPerCu + 1));
     // After the colour backward of a chunk the step forks: the weight-gradient GEMMs (sx) and the colour-plane scatter (sb) leave the
     // caller's stream, which goes on with the density / gauge backward and waits for both before it returns to the caller's order.  None of
@@ -1487,7 +1529,7 @@ static int train_backward_body(ngf_trainer *t, const float *rays, const float *r
         FA.texels[p] = (int64_t)(d.plane_h[p] + 2) * (d.plane_w[p] + 2); FA.g_dens[p] = t->g_d[p];
         U.src[p] = t->g_gb[p]; U.dst[p] = t->g_g[p]; U.w2[p] = d.gauge_w[p] + 2; U.h2[p] = d.gauge_h[p] + 2; U.bw[p] = T.g_bw[p];
     }
-    U.loss_src = T.loss; U.loss_dst = rgb_loss; U.loss_len = loss_len; U.inv_count = 1.0 / (3.0 * (double)n);        // the loss travels with the last kernel of the caller's stream (a copy of 8 bytes is a launch of its own)
+    U.loss_src = T.loss; U.loss_dst = rgb_loss; U.loss_len = loss_len; U.inv_count = 1.0 / (3.0 * (double)n); U.overflow = t->overflow;        // the loss travels with the last kernel of the caller's stream (a copy of 8 bytes is a launch of its own)
     hipLaunchKernelGGL(train_density_finish_kernel, dim3(128, 3), dim3(256), 0, st, FA);
     hipLaunchKernelGGL(train_unblock_gauge_kernel, dim3(128, 3), dim3(256), 0, st, U);
     if (int jrc = join()) return jrc;
@@ -1495,18 +1537,64 @@ static int train_backward_body(ngf_trainer *t, const float *rays, const float *r
     return NGF_OK;
 }
 
-static int train_backward_joined(ngf_trainer *t, const float *rays, const float *rgb_train, const float *jitter, int64_t n, int32_t n_samples,
-                                 int32_t white_bg, int32_t gauge_on, double *rgb_loss, int32_t loss_len, int64_t *n_active_host, void *hip_stream)
+// error exit after a fork: the caller's stream still waits for what the aux streams hold (best effort: the error being reported stands)
+static int rescue_join(ngf_trainer *t, int rc, const ForkState &fs, void *hip_stream)
 {
-    ForkState fs;
-    const int rc = train_backward_body(t, rays, rgb_train, jitter, n, n_samples, white_bg, gauge_on, rgb_loss, loss_len, n_active_host, hip_stream, fs);
     if (rc != NGF_OK && t && (fs.fold || fs.chains)) {
-        // error exit after a fork: the caller's stream still waits for what the aux streams hold (best effort: the error being reported stands)
         hipStream_t st = (hipStream_t)hip_stream;
         (void)hipStreamWaitEvent(st, t->ev_join[0], 0);
         if (fs.chains) (void)hipStreamWaitEvent(st, t->ev_join[1], 0);
     }
     return rc;
+}
+
+static int train_backward_joined(ngf_trainer *t, const float *rays, const float *rgb_train, const float *jitter, int64_t n, int32_t n_samples,
+                                 int32_t white_bg, int32_t gauge_on, double *rgb_loss, int32_t loss_len, int64_t *n_active_host, void *hip_stream)
+{
+    if (!t || !rays || !rgb_train || !rgb_loss) return fail(NGF_E_ARG, "ngf_train_backward: null argument");
+    if (loss_len < 1) return fail(NGF_E_ARG, "ngf_train_backward2: loss_len=%d (1 = the sum of squared residuals, 2 = sum and mean)", loss_len);
+    ForkState fs;
+    ngf_trainer::Pending P;                 // the fused call keeps its state to itself: a pending ngf_train_forward is not disturbed ...
+    t->pending.valid = false;               // ... but the trainer's per-sample buffers are: its backward must re-run the forward
+    int rc = train_forward_part(t, rays, jitter, n, n_samples, white_bg, gauge_on, n_active_host, hip_stream, fs, P);
+    if (rc == NGF_OK) {
+        P.T.target = rgb_train;
+        hipLaunchKernelGGL(train_composite_bwd_kernel<0>, comp_grid(n), dim3(64), 0, (hipStream_t)hip_stream, P.T);
+        rc = train_backward_part(t, P, rgb_loss, loss_len, hip_stream, fs);
+    }
+    return rescue_join(t, rc, fs, hip_stream);
+}
+
+// ---- the two-call form: the torch.autograd boundary of Base.forward(is_train=True) (TriPlane/main.py:272-296) -----------------------------
+extern "C" int ngf_train_forward(ngf_trainer *t, const float *rays, const float *jitter, int64_t n, int32_t n_samples, int32_t white_bg,
+                                 int32_t gauge_on, float *rgb_map, float *depth_map, int64_t *n_active_host, int64_t *ticket, void *hip_stream)
+{
+    if (!t || !rays || !rgb_map || !depth_map || !ticket) return fail(NGF_E_ARG, "ngf_train_forward: null argument");
+    ForkState fs;
+    int rc = train_forward_part(t, rays, jitter, n, n_samples, white_bg, gauge_on, n_active_host, hip_stream, fs, t->pending);
+    if (rc == NGF_OK) {
+        t->pending.T.rgb_out = rgb_map; t->pending.T.depth_out = depth_map;
+        hipLaunchKernelGGL(train_composite_bwd_kernel<1>, comp_grid(n), dim3(64), 0, (hipStream_t)hip_stream, t->pending.T);
+        rc = hipGetLastError() == hipSuccess ? NGF_OK : fail(NGF_E_HIP, "ngf_train_forward: launch failed");
+        t->pending.ticket = *ticket = ++t->tickets;
+    }
+    if (rc != NGF_OK) t->pending.valid = false;
+    return rescue_join(t, rc, fs, hip_stream);
+}
+
+extern "C" int ngf_train_backward_grad(ngf_trainer *t, int64_t ticket, const float *d_rgb_map, void *hip_stream)
+{
+    if (!t || !d_rgb_map) return fail(NGF_E_ARG, "ngf_train_backward_grad: null argument");
+    if (!t->pending.valid || t->pending.ticket != ticket)
+        return fail(NGF_E_ARG, "ngf_train_backward_grad: ticket %lld is not the trainer's last forward (%s) -- another forward or a fused step used the "
+                    "trainer's buffers since; run ngf_train_forward again", (long long)ticket, t->pending.valid ? "a newer one is pending" : "none is pending");
+    ForkState fs;
+    ngf_trainer::Pending &P = t->pending;
+    P.T.d_rgb = d_rgb_map;
+    hipLaunchKernelGGL(train_composite_bwd_kernel<2>, comp_grid(P.n), dim3(64), 0, (hipStream_t)hip_stream, P.T);
+    const int rc = train_backward_part(t, P, nullptr, 0, hip_stream, fs);
+    P.valid = false;                        // the gradients are in the trainer's buffers (ngf_train_get_grad); the per-sample state is spent
+    return rescue_join(t, rc, fs, hip_stream);
 }
 
 // ABI 3: the loss buffer's length travels with the call (loss_len = 2: [0] the sum of squared residuals, [1] their mean)
@@ -1554,6 +1642,7 @@ extern "C" int ngf_train_adam(ngf_trainer *t, int32_t which, int32_t step_count,
                               void *hip_stream)
 {
     if (!t || which < 0 || which >= TP_COUNT || step_count < 1) return fail(NGF_E_ARG, "ngf_train_adam: bad argument");
+    if (!t->has_adam) return fail(NGF_E_ARG, "ngf_train_adam: the trainer was made without Adam moments (ngf_train_desc.exp_avg / exp_avg_sq all NULL)");
     hipStream_t st = (hipStream_t)hip_stream;
     const ngf_train_desc &d = t->d;
     AdamArgs a;

@@ -100,6 +100,9 @@ struct TrainArgs {
     int32_t store;           // colour forward: also write F, V, H1, H2 rows of the chunk
     unsigned long long *prof; // [16] section clocks of the colour backward (ablate bit 1 << 20; profiles/exp_train_sections.py), else unused
     float inv_count;         // 1 / (3 n): the mean of the MSE
+    // the two-call form of the step (ngf_train_forward / ngf_train_backward_grad: the torch.autograd boundary of Base.forward)
+    float *rgb_out, *depth_out;       // [n,3], [n]: rgb_map after the clamp and depth_map (FieldBase.py:296-306), written by the forward call
+    const float *d_rgb;               // [n,3]: d loss / d rgb_map handed in by the caller (instead of the MSE residual against `target`)
 };
 
 static_assert(offsetof(TrainArgs, R) == 0, "karg_tex (ngf_render.hpp) reads the RenderArgs at offset 0 of the kernel arguments");
@@ -628,6 +631,10 @@ __global__ void __launch_bounds__(kTrainWaves * 64) __attribute__((amdgpu_waves_
 // (what ATen's reverse cumsum does on the CPU), T_i was parked in dx by the scan.
 constexpr int kCompAhead = 4;
 constexpr int kCompLanes = 16;                   // lanes per ray (eight -- two waves per SIMD for a 4096-ray batch -- measured slower: 71 vs 64 us)
+// PHASE 0: the fused step (residual against T.target, loss, backward).  PHASE 1: the forward call of the two-call form -- the same sums, then
+// rgb_map (clamped) and depth_map are written and the kernel ends.  PHASE 2: its backward call -- the same sums again (they decide where the
+// clamp passes a gradient), G = T.d_rgb where it does.
+template <int PHASE>
 __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs T)
 {
     const RenderArgs &A = T.R;
@@ -636,7 +643,9 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
     const bool live = r0 < A.n;
     const int64_t r = live ? r0 : A.n - 1;
     const float bg = A.white_bg ? 1.0f : 0.0f;
-    float acc = 0.0f, rgb[3] = {0.0f, 0.0f, 0.0f};
+    float acc = 0.0f, rgb[3] = {0.0f, 0.0f, 0.0f}, dep = 0.0f;
+    const float tmin = ray_tmin(A, r);
+    const float jit = A.jitter ? A.jitter[r] : 0.0f;
     // one wave per SIMD: the loads of kCompAhead blocks are requested together (as in the scan); the colours are read whether the
     // sample is active or not (inactive entries are never written: whatever they hold is dropped by the select below)
     for (int i0 = seg; i0 < A.S; i0 += kCompLanes * kCompAhead) {
@@ -653,6 +662,7 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
         for (int u = 0; u < kCompAhead; ++u) {
             if (i0 + kCompLanes * u >= A.S) continue;
             acc += wv[u];
+            if (PHASE == 1) dep += wv[u] * (tmin + A.step * ((float)(i0 + kCompLanes * u) + jit));      // depth_map: sum of weight * z_vals (FieldBase.py:305)
             if (wv[u] > A.thr) {
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) rgb[ch] += wv[u] * cv[u][ch];
@@ -662,6 +672,7 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
 #pragma unroll
     for (int d = 1; d < kCompLanes; d <<= 1) {
         acc += __shfl_xor(acc, d);
+        if (PHASE == 1) dep += __shfl_xor(dep, d);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) rgb[ch] += __shfl_xor(rgb[ch], d);
     }
@@ -672,14 +683,26 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
         float pre = rgb[ch];
         if (A.white_bg) pre = pre + (1.0f - acc);
         const float out = fminf(fmaxf(pre, 0.0f), 1.0f);
-        const float res = out - T.target[r * 3 + ch];
-        if (live && seg == 0) sq += (double)(res * res);
-        G[ch] = (pre >= 0.0f && pre <= 1.0f) ? 2.0f * res * T.inv_count : 0.0f;      // clamp passes the gradient on [0,1]
+        if (PHASE == 1) {
+            if (live && seg == 0) T.rgb_out[r * 3 + ch] = out;
+            G[ch] = 0.0f;
+            continue;
+        }
+        const bool pass = (pre >= 0.0f) & (pre <= 1.0f);                            // clamp passes the gradient on [0,1]
+        if (PHASE == 2) {
+            G[ch] = pass ? T.d_rgb[r * 3 + ch] : 0.0f;
+        } else {
+            const float res = out - T.target[r * 3 + ch];
+            if (live && seg == 0) sq += (double)(res * res);
+            G[ch] = pass ? 2.0f * res * T.inv_count : 0.0f;
+        }
         if (live && seg == 0) T.G[r * 3 + ch] = G[ch];
     }
+    if (PHASE == 1) {
+        if (live && seg == 0) T.depth_out[r] = dep + (1.0f - acc) * A.rays[r * 6 + 5];      // + (1 - acc_map) * rays_chunk[..., -1] (FieldBase.py:306)
+        return;
+    }
     const float gbg = (G[0] + G[1] + G[2]) * bg;
-    const float tmin = ray_tmin(A, r);
-    const float jit = A.jitter ? A.jitter[r] : 0.0f;
     double carry = 0.0;                                       // sum of the terms of all steps above the current block
     for (int j0 = ((A.S - 1) / kCompLanes) * kCompLanes; j0 >= 0; j0 -= kCompLanes * kCompAhead) {
         float xv[kCompAhead], sv[kCompAhead], tv[kCompAhead], wv[kCompAhead], cv[kCompAhead][3];
@@ -727,10 +750,11 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
             carry += __shfl(incl, rl * kCompLanes);
         }
     }
-    // one double atomic per wave for the loss
+    if (PHASE == 0) {      // one double atomic per wave for the loss
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) sq += __shfl_xor(sq, s);
-    if (lane == 0) atomicAdd(T.loss, sq);
+        for (int s = 32; s > 0; s >>= 1) sq += __shfl_xor(sq, s);
+        if (lane == 0) atomicAdd(T.loss, sq);
+    }
 }
 
 // ---- 5. colour backward over the active list --------------------------------------------------------------------------------
@@ -1603,12 +1627,16 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
 }
 
 // blocked gauge-gradient plane -> [texel][2] (what the Adam kernel and ngf_train_get_grad read); blockIdx.y = plane
-struct UnblockArgs { const float *src[3]; float *dst[3]; int32_t w2[3], h2[3], bw[3]; const double *loss_src; double *loss_dst; int32_t loss_len; double inv_count; };   // + the step's loss to the caller's buffer: [0] sum of squared residuals, [1] their mean
+struct UnblockArgs { const float *src[3]; float *dst[3]; int32_t w2[3], h2[3], bw[3]; const double *loss_src; double *loss_dst; int32_t loss_len; double inv_count; const int32_t *overflow; };   // + the step's loss to the caller's buffer: [0] sum of squared residuals, [1] their mean -- NaN when the step overflowed its speculative rows (train_prefix_kernel): the colour forward of such a step was truncated, its loss means nothing
 __global__ void __launch_bounds__(256) train_unblock_gauge_kernel(const UnblockArgs U)
 {
     const int p = blockIdx.y;
     const int total = U.w2[p] * U.h2[p];
-    if (U.loss_dst && blockIdx.x == 0 && p == 0 && threadIdx.x == 0) { U.loss_dst[0] = *U.loss_src; if (U.loss_len >= 2) U.loss_dst[1] = *U.loss_src * U.inv_count; }
+    if (U.loss_dst && blockIdx.x == 0 && p == 0 && threadIdx.x == 0) {
+        const double sum = (U.overflow && U.overflow[0]) ? __longlong_as_double(0x7FF8000000000000ll) : *U.loss_src;
+        U.loss_dst[0] = sum;
+        if (U.loss_len >= 2) U.loss_dst[1] = sum * U.inv_count;
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int y = i / U.w2[p], x = i - y * U.w2[p];
         const f32x2 v = *reinterpret_cast<const f32x2 *>(U.src[p] + blocked_offset<1, 2>(x, y, U.bw[p]));

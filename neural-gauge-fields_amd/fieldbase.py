@@ -152,6 +152,42 @@ class Base(torch.nn.Module):
         return (tuple(ps), m, float(self.stepSize), self._aabb_host(), self.bake_density, self.bake_color, self.no_fold, self.split_bf16,
                 tuple(self.near_far), float(self.distance_scale), float(self.rayMarch_weight_thres))
 
+    # --- differentiable training-mode forward (FieldBase.py:251-312 under autograd; the loop of TriPlane/main.py:272-296) ------------------
+    def _render_grad_engine(self, n, S):
+        """The device trainer behind ``forward(is_train=True)`` with autograd on (ngf_amd.train.RenderGrad); rebuilt when the batch outgrows it
+        or the parameter tensors were re-allocated (up_sampling / shrink / load)."""
+        from . import train
+        eng = getattr(self, '_grad_engine', None)
+        if eng is not None and eng._h is not None and eng.fits(n, S):
+            return eng
+        if eng is not None:
+            eng.release()
+        eng = train.RenderGrad(self, max(int(n), getattr(eng, 'max_rays', 0)), max(int(S), getattr(eng, 'max_samples', 0)))
+        self._grad_engine = eng
+        return eng
+
+    def _wants_grad(self, is_train):
+        return bool(is_train) and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def _render_train(self, rays_chunk, white_bg, N_samples, gauge_on, jitter=None, coin=None):
+        """``forward(is_train=True)`` with gradients: the same random draws as ``_render`` (jitter: torch.rand_like of sample_ray,
+        FieldBase.py:128-130; background coin: FieldBase.py:299), then one torch.autograd.Function over the fifteen parameters.  The
+        reference's loop works unchanged on the result: ``loss(out['rgb_map'], ...) + w * field.density_L1()``, ``.backward()``,
+        ``torch.optim.Adam(field.get_optparam_groups(...)).step()`` (TriPlane/main.py:272-296)."""
+        from . import train
+        dev = torch.device(self.device)
+        rays = rays_chunk.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if rays.dim() != 2 or rays.shape[1] != 6:
+            raise ValueError(f"rays_chunk must be [n,6], got {tuple(rays.shape)}")
+        n = rays.shape[0]
+        if n == 0:
+            raise ValueError("a differentiable forward needs at least one ray")
+        S = int(N_samples) if N_samples > 0 else int(self.nSamples)
+        jitter = torch.rand((n,), device=dev) if jitter is None else jitter.detach().to(device=dev, dtype=torch.float32).reshape(n).contiguous()
+        white = bool(white_bg or ((torch.rand((1,)) if coin is None else torch.tensor([float(coin)])) < 0.5))
+        rgb, depth = train._TrainRender.apply(self, rays, jitter, S, white, bool(gauge_on), *train._train_params(self))
+        return {'rgb_map': rgb, 'depth_map': depth}
+
     def invalidate(self):
         """Force the packed device image to be rebuilt at the next call.  The handle is rebuilt automatically when a parameter
         tensor is replaced or modified through autograd-tracked in-place ops (optimizer.step(), load_state_dict, up_sampling,
@@ -159,6 +195,7 @@ class Base(torch.nn.Module):
         pointer writes from another library -- are invisible to it: call ``invalidate()`` after them, or set
         ``field.check_params = True`` (debug: the key then carries a device-side checksum of every parameter, one sync per call)."""
         self._handle_key = None
+        self._grad_stale = True           # the differentiable forward's packed plane copies as well (train.RenderGrad.forward)
 
     def _fill_desc(self, d: _lib.FieldDesc, keep: list):
         raise NotImplementedError

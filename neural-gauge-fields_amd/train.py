@@ -49,6 +49,9 @@ def _bind(L):
     L.ngf_trainer_bytes.argtypes = [C.c_void_p]
     L.ngf_train_backward2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                       C.POINTER(C.c_int64), C.c_void_p]
+    L.ngf_train_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]
+    L.ngf_train_backward_grad.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.ngf_train_get_grad.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.ngf_train_get_active.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.ngf_train_overflow_count.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]
@@ -60,6 +63,55 @@ def _bind(L):
     L._ngf_train_bound = True
 
 
+def _train_params(field):
+    """The fifteen parameters in ngf_train_desc order (PARAM_NAMES), checked for what the kernels read: contiguous float32 device tensors."""
+    sd = dict(field.named_parameters())
+    params = []
+    for name in PARAM_NAMES:
+        p = sd[name]
+        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+            raise RuntimeError(f"parameter {name} must be a contiguous float32 device tensor")
+        params.append(p)
+    return params
+
+
+def _train_desc(f, params, exp_avg, exp_avg_sq, max_rays, max_samples, chunk_samples):
+    """ngf_train_desc of field ``f``; ``exp_avg`` / ``exp_avg_sq`` None = a trainer without optimiser (ngf_train_forward / _backward_grad only)."""
+    d = TrainDesc()
+    dev = torch.device(f.device)
+    d.aabb = (C.c_float * 6)(*f._aabb_host())
+    d.near_, d.far_ = float(f.near_far[0]), float(f.near_far[1])
+    d.step = float(f.stepSize)
+    d.distance_scale = float(f.distance_scale)
+    d.weight_thres = float(np.float32(f.rayMarch_weight_thres))
+    for k in range(3):
+        d.plane[k] = params[k].data_ptr()
+        d.plane_h[k], d.plane_w[k] = params[k].shape[2], params[k].shape[3]
+        d.gauge[k] = params[3 + k].data_ptr()
+        d.gauge_h[k], d.gauge_w[k] = params[3 + k].shape[2], params[3 + k].shape[3]
+    (d.dens_w, d.dens_b, d.basis, d.w1, d.b1, d.w2, d.b2, d.w3, d.b3) = [p.data_ptr() for p in params[6:]]
+    if exp_avg is not None:
+        for k in range(15):
+            d.exp_avg[k] = exp_avg[k].data_ptr()
+            d.exp_avg_sq[k] = exp_avg_sq[k].data_ptr()
+    keep = []
+    if f.alphaMask is not None:
+        bits = f.alphaMask.packed_bits_device().to(dev)
+        keep.append(bits)
+        d.mask_bits = bits.data_ptr()
+        shp = f.alphaMask.alpha_volume.shape
+        d.mask_d, d.mask_h, d.mask_w = int(shp[-3]), int(shp[-2]), int(shp[-1])
+        d.mask_aabb = (C.c_float * 6)(*f.alphaMask.aabb.reshape(-1).tolist())
+    d.max_rays, d.max_samples, d.chunk_samples = int(max_rays), int(max_samples), int(chunk_samples)
+    return d, keep
+
+
+def _field_key(f, params):
+    return (tuple((p.data_ptr(), tuple(p.shape)) for p in params), float(f.stepSize), f._aabb_host(),
+            None if f.alphaMask is None else f.alphaMask.alpha_volume.data_ptr(),
+            tuple(f.near_far), float(f.distance_scale), float(f.rayMarch_weight_thres))
+
+
 class Trainer:
     """Adam state + the device trainer of one TriPlane field.
 
@@ -68,26 +120,29 @@ class Trainer:
 
     def __init__(self, field, batch_size=4096, max_samples=None, lr_init=0.02, lr_basis=1e-3, lr_decay_iters=-1,
                  lr_decay_target_ratio=0.1, n_iters=30000, L1_reg_weight=L1_REG_WEIGHT, betas=(0.9, 0.99), eps=1e-8, chunk_samples=None,
-                 frozen=(), state_from=None):
-        """``chunk_samples`` sizes the activation rows (2.4 KB per active sample), ngf_train_desc.chunk_samples of include/ngf.h:
-        ``None`` (default) = SPECULATIVE rows for a third of the batch's (ray, sample) pairs, at least 262 144 -- 3.4 GiB for 4096 rays x 884
-        samples instead of the 9.0 GiB of rows for every pair -- with no host round trip; a batch with more active samples than rows is flagged
-        on the device, its optimizer_step leaves parameters and moments untouched, and ``check_rows()`` (called by ``fit`` at every progress
-        refresh) reports it and doubles the rows.  ``0`` = rows for every pair (never overflows); ``> 0`` = that many rows, the step reads the
-        active count on the host (one sync per step); ``< 0`` = speculative with that many rows."""
+                 frozen=(), state_from=None, speculative=False, check_every=16):
+        """``chunk_samples`` sizes the activation rows (2.4 KB per active sample), ngf_train_desc.chunk_samples of include/ngf.h.
+        ``None`` (default): rows for a third of the batch's (ray, sample) pairs, at least 262 144 -- 3.4 GiB for 4096 rays x 884 samples instead
+        of the 9.0 GiB of rows for every pair.  What happens when a batch has more active samples than rows is ``speculative``'s choice:
+
+        * ``speculative=False`` (DEFAULT, fail-safe): the step reads the active count on the host (ONE stream synchronisation per step -- the
+          reference's loop synchronises every iteration as well, ``rgb_loss.detach().item()``, main.py:297) and works a longer list through
+          chunk by chunk: every step applies a complete gradient, nothing is ever skipped.
+        * ``speculative=True`` (opt-in, no host round trip at all): a batch that does not fit is flagged ON THE DEVICE -- its Adam update leaves
+          parameters and moments untouched (a truncated gradient is never applied) and its loss is NaN.  ``optimizer_step`` looks at the flag
+          counter every ``check_every`` steps (one synchronisation each; ``check_rows()`` does it on demand), warns, doubles the rows and takes
+          the skipped steps back out of its step counters and learning-rate decay.  Steps taken between an overflow and its detection ran with
+          counters advanced by the skipped ones (bias correction / lr decay off by that many steps); use the default when that matters.
+
+        An explicit ``chunk_samples``: ``0`` = rows for every pair (never overflows, no synchronisation); ``> 0`` = that many rows, host count
+        (the default's path); ``< 0`` = speculative with that many rows."""
         self.field = field
         self.dev = torch.device(field.device)
         if self.dev.type != "cuda":
             raise RuntimeError("ngf_amd.train.Trainer runs on the GPU only (device='cuda'); there is no CPU path")
         self.L = _lib.lib()
         _bind(self.L)
-        sd = dict(field.named_parameters())
-        self.params = []
-        for name in PARAM_NAMES:
-            p = sd[name]
-            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
-                raise RuntimeError(f"parameter {name} must be a contiguous float32 device tensor")
-            self.params.append(p)
+        self.params = _train_params(field)
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.steps = [0] * 15                       # torch.optim.Adam keeps one step counter per parameter
@@ -104,9 +159,12 @@ class Trainer:
         self.max_samples = int(max_samples if max_samples is not None else field.nSamples)
         pairs = self.batch_size * self.max_samples
         if chunk_samples is None:
-            rows = max(1 << 18, -(-pairs // 3))
-            chunk_samples = 0 if rows >= pairs else -((rows + 15) // 16 * 16)
+            rows = (max(1 << 18, -(-pairs // 3)) + 15) // 16 * 16
+            chunk_samples = 0 if rows >= pairs else (-rows if speculative else rows)
         self.chunk_samples = int(chunk_samples)
+        self.check_every = max(1, int(check_every))
+        self._since_check = 0
+        self._applied = []                          # speculative rows: (parameter indices, lr factor) of the optimizer steps since the last check
         self._overflows_seen = 0
         self._h = None
         if state_from is not None:                  # carry the optimiser state of parameters that kept their shape
@@ -122,31 +180,7 @@ class Trainer:
         self._build()
 
     def _build(self):
-        f = self.field
-        d = TrainDesc()
-        d.aabb = (C.c_float * 6)(*f._aabb_host())
-        d.near_, d.far_ = float(f.near_far[0]), float(f.near_far[1])
-        d.step = float(f.stepSize)
-        d.distance_scale = float(f.distance_scale)
-        d.weight_thres = float(np.float32(f.rayMarch_weight_thres))
-        for k in range(3):
-            d.plane[k] = self.params[k].data_ptr()
-            d.plane_h[k], d.plane_w[k] = self.params[k].shape[2], self.params[k].shape[3]
-            d.gauge[k] = self.params[3 + k].data_ptr()
-            d.gauge_h[k], d.gauge_w[k] = self.params[3 + k].shape[2], self.params[3 + k].shape[3]
-        (d.dens_w, d.dens_b, d.basis, d.w1, d.b1, d.w2, d.b2, d.w3, d.b3) = [p.data_ptr() for p in self.params[6:]]
-        for k in range(15):
-            d.exp_avg[k] = self.exp_avg[k].data_ptr()
-            d.exp_avg_sq[k] = self.exp_avg_sq[k].data_ptr()
-        self._keep = []
-        if f.alphaMask is not None:
-            bits = f.alphaMask.packed_bits_device().to(self.dev)
-            self._keep.append(bits)
-            d.mask_bits = bits.data_ptr()
-            shp = f.alphaMask.alpha_volume.shape
-            d.mask_d, d.mask_h, d.mask_w = int(shp[-3]), int(shp[-2]), int(shp[-1])
-            d.mask_aabb = (C.c_float * 6)(*f.alphaMask.aabb.reshape(-1).tolist())
-        d.max_rays, d.max_samples, d.chunk_samples = self.batch_size, self.max_samples, self.chunk_samples
+        d, self._keep = _train_desc(self.field, self.params, self.exp_avg, self.exp_avg_sq, self.batch_size, self.max_samples, self.chunk_samples)
         out = C.c_void_p()
         with torch.cuda.device(self.dev):
             _lib.check(self.L.ngf_trainer_create(C.byref(d), C.byref(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
@@ -156,9 +190,7 @@ class Trainer:
         self._versions = self._param_versions()
 
     def _key(self):
-        f = self.field
-        return (tuple((p.data_ptr(), tuple(p.shape)) for p in self.params), float(f.stepSize), f._aabb_host(),
-                None if f.alphaMask is None else f.alphaMask.alpha_volume.data_ptr())
+        return _field_key(self.field, self.params)
 
     def _param_versions(self):
         """torch's in-place version counters of the six plane / gauge-plane tensors (the ones the trainer keeps packed copies of).
@@ -195,11 +227,21 @@ class Trainer:
         return int(cnt.value), int(rows.value)
 
     def check_rows(self, grow=True) -> int:
-        """Speculative rows: report batches that did not fit since the last check (their steps changed nothing) and, with ``grow``, rebuild the
-        device trainer with twice the rows (the Adam state is the caller's tensors and stays).  Returns the number of new overflows."""
+        """Speculative rows: report batches that did not fit since the last check (their steps changed nothing on the device) and, with
+        ``grow``, rebuild the device trainer with twice the rows (the Adam state is the caller's tensors and stays).  The skipped steps are
+        taken back out of the per-parameter step counters and the learning-rate decay (``optimizer_step`` advanced them on the host before
+        the device's verdict was known).  Returns the number of new overflows.  Synchronises."""
         cnt, rows = self.overflows()
         new = cnt - self._overflows_seen
         self._overflows_seen = cnt
+        self._since_check = 0
+        if new > 0:
+            # WHICH of the steps since the last check were skipped is not recorded (one counter on the device): take the most recent ones
+            for idx, factor in self._applied[-new:]:
+                for k in idx:
+                    self.steps[k] -= 1
+                self.lr = [x / factor for x in self.lr]
+        self._applied = []
         if new > 0 and grow and self.chunk_samples < 0:
             import warnings
             warnings.warn(f"ngf_amd.train.Trainer: {new} step(s) had more active samples than the {rows} activation rows and were skipped; "
@@ -278,17 +320,24 @@ class Trainer:
         """optimizer.step() + the lr decay of main.py:298-299.  Gauge planes without a gradient (iteration <
         gauge_start) are skipped like torch.optim skips parameters whose .grad is None."""
         counts = (C.c_int32 * 15)()
+        idx = []
         for k in range(15):
             if (3 <= k < 6 and not self._gauge_on) or k in self.frozen:
                 continue                              # count 0 = skipped
             self.steps[k] += 1
             counts[k] = self.steps[k]
+            idx.append(k)
         lrs = (C.c_float * 15)(*[float(x) for x in self.lr])
         with torch.cuda.device(self.dev):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             _lib.check(self.L.ngf_train_adam_all(self._h, counts, lrs, float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.l1), st))
         self.field.invalidate()      # parameters changed behind torch's back: the eval image is re-packed on the next render
         self.lr = [x * self.lr_factor for x in self.lr]
+        if self.chunk_samples < 0:   # speculative rows: the device may have refused this update -- look every check_every steps
+            self._applied.append((idx, self.lr_factor))
+            self._since_check += 1
+            if self._since_check >= self.check_every:
+                self.check_rows()
 
     def step(self, rays_train, rgb_train, iteration, N_samples=-1, white_bg=True, jitter=None, coin=None, keep_loss=False):
         """One iteration of main.py:264-299.  Returns the rgb loss (0-dim float64 device tensor; ``.item()`` for PSNR) -- a view of the
@@ -296,6 +345,123 @@ class Trainer:
         loss = self.backward(rays_train, rgb_train, N_samples, white_bg, iteration, jitter, coin, keep_loss=keep_loss)
         self.optimizer_step()
         return loss
+
+
+class RenderGrad:
+    """The device side of a DIFFERENTIABLE ``field(rays, is_train=True)`` (TriPlane/models/FieldBase.py:251-312 under autograd, as the reference's
+    training loop uses it, TriPlane/main.py:272-296): a device trainer without optimiser state, driven in two calls -- ``forward`` renders the
+    batch in training mode with the trainer's kernels and keeps its per-sample buffers, ``backward`` takes d loss / d rgb_map and returns the
+    gradients of the fifteen parameters in their reference layouts.  ``Base.forward`` owns one per field (``_TrainRender`` below is the
+    torch.autograd.Function around it); the caller's own loss, ``density_L1`` and ``torch.optim.Adam`` do the rest, unchanged.
+
+    Activation rows: a third of the batch's (ray, sample) pairs (at least 262 144) and the active count read on the host in ``forward`` -- one
+    stream synchronisation per step, like the reference's own ``rgb_mask.any()`` (FieldBase.py:291) -- so the gradient is always complete: a
+    batch with more active samples than rows is worked through chunk by chunk, never truncated."""
+
+    def __init__(self, field, max_rays, max_samples):
+        self.field = field
+        self.dev = torch.device(field.device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("a differentiable field(..., is_train=True) renders on the GPU only (device='cuda'); there is no CPU path")
+        self.L = _lib.lib()
+        _bind(self.L)
+        self.params = _train_params(field)
+        self.max_rays, self.max_samples = int(max_rays), int(max_samples)
+        pairs = self.max_rays * self.max_samples
+        rows = min(pairs, max(1 << 18, -(-pairs // 3)))
+        self.chunk_samples = (rows + 15) // 16 * 16
+        d, self._keep = _train_desc(field, self.params, None, None, self.max_rays, self.max_samples, self.chunk_samples)
+        out = C.c_void_p()
+        with torch.cuda.device(self.dev):
+            _lib.check(self.L.ngf_trainer_create(C.byref(d), C.byref(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        self._h = out
+        self.key = _field_key(field, self.params)
+        self._versions = tuple(int(p._version) for p in self.params[:6])
+        self.last_active = 0
+
+    def fits(self, n, S):
+        return n <= self.max_rays and S <= self.max_samples and self.key == _field_key(self.field, _train_params(self.field))
+
+    def release(self):
+        if getattr(self, "_h", None) is not None:
+            self.L.ngf_trainer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def forward(self, rays, jitter, S, white_bg, gauge_on):
+        """-> (rgb_map [n,3], depth_map [n], ticket).  The planes' packed copies follow torch's in-place version counters (optimizer.step(),
+        load_state_dict); ``field.invalidate()`` marks them stale for writes that bypass the counters."""
+        v = tuple(int(p._version) for p in self.params[:6])
+        if v != self._versions or getattr(self.field, "_grad_stale", False):
+            _lib.check(self.L.ngf_train_params_changed(self._h))
+            self._versions = v
+            self.field._grad_stale = False
+        n = rays.shape[0]
+        rgb = torch.empty((n, 3), device=self.dev, dtype=torch.float32)
+        depth = torch.empty((n,), device=self.dev, dtype=torch.float32)
+        n_active, ticket = C.c_int64(0), C.c_int64(0)
+        with torch.cuda.device(self.dev):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(self.L.ngf_train_forward(self._h, rays.data_ptr(), jitter.data_ptr(), n, int(S), int(bool(white_bg)), int(bool(gauge_on)),
+                                                rgb.data_ptr(), depth.data_ptr(), C.byref(n_active), C.byref(ticket), st))
+        self.last_active = int(n_active.value)
+        return rgb, depth, int(ticket.value)
+
+    def backward(self, ticket, d_rgb, want):
+        """``want[k]``: return parameter k's gradient (else None).  -1 = the ticket is stale (another forward used the buffers): re-run forward."""
+        with torch.cuda.device(self.dev):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if self.L.ngf_train_backward_grad(self._h, int(ticket), d_rgb.data_ptr(), st) != 0:
+                return None
+            grads = []
+            for k in range(15):
+                if not want[k]:
+                    grads.append(None)
+                    continue
+                g = torch.empty_like(self.params[k])
+                _lib.check(self.L.ngf_train_get_grad(self._h, k, g.data_ptr(), st))
+                grads.append(g)
+        return grads
+
+
+class _TrainRender(torch.autograd.Function):
+    """``rgb_map, depth_map = field(rays, is_train=True)`` as one autograd node over the fifteen parameters.  depth_map is not differentiable
+    (the reference computes it under torch.no_grad(), FieldBase.py:304-306); rays carry no gradient (the reference's are data)."""
+
+    @staticmethod
+    def forward(ctx, field, rays, jitter, S, white_bg, gauge_on, *params):
+        eng = field._render_grad_engine(rays.shape[0], S)
+        rgb, depth, ticket = eng.forward(rays, jitter, S, white_bg, gauge_on)
+        ctx.field, ctx.engine, ctx.ticket = field, eng, ticket
+        ctx.cfg = (int(S), bool(white_bg), bool(gauge_on))
+        ctx.save_for_backward(rays, jitter, *params)          # saved tensors: autograd refuses a backward after an in-place write to any of them
+        ctx.mark_non_differentiable(depth)
+        return rgb, depth
+
+    @staticmethod
+    def backward(ctx, d_rgb, _d_depth):
+        saved = ctx.saved_tensors
+        rays, jitter = saved[0], saved[1]
+        S, white_bg, gauge_on = ctx.cfg
+        eng = ctx.engine
+        if eng._h is None or not eng.fits(rays.shape[0], S):
+            raise RuntimeError("the field's parameters were re-allocated (up_sampling / shrink / load) between forward and backward")
+        d = d_rgb.to(dtype=torch.float32).contiguous()
+        want = [bool(w) for w in ctx.needs_input_grad[6:]]
+        if not gauge_on:                                   # compute_gauge was not evaluated (Field.py:58,73): the gauge planes are not in the graph
+            want[3:6] = [False, False, False]
+        grads = eng.backward(ctx.ticket, d, want)
+        if grads is None:                                  # another forward went through the engine since: render this batch again, then its backward
+            _, _, ticket = eng.forward(rays, jitter, S, white_bg, gauge_on)
+            grads = eng.backward(ticket, d, want)
+            if grads is None:
+                raise RuntimeError(_lib.lib().ngf_last_error().decode())
+        return (None,) * 6 + tuple(grads)
 
 
 class SimpleSampler:
@@ -345,10 +511,13 @@ def fit(field, allrays, allrgbs, args, white_bg=True, on_iteration=None):
     PSNRs = []
     for iteration in range(args.n_iters):
         ids = sampler.nextids()
-        rgb_loss = trainer.step(allrays[ids].to(dev), allrgbs[ids].to(dev), iteration, N_samples=nSamples, white_bg=white_bg).item()
+        rays_train, rgb_train = allrays[ids].to(dev), allrgbs[ids].to(dev)
+        rgb_loss = trainer.step(rays_train, rgb_train, iteration, N_samples=nSamples, white_bg=white_bg).item()
+        while rgb_loss != rgb_loss and trainer.chunk_samples < 0 and trainer.check_rows() > 0:
+            # speculative rows (opt-in): the batch did not fit, the device skipped its update and marked the loss NaN; check_rows doubled the
+            # rows and took the step back out of the counters -- take it again
+            rgb_loss = trainer.step(rays_train, rgb_train, iteration, N_samples=nSamples, white_bg=white_bg).item()
         PSNRs.append(-10.0 * np.log(rgb_loss) / np.log(10.0))
-        if iteration % max(1, int(getattr(args, "progress_refresh_rate", 10))) == 0:
-            trainer.check_rows()                      # speculative activation rows: a batch that did not fit was skipped on the device
         if on_iteration is not None:
             on_iteration(iteration, rgb_loss)
         if iteration in mask_list:

@@ -1,0 +1,188 @@
+"""GPU: ``field(rays, is_train=True)`` is differentiable -- the reference's own training loop (TriPlane/main.py:272-299) runs UNCHANGED on the
+drop-in field: its ``torch.mean((rgb_map - rgb_train) ** 2)``, its ``density_L1``, ``total_loss.backward()`` and
+``torch.optim.Adam(field.get_optparam_groups(...), betas=(0.9, 0.99))``.  Checked against what the reference module itself produced for the
+same two iterations (tests/golden/train_r1.npz: rgb_map, every gradient INCLUDING the L1 term, the parameters after two Adam steps), and
+against the fused device trainer (ngf_amd.train.Trainer) that the same kernels serve.  C ABI: ngf_train_forward / ngf_train_backward_grad."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import field_for_case, load_case, load_train_case  # noqa: E402
+import ngf_amd  # noqa: E402,F401
+from ngf_amd import train  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GRAD_TOL = 1e-4
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-30)
+
+
+def test_the_references_training_loop_runs_unchanged_and_matches_its_gradients():
+    """The loop body below is main.py:272-299 line for line (names kept); only the two random draws of the forward are pinned to the captured
+    ones (jitter=, coin=: keyword extras of the drop-in's forward) so that the reference's numbers can be compared."""
+    g, params = load_train_case("train_r1")
+    field = field_for_case(g, params, None)
+    nSamples = int(g["S"])
+    rays_train, rgb_train = torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["rgb_train"]).cuda()
+    grad_vars = field.get_optparam_groups(0.02, 1e-3)                       # main.py:234 (args.lr_init, args.lr_basis)
+    optimizer = torch.optim.Adam(grad_vars, betas=(0.9, 0.99))              # main.py:241
+    lr_factor = float(g["lr_factor"])
+    L1_reg_weight = 8e-5
+    PSNRs = []
+    for iteration in range(int(g["steps"])):
+        output = field(rays_train, is_train=True, white_bg=bool(g[f"white{iteration}"]), N_samples=nSamples, iteration=iteration,
+                       jitter=torch.from_numpy(g[f"jitter{iteration}"]), coin=0.7)
+        rgb_map = output['rgb_map']
+        assert rgb_map.requires_grad and not output['depth_map'].requires_grad
+
+        rgb_loss = torch.mean((rgb_map - rgb_train) ** 2)
+        total_loss = rgb_loss
+        if L1_reg_weight > 0:
+            loss_reg_L1 = field.density_L1()
+            total_loss += L1_reg_weight * loss_reg_L1
+
+        optimizer.zero_grad()
+        total_loss.backward()
+        if iteration == 0:
+            np.testing.assert_allclose(rgb_map.detach().cpu().numpy(), g["rgb_map0"], rtol=1e-4, atol=2e-6)
+            assert abs(float(total_loss.detach()) - float(g["total_loss0"])) < 2e-6
+            sd = dict(field.named_parameters())
+            for name in train.PARAM_NAMES:
+                got = sd[name].grad.cpu().numpy()
+                assert rel(got, g[f"grad0.{name}"]) < GRAD_TOL, (name, rel(got, g[f"grad0.{name}"]))
+        optimizer.step()
+
+        rgb_loss = rgb_loss.detach().item()
+        PSNRs.append(-10.0 * np.log(rgb_loss) / np.log(10.0))
+        for param_group in optimizer.param_groups:
+            param_group['lr'] = param_group['lr'] * lr_factor
+    assert abs(rgb_loss - float(g["rgb_loss1"])) < 2e-3 * float(g["rgb_loss1"])
+    sd = field.state_dict()
+    for name in train.PARAM_NAMES:                                          # the trajectory, as test_gradients_and_two_adam_steps_match_reference holds it
+        d = np.abs(sd[name].cpu().numpy() - g[f"after.{name}"])
+        assert not np.array_equal(sd[name].cpu().numpy(), params[name])
+        assert np.median(d) < 1e-5 and np.mean(d > 1e-3) < 0.02, (name, float(np.median(d)), float(np.mean(d > 1e-3)))
+    # the eval launch sees torch.optim's in-place updates (Parameter._version moved: the packed image is rebuilt)
+    with torch.no_grad():
+        out = field(rays_train, N_samples=nSamples, iteration=30001)
+    assert torch.isfinite(out["rgb_map"]).all() and not out["rgb_map"].requires_grad
+
+
+@pytest.mark.parametrize("name", ["triplane_r1_train_white", "triplane_r1_train_black"])
+def test_differentiable_forward_matches_the_references_train_mode_forward(name):
+    """The trainer's forward kernels (what the autograd path renders with) against the reference's own is_train=True forward: rgb_map and
+    depth_map of the captured cases, and the fused eval launch on the same jitter."""
+    g, params, step, mask = load_case(name)
+    S, wb = int(g["S"]), bool(int(g["white_bg"]))
+    f = field_for_case(g, params, mask)
+    rays = torch.from_numpy(g["rays"]).cuda()
+    kw = dict(white_bg=wb, is_train=True, N_samples=S, iteration=30001 if int(g["gauge_on"]) else -1, jitter=torch.from_numpy(g["jitter"]),
+              coin=float(g["coin"]))
+    f.gauge_start = 0
+    out = f(rays, **kw)
+    assert out["rgb_map"].requires_grad
+    with torch.no_grad():
+        fused = f(rays, **kw)
+    assert not fused["rgb_map"].requires_grad
+    rgb, depth = out["rgb_map"].detach().cpu().numpy(), out["depth_map"].cpu().numpy()
+    np.testing.assert_allclose(rgb, g["rgb_map"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(depth, g["depth_map"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(rgb, fused["rgb_map"].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(depth, fused["depth_map"].cpu().numpy(), rtol=1e-4, atol=5e-5)
+
+
+def test_arbitrary_loss_two_batches_in_one_graph_and_the_fused_trainer_agree():
+    """d loss / d rgb_map is whatever the caller's loss makes it (here an L1 photometric loss over TWO batches rendered before one backward):
+    the second forward takes the engine's buffers, so the first batch's backward renders it again (stale ticket) -- gradients equal the sum
+    of the two batches done one at a time.  With an MSE loss the autograd path reproduces the fused trainer's gradients."""
+    g, params, step, mask = load_case("triplane_r1_gauge")
+    from ngf_amd import synth
+    rays = torch.from_numpy(g["rays"]).cuda()
+    n, S = rays.shape[0], 48
+    tgt = torch.from_numpy(synth.hash_uniform(31, 1, (n, 3))).cuda()
+    j1, j2 = (torch.from_numpy(synth.hash_uniform(31, k, (n,))) for k in (2, 3))
+    f = field_for_case(g, params, None)
+    ps = dict(f.named_parameters())
+
+    def grads_of(loss):
+        f.zero_grad(set_to_none=True)
+        loss.backward()
+        return {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in ps.items()}
+
+    l1 = lambda j: (f(rays, is_train=True, N_samples=S, iteration=5, jitter=j)["rgb_map"] - tgt).abs().mean()      # noqa: E731
+    ga, gb = grads_of(l1(j1)), grads_of(l1(j2))
+    both = grads_of(l1(j1) + l1(j2))
+    for k in train.PARAM_NAMES:
+        want = ga[k] + gb[k]
+        assert float((both[k] - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1e-30), k
+    # MSE: the fused trainer's gradient of the same batch
+    tr = train.Trainer(field_for_case(g, params, None), batch_size=n, max_samples=S, chunk_samples=0)
+    tr.backward(rays, tgt, S, white_bg=True, iteration=5, jitter=j1)
+    mse = grads_of(torch.mean((f(rays, is_train=True, N_samples=S, iteration=5, jitter=j1)["rgb_map"] - tgt) ** 2))
+    for k, name in enumerate(train.PARAM_NAMES):
+        a, b = mse[name], tr.gradient(k)
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-30), name
+    tr.release()
+
+
+def test_gauge_off_frozen_parameters_and_the_guards():
+    g, params = load_train_case("train_r1")
+    f = field_for_case(g, params, None)
+    f.gauge_start = 10
+    S = int(g["S"])
+    rays, tgt = torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["rgb_train"]).cuda()
+    f.rgb_decoder.basis.weight.requires_grad_(False)
+    out = f(rays, is_train=True, N_samples=S, iteration=0, jitter=torch.from_numpy(g["jitter0"]))
+    torch.mean((out["rgb_map"] - tgt) ** 2).backward()
+    # iteration < gauge_start: compute_gauge is not evaluated (Field.py:58,73) -> .grad stays None and torch.optim skips the gauge planes
+    assert f.gauge_xy.grad is None and f.rgb_decoder.basis.weight.grad is None and f.plane_xy.grad is not None
+    # in-place write between forward and backward: autograd refuses (saved tensors' version counters), as it does for the reference
+    out = f(rays, is_train=True, N_samples=S, iteration=0, jitter=torch.from_numpy(g["jitter0"]))
+    with torch.no_grad():
+        f.plane_xy.mul_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out["rgb_map"].sum().backward()
+    # no graph is built where the reference builds none
+    with torch.no_grad():
+        assert not f(rays, is_train=True, N_samples=S, iteration=0)["rgb_map"].requires_grad
+    assert not f(rays, is_train=False, N_samples=S, iteration=0)["rgb_map"].requires_grad
+    # the InfoInv tree has no backward (out of scope): it raises instead of returning pixels without a graph
+    gi, pi, _, mi = load_case("infoinv_r1_on")
+    fi = field_for_case(gi, pi, mi)
+    with pytest.raises(NotImplementedError):
+        fi(torch.from_numpy(gi["rays"]).cuda(), is_train=True, N_samples=int(gi["S"]))
+    with torch.no_grad():
+        assert torch.isfinite(fi(torch.from_numpy(gi["rays"]).cuda(), is_train=True, N_samples=int(gi["S"]))["rgb_map"]).all()
+
+
+def test_full_size_batch_through_the_autograd_path_matches_the_fused_trainer():
+    """The reference's training shape (4096 rays x 884 samples, 256^2 planes): gradients of the two-call form against the fused step's."""
+    from helpers import big_case
+    from ngf_amd import synth
+    g, params, step = big_case("triplane", "R1")
+    f = field_for_case(g, params, None)
+    S = int(f.nSamples)
+    frame = synth.lookat_rays(800, 800)
+    pick = (synth.hash_uniform(9, 1, (4096,)) * np.float32(frame.shape[0])).astype(np.int64)
+    rays = torch.from_numpy(frame[pick]).cuda()
+    tgt = torch.from_numpy(synth.hash_uniform(9, 2, (4096, 3))).cuda()
+    jit = torch.from_numpy(synth.hash_uniform(9, 3, (4096,)))
+    out = f(rays, is_train=True, N_samples=S, iteration=7, jitter=jit)
+    loss = torch.mean((out["rgb_map"] - tgt) ** 2)
+    loss.backward()
+    tr = train.Trainer(field_for_case(g, params, None), batch_size=4096, max_samples=S)
+    l2 = tr.backward(rays, tgt, S, white_bg=True, iteration=7, jitter=jit)
+    assert abs(loss.item() - l2.item()) < 1e-7 and f._grad_engine.last_active == tr.last_active
+    sd = dict(f.named_parameters())
+    for k, name in enumerate(train.PARAM_NAMES):
+        a, b = sd[name].grad, tr.gradient(k)
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-30), name
+    tr.release()

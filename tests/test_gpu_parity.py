@@ -89,7 +89,8 @@ def test_render_matches_oracle_and_reference(name, bake):
         train_kw = {"jitter": torch.from_numpy(jitter), "coin": float(g["coin"])}
     o_rgb, o_depth = orc.render(g["rays"], S, white_bg=eff_white, jitter=jitter)
     f = field_for_case(g, params, mask, bake=bool(bake & 1), bake_color=bool(bake & 2))
-    out = f(torch.from_numpy(g["rays"]).cuda(), white_bg=wb, is_train="is_train" in g, N_samples=S, collect_stats=True, **_mode(g), **train_kw)
+    with torch.no_grad():           # the fused launch; with autograd on, is_train=True goes through the differentiable path (tests/test_gpu_autograd.py)
+        out = f(torch.from_numpy(g["rays"]).cuda(), white_bg=wb, is_train="is_train" in g, N_samples=S, collect_stats=True, **_mode(g), **train_kw)
     rgb, depth = out["rgb_map"].cpu().numpy(), out["depth_map"].cpu().numpy()
     e1 = _close(rgb, o_rgb, "rgb vs oracle")
     _close(depth, o_depth, "depth vs oracle", atol=5e-5)

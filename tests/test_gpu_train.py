@@ -118,20 +118,23 @@ def test_speculative_rows_overflow_skips_the_step_and_is_reported():
     assert n_active > 200
     tr = train.Trainer(fa, batch_size=n, max_samples=S, chunk_samples=-64)
     before = [p.detach().clone() for p in tr.params]
-    tr.backward(rays, tgt, S, white_bg=True, iteration=5, jitter=jit)
+    lr0 = list(tr.lr)
+    loss = tr.backward(rays, tgt, S, white_bg=True, iteration=5, jitter=jit)
+    assert np.isnan(loss.item())                      # the loss of a step whose colour forward was truncated means nothing: NaN, not a number that looks like one
     tr.optimizer_step()
     assert tr.overflows() == (1, 64)
     for k in range(15):
         assert torch.equal(tr.params[k].detach(), before[k]) and not tr.exp_avg[k].any() and not tr.exp_avg_sq[k].any(), train.PARAM_NAMES[k]
-    tr.steps = [0] * 15                               # the skipped step did not happen
+    assert tr.steps[0] == 1                           # the host advanced its counters before the device's verdict was known ...
     with pytest.warns(UserWarning):
         assert tr.check_rows() == 1
+    assert tr.steps == [0] * 15 and np.allclose(tr.lr, lr0, rtol=1e-12)      # ... and check_rows takes the skipped step back out
     while -tr.chunk_samples < n_active and tr.chunk_samples != 0:      # 128, 256, ... rows: every attempt is flagged and skipped
         tr.backward(rays, tgt, S, white_bg=True, iteration=5, jitter=jit)
         tr.optimizer_step()
-        tr.steps = [0] * 15
         with pytest.warns(UserWarning):
             assert tr.check_rows() == 1
+        assert tr.steps == [0] * 15
     tr.backward(rays, tgt, S, white_bg=True, iteration=5, jitter=jit)
     assert tr.last_active == n_active and tr.check_rows() == 0
     for k, name in enumerate(train.PARAM_NAMES):
@@ -142,6 +145,45 @@ def test_speculative_rows_overflow_skips_the_step_and_is_reported():
     for k, name in enumerate(train.PARAM_NAMES):
         assert torch.allclose(tr.params[k], ref.params[k], rtol=0, atol=2e-3 * tr.lr[k] + 1e-7), name
     tr.release(); ref.release()
+
+
+def test_speculative_trainer_checks_itself_and_the_default_never_skips():
+    """a caller that loops on Trainer.step() never called check_rows().  Opt-in speculative rows now look at the device's
+    counter from optimizer_step every check_every steps; the DEFAULT trainer (host count, chunked rows) applies a complete gradient whatever
+    the row count and never skips."""
+    g, params, step, mask = load_case("triplane_r1_gauge")
+    from ngf_amd import synth
+    rays = torch.from_numpy(g["rays"]).cuda()
+    n, S = rays.shape[0], 48
+    tgt = torch.from_numpy(synth.hash_uniform(78, 1, (n, 3))).cuda()
+    jit = torch.from_numpy(synth.hash_uniform(78, 2, (n,)))
+    fa, fb, fc = (field_for_case(g, params, None) for _ in range(3))
+    ref = train.Trainer(fb, batch_size=n, max_samples=S, chunk_samples=0)
+    l_ref = ref.step(rays, tgt, 5, N_samples=S, jitter=jit).item()
+    # opt-in speculative rows, far too few: step() alone finds out (check_every=2), grows, and says so
+    tr = train.Trainer(fa, batch_size=n, max_samples=S, chunk_samples=-64, check_every=2)
+    with pytest.warns(UserWarning):
+        for _ in range(2):
+            assert np.isnan(tr.step(rays, tgt, 5, N_samples=S, jitter=jit).item())
+    assert tr.steps == [0] * 15 and -tr.chunk_samples == 128
+    # the default path with the same 64 rows: host count, four or more chunks, the reference step
+    trd = train.Trainer(fc, batch_size=n, max_samples=S, chunk_samples=64)
+    l_def = trd.step(rays, tgt, 5, N_samples=S, jitter=jit).item()
+    assert abs(l_def - l_ref) < 1e-9 and trd.overflows()[0] == 0
+    for k, name in enumerate(train.PARAM_NAMES):
+        assert torch.allclose(trd.params[k], ref.params[k], rtol=0, atol=2e-3 * ref.lr[k] + 1e-7), name
+    # a speculative trainer that is ALSO handed a host count pointer takes the chunked path: complete gradient, no flag (ADVICE r4, low)
+    import ctypes as C
+    tr2 = train.Trainer(field_for_case(g, params, None), batch_size=n, max_samples=S, chunk_samples=-64)
+    loss2 = torch.zeros(2, dtype=torch.float64, device="cuda")
+    na = C.c_int64(0)
+    r32, t32, j32 = rays.contiguous(), tgt.contiguous(), jit.cuda().contiguous()
+    from ngf_amd import _lib
+    _lib.check(tr2.L.ngf_train_backward2(tr2._h, r32.data_ptr(), t32.data_ptr(), j32.data_ptr(), n, S, 1, 1, loss2.data_ptr(), 2, C.byref(na),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert tr2.overflows()[0] == 0 and na.value == ref.last_active and abs(loss2[1].item() - l_ref) < 1e-9
+    for t in (tr, trd, tr2, ref):
+        t.release()
 
 
 def test_gauge_off_before_gauge_start():
@@ -274,8 +316,9 @@ def test_full_size_batch_matches_autograd_oracle():
     orc = otrain.EagerTrainer(params, g["aabb"], step, g["near_far"], float(g["distance_scale"]), float(g["thr"]))
     grads, rgb_loss, _, aux = orc.gradients(torch.from_numpy(rays_np), torch.from_numpy(tgt_np), S, torch.from_numpy(jit_np), True, 7)
     tr = train.Trainer(f, batch_size=4096, max_samples=S)
-    # the default: speculative activation rows for a third of the 4096 x 884 pairs -- 3.4 GiB of scratch instead of 9.0 (<= 4 GiB)
-    assert tr.chunk_samples < 0 and tr.scratch_bytes() < 4 * 2 ** 30, (tr.chunk_samples, tr.scratch_bytes() / 2 ** 30)
+    # the default: activation rows for a third of the 4096 x 884 pairs -- 3.4 GiB of scratch instead of 9.0 (<= 4 GiB) -- and the
+    # active count read on the host (fail-safe: a longer list is cut into chunks, never truncated; speculative=True is the opt-in without it)
+    assert tr.chunk_samples > 0 and tr.scratch_bytes() < 4 * 2 ** 30, (tr.chunk_samples, tr.scratch_bytes() / 2 ** 30)
     loss = tr.backward(torch.from_numpy(rays_np), torch.from_numpy(tgt_np), S, white_bg=True, iteration=7, jitter=torch.from_numpy(jit_np))
     assert tr.overflows()[0] == 0
     n_ref = int(aux["active"].sum())
