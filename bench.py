@@ -46,7 +46,7 @@ def so_sha16():
     return hashlib.sha256(open(_lib.SO_PATH, "rb").read()).hexdigest()[:16]
 
 
-PMC_ROUNDS = ("r04", "r03", "r02")
+PMC_ROUNDS = ("r05", "r04", "r03", "r02")
 
 
 def load_pmc(tag):
@@ -64,7 +64,18 @@ def load_pmc(tag):
     return None
 
 
+# Necessary vector arithmetic of the level-3 formulation, in wave instructions (one instruction = one operation in each of 64 lanes); the
+# itemised table is DESIGN.md section 4.11.  "Necessary" = the arithmetic the formulation (SURVEY.md Appendix A.1 with folds (i)-(iii)) prescribes
+# for one lane's sample / one lane's share of a pass, counted at one instruction per fp32 operation (an FMA where the reference's op order allows
+# one); addressing, masks, queue bookkeeping, lane permutations, selects of the collect loop are NOT in it.
+NECESSARY_VALU = {"march_iteration": 258, "shade_pass": 313, "per_tile": 92}
+
+
 NOTES = {
+    "useful_op_frac": "(necessary VALU instructions x 4 cycles + executed MFMA cycles) / (issued VALU instructions x 4 + executed MFMA cycles): necessary = "
+                      "NECESSARY_VALU (DESIGN.md section 4.11) x this run's march iterations (evaluated samples / 64, a lower bound: partial waves count "
+                      "as fractions), shade passes and tiles; issued = SQ_INSTS_VALU of the committed PMC run minus its MFMA instructions; an fp32 MFMA "
+                      "16x16x4 occupies the SIMD for 32 cycles, a wave64 VALU instruction for 4 (transcendentals 16: counted as 4 on both sides)",
     "simd_vector_datapath": "MFMA (fp32 and bf16) and VALU instructions of a SIMD execute one after the other on gfx950 (profiles/micro/"
                             "mfma_valu_overlap.hip, profiles/r02_micro_mfma_valu_overlap.txt: 8.75 ms of fp32 MFMA + 3.07 ms of VALU run together in "
                             "11.63 ms; bf16: 4.44 + 3.07 -> 7.39), so their busy cycles add and this sum is the binding roof of the kernel.  "
@@ -131,8 +142,8 @@ def compact_line(result: dict) -> str:
         out[k] = _r(out[k], 6)
     out["config"] = result["config"]
     rf = result.get("roofline") or {}
-    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "flops_per_launch", "active_samples_per_ray",
-            "evaluated_samples_per_ray", "binding")
+    keep = ("bound", "achieved", "peak", "unit", "frac", "mfma_frac", "mfma_TFLOPs", "useful_op_frac", "traffic", "kernel", "kernel_ms", "flops_per_launch",
+            "active_samples_per_ray", "evaluated_samples_per_ray", "binding")
     crf = {k: _r(rf.get(k), 5) for k in keep if k in rf}
     ph = rf.get("physical")
     if ph:
@@ -153,6 +164,9 @@ def compact_line(result: dict) -> str:
         tr = result["extras"].get("train_step_R1", {})
         if "ms_per_iteration" in tr:
             out["train_ms_per_iteration"] = _r(tr["ms_per_iteration"], 4)
+        hbm = result["extras"].get("handle_build_ms", {})
+        if hbm and "error" not in hbm:
+            out["handle_build_ms"] = {k.replace("triplane_", ""): _r(v, 3) for k, v in hbm.items() if isinstance(v, float)}
         out["extras_file"] = "bench_extras.json"
     line = json.dumps(out, separators=(",", ":"))
     for k in ("extras_Mray_s", "parity", "speedup_vs_cpu_port"):     # never reached with today's keys; a guard, not a plan
@@ -422,10 +436,22 @@ def main():
         roofline = {"bound": "hbm", "achieved": None if hb is None else hb / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": None if hb is None else hb / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": hb}
     roofline["physical"] = physical_roofs(pmc, k_ms, n_local / n_total)
-    if model == "triplane" and args.bake_color:
-        # level 3 trades 69 % of level 2's matrix flops for 64-channel gathers and FMA interpolation: the MFMA fraction falls by construction;
-        # what binds the launch is the SIMD's fp32 datapath, which matrix and vector instructions share (physical.simd_busy)
-        roofline["binding"] = "simd fp32 datapath: MFMA + VALU busy (physical.simd_busy); the MFMA fraction is 1/3 of level 2's by construction"
+    ph = roofline["physical"]
+    if ph is not None and ph.get("simd_busy") is not None and mfma_flops is not None:
+        # What binds these launches is the SIMD's fp32 datapath: on gfx950 a SIMD executes its MFMA and its VALU instructions one after the
+        # other (profiles/r02_micro_mfma_valu_overlap.txt), so `bound` names that roof and `frac` is its measured busy fraction (MFMA busy + VALU
+        # busy without the MFMA issue cycles; counters of the committed PMC run of this workload, `physical.pmc_stale` when the library differs).
+        # The executed-MFMA fraction (matrix flops against the 157.3 TFLOP/s peak) stays next to it as mfma_frac.
+        roofline.update({"bound": "simd", "mfma_frac": roofline["frac"], "mfma_TFLOPs": roofline["achieved"],
+                         "frac": ph["simd_busy"], "achieved": ph["simd_busy"] * MFMA_F32_PEAK_TF, "unit": "TFLOP/s-equivalent of fp32 SIMD slots"})
+        roofline["binding"] = "simd fp32 datapath (MFMA + VALU share it): frac = MFMA busy + VALU busy - MFMA issue, from rocprofv3 --pmc"
+        if model == "triplane" and args.bake_color and pmc.get("valu_insts_per_launch"):
+            mfma_cyc = mfma_flops / 64.0                                   # 64 fp32 flops per SIMD cycle
+            issued = (pmc["valu_insts_per_launch"] - pmc.get("mfma_flops_per_dispatch", 0.0) / 2048.0) * n_local / n_total
+            need = (st[0] / 64.0) * NECESSARY_VALU["march_iteration"] + st[2] * NECESSARY_VALU["shade_pass"] + n_tiles * NECESSARY_VALU["per_tile"]
+            roofline["useful_op_frac"] = (4.0 * need + mfma_cyc) / (4.0 * issued + mfma_cyc)
+            roofline["valu_insts_issued"] = issued
+            roofline["valu_insts_necessary"] = need
     roofline.update({"kernel": "ngf::render_kernel", "kernel_ms": k_ms, "active_samples_per_ray": s_active,
                      "evaluated_samples_per_ray": st[0] / n_local,      # in-box samples the march evaluated (exact early termination skips the rest)
                       "mlp_passes": st[2], "algorithmic_d3": alg})
@@ -545,6 +571,58 @@ def main():
                     fx.release()
                 except Exception as ex:  # an extra must never take the headline number down with it
                     extras[f"{mdl}_{preset}"] = {"error": repr(ex)}
+            # The reference's own evaluation shape: renderer(rays, field, chunk=4096, N_samples=-1) = 884 steps (TriPlane/main.py:94,
+            # FieldBase.py:71-72) through an alpha mask like every trained model carries (FieldBase.py:261-267) -- `mask`: the one the repo's own
+            # updateAlphaMask((256,)*3) builds from the seeded field (main.py:330); `ball`: occupancy = a ball of radius 0.8, 15 % of the box (an
+            # object in empty space, as a trained lego is).  Module default level, whole frame in one launch.
+            from ngf_amd.fieldbase import renderer as _renderer
+            for preset, shape in (("R1", "mask"), ("R2", "mask"), ("R1", "ball")):
+                key = f"triplane_{preset}_S884_{shape}"
+                try:
+                    fx, gx, _, _ = build_field("triplane", preset, device, True, True)
+                    if shape == "mask":
+                        fx.updateAlphaMask((256, 256, 256))
+                    else:
+                        from ngf_amd import triplane as _tp
+                        ax = torch.linspace(-1.5, 1.5, 128)
+                        zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+                        fx.alphaMask = _tp.AlphaGridMask(device, torch.tensor(np.asarray(gx["aabb"], np.float32)), ((xx ** 2 + yy ** 2 + zz ** 2) < 0.64).float().to(device))
+                        fx.invalidate()
+                    Sx = int(fx.nSamples)
+                    go = lambda: _renderer(rays, fx, chunk=4096, N_samples=-1, white_bg=True, device=device)
+                    kernel_ms(go, 3, device)
+                    ms = kernel_ms(go, 8, device)
+                    fx(rays, N_samples=-1, collect_stats=True, iteration=30001)
+                    sx = fx.last_stats.cpu().numpy().astype(np.float64)
+                    fl = sx[2] * 64 * 2048.0 + plan_tiles(n_total, 8, torch.cuda.get_device_properties(device).multi_processor_count * 12) * 16 * 2048.0
+                    extras[key] = {"Mray/s": n_total / ms / 1e3, "kernel_ms": ms, "samples_per_ray": Sx, "mask_occupancy": float(fx.alphaMask.alpha_volume.mean()),
+                                   "evaluated_samples_per_ray": sx[0] / n_total, "active_samples_per_ray": sx[1] / n_total,
+                                   "executed_mfma_TFLOPs": fl / (ms * 1e-3) / 1e12, "mfma_frac_of_157.3": fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                                   "physical": physical_roofs(load_pmc(f"triplane_{preset}_bdc_S884{shape}"), ms)}
+                    fx.release()
+                except Exception as ex:
+                    extras[key] = {"error": repr(ex)}
+            # What a parameter change costs before the next render: ngf_field_create = texture packing, the pre-compositions of
+            # the level (fp64 folds), the MLP image; timed from invalidate() to the handle being ready, median of 5 (the render itself excluded).
+            try:
+                hb = {}
+                for label, mdl, flags in (("triplane_level0", "triplane", {"no_fold": True}), ("triplane_level1", "triplane", {}),
+                                          ("triplane_level2", "triplane", {"bake": True}), ("triplane_level3", "triplane", {"bake": True, "bake_color": True}),
+                                          ("infoinv", "infoinv", {}), ("infoinv_split_bf16", "infoinv", {"split_bf16": True})):
+                    fx, _, _, _ = build_field(mdl, "R1", device, **flags)
+                    ts = []
+                    for _ in range(5):
+                        fx.invalidate()
+                        torch.cuda.synchronize(device)
+                        t0 = time.perf_counter()
+                        fx.handle()
+                        torch.cuda.synchronize(device)
+                        ts.append((time.perf_counter() - t0) * 1e3)
+                    hb[label] = float(np.median(ts))
+                    fx.release()
+                extras["handle_build_ms"] = hb
+            except Exception as ex:
+                extras["handle_build_ms"] = {"error": repr(ex)}
             try:    # BASELINE config 4: UV-Mapping (NeuTex) colour path, DTU camera 0 (800x600), 64 samples/ray, sphere gauge
                 from ngf_amd import rays as nrays
                 from ngf_amd import uvmapping
@@ -559,6 +637,18 @@ def main():
                     net.load_params(up)
                     for _ in range(2):          # two warm calls (the first packs the weights), then the median of five launches of 40-70 ms
                         net(cam_t, dirs_t, None, jitter_u=Uj)
+                    try:                        # the UV handle's (re)build: ngf_uv_create = 29 layers packed / split
+                        tb = []
+                        for _ in range(3):
+                            net.load_params(up)
+                            torch.cuda.synchronize(device)
+                            t0 = time.perf_counter()
+                            net.handle()
+                            torch.cuda.synchronize(device)
+                            tb.append((time.perf_counter() - t0) * 1e3)
+                        extras.setdefault("handle_build_ms", {})["uvmapping" + ("_split_bf16" if split else "")] = float(np.median(tb))
+                    except Exception as ex:
+                        extras.setdefault("handle_build_ms", {})["uvmapping_error"] = repr(ex)
                     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
                     for ea, eb in ev:
                         ea.record(); net(cam_t, dirs_t, None, jitter_u=Uj); eb.record()
@@ -607,6 +697,9 @@ def main():
                 pick = (synth.hash_uniform(9, 1, (4096,)) * np.float32(rays_np.shape[0])).astype(np.int64)
                 tr_rays = torch.from_numpy(rays_np[pick]).to(device)
                 tr_rgb = torch.from_numpy(synth.hash_uniform(9, 2, (4096, 3))).to(device)
+                # the Trainer's default (fail-safe: the active count is read on the host, one synchronisation per step; a longer list is cut into
+                # chunks) -- what the headline "ms_per_iteration" is --, then the same iterations with speculative=True (opt-in: no host round trip)
+                # on a field of its own, and the reference's loop as written on the differentiable forward + torch.optim.Adam
                 trn = ntrain.Trainer(ft, batch_size=4096, max_samples=Str)
                 for it in range(3):
                     trn.step(tr_rays, tr_rgb, it, N_samples=Str)
@@ -617,7 +710,47 @@ def main():
                 torch.cuda.synchronize(device)
                 it_ms = (time.perf_counter() - t0) / 10 * 1e3
                 tr_extra = {"ms_per_iteration": it_ms, "iterations_per_s": 1e3 / it_ms, "batch_rays": 4096, "samples_per_ray": Str,
-                            "active_samples": trn.last_active, "scratch_GiB": trn.scratch_bytes() / 2 ** 30}
+                            "active_samples": trn.last_active, "scratch_GiB": trn.scratch_bytes() / 2 ** 30,
+                            "mode": "Trainer default: activation rows for a third of the pairs, active count read on the host (1 sync / step), nothing ever skipped"}
+                try:
+                    fs_, _, _, _ = build_field("triplane", args.preset, device, True, False)
+                    trs = ntrain.Trainer(fs_, batch_size=4096, max_samples=Str, speculative=True)
+                    for it in range(3):
+                        trs.step(tr_rays, tr_rgb, it, N_samples=Str)
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    for it in range(10):
+                        trs.step(tr_rays, tr_rgb, 3 + it, N_samples=Str)
+                    torch.cuda.synchronize(device)
+                    tr_extra["speculative_rows_ms_per_iteration"] = (time.perf_counter() - t0) / 10 * 1e3
+                    tr_extra["speculative_rows_overflows"] = trs.overflows()[0]
+                    trs.release()
+                    fs_.release()
+                except Exception as ex:
+                    tr_extra["speculative_rows_ms_per_iteration"] = repr(ex)
+                try:    # TriPlane/main.py:272-299 unchanged on the drop-in field: differentiable forward, torch's MSE + density_L1, torch.optim.Adam
+                    fa_, _, _, _ = build_field("triplane", args.preset, device, True, False)
+                    opt_ = torch.optim.Adam(fa_.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+                    def ref_iter(it):
+                        out_ = fa_(tr_rays, is_train=True, white_bg=True, N_samples=Str, iteration=it)
+                        loss_ = torch.mean((out_["rgb_map"] - tr_rgb) ** 2)
+                        tot_ = loss_ + 8e-5 * fa_.density_L1()
+                        opt_.zero_grad()
+                        tot_.backward()
+                        opt_.step()
+                        return loss_
+                    for it in range(3):
+                        ref_iter(it)
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    for it in range(10):
+                        ref_iter(3 + it).item()                      # the reference reads the loss every iteration (main.py:297)
+                    torch.cuda.synchronize(device)
+                    tr_extra["reference_loop_on_autograd_path_ms_per_iteration"] = (time.perf_counter() - t0) / 10 * 1e3
+                    fa_._grad_engine.release()
+                    fa_.release()
+                except Exception as ex:
+                    tr_extra["reference_loop_on_autograd_path_ms_per_iteration"] = repr(ex)
                 # A/B of the trainer's streams (it forks onto two streams of its own after the colour backward: DESIGN.md section 8 N3): ten
                 # more iterations, alternately forked and with the whole step on the caller's stream -- the active count falls as the field
                 # trains, so the two are interleaved; every step is synchronised here, which the headline figure above is not

@@ -46,7 +46,9 @@ struct RenderArgs {
     float *dbg_sigma;      // [n,S] or NULL   (ngf_field_march)
     float *dbg_weight;     // [n,S] or NULL
     unsigned long long *stats;  // 4 counters or NULL
-    unsigned int *tile_counter; // queue heads, zeroed before the launch: [0] alone (one queue) or [0..7] (one queue per XCD, xcd_queues = 8)
+    unsigned int *tile_counter; // the launch's slot of queue heads, all zero when the launch starts: [0] alone (one queue) or [0..7] (one queue per XCD,
+                                // xcd_queues = 8); [8] counts the waves that found their queue empty -- the last of `queue_waves` zeroes the slot again
+                                // (queue_done), so no fill kernel runs in front of a render launch
     int64_t n;
     int32_t S, white_bg, mode, skip_rgb;
     int32_t tile_w;        // rays per wave tile of the launch's FIRST (widest) plan segment: 64 (unsplit kernel) or 32 .. 1
@@ -64,6 +66,7 @@ struct RenderArgs {
     int32_t waves_active;  // waves of a workgroup that take tiles (the others leave after the LDS image barrier): < WAVES for launches with fewer tiles than
                            // resident waves, so that the working waves are spread over all CUs and SIMDs
     uint32_t tiles;        // number of tiles of the launch
+    uint32_t queue_waves;  // waves of the launch that take tiles (workgroups x waves_active): what tile_counter[8] counts up to
     int32_t ablate;        // debug instantiations only (render_kernel<.., DBG = true>): 32 no early termination, 64 no empty-iteration skip -- both
                            // EXACT (A/B timing and the bit-identity tests).  Round 1-2's bits 1 / 2 / 4 / 16 (skip collect, skip layers 2-3, cached
                            // gathers, wave priority) produced wrong images and are gone; the trainer keeps its own bits (ngf_train.hpp)
@@ -104,6 +107,20 @@ __device__ __forceinline__ bool next_tile(const RenderArgs &A, int xcd, int lane
         if (t < hi - lo) { tile = lo + t; return true; }
     }
     return false;
+}
+
+// A wave that found the queue empty reports here; the last one of the launch zeroes the slot for the slot's next launch.  Every wave's queue
+// atomics have returned before its own report (it used their values), and the report is an agent-scope atomic on the same line: when the count
+// reaches queue_waves nobody will touch the heads again.  Replaces a hipMemsetAsync per launch (a 4 us fill kernel + its launch gap in front
+// of every render: 1 % of one rank's 80 000-ray shard, 4 % of a 4096-ray chunk).
+__device__ __forceinline__ void queue_done(unsigned int *slot, unsigned waves, int lane)
+{
+    if (lane != 0) return;
+    const unsigned done = __hip_atomic_fetch_add(slot + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done + 1u == waves) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) __hip_atomic_store(slot + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // A Tex of the kernel's RenderArgs (byte offset `off` inside it), re-read from the kernel-argument segment on the scalar memory pipe at

@@ -674,6 +674,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
         }
     }
     if (hipMalloc((void **)&f->counters, (size_t)kCounters * kQueueHeads * sizeof(unsigned)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(counters) failed"));
+    if (hipMemsetAsync(f->counters, 0, (size_t)kCounters * kQueueHeads * sizeof(unsigned), st) != hipSuccess) return bail(fail(NGF_E_HIP, "zeroing the queue heads failed"));
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "packing failed: %s", hipGetErrorString(hipGetLastError())));
     *out = f;
     return NGF_OK;
@@ -723,9 +724,9 @@ extern "C" int ngf_debug_tile_plan(int64_t n, int32_t wide, int64_t resident, in
 template <typename K>
 static int launch_render(K kernel, K kernel_split, K kernel_prod, const ngf_field *f, RenderArgs &A, int threads, size_t lds_bytes, hipStream_t st, int wide_tile)
 {
+    // the slot's queue heads are zero: ngf_field_create zeroed all slots, and the last wave of every launch zeroes its slot again (queue_done)
     const unsigned slot = f->next_counter.fetch_add(1) % kCounters;
     A.tile_counter = f->counters + (size_t)slot * kQueueHeads;
-    HIP_TRY(hipMemsetAsync(A.tile_counter, 0, kQueueHeads * sizeof(unsigned), st));
     if (int rc = poison_lds(st)) return rc;
     // Split march (render_kernel<P, true>): a tile holds tile_w rays and every ray is marched by 64 / tile_w lanes on
     // consecutive steps (bit-identical results).  Small tiles shorten the critical path of a tile and even out the
@@ -794,6 +795,7 @@ static int launch_render(K kernel, K kernel_split, K kernel_prod, const ngf_fiel
     if (grid < 1) grid = 1;
     const int64_t per_wg = (tiles + grid - 1) / grid;
     A.waves_active = per_wg < waves ? (int)per_wg : waves;
+    A.queue_waves = (uint32_t)(grid * A.waves_active);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds_bytes, st, A);
     HIP_TRY(hipGetLastError());
     return NGF_OK;
@@ -832,6 +834,7 @@ static int launch_pc(const ngf_field *f, RenderArgs &A, hipStream_t st)
     if (grid > f->num_cus) grid = f->num_cus;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3((NM + NS) * kWave), lds, st, A);
+    HIP_TRY(hipMemsetAsync(A.tile_counter, 0, kQueueHeads * sizeof(unsigned), st));      // this kernel does not zero its slot itself (render_kernel does: queue_done)
     HIP_TRY(hipGetLastError());
     return NGF_OK;
 }

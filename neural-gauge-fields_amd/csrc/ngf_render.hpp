@@ -316,6 +316,7 @@ struct TriPlaneNoFoldPolicy : TriPlanePolicy<false, false, 8, 1> {
         w = alpha * Tin;                                                                                                                            \
         const float wz = w * z;                                                                                                                     \
         float Pa = acc + w, Pd = dep + wz;                                                                                                          \
+        asm volatile("s_nop 0" : "+v"(Pa), "+v"(Pd));   /* with the s_nop 0 below: 2 wait states between the VALU writes above and the first DPP read, whichever hipcc emits last */ \
         _Pragma("unroll") for (int r = 1; r < K; ++r)                                                                                               \
             asm volatile("s_nop 0\n\tv_add_f32_dpp %0, %0, %2 row_shr:" NGF_STR(M) " row_mask:0xf bank_mask:0xf\n\t"                                \
                          "v_add_f32_dpp %1, %1, %3 row_shr:" NGF_STR(M) " row_mask:0xf bank_mask:0xf" : "+v"(Pa), "+v"(Pd) : "v"(w), "v"(wz));      \
@@ -730,6 +731,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         }
         if constexpr (DBG) st_rays += __popcll(__ballot(live && seg == 0));
     }
+    queue_done(A.tile_counter, A.queue_waves, lane);
 #ifdef NGF_EXP_TIMELINE
     if (!DBG && A.stats && lane == 0) {
         unsigned long long *row = A.stats + 16 + 8 * ((size_t)blockIdx.x * P::WAVES + wave);

@@ -20,6 +20,14 @@
 namespace ngf {
 
 #define NGF_UV_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// Wait states between a layer's last matrix instructions and the LDS stores that take their data from the accumulator registers (inline assembly:
+// hipcc's hazard recogniser does not see the pair).  16 + 4 = 20 states cover every matrix shape (gfx950: 8-pass 12, 16-pass 20).
+// profiles/isa_hazards.py --hand counts them on the shipped assembly (tests/test_isa_lint.py); -DNGF_EXP_UV_SHORT_NOPS is that lint's negative control.
+#ifdef NGF_EXP_UV_SHORT_NOPS
+#define NGF_UV_MFMA_LDS_NOPS "s_nop 1"
+#else
+#define NGF_UV_MFMA_LDS_NOPS "s_nop 15\n\ts_nop 3"
+#endif
 
 // EXPERIMENT builds (make expuv; profiles/exp_uv_sections.py): -DNGF_EXP_UV_SECTIONS accumulates a wave's cycles per code section (s_memtime at the
 // section boundaries, never inside the k loop) into UvArgs::stats[2 + i]; -DNGF_EXP_UV_SAMEW lets every 256 -> 256 layer read the weights of geometry
@@ -550,7 +558,7 @@ __device__ __forceinline__ void store_act(float *act, int lane, const f32x4 acc[
     if constexpr (ACT < 0) {
         static_assert(NS * kUvActSteps <= 256, "ds_write2st64 offsets are 8 bits");
         const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(act + lane);
-        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        asm volatile(NGF_UV_MFMA_LDS_NOPS ::: "memory");
         store_act_rows<NT, NS>(addr, acc);
     } else {
 #pragma unroll
@@ -695,10 +703,15 @@ __device__ __forceinline__ void store_pe(float *act, int t0, int KT, int lane, c
         // the samples of the split kernel (or in 8 samples of the fp32 kernel, depending on the build), deterministically, while each change alone
         // passed every test.  The cause below the source was not found; the kernel keeps the property rounds 1-3 had by
         // accident: no divergent control flow between the ray set-up and the compositing.
+#ifdef NGF_EXP_UV_LANE_LOOPS     // EXPERIMENT (tests/test_isa_lint.py, profiles/micro/uv_exec_agpr): round 4's first form, the lane-dependent trip count -- an EXEC-masked loop
+#pragma unroll 1
+        for (int g = kq; g < N; g += 4) {
+#else
 #pragma unroll 1
         for (int i = 0; i < (N + 3) / 4; ++i) {
             int g = kq + 4 * i;
             g = g < N ? g : g - 4;
+#endif
             const int dim = g / F, fr = g - dim * F;
             const float xd = dim == 0 ? x0 : (dim == 1 ? x1 : x2);
             float sn, cs;
@@ -743,7 +756,7 @@ __device__ __forceinline__ void kstep_last(const KStepA<16, NS> &k, f32x4 acc[NS
     kload_wg<16, NS>(w, t, g, lane, kn);
     // (the wait states in front of every group's stores as well: the MFMAs of group g normally stand between group g - 1's last write and its stores, but
     // they are pure values the instruction selector may emit elsewhere, and the hazard recogniser does not look into inline assembly)
-#define NGF_UV_STORE_GROUP(g) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); store_act_rows_next_bias_range<NS, 4 * (g), 4 * (g) + 4>(addr, acc, bias_lane);
+#define NGF_UV_STORE_GROUP(g) asm volatile(NGF_UV_MFMA_LDS_NOPS ::: "memory"); store_act_rows_next_bias_range<NS, 4 * (g), 4 * (g) + 4>(addr, acc, bias_lane);
     NGF_UV_LAST_GROUP(0) __builtin_amdgcn_sched_barrier(0);
     NGF_UV_LAST_GROUP(1) NGF_UV_STORE_GROUP(0) __builtin_amdgcn_sched_barrier(0);
     NGF_UV_LAST_GROUP(2) NGF_UV_STORE_GROUP(1) __builtin_amdgcn_sched_barrier(0);
@@ -863,7 +876,7 @@ __device__ __forceinline__ void hidden_run_deep(const float *w, const float *b, 
 #if defined(NGF_EXP_UV_STORE_AFTER_LOOP) || defined(NGF_EXP_UV_ACT_PER_GROUP)
         {
             const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) float *)(act + lane);
-            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+            asm volatile(NGF_UV_MFMA_LDS_NOPS ::: "memory");
             // (behind the run's last layer: the same bias again, unused)
             store_act_rows_next_bias<16, NS>(addr, x, b + (more ? l + 1 : l) * 256 + kq * 64);
         }

@@ -90,7 +90,14 @@ class PipelinedGather:
         reuses the receive buffer wait for the copy.  The caller synchronises with ``stream`` before it reads ``out`` (bench.py: the device-wide
         synchronise that ends the timed region)."""
         i = k % len(self.send)
+        if H % (self.world * block) != 0 or (H // (self.world * block)) * block * W * self.world != self.world * self.per:
+            raise ValueError(f"frame_in_image_order: {H} rows do not split into blocks of {block} rows dealt out to {self.world} ranks "
+                             f"({self.per} pixels per rank, width {W}): H must be a multiple of world x block and per = H W / world")
         if stream is not None and self.recv[i].is_cuda:
+            if out is None:
+                # tensors allocated inside the side-stream context would be handed to the caller's stream with no ordering and no record_stream
+                # (the caching allocator could reuse their memory while the copy still runs): the caller owns the output buffers (ADVICE r4)
+                raise ValueError("frame_in_image_order(stream=...) writes into caller-owned buffers: pass out=(rgb [H*W,3], depth [H*W])")
             with torch.cuda.stream(stream):
                 res = self.frame_in_image_order(k, H, W, block, out=out)
                 ev = torch.cuda.Event()

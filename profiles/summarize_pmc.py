@@ -123,6 +123,9 @@ if "GRBM_GUI_ACTIVE" in m and "valu_busy_frac" in out and "mfma_busy_frac" in ou
 if "SQ_VALU_MFMA_COEXEC_CYCLES" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
     out["mfma_valu_coexec_frac_of_mfma_busy"] = m["SQ_VALU_MFMA_COEXEC_CYCLES"] / max(m["SQ_VALU_MFMA_BUSY_CYCLES"], 1.0)
     print(f"VALU / MFMA co-execution = {100 * out['mfma_valu_coexec_frac_of_mfma_busy']:.1f} % of the MFMA-busy cycles (SQ_VALU_MFMA_COEXEC_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES)")
+if "SQ_INSTS_VALU" in m:
+    out["valu_insts_per_launch"] = m["SQ_INSTS_VALU"]          # wave-level VALU instructions, MFMA included
+    print(f"VALU instructions / dispatch = {m['SQ_INSTS_VALU']:.4g} (wave level, MFMA included: {out.get('mfma_flops_per_dispatch', 0.0) / 2048.0:.4g} fp32 MFMA 16x16x4-equivalents)")
 if "SQ_INSTS_VMEM_RD" in m:
     out["vmem_read_insts_per_launch"] = m["SQ_INSTS_VMEM_RD"]
 so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neural-gauge-fields_amd", "csrc", "libngf_hip.so")

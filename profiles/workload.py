@@ -3,7 +3,9 @@
 
     python profiles/workload.py <name> [reps]
 names: triplane_R0 | triplane_R1 | triplane_R2 | triplane_R1_bd (bake density) | triplane_R1_bdc (both bakes) | triplane_R1_nofold | infoinv_R1
-       (800x800 frame, S = 192, BASELINE configs 2 / 3) | uv_sphere (BASELINE config 4: 76 800 DTU-camera rays x 64 samples)
+       (800x800 frame, S = 192, BASELINE configs 2 / 3) | <any triplane name>_S884mask: the reference's own evaluation shape -- renderer(..., N_samples=-1)
+       = 884 steps (TriPlane/main.py:94, FieldBase.py:71-72) through the alpha mask updateAlphaMask((256,)*3) builds from the field (main.py:330) --
+       | ..._S884ball: the same steps, occupancy = a ball of radius 0.8 (15 % of the box: an object, like a trained lego) | uv_sphere (BASELINE config 4: 76 800 DTU-camera rays x 64 samples)
        | train_R1 (4096-ray training iteration)
 Optional knobs through the environment of THIS script (mapped to ngf_debug_set): NGF_KERNEL, NGF_TILE_W, NGF_STAGE, ..."""
 import os
@@ -42,12 +44,26 @@ if name.startswith(("triplane", "infoinv")):
                              bake_color=model == "triplane" and plain and "c" in bake, no_fold=nofold, split_bf16=split)
     rays = nrays.generate_rays(800, 800, nrays.blender_focal(800), synth.lookat_pose())
     kw = {"iteration": 30001} if model == "triplane" else {"infoinv": True}
-    run = lambda: f(rays, N_samples=192, white_bg=True, **kw)
-    run(); run()
-    ms = timed(run, reps)
-    f(rays, N_samples=192, white_bg=True, collect_stats=True, **kw)
+    shape = parts[3] if len(parts) > 3 else ""
+    NS = 192
+    if shape.startswith("S884"):
+        NS = -1                                                   # the model's own nSamples (884 for the 256^3 grid at step_ratio 0.5)
+        if shape == "S884mask":
+            f.updateAlphaMask((256, 256, 256))
+        else:
+            from ngf_amd import triplane
+            ax = torch.linspace(-1.5, 1.5, 128)
+            zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+            f.alphaMask = triplane.AlphaGridMask(dev, torch.tensor(np.asarray(g["aabb"], np.float32)), ((xx ** 2 + yy ** 2 + zz ** 2) < 0.8 ** 2).float().to(dev))
+            f.invalidate()
+    run = lambda: f(rays, N_samples=NS, white_bg=True, **kw)
+    with torch.no_grad():
+        run(); run()
+        ms = timed(run, reps)
+        f(rays, N_samples=NS, white_bg=True, collect_stats=True, **kw)
     st = f.last_stats.cpu().numpy().astype(np.float64)
-    print(f"{name}: {ms:.3f} ms/frame = {640000 / ms / 1e3:.2f} Mray/s; evaluated {st[0] / 640000:.1f} active {st[1] / 640000:.2f} samples/ray, {st[2]:.0f} passes")
+    occ = "" if f.alphaMask is None else f", mask occupancy {float(f.alphaMask.alpha_volume.mean()):.3f}"
+    print(f"{name}: {ms:.3f} ms/frame = {640000 / ms / 1e3:.2f} Mray/s; S={NS if NS > 0 else f.nSamples}{occ}; evaluated {st[0] / 640000:.1f} active {st[1] / 640000:.2f} samples/ray, {st[2]:.0f} passes")
 elif name in ("uv_sphere", "uv_sphere_split"):
     from ngf_amd import uvmapping
     net = uvmapping.NeuTex(primitive_type="sphere", sample_num=64, device=dev, split_bf16=name.endswith("split"))

@@ -22,7 +22,8 @@ def asm(tmp_path_factory):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not found")
     jobs = {}
-    for tag, src, defs in (("field", "ngf_field.hip", []), ("uv", "ngf_uv.hip", []), ("field_packed", "ngf_field.hip", ["-DNGF_EXP_PACKED_PE=1"])):
+    for tag, src, defs in (("field", "ngf_field.hip", []), ("uv", "ngf_uv.hip", []), ("field_packed", "ngf_field.hip", ["-DNGF_EXP_PACKED_PE=1"]),
+                           ("uv_short_nops", "ngf_uv.hip", ["-DNGF_EXP_UV_SHORT_NOPS=1"])):
         d = tmp_path_factory.mktemp(tag)
         jobs[tag] = (d, src, subprocess.Popen([hipcc] + FLAGS + defs + [os.path.join(CSRC, src), "-o", "out.o"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     out = {}
@@ -153,3 +154,55 @@ def test_infoinv_density_pass_keeps_its_matrix_instructions_in_runs(asm):
             assert runs <= 2, (name, runs, kinds.count("M"))
             checked += kinds.count("M")
     assert checked == 104, checked          # 3 planes x 24 + 32
+
+
+# ---- hand-placed wait states (round 5) ------------------------------------------------------------------------------
+def test_matrix_results_stored_to_lds_from_agprs_wait_long_enough(asm):
+    """csrc/ngf_uv.hpp stores a layer's rows with `ds_write2st64_b32 v, a, a` written in inline assembly (LDS stores take AGPR data operands;
+    from C++ hipcc copies every accumulator to a VGPR first) -- a matrix-write -> memory-read hazard hipcc's recogniser does not see.  The
+    shipped assembly must keep every such store >= 12 (16x16 shapes) / 20 (32x32) wait states behind the matrix instruction that writes its
+    data register; the -DNGF_EXP_UV_SHORT_NOPS build (the hand-counted `s_nop 15; s_nop 3` cut to `s_nop 1`) must be flagged."""
+    import isa_hazards
+    bad, checked = isa_hazards.lint_mfma_to_lds(asm["uv"], "uv_render_kernel")
+    assert checked >= 900, checked                      # 744 + 248 stores in the two fp32 kernels
+    assert not bad, bad[:5]
+    bad_short, checked_short = isa_hazards.lint_mfma_to_lds(asm["uv_short_nops"], "uv_render_kernel")
+    assert checked_short == checked and bad_short, "the lint does not see the shortened wait states"
+    # no other translation unit stores from AGPRs by hand
+    assert isa_hazards.lint_mfma_to_lds(asm["field"])[1] == 0
+
+
+def test_dpp_reads_keep_two_wait_states_behind_valu_writes(asm):
+    """The transmittance / acc / depth chains of the split march are in-place DPP instructions in inline assembly (csrc/ngf_render.hpp
+    split_chain, split_chain_rows; the trainer's scan): a VALU write of a VGPR followed by a DPP read of it needs 2 wait states.  Held on the
+    shipped assembly -- and shown to bite on a synthetic kernel."""
+    import isa_hazards
+    bad, checked = isa_hazards.lint_valu_to_dpp(asm["field"])
+    assert checked > 5000, checked
+    assert not bad, bad[:5]
+    import tempfile
+    snippet = "_Zfake:\n\tv_add_f32_e32 v1, v2, v3\n\ts_nop 0\n\tv_add_f32_dpp v4, v1, v1 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_endpgm\n"
+    ok = snippet.replace("s_nop 0", "s_nop 1")
+    with tempfile.TemporaryDirectory() as d:
+        for text, want in ((snippet, 1), (ok, 0)):
+            path = os.path.join(d, "k.s")
+            open(path, "w").write(text)
+            got, n = isa_hazards.lint_valu_to_dpp(path)
+            assert n == 1 and len(got) == want, (text, got)
+
+
+def test_uv_kernels_hold_no_agpr_copy_inside_exec_narrowed_regions(asm):
+    """the one intermediate build of uv_render_kernel with wrong densities differed from its working neighbours in AGPR spill
+    copies (v_accvgpr_write_b32) inside EXEC-narrowed regions; the cause below the source is not established, the shipped kernels are kept free of the
+    pattern (no divergent control flow between ray set-up and compositing).  The lint's region tracking is checked on a synthetic kernel."""
+    import isa_hazards
+    bad, seen = isa_hazards.lint_accvgpr_write_in_exec_regions(asm["uv"], "uv_render_kernel")
+    assert not bad, bad[:5]
+    import tempfile
+    text = ("_Zfake:\n\tv_accvgpr_write_b32 a0, v1\n\ts_and_saveexec_b64 s[0:1], vcc\n\tv_accvgpr_write_b32 a1, v2\n\ts_or_b64 exec, exec, s[0:1]\n"
+            "\tv_accvgpr_write_b32 a2, v3\n\ts_endpgm\n")
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "k.s")
+        open(path, "w").write(text)
+        got, n = isa_hazards.lint_accvgpr_write_in_exec_regions(path)
+        assert n == 3 and len(got) == 1 and "a1" in got[0][2], got
