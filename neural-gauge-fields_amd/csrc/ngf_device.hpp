@@ -47,7 +47,7 @@ struct RenderArgs {
     float *dbg_weight;     // [n,S] or NULL
     unsigned long long *stats;  // 4 counters or NULL
     unsigned int *tile_counter; // the launch's slot of queue heads, all zero when the launch starts: [0] alone (one queue) or [0..7] (one queue per XCD,
-                                // xcd_queues = 8); [8] counts the waves that found their queue empty -- the last of `queue_waves` zeroes the slot again
+                                // xcd_queues = 8); [8] counts the workgroups whose waves all found their queue empty -- the last of `queue_waves` zeroes the slot again
                                 // (queue_done), so no fill kernel runs in front of a render launch
     int64_t n;
     int32_t S, white_bg, mode, skip_rgb;
@@ -66,7 +66,7 @@ struct RenderArgs {
     int32_t waves_active;  // waves of a workgroup that take tiles (the others leave after the LDS image barrier): < WAVES for launches with fewer tiles than
                            // resident waves, so that the working waves are spread over all CUs and SIMDs
     uint32_t tiles;        // number of tiles of the launch
-    uint32_t queue_waves;  // waves of the launch that take tiles (workgroups x waves_active): what tile_counter[8] counts up to
+    uint32_t queue_waves;  // workgroups of the launch (each reports once, when its last working wave found the queue empty): what tile_counter[8] counts up to
     int32_t ablate;        // debug instantiations only (render_kernel<.., DBG = true>): 32 no early termination, 64 no empty-iteration skip -- both
                            // EXACT (A/B timing and the bit-identity tests).  Round 1-2's bits 1 / 2 / 4 / 16 (skip collect, skip layers 2-3, cached
                            // gathers, wave priority) produced wrong images and are gone; the trainer keeps its own bits (ngf_train.hpp)
@@ -109,15 +109,18 @@ __device__ __forceinline__ bool next_tile(const RenderArgs &A, int xcd, int lane
     return false;
 }
 
-// A wave that found the queue empty reports here; the last one of the launch zeroes the slot for the slot's next launch.  Every wave's queue
-// atomics have returned before its own report (it used their values), and the report is an agent-scope atomic on the same line: when the count
-// reaches queue_waves nobody will touch the heads again.  Replaces a hipMemsetAsync per launch (a 4 us fill kernel + its launch gap in front
-// of every render: 1 % of one rank's 80 000-ray shard, 4 % of a 4096-ray chunk).
-__device__ __forceinline__ void queue_done(unsigned int *slot, unsigned waves, int lane)
+// A wave that found the queue empty reports to its workgroup's LDS counter; the workgroup's last wave reports to the launch's slot, and the last
+// WORKGROUP zeroes the slot for the slot's next launch.  Every wave's queue atomics have returned before its own report (it used their values), so
+// when the count reaches queue_waves / waves_active nobody will touch the heads again.  Replaces a hipMemsetAsync per launch (a 4 us fill kernel +
+// its launch gap in front of every render).  One global atomic per WORKGROUP: a first version had every wave report to the slot -- 3072 returning
+// atomics on one address at the moment the launch ends, +30 us on every launch (profiles/r05_shard_latency.txt, first block).
+__device__ __forceinline__ void queue_done(unsigned int *slot, unsigned *wg_done, unsigned waves_in_wg, unsigned workgroups, int lane)
 {
     if (lane != 0) return;
+    const unsigned d = __hip_atomic_fetch_add(wg_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (d + 1u != waves_in_wg) return;
     const unsigned done = __hip_atomic_fetch_add(slot + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (done + 1u == waves) {
+    if (done + 1u == workgroups) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) __hip_atomic_store(slot + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -197,6 +200,9 @@ __device__ __forceinline__ Bil bil_setup(float u, float v, const Tex &t)
     float cx = MED3 ? __builtin_amdgcn_fmed3f(fx, -1.0f, t.fw) : fminf(fmaxf(fx, -1.0f), t.fw);
     float cy = MED3 ? __builtin_amdgcn_fmed3f(fy, -1.0f, t.fh) : fminf(fmaxf(fy, -1.0f), t.fh);
     bool in = (cx == fx) & (cy == fy);
+#ifdef NGF_EXP_NOMASK       // TIMING EXPERIMENT (wrong pixels at the plane borders): what the in-range compares and selects cost
+    in = true;
+#endif
     Bil b;
     b.wx1 = wx1; b.wy1 = wy1; b.in = in ? 1 : 0;
     wx0 = in ? wx0 : 0.0f;
@@ -238,6 +244,55 @@ __device__ __forceinline__ Bil bil_from_rec(int32_t idx, float wx1, float wy1, b
     b.w10 = wx1 * wy0;
     b.w01 = wx0 * wy1;
     b.w11 = wx1 * wy1;
+    return b;
+}
+
+// ---- packed fp32 (v_pk_*_f32: two IEEE operations per lane and instruction, the same roundings as the scalar forms) ------------------------------
+// Written as inline assembly: from `__builtin_elementwise_fma` on splatted weights hipcc builds the weight pairs it wants THROUGH SCRATCH (a 20-byte
+// stack array per stage, 48 B per lane measured), and whether two scalars share an aligned register pair is the allocator's business otherwise.
+// op_sel picks the source half for the LOW result, op_sel_hi for the HIGH result (default: low / high): a weight is broadcast to both halves by
+// naming one half of its pair twice.  No packed result of these helpers feeds a bf16 matrix instruction (tests/test_isa_lint.py's fence).
+__device__ __forceinline__ f32x2 pk_fma_wlo(f32x2 w, f32x2 t, f32x2 acc)          // acc + w.lo * t
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(w), "v"(t));
+    return acc;
+}
+__device__ __forceinline__ f32x2 pk_fma_whi(f32x2 w, f32x2 t, f32x2 acc)          // acc + w.hi * t
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc) : "v"(w), "v"(t));
+    return acc;
+}
+__device__ __forceinline__ f32x2 pk_mul_wlo(f32x2 w, f32x2 t)                      // w.lo * t
+{
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_mul_whi(f32x2 w, f32x2 t)                      // w.hi * t
+{
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(w), "v"(t));
+    return r;
+}
+
+// The four tap weights of a queued sample's cell as two register pairs, wa = {w00, w10}, wb = {w01, w11}: the operations of bil_from_rec (its
+// products, hence its bits), the products two at a time.
+struct BilPk {
+    int32_t idx;
+    f32x2 wa, wb;
+};
+__device__ __forceinline__ BilPk bil_from_rec_pk(int32_t idx, float wx1, float wy1, bool in)
+{
+    BilPk b;
+    b.idx = idx;
+#ifdef NGF_EXP_NOMASK
+    in = true;
+#endif
+    float wx0 = 1.0f - wx1;
+    float wy0 = 1.0f - wy1;
+    const f32x2 X = {in ? wx0 : 0.0f, in ? wx1 : 0.0f}, Y = {in ? wy0 : 0.0f, in ? wy1 : 0.0f};
+    b.wa = pk_mul_wlo(Y, X);          // {wx0 wy0, wx1 wy0}
+    b.wb = pk_mul_whi(Y, X);          // {wx0 wy1, wx1 wy1}
     return b;
 }
 

@@ -687,6 +687,28 @@ static constexpr int kTailDefault16 = 16;
 static int make_tile_plan(int64_t n, int wide, int64_t resident, int tail16, int64_t seg_rays[4], int seg_shift[4])
 {
     auto shift_of = [](int w) { int sft = 0; while ((1 << sft) < w) ++sft; return sft; };
+    // A launch that fits the persistent grid with ONE tile per wave (n <= resident x wide): the narrowest pair of widths (w, w / 2) that does it, as
+    // many w / 2-ray tiles as the wave count allows -- the launch then lasts one w-ray tile.  (Round 5.  The tail rule below gave a 4096-ray chunk on
+    // 3072 waves 512 two-ray and 3072 one-ray tiles: 512 waves took a second tile behind their first, 0.114 ms; 1024 two-ray + 2048 one-ray tiles are
+    // one tile per wave, profiles/r05_shard_latency.txt.)  Knob tail = 0 keeps its meaning: wide tiles only.
+    if (tail16 > 0 && resident > 0 && n > 0 && n <= resident * wide) {
+        int w = 1;
+        while ((int64_t)w * resident < n) w <<= 1;                  // smallest width whose tiles cover n rays with <= resident tiles
+        if (w == 1) { seg_rays[0] = n; seg_shift[0] = 0; return 1; }
+        const int a = w >> 1;
+        auto allowed = [&](int v) { return v == wide || v == 4 || v == 2 || v == 1; };      // the widths the kernels' tile plans are tested with
+        if (allowed(w) && allowed(a)) {
+        // x tiles of w rays first, then tiles of a rays: x + y <= resident, w x + a y >= n  ->  x = ceil((n - a resident) / a)
+        int64_t x = (n - (int64_t)a * resident + a - 1) / a;
+        if (x < 0) x = 0;
+        if (x * w > n) x = n / w;
+        const int64_t rw = x * w, ra = n - rw;
+        int nseg = 0;
+        if (rw > 0) { seg_rays[nseg] = rw; seg_shift[nseg] = shift_of(w); ++nseg; }
+        if (ra > 0) { seg_rays[nseg] = ra; seg_shift[nseg] = shift_of(a); ++nseg; }
+        return nseg;
+        }
+    }
     const int widths[4] = {wide, 4, 2, 1};
     int64_t left = n, want[4] = {0, 0, 0, 0};
     for (int k = 3; k >= 1; --k) {      // the narrow segments are sized from the END of the ray list
@@ -795,7 +817,7 @@ static int launch_render(K kernel, K kernel_split, K kernel_prod, const ngf_fiel
     if (grid < 1) grid = 1;
     const int64_t per_wg = (tiles + grid - 1) / grid;
     A.waves_active = per_wg < waves ? (int)per_wg : waves;
-    A.queue_waves = (uint32_t)(grid * A.waves_active);
+    A.queue_waves = (uint32_t)grid;          // one report per workgroup (queue_done)
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds_bytes, st, A);
     HIP_TRY(hipGetLastError());
     return NGF_OK;

@@ -403,6 +403,8 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
     const unsigned long long tl_t0 = wall_clock64();
     unsigned long long tl_tiles = 0, tl_pass = 0, tl_iter = 0, tl_first = 0;
 #endif
+    __shared__ unsigned wg_done;          // working waves of this workgroup that found the tile queue empty (queue_done)
+    if (threadIdx.x == 0) wg_done = 0;
     stage_blob(smem, A.blob, A.blob_floats);
     __syncthreads();
 #ifdef NGF_EXP_TIMELINE
@@ -731,7 +733,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
         }
         if constexpr (DBG) st_rays += __popcll(__ballot(live && seg == 0));
     }
-    queue_done(A.tile_counter, A.queue_waves, lane);
+    queue_done(A.tile_counter, &wg_done, (unsigned)A.waves_active, A.queue_waves, lane);
 #ifdef NGF_EXP_TIMELINE
     if (!DBG && A.stats && lane == 0) {
         unsigned long long *row = A.stats + 16 + 8 * ((size_t)blockIdx.x * P::WAVES + wave);

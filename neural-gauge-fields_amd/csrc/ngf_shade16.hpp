@@ -101,10 +101,15 @@ __device__ __forceinline__ void mlp_tail16(const float *blob, int oW2, int oB2, 
 #pragma unroll
     for (int t = 0; t < 16; ++t) h[t] = relu1(acc[t >> 2][t & 3]);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef NGF_EXP_NO_LAYER2      // TIMING EXPERIMENT (wrong pixels): a sixteenth of layer 2's matrix instructions -- what the matrix pipe's share of the pass costs
+#pragma unroll
+    for (int t = 0; t < 16; ++t) c[t & 3] = NGF_MFMA16(w2[((t & 3) * 16 + t) * 64], h[t], c[t & 3]);
+#else
 #pragma unroll
     for (int t = 0; t < 16; ++t)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) c[mt] = NGF_MFMA16(w2[(mt * 16 + t) * 64], h[t], c[mt]);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #else
 #pragma unroll
@@ -397,6 +402,7 @@ __device__ __forceinline__ void mlp_pass16_nofold(const RenderArgs &A, const flo
 struct BakedHalf {                // half a plane: 4 taps x 2 float4 = accumulator tiles 2h, 2h+1
     f32x4 raw[4][2];
     Bil b;
+    f32x2 wa, wb;                 // {w00, w10}, {w01, w11} as register pairs (cells from a queue record: bil_from_rec_pk), else made from b
 };
 
 template <int ST>                 // stage = plane * 2 + half; cells: the sample's bilinear cells from a 12-float queue record (else from its coordinates)
@@ -404,32 +410,64 @@ __device__ __forceinline__ void baked16_issue(const RenderArgs &A, const float r
 {
     constexpr int P = ST >> 1, H = ST & 1;
     const Tex t = karg_tex(offsetof(RenderArgs, app) + P * sizeof(Tex));
-    if (cells) g.b = bil_from_rec(cells->idx[P], cells->wx1[P], cells->wy1[P], (cells->bits >> (8 + P)) & 1);
-    else g.b = bil_setup(rec[2 + 2 * P], rec[3 + 2 * P], t);
+    if (cells) {
+        const BilPk bp = bil_from_rec_pk(cells->idx[P], cells->wx1[P], cells->wy1[P], (cells->bits >> (8 + P)) & 1);
+        g.b.idx = bp.idx; g.wa = bp.wa; g.wb = bp.wb;
+    } else {
+        g.b = bil_setup(rec[2 + 2 * P], rec[3 + 2 * P], t);
+        g.wa = f32x2{g.b.w00, g.b.w10}; g.wb = f32x2{g.b.w01, g.b.w11};
+    }
     // channel 16*mt + 4*kq + r = hidden unit of accumulator (mt, r): natural order; 4 lanes read 64 contiguous bytes
     const f32x4 *t00 = tex_at<f32x4>(t.p, (uint32_t)g.b.idx * 64u + 4u * (kq + 8 * H));
     const f32x4 *t01 = tex_at<f32x4>(t.p, (uint32_t)(g.b.idx + t.stride) * 64u + 4u * (kq + 8 * H));
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         g.raw[0][q] = t00[4 * q];
+#ifdef NGF_EXP_L3_ONE_TAP      // TIMING EXPERIMENT (wrong pixels): a quarter of the colour-plane load instructions -- what the L1 / texture-addresser traffic of the gather costs
+        g.raw[1][q] = g.raw[0][q]; g.raw[2][q] = g.raw[0][q]; g.raw[3][q] = g.raw[0][q];
+        (void)t01;
+#else
         g.raw[1][q] = t00[16 + 4 * q];
         g.raw[2][q] = t01[4 * q];
         g.raw[3][q] = t01[16 + 4 * q];
+#endif
     }
 }
 
+// The interpolation: four FMAs onto the running sum per channel (bil_mix + add would be five; the sums are compared with the oracle at 1e-5, not bit
+// for bit).  -DNGF_PK_MIX (round 5, measured, NOT the default): the 16 channels of a lane as eight register pairs and one v_pk_fma_f32 per (tap, pair) --
+// the same fused multiply-add per element (bit-identical sums), 96 instead of 192 vector instructions per pass, 102 fewer in the pass's gather block
+// (274 -> 172) -- and the frame takes exactly as long: 4.345 ms either way (profiles/r05_level3_ablations.txt).  A wave64 v_fma_f32 costs the SIMD ~2.9
+// cycles, a v_pk_fma_f32 ~4.8 (profiles/r05_micro_valu_cost.txt), and beside other waves' MFMAs a packed instruction costs more than its two halves
+// (MI355X_MICROARCH.md); the pass is bound by its matrix instructions and its L1 traffic, not by its vector instruction count.
 template <int ST>
-__device__ __forceinline__ void baked16_consume(const BakedHalf &g, float sum[16])
+__device__ __forceinline__ void baked16_consume(const BakedHalf &g, f32x2 sum[8])
 {
     constexpr int H = ST & 1;
+#ifndef NGF_PK_MIX
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-        {       // four FMAs onto the running sum (bil_mix + add would be five; the sums are compared with the oracle at 1e-5, not bit for bit)
+        for (int e = 0; e < 4; ++e) {
             const int k = (2 * H + q) * 4 + e;
-            sum[k] = fmaf(g.b.w11, g.raw[3][q][e], fmaf(g.b.w01, g.raw[2][q][e], fmaf(g.b.w10, g.raw[1][q][e], fmaf(g.b.w00, g.raw[0][q][e], sum[k]))));
+            const float s0 = ST < 2 ? 0.0f : sum[k >> 1][k & 1];
+            sum[k >> 1][k & 1] = fmaf(g.wb[1], g.raw[3][q][e], fmaf(g.wb[0], g.raw[2][q][e], fmaf(g.wa[1], g.raw[1][q][e], fmaf(g.wa[0], g.raw[0][q][e], s0))));
         }
+#else
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const int k = ((2 * H + q) * 4 + e) >> 1;
+                const f32x2 t = {g.raw[tap][q][e], g.raw[tap][q][e + 1]};
+                if (tap == 0) sum[k] = ST < 2 ? pk_mul_wlo(g.wa, t) : pk_fma_wlo(g.wa, t, sum[k]);
+                else if (tap == 1) sum[k] = pk_fma_whi(g.wa, t, sum[k]);
+                else if (tap == 2) sum[k] = pk_fma_wlo(g.wb, t, sum[k]);
+                else sum[k] = pk_fma_whi(g.wb, t, sum[k]);
+            }
+#endif
 }
 
 // Two half-plane buffers (32 VGPRs each): stage s+1 is in flight while stage s is accumulated.  The interpolated
@@ -466,10 +504,7 @@ __device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const floa
     __builtin_amdgcn_sched_barrier(0);
     baked16_issue<1>(A, rg, kqg, gb, gcells);
     __builtin_amdgcn_sched_barrier(0);
-    float sum[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) sum[k] = 0.0f;
-    __builtin_amdgcn_sched_barrier(0);
+    f32x2 sum[8];
     baked16_consume<0>(ga, sum);
     __builtin_amdgcn_sched_barrier(0);
     baked16_issue<2>(A, rg, kqg, ga, gcells);
@@ -497,7 +532,7 @@ __device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const floa
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[mt][e] = b0[4 * mt + e] + __shfl(sum[4 * mt + e], src);
+        for (int e = 0; e < 4; ++e) acc[mt][e] = b0[4 * mt + e] + __shfl(sum[(4 * mt + e) >> 1][e & 1], src);
     if (!pre) {
         const float *w1 = blob + L::W1V + lane;
 #pragma unroll

@@ -578,7 +578,10 @@ def test_bench_default_line_is_parseable_with_extras():
     d, root = _run_bench(["--steps", "3", "--warmup", "1", "--cpu-seconds", "2"], {})
     assert d["value"] > 1 and d["ms_per_step"] > 0 and d["unit"] == "Mray/s" and d["dtype"] == "f32"
     rf = d["roofline"]
-    assert rf["bound"] in ("mfma", "hbm") and 0 < rf["frac"] <= 1.0 and rf["kernel_ms"] > 0
+    # round 5: `bound` names what binds -- the SIMD's fp32 datapath, which MFMA and VALU instructions share -- with its busy
+    # fraction from the committed PMC run; the executed-MFMA fraction and the useful-op fraction travel next to it
+    assert rf["bound"] == "simd" and 0 < rf["frac"] <= 1.0 and rf["kernel_ms"] > 0 and 0 < rf["mfma_frac"] < rf["frac"]
+    assert 0 < rf.get("useful_op_frac", 0.5) <= 1.0
     # the per-step launch times come from HIP events INSIDE the timed loop; roofline.kernel_ms is their median
     assert d["launch_ms"]["min"] <= d["ms_per_step_median"] <= d["launch_ms"]["max"] and rf["kernel_ms"] == pytest.approx(d["ms_per_step_median"], rel=1e-3)
     assert d["ms_per_step_median"] <= d["ms_per_step"] * 1.02           # the wall clock per step also holds the launch gaps
@@ -589,8 +592,10 @@ def test_bench_default_line_is_parseable_with_extras():
     side = json.load(open(os.path.join(root, d["extras_file"])))
     assert side["value"] == pytest.approx(d["value"], rel=1e-4)
     assert not [k for k, v in side["extras"].items() if "error" in v], side["extras"]
-    for k in ("triplane_R0", "triplane_R2", "infoinv_R1", "uvmapping_sphere", "train_step_R1", "eval_output_stage_800x800"):
+    for k in ("triplane_R0", "triplane_R2", "infoinv_R1", "uvmapping_sphere", "train_step_R1", "eval_output_stage_800x800", "triplane_R1_S884_mask",
+              "triplane_R2_S884_mask", "triplane_R1_S884_ball", "handle_build_ms"):
         assert k in side["extras"]
+    assert set(side["extras"]["handle_build_ms"]) >= {"triplane_level0", "triplane_level3", "infoinv", "uvmapping"} and "handle_build_ms" in d
     assert set(d["extras_Mray_s"]) <= set(side["extras"])
 
 

@@ -276,5 +276,11 @@ def test_tile_plan_covers_every_ray_once_with_whole_tiles():
     p = plan(640000, 8, 3072, -1)
     assert p[0][1] == 8 and p[0][0] >= 0.95 * 640000 and p[-1] == (3072, 1)
     assert plan(2000, 8, 3072, -1) == [(2000, 1)]
+    # round 5: a launch that fits the grid with one tile per wave takes the narrowest pair of widths that does it -- never a second tile behind the first
+    assert plan(4096, 8, 3072, -1) == [(2048, 2), (2048, 1)] and plan(3073, 8, 3072, -1) == [(2, 2), (3071, 1)]
+    assert plan(8000, 8, 3072, -1) == [(3712, 4), (4288, 2)] and plan(6144, 8, 3072, -1) == [(6144, 2)]
+    for n in (3072, 4096, 5000, 6144, 9000, 12288, 20000, 24576):
+        p = plan(n, 8, 3072, -1)
+        assert sum((r + w - 1) // w for r, w in p) <= 3072, (n, p)
     assert plan(640000, 8, 3072, 0) == [(640000, 8)]
     assert plan(80000, 8, 3072, 16) == [(58496, 8), (12288, 4), (6144, 2), (3072, 1)]
