@@ -537,6 +537,8 @@ def main():
                         ("triplane", args.preset, {"bake": True, "split_bf16": True}, "_level2_split_bf16", "_splitd"),   # colour MLP on bf16 MFMA, 3-term split operands
                         ("triplane", args.preset, {"split_bf16": True}, "_level1_split_bf16", "_split"),
                         ("triplane", "R2", {"bake": True, "split_bf16": True}, "_level2_split_bf16", "_splitd"),
+                        ("triplane", args.preset, {"bake": True, "bake_color": True, "split_bf16": True}, "_level3_split_bf16", "_bdcs"),      # round 5: level 3, layer 2 as split bf16 products
+                        ("triplane", "R2", {"bake": True, "bake_color": True, "split_bf16": True}, "_level3_split_bf16", "_bdcs"),
                         ("triplane", "R0", {}, "_level1_no_bake", ""),
                         ("triplane", "R2", {"bake": True}, "_level2", "_bd"),
                         ("infoinv", "R1", {}, "", ""),
@@ -555,7 +557,7 @@ def main():
                     if flags.get("split_bf16") and mdl == "infoinv":
                         entry["note"] = "rgb_decoder and density MLP as 3-term split bf16 products on v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16"
                     elif flags.get("split_bf16"):
-                        bf = sx[2] * 168 * 2 * 16 * 16 * 32                    # executed bf16 MFMA flops: 168 v_mfma_f32_16x16x32_bf16 per pass
+                        bf = sx[2] * (48 if flags.get("bake_color") else 168) * 2 * 16 * 16 * 32                    # executed bf16 MFMA flops: 168 (level 3: 48) v_mfma_f32_16x16x32_bf16 per pass
                         entry.update({"executed_bf16_mfma_TFLOPs": bf / (ms * 1e-3) / 1e12, "bf16_mfma_frac_of_2500": bf / (ms * 1e-3) / 1e12 / 2500.0})
                     else:
                         if mdl == "triplane":

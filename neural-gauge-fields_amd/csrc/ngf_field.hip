@@ -308,6 +308,31 @@ static void build_rgb_image_bf16(int F, const std::vector<float> &basis, const s
     img[L::B3 + 3] = 0.0f;
 }
 
+// NGF_F_BAKE_COLOR | NGF_F_SPLIT_BF16: the level-3 image (built by build_rgb_image16 with bake = true) with its fp32 layer-2 matrix replaced by the
+// bf16 A fragments of build_rgb_image_bf16's layer 2 (MlpLayout16BakedBf16: the view k-steps stay where they are, the fp32 tables move behind)
+static void rebuild_baked_image_bf16(const std::vector<float> &baked, const std::vector<float> &w2, float *img)
+{
+    using LS = MlpLayout16Baked;
+    using LD = MlpLayout16BakedBf16;
+    memcpy(img + LD::W1V, baked.data() + LS::W1V, sizeof(float) * 4 * 4 * 64);
+    memcpy(img + LD::B1, baked.data() + LS::B1, sizeof(float) * 64);
+    memcpy(img + LD::B2, baked.data() + LS::B2, sizeof(float) * 64);
+    memcpy(img + LD::W3, baked.data() + LS::W3, sizeof(float) * 192);
+    memcpy(img + LD::B3, baked.data() + LS::B3, sizeof(float) * 4);
+    auto hidden = [](int mt, int r, int kq) { return mt * 16 + 4 * kq + r; };
+    uint16_t *h16 = reinterpret_cast<uint16_t *>(img);
+    for (int mt = 0; mt < 4; ++mt)
+        for (int kb = 0; kb < 2; ++kb)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int kq = l >> 4, n = mt * 16 + (l & 15), j = kb * 8 + e;
+                    uint16_t p3[3];
+                    split3(w2[(size_t)n * 64 + hidden(j >> 2, j & 3, kq)], p3);
+                    for (int part = 0; part < 3; ++part)
+                        h16[((size_t)LD::W2 + ((((size_t)mt * 2 + kb) * 3 + part) * 64 + l) * 4) * 2 + e] = p3[part];
+                }
+}
+
 // NGF_F_SPLIT_BF16 for InfoInv (ngf_infoinv.hpp mlp_pass16_bf16_ii): A fragments as in build_rgb_image_bf16 -- lane (i, kq), element e of
 // k-block kb holds the weight of unit mt*16 + i for the lane quarter's (8 kb + e)-th input: 18 channels of each plane in the PACKED
 // channel order (infoinv_split_channel), its 4 view entries, 6 zero pads.  Layer 1: hi / mid parts in the LDS image
@@ -566,7 +591,9 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     const bool split_bf16 = tri && (d->flags & NGF_F_SPLIT_BF16);
     const bool split_ii = !tri && (d->flags & NGF_F_SPLIT_BF16);
     if (no_fold && (bake || bake_c)) return bail(fail(NGF_E_ARG, "NGF_F_NO_FOLD is the un-composed formulation: it excludes the NGF_F_BAKE_* flags"));
-    if (split_bf16 && (bake_c || no_fold)) return bail(fail(NGF_E_ARG, "NGF_F_SPLIT_BF16 applies to the pre-composed layer-1 formulation (no NGF_F_BAKE_COLOR / NGF_F_NO_FOLD)"));
+    if (split_bf16 && no_fold) return bail(fail(NGF_E_ARG, "NGF_F_SPLIT_BF16 applies to the pre-composed formulations (not with NGF_F_NO_FOLD)"));
+    if (split_bf16 && bake_c && !bake) return bail(fail(NGF_E_ARG, "NGF_F_BAKE_COLOR | NGF_F_SPLIT_BF16 (level 3 with layer 2 on the bf16 matrix pipe) is built on top of NGF_F_BAKE_DENSITY"));
+    const bool split_l3 = split_bf16 && bake_c;        // round 5: level 3, layer 2 as split bf16 products (layer 1 is folded into the planes there)
 
     // MLP weights: to the host once, pre-compose, permute, back to HBM as one LDS image
     std::vector<float> basis, w1, b1, w2, b2, w3, b3;
@@ -585,11 +612,15 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     }
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "hipStreamSynchronize failed in ngf_field_create"));
 
-    const int rgb_floats = tri ? (split_bf16 ? MlpLayoutBf16::TOTAL : no_fold ? MlpLayout16NoFold::TOTAL : (bake_c ? MlpLayout16Baked::TOTAL : MlpLayout16<48>::TOTAL)) : (split_ii ? MlpLayoutBf16II::TOTAL : MlpLayout16<72>::TOTAL);
+    const int rgb_floats = tri ? (split_l3 ? MlpLayout16BakedBf16::TOTAL : split_bf16 ? MlpLayoutBf16::TOTAL : no_fold ? MlpLayout16NoFold::TOTAL : (bake_c ? MlpLayout16Baked::TOTAL : MlpLayout16<48>::TOTAL)) : (split_ii ? MlpLayoutBf16II::TOTAL : MlpLayout16<72>::TOTAL);
     const int dens_floats = tri ? 0 : (split_ii ? InfoInvDensLayoutBf16::TOTAL : InfoInvDensLayout::TOTAL);
     std::vector<float> img((size_t)rgb_floats + dens_floats, 0.0f), wp;
     std::vector<float> bpack;
-    if (split_bf16) build_rgb_image_bf16(F, basis, w1, b1, w2, b2, w3, b3, img.data());
+    if (split_l3) {
+        std::vector<float> baked((size_t)MlpLayout16Baked::TOTAL, 0.0f);
+        build_rgb_image16(F, true, basis, w1, b1, w2, b2, w3, b3, baked.data(), wp);
+        rebuild_baked_image_bf16(baked, w2, img.data());
+    } else if (split_bf16) build_rgb_image_bf16(F, basis, w1, b1, w2, b2, w3, b3, img.data());
     else if (no_fold) build_rgb_image16_nofold(F, basis, w1, b1, w2, b2, w3, b3, img.data(), bpack);
     else if (tri) build_rgb_image16(F, bake_c, basis, w1, b1, w2, b2, w3, b3, img.data(), wp);
     else if (split_ii) build_rgb_image_bf16_ii(F, basis, w1, b1, w2, b2, w3, b3, img.data(), bpack);
@@ -935,6 +966,7 @@ static int render_common(const ngf_field *f, RenderArgs &A, hipStream_t st)
         return wide ? launch_policy<InfoInvWidePolicy>(f, A, st) : launch_policy<InfoInvPolicy>(f, A, st);
     }
     if (f->flags & NGF_F_NO_FOLD) return launch_policy<TriPlaneNoFoldPolicy>(f, A, st);
+    if ((f->flags & NGF_F_SPLIT_BF16) && (f->flags & NGF_F_BAKE_COLOR)) return launch_policy<TriPlaneBakedBf16Policy>(f, A, st);
     if (f->flags & NGF_F_SPLIT_BF16) {
         if (knob(KNOB_TILE_W) > 8 || knob(KNOB_SPLIT) == 0) return fail(NGF_E_ARG, "NGF_F_SPLIT_BF16 renders with split tiles of 4 or 8 rays");
         // 8 waves per CU: the pass keeps 48 registers of A fragments next to the gather buffer -- at the 168 registers that 12 waves
@@ -1000,6 +1032,7 @@ extern "C" int ngf_field_decode_rgb(const ngf_field *f, const float *coords, con
     int rc;
     if (f->model == NGF_MODEL_INFOINV) rc = (f->flags & NGF_F_SPLIT_BF16) ? go(decode_rgb_kernel<InfoInvSplitPolicy>) : go(decode_rgb_kernel<InfoInvPolicy>);
     else if (f->flags & NGF_F_NO_FOLD) rc = go(decode_rgb_kernel<TriPlaneNoFoldPolicy>);
+    else if ((f->flags & NGF_F_SPLIT_BF16) && (f->flags & NGF_F_BAKE_COLOR)) rc = go(decode_rgb_kernel<TriPlaneBakedBf16Policy>);
     else if (f->flags & NGF_F_SPLIT_BF16) rc = go(decode_rgb_kernel<TriPlaneBf16Policy<false, 8>>);
     else if (f->flags & NGF_F_BAKE_COLOR) rc = go(decode_rgb_kernel<TriPlanePolicy<false, true, 8, 1>>);
     else rc = go(decode_rgb_kernel<TriPlanePolicy<false, false, 8, 1>>);

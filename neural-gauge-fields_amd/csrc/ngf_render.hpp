@@ -274,6 +274,35 @@ struct TriPlaneBf16Policy : TriPlanePolicy<BAKE_D, false, WAVES_, 1> {
     }
 };
 
+// NGF_F_BAKE_DENSITY | NGF_F_BAKE_COLOR | NGF_F_SPLIT_BF16 (round 5, opt-in): level 3 with layer 2 on the bf16 matrix pipe (ngf_shade_bf16.hpp
+// mlp_pass16_baked_bf16); everything else -- march, queue records, tile plan, twelve waves per CU -- is the level-3 policy's.
+struct TriPlaneBakedBf16Policy : TriPlanePolicy<true, true, 12, 1> {
+    using LB = MlpLayout16BakedBf16;
+    __device__ static __forceinline__ void fold_view(const float *smem, const float *vfeat, float *pre, int n_rays, int lane)
+    {
+        view_fold16<LB::W1V / 64, LB::B1, 4>(per_pass16(smem), vfeat, pre, n_rays, lane);
+    }
+    __device__ static __forceinline__ void fold_view_regs(const float *smem, const f32x4 v, float *pre, int n_rays, int lane)
+    {
+        view_fold16_regs<LB::W1V / 64, LB::B1, 4>(per_pass16(smem), v, pre, n_rays, lane);
+    }
+    __device__ static __forceinline__ void shade(const RenderArgs &A, const float *smem, const float rec[kRecFloats], const float *vf,
+                                                 const float od[3], int lane, float c[3], unsigned long long * = nullptr, const float *pre = nullptr)
+    {
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (!pre) v = *reinterpret_cast<const f32x4 *>(vf + (lane >> 4) * 4);
+        mlp_pass16_baked_bf16(A, smem, rec, v, lane, c, pre);
+    }
+    __device__ static __forceinline__ void shade12(const RenderArgs &A, const float *smem, const RecCells &cells, const float *vf, int lane, float c[3],
+                                                   const float *pre)
+    {
+        const float rec[kRecFloats] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (!pre) v = *reinterpret_cast<const f32x4 *>(vf + (lane >> 4) * 4);
+        mlp_pass16_baked_bf16(A, smem, rec, v, lane, c, pre, &cells);
+    }
+};
+
 // NGF_F_NO_FOLD (level 0): un-composed rgb_decoder, view inputs per sample; 8 waves per CU (the basis stage keeps 36 more accumulators)
 struct TriPlaneNoFoldPolicy : TriPlanePolicy<false, false, 8, 1> {
     static constexpr bool PROD = false;

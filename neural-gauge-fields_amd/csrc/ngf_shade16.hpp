@@ -45,6 +45,19 @@ struct MlpLayout16Baked {                 // NGF_F_BAKE_COLOR: only the view-inp
     static constexpr int TOTAL = B3 + 4;
 };
 
+// NGF_F_BAKE_COLOR | NGF_F_SPLIT_BF16 (round 5, opt-in): level 3 with LAYER 2 on the bf16 matrix pipe as 3-term split products (ngf_shade_bf16.hpp
+// mlp_pass16_baked_bf16).  Same front part as MlpLayout16Baked (the view-input k-steps at offset 0), then W2 as bf16 A fragments
+// [4 mt][2 k-blocks][3 parts][64 lanes][8 bf16] (= 4 floats per fragment), then the fp32 tables.
+struct MlpLayout16BakedBf16 {
+    static constexpr int W1V = 0;                 // [4 mt][4][64 lanes] fp32
+    static constexpr int W2 = W1V + 4 * 4 * 64;   // bf16 fragments: 4 x 2 x 3 x 64 x 4 floats
+    static constexpr int B1 = W2 + 4 * 2 * 3 * 64 * 4;
+    static constexpr int B2 = B1 + 64;
+    static constexpr int W3 = B2 + 64;
+    static constexpr int B3 = W3 + 192;
+    static constexpr int TOTAL = B3 + 4;
+};
+
 __device__ __forceinline__ const float *per_pass16(const float *blob)
 {
     int z = 0;
@@ -482,11 +495,12 @@ __device__ __forceinline__ void baked16_consume(const BakedHalf &g, f32x2 sum[8]
 // sums reach their matrix lane through sixteen ds_bpermute_b32 (a lane permutation through the LDS crossbar: no LDS memory, no VALU slot).
 // gcells: the bilinear cells of the GATHER lane's sample (lane >> 2) from its 12-float queue record, or null: then its coordinates are
 // fetched from the record of matrix lane (lane >> 2, 0) with six lane permutations
-__device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v,
-                                                 int lane, float rgb[3], const float *pre = nullptr, const RecCells *gcells = nullptr)
+// The front part of the baked pass for the image layout L (MlpLayout16Baked / MlpLayout16BakedBf16): gathers, interpolation, the lane permutation
+// and the per-ray view fold (or bias + view-input MFMAs) -> acc = layer-1 pre-activations of the lane's sample, accumulator order.  blob: per_pass16'd.
+template <typename L>
+__device__ __forceinline__ void baked16_layer1(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v,
+                                               int lane, f32x4 acc[4], const float *pre, const RecCells *gcells)
 {
-    using L = MlpLayout16Baked;
-    blob = per_pass16(blob);
     const int kq = lane >> 4;
     // gather role: sample lane >> 2, channel quarter lane & 3
     const int sg = lane >> 2, kqg = lane & 3;
@@ -528,7 +542,6 @@ __device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const floa
     // gather lane 4 s + kq -> matrix lane kq * 16 + s, plus the per-ray view fold (or the bias) of the matrix lane's own sample
     const int src = 4 * (lane & 15) + kq;
     const float *b0 = pre ? pre + kq * 16 : blob + L::B1 + kq * 16;
-    f32x4 acc[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -540,6 +553,15 @@ __device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const floa
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc[mt] = NGF_MFMA16(w1[(mt * 4 + j) * 64], v[j], acc[mt]);
     }
+}
+
+__device__ __forceinline__ void mlp_pass16_baked(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v,
+                                                 int lane, float rgb[3], const float *pre = nullptr, const RecCells *gcells = nullptr)
+{
+    using L = MlpLayout16Baked;
+    blob = per_pass16(blob);
+    f32x4 acc[4];
+    baked16_layer1<L>(A, blob, rec, v, lane, acc, pre, gcells);
     mlp_tail16(blob, L::W2, L::B2, L::W3, L::B3, lane, acc, rgb);
 }
 

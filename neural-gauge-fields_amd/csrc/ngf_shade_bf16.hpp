@@ -183,6 +183,35 @@ __device__ __forceinline__ void mlp_pass16_bf16(const RenderArgs &A, const float
     mlp_layer3_16(blob, L::W3, L::B3, lane, c, rgb);
 }
 
+// ---- NGF_F_BAKE_COLOR | NGF_F_SPLIT_BF16 (round 5, opt-in): level 3 with layer 2 as six bf16 products per fp32 product -------------------------
+// What binds the level-3 frame is its 64 fp32 matrix instructions per pass (2048 matrix-pipe cycles) and its L1 traffic, not its vector
+// instructions (profiles/r05_level3_ablations.txt).  Layer 1 is folded into the planes at level 3, so layer 2 IS the matrix work:
+// here its 64 x 64 x 16 product runs as 48 v_mfma_f32_16x16x32_bf16 (~17 cycles each) on 3-term split operands -- the same technique, the same
+// weight-fragment image and the same order of the six products as mlp_pass16_bf16's layer 2; fp32-level error, other last bits than the fp32 path.
+__device__ __forceinline__ void mlp_pass16_baked_bf16(const RenderArgs &A, const float *blob, const float rec[kRecFloats], const f32x4 v, int lane,
+                                                      float rgb[3], const float *pre = nullptr, const RecCells *gcells = nullptr)
+{
+    using L = MlpLayout16BakedBf16;
+    blob = per_pass16(blob);
+    const int kq = lane >> 4;
+    f32x4 acc[4];
+    baked16_layer1<L>(A, blob, rec, v, lane, acc, pre, gcells);
+    constexpr int KB_STRIDE = 3 * 64 * 4, MT2 = 2 * KB_STRIDE;
+    const float *w2 = blob + L::W2 + lane * 4;
+    f32x4 c[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) c[mt] = *reinterpret_cast<const f32x4 *>(blob + L::B2 + kq * 16 + mt * 4);
+    {
+        float h[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) h[k] = relu1(acc[k >> 2][k & 3]);
+        kblock_bf16<MT2>(w2, split8(h), c);
+        kblock_bf16<MT2>(w2 + KB_STRIDE, split8(h + 8), c);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mlp_layer3_16(blob, L::W3, L::B3, lane, c, rgb);
+}
+
 // ---- the same pass in the register budget of 12 waves per CU (168) ------------------------------------------------------------------
 // mlp_pass16_bf16 keeps a plane's four taps (48 registers) and four tiles' fragments (48) in flight and needs ~240 registers with the
 // march state around it.  Here a cell's taps arrive in two ROWS of 24 registers -- the bilinear sum is accumulated in bil_mix's order

@@ -38,10 +38,10 @@ if name.startswith(("triplane", "infoinv")):
     parts = name.split("_")
     model, preset, bake = parts[0], parts[1], (parts[2] if len(parts) > 2 else "")
     g, params, step = cases.big_case(model, preset)
-    nofold, split = bake == "nofold", bake.startswith("split")          # "split" | "splitd" (with baked density)
+    nofold, split = bake == "nofold", bake.startswith("split") or bake == "bdcs"          # "split" | "splitd" (with baked density) | "bdcs" (level 3 + bf16 layer 2)
     plain = not (nofold or split)
-    f = cases.field_for_case(g, params, None, device=dev, bake=model == "triplane" and ((plain and "d" in bake) or bake == "splitd"),
-                             bake_color=model == "triplane" and plain and "c" in bake, no_fold=nofold, split_bf16=split)
+    f = cases.field_for_case(g, params, None, device=dev, bake=model == "triplane" and ((plain and "d" in bake) or bake in ("splitd", "bdcs")),
+                             bake_color=model == "triplane" and ((plain and "c" in bake) or bake == "bdcs"), no_fold=nofold, split_bf16=split)
     rays = nrays.generate_rays(800, 800, nrays.blender_focal(800), synth.lookat_pose())
     kw = {"iteration": 30001} if model == "triplane" else {"infoinv": True}
     shape = parts[3] if len(parts) > 3 else ""

@@ -28,6 +28,7 @@ LAUNCHES_BF16 = 50000
     ("triplane_r1_gauge", {"iteration": 30001}, {"split_bf16": True}),
     ("triplane_r1_mask", {"iteration": 30001}, {"bake": True, "split_bf16": True}),
     ("triplane_r1_mask", {"iteration": 30001}, {"bake": True, "bake_color": True}),
+    ("triplane_r1_gauge", {"iteration": 30001}, {"bake": True, "bake_color": True, "split_bf16": True}),        # round 5: level 3 with layer 2 on the bf16 pipe
 ])
 def test_render_repeats_bit_for_bit(name, kw, flags):
     g, params, step, mask = load_case(name)

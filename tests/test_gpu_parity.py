@@ -229,6 +229,57 @@ def test_infoinv_split_bf16_keeps_fp32_accuracy(name):
     np.testing.assert_allclose(fs.compute_alpha(pts, 0.3).cpu().numpy(), fd.compute_alpha(pts, 0.3).cpu().numpy(), rtol=2e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("name", ["triplane_r1_gauge", "triplane_r2_nogauge", "triplane_r1_mask", "triplane_r1_train_white"])
+def test_level3_with_layer2_on_the_bf16_pipe_keeps_fp32_accuracy(name):
+    """NGF_F_BAKE_DENSITY | NGF_F_BAKE_COLOR | NGF_F_SPLIT_BF16 (round 5, opt-in): level 3 with layer 2 -- all the matrix work level 3 has left --
+    as six bf16 products per fp32 product (csrc/ngf_shade_bf16.hpp mlp_pass16_baked_bf16).  Same tolerances against the oracle and the
+    reference's golden pixels as the fp32 path, within fp32 rounding noise of level 3 itself, the march untouched (depth bit-identical),
+    every launch shape the same bits."""
+    g, params, step, mask = load_case(name)
+    orc = oracle_for_case(g, params, step, mask)
+    fs = field_for_case(g, params, mask, bake=True, bake_color=True, split_bf16=True)
+    fd = field_for_case(g, params, mask, bake=True, bake_color=True)
+    rays = torch.from_numpy(g["rays"]).cuda()
+    S, white = int(g["S"]), bool(int(g["white_bg"]))
+    kw = _mode(g)
+    train_kw, jitter, eff_white = {}, None, white
+    if "is_train" in g:
+        jitter = g["jitter"]
+        eff_white = white or float(g["coin"]) < 0.5
+        train_kw = {"jitter": torch.from_numpy(jitter), "coin": float(g["coin"]), "is_train": True}
+    with torch.no_grad():
+        a = fs(rays, N_samples=S, white_bg=white, **kw, **train_kw)
+        b = fd(rays, N_samples=S, white_bg=white, **kw, **train_kw)
+    o_rgb, o_depth = orc.render(g["rays"], S, white_bg=eff_white, jitter=jitter)
+    ea = _close(a["rgb_map"].cpu().numpy(), o_rgb, "level 3 + bf16 layer 2: rgb vs oracle")
+    _close(a["rgb_map"].cpu().numpy(), g["rgb_map"], "level 3 + bf16 layer 2: rgb vs reference golden")
+    _close(a["depth_map"].cpu().numpy(), g["depth_map"], "level 3 + bf16 layer 2: depth vs reference golden", atol=5e-5)
+    assert ea < 5e-6
+    assert torch.equal(a["depth_map"], b["depth_map"])                                   # the march is the same code
+    assert float((a["rgb_map"] - b["rgb_map"]).abs().max()) < 2e-6
+    from ngf_amd._lib import knobs
+    if "is_train" not in g:
+        for n in (1, 7, 65):                                                             # ragged launches
+            c = fs(rays[:n], N_samples=S, white_bg=white, **kw)
+            assert torch.equal(c["rgb_map"], a["rgb_map"][:n])
+        for tw in (1, 2, 4, 8, 64):                                                      # every tile shape, the unsplit 64-ray tile included (view-input MFMAs instead of the per-ray fold)
+            with knobs(tile_w=tw):
+                c = fs(rays, N_samples=S, white_bg=white, **kw)
+            if tw <= 8:
+                assert torch.equal(c["rgb_map"], a["rgb_map"]) and torch.equal(c["depth_map"], a["depth_map"]), tw
+            else:
+                assert float((c["rgb_map"] - a["rgb_map"]).abs().max()) < 2e-6, tw
+    # the colour stage alone, per sample
+    from ngf_amd import synth
+    n = 203
+    coords = (synth.hash_uniform(78, 1, (n, 6)) * np.float32(2.2) - np.float32(1.1)).astype(np.float32)
+    dirs = synth.hash_normal(78, 2, (n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    got = fs.decode_rgb(torch.from_numpy(coords), torch.from_numpy(dirs), mode=1).cpu().numpy()
+    assert np.abs(got - orc.color_at(coords, dirs)).max() < 5e-6
+    fs.release(); fd.release()
+
+
 @pytest.mark.parametrize("bake_density", [False, True])
 @pytest.mark.parametrize("name", ["triplane_r1_gauge", "triplane_r2_nogauge", "triplane_r1_mask"])
 def test_split_bf16_colour_mlp_keeps_fp32_accuracy(name, bake_density):
