@@ -14,18 +14,21 @@ pytestmark = pytest.mark.gpu
 
 PIX_TOL = 2e-5          # composited pixels vs oracle / reference golden
 T_TOL = 1e-5            # transmittance
-SIGMA_RTOL = 5e-4       # per-sample density (relative)
-PCOL_TOL = 5e-3         # per-sample colour (absolute): the ill-conditioned quantity
+SIGMA_RTOL = 2e-5       # per-sample density (relative); measured 1.5e-6 ... 2.2e-6 in both kernels (round 5: was 5e-4)
+PCOL_TOL = 1e-3         # per-sample colour (absolute): the ill-conditioned quantity; measured 1.8e-4 (sphere) / 4.8e-5 (square) (round 5: was 5e-3)
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("name", ["uv_sphere", "uv_square"])
-def test_uv_matches_oracle_and_reference(name):
+def test_uv_matches_oracle_and_reference(name, split):
+    """Per-sample density AND composited pixels, fp32 kernel and NGF_UV_F_SPLIT_BF16 (round 5: both modes -- the one intermediate build of round 4 with
+    wrong densities, DESIGN.md section 6.7, was wrong in ONE of the two instantiations only; profiles/exp_uv_split_check.py is this check as a script)."""
     from ngf_amd import uvmapping
     g, params = load_uv_case(name)
     pt = str(g["primitive_type"])
     orc = OracleUV(params, pt)
     o_color, o_trans, dbg = orc.render(g["campos"], g["raydir"], g["U"], bg=g["bg"], debug=True)
-    m = uvmapping.NeuTex(primitive_type=pt, sample_num=int(g["S"]), device="cuda")
+    m = uvmapping.NeuTex(primitive_type=pt, sample_num=int(g["S"]), device="cuda", split_bf16=split)
     m.load_params(params)
     out = m(torch.from_numpy(g["campos"])[None], torch.from_numpy(g["raydir"])[None], torch.from_numpy(g["bg"])[None],
             jitter_u=torch.from_numpy(g["U"])[None], debug=True)
@@ -40,7 +43,7 @@ def test_uv_matches_oracle_and_reference(name):
     e_t = np.abs(trans - o_trans).max()
     e_c = np.abs(color - o_color).max()
     e_r = np.abs(color - g["color"]).max()
-    print(f"{name}: max|T-oracle| {e_t:.2e}  max|color-oracle| {e_c:.2e}  max|color-reference| {e_r:.2e}  per-sample: sigma rel {e_s:.2e} colour {e_p:.2e}")
+    print(f"{name} split={int(split)}: max|T-oracle| {e_t:.2e}  max|color-oracle| {e_c:.2e}  max|color-reference| {e_r:.2e}  per-sample: sigma rel {e_s:.2e} colour {e_p:.2e}")
     assert e_t < T_TOL and e_c < PIX_TOL and e_r < PIX_TOL
     # deterministic
     out2 = m(torch.from_numpy(g["campos"])[None], torch.from_numpy(g["raydir"])[None], torch.from_numpy(g["bg"])[None],
@@ -182,7 +185,7 @@ def test_uv_split_bf16_keeps_the_fp32_tolerances(name):
     np.testing.assert_allclose(sigma[valid], dbg["sigma"][valid], rtol=SIGMA_RTOL, atol=1e-6)
     assert np.abs(pcol[valid] - dbg["col"][valid]).max() < PCOL_TOL
     e = {s: (np.abs(res[s][1] - o_trans).max(), np.abs(res[s][0] - o_color).max(), np.abs(res[s][0] - g["color"]).max()) for s in (False, True)}
-    print(f"{name}: max|T-oracle| fp32 {e[False][0]:.2e} split {e[True][0]:.2e}; max|color-oracle| fp32 {e[False][1]:.2e} split {e[True][1]:.2e}; "
+    print(f"{name} split={int(split)}: max|T-oracle| fp32 {e[False][0]:.2e} split {e[True][0]:.2e}; max|color-oracle| fp32 {e[False][1]:.2e} split {e[True][1]:.2e}; "
           f"max|color-reference| fp32 {e[False][2]:.2e} split {e[True][2]:.2e}; max|color split - fp32| {np.abs(res[True][0] - res[False][0]).max():.2e}")
     assert e[True][0] < T_TOL and e[True][1] < PIX_TOL and e[True][2] < PIX_TOL
     assert e[True][1] < 3 * e[False][1] + 2e-5             # no worse than the fp32 kernel's own rounding noise (x3 slack)
