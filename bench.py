@@ -68,7 +68,7 @@ def load_pmc(tag):
 # itemised table is DESIGN.md section 4.11.  "Necessary" = the arithmetic the formulation (SURVEY.md Appendix A.1 with folds (i)-(iii)) prescribes
 # for one lane's sample / one lane's share of a pass, counted at one instruction per fp32 operation (an FMA where the reference's op order allows
 # one); addressing, masks, queue bookkeeping, lane permutations, selects of the collect loop are NOT in it.
-NECESSARY_VALU = {"march_iteration": 258, "shade_pass": 313, "per_tile": 92}
+NECESSARY_VALU = {"march_iteration": 258, "shade_pass": 321, "per_tile": 92}
 
 
 NOTES = {
@@ -81,6 +81,8 @@ NOTES = {
                             "11.63 ms; bf16: 4.44 + 3.07 -> 7.39), so their busy cycles add and this sum is the binding roof of the kernel.  "
                             "SQ_ACTIVE_INST_VALU also counts the issue cycles of the MFMA instructions (profiles/r02_counter_semantics.txt: 4 of "
                             "every 33 fp32 / 16 bf16 MFMA cycles); they are subtracted.",
+    "l1_tag_frac": "TCP_TOTAL_CACHE_ACCESSES of the committed PMC run / (256 CUs x the counters' effective clock x THIS run's kernel time): the L1 looks up one 64-byte "
+                   "piece per cycle and CU; with the SIMD roof the other resource that paces the level-3 frame (DESIGN.md section 4.11, profiles/r05_level3_ablations.txt)",
     "hbm_fabric": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE; includes Infinity-Cache hits",
     "algorithmic_d3": "model, not a bound (SURVEY 8 D3 accounting: every bilinear tap counted once, no cache credit; the 52 MB texture set is "
                       "L1/L2/Infinity-Cache resident, so this exceeds the HBM peak by construction)",
@@ -109,6 +111,9 @@ def physical_roofs(pmc, k_ms, share=1.0):
     if "l2_read_bytes_per_launch" in pmc:
         l2 = pmc["l2_read_bytes_per_launch"] * share / t / 1e12
         out.update({"l2_read_TBps": l2, "l2_frac": l2 / L2_PEAK_TBS, "l2_hit": pmc.get("l2_hit_frac"), "l1_hit": pmc.get("l1_hit_frac")})
+    if "tcp_accesses_per_launch" in pmc and pmc.get("effective_clock_ghz"):
+        # L1 (TCP) tag look-ups: one per cycle and CU, each serving a quad of lanes one 64-byte piece; 256 CUs
+        out["l1_tag_frac"] = pmc["tcp_accesses_per_launch"] * share / (256.0 * pmc["effective_clock_ghz"] * 1e9 * t)
     if "hbm_traffic_bytes_per_launch" in pmc:
         hb = pmc["hbm_traffic_bytes_per_launch"] * share / t / 1e9
         out.update({"hbm_fabric_GBps": hb, "hbm_frac": hb / HBM_PEAK_GBS})
@@ -147,7 +152,7 @@ def compact_line(result: dict) -> str:
     crf = {k: _r(rf.get(k), 5) for k in keep if k in rf}
     ph = rf.get("physical")
     if ph:
-        crf["physical"] = _r({k: ph[k] for k in ("simd_busy", "mfma_busy", "valu_busy_raw", "mfma_issue_in_valu", "ta_busy", "l2_hit", "hbm_frac",
+        crf["physical"] = _r({k: ph[k] for k in ("simd_busy", "mfma_busy", "valu_busy_raw", "mfma_issue_in_valu", "ta_busy", "l1_tag_frac", "l2_hit", "hbm_frac",
                                                "pmc_stale", "source", "vgpr", "scratch_bytes_per_lane") if k in ph})
     out["roofline"] = crf
     if "cpu_baseline" in result:

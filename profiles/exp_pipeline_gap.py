@@ -16,6 +16,7 @@ import torch.distributed as dist
 import ngf_amd  # noqa: F401
 from ngf_amd import _lib, cases, dist as ndist, synth
 
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29581")
 dist.init_process_group("nccl", rank=0, world_size=1)
 dev = torch.device("cuda:0")
 g, params, step = cases.big_case("triplane", "R1")

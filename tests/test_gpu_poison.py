@@ -71,7 +71,8 @@ def test_triplane_under_poison(poisoned, waves):
 def test_uv_under_poison(poisoned):
     import test_gpu_uv as tu
     for name in ("uv_sphere", "uv_square"):
-        tu.test_uv_matches_oracle_and_reference(name)
+        for split in (False, True):
+            tu.test_uv_matches_oracle_and_reference(name, split)
         tu.test_uv_split_bf16_keeps_the_fp32_tolerances(name)
     tu.test_uv_no_background_and_short_chunks()
     tu.test_two_rays_per_wave_is_bit_identical()
