@@ -10,11 +10,16 @@ from helpers import big_case, field_for_case, oracle_for_case
 from ngf_amd import synth
 
 rays = synth.lookat_rays(800, 800)
+# round 5: the module's default level (3) and, with SPLIT=1, level 3 with layer 2 on the bf16 pipe (TriPlane rows); LEVEL=1 is round 1's run
+LEVEL, SPLIT = int(os.environ.get("LEVEL", "3")), bool(int(os.environ.get("SPLIT", "0")))
+print(f"TriPlane level {LEVEL}{' + layer 2 as split bf16 products' if SPLIT else ''}; every pixel of the 800x800 / S=192 frame against the C oracle", flush=True)
 for model, preset in (("triplane", "R1"), ("triplane", "R2"), ("infoinv", "R1")):
+    if SPLIT and model != "triplane":
+        continue
     g, params, step = big_case(model, preset)
     g["gauge_on"] = np.array(1); g["infoinv"] = np.array(1)
     orc = oracle_for_case(g, params, step, None)
-    f = field_for_case(g, params, None)
+    f = field_for_case(g, params, None, bake=LEVEL >= 2, bake_color=LEVEL >= 3, split_bf16=SPLIT) if model == "triplane" else field_for_case(g, params, None)
     kw = {"iteration": 30001} if model == "triplane" else {"infoinv": True}
     out = f(torch.from_numpy(rays).cuda(), N_samples=192, white_bg=True, **kw)
     rgb, depth = out["rgb_map"].cpu().numpy(), out["depth_map"].cpu().numpy()
