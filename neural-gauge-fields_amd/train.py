@@ -448,15 +448,16 @@ class _TrainRender(torch.autograd.Function):
         saved = ctx.saved_tensors
         rays, jitter = saved[0], saved[1]
         S, white_bg, gauge_on = ctx.cfg
-        eng = ctx.engine
-        if eng._h is None or not eng.fits(rays.shape[0], S):
-            raise RuntimeError("the field's parameters were re-allocated (up_sampling / shrink / load) between forward and backward")
+        # the field's CURRENT engine: the one of the forward, unless a larger batch had it rebuilt in between (then this batch is rendered again below)
+        eng = ctx.field._render_grad_engine(rays.shape[0], S)
+        if any(a.data_ptr() != b.data_ptr() or a.shape != b.shape for a, b in zip(saved[2:], eng.params)):
+            raise RuntimeError("the field's parameter tensors were re-allocated (up_sampling / shrink / load) between forward and backward")
         d = d_rgb.to(dtype=torch.float32).contiguous()
         want = [bool(w) for w in ctx.needs_input_grad[6:]]
         if not gauge_on:                                   # compute_gauge was not evaluated (Field.py:58,73): the gauge planes are not in the graph
             want[3:6] = [False, False, False]
-        grads = eng.backward(ctx.ticket, d, want)
-        if grads is None:                                  # another forward went through the engine since: render this batch again, then its backward
+        grads = eng.backward(ctx.ticket, d, want) if eng is ctx.engine else None
+        if grads is None:                                  # another forward went through the engine since (or the engine is a new one): render this batch again, then its backward
             _, _, ticket = eng.forward(rays, jitter, S, white_bg, gauge_on)
             grads = eng.backward(ticket, d, want)
             if grads is None:

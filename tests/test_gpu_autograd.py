@@ -123,6 +123,15 @@ def test_arbitrary_loss_two_batches_in_one_graph_and_the_fused_trainer_agree():
     for k in train.PARAM_NAMES:
         want = ga[k] + gb[k]
         assert float((both[k] - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1e-30), k
+    # a LARGER batch between a forward and its backward rebuilds the engine: the pending batch is rendered again on the new one
+    out_small = f(rays[:64], is_train=True, N_samples=S, iteration=5, jitter=j1[:64])["rgb_map"]
+    small_alone = grads_of((f(rays[:64], is_train=True, N_samples=S, iteration=5, jitter=j1[:64])["rgb_map"] - tgt[:64]).abs().mean())
+    big = torch.cat([rays, rays], 0)
+    out_big = f(big, is_train=True, N_samples=S + 8, iteration=5, jitter=torch.cat([j1, j2]))["rgb_map"]        # outgrows max_rays and max_samples
+    got = grads_of((out_small - tgt[:64]).abs().mean())
+    for k in train.PARAM_NAMES:
+        assert float((got[k] - small_alone[k]).abs().max()) <= 2e-5 * max(float(small_alone[k].abs().max()), 1e-30), k
+    del out_big
     # MSE: the fused trainer's gradient of the same batch
     tr = train.Trainer(field_for_case(g, params, None), batch_size=n, max_samples=S, chunk_samples=0)
     tr.backward(rays, tgt, S, white_bg=True, iteration=5, jitter=j1)
