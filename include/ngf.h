@@ -46,7 +46,10 @@ enum {
     NGF_F_SPLIT_BF16 = 8,   /* colour-MLP products on v_mfma_f32_16x16x32_bf16 with every fp32 operand split into three bf16 terms and
                               fp32 accumulation: fp32-level error (dropped cross terms < 2^-24 of a product) at ~0.4 x the matrix
                               cycles of the fp32 MFMA path, which on gfx950 runs on the vector datapath.  Not bit-identical to the
-                              default (different summation tree); opt-in, see DESIGN.md. */
+                              default (different summation tree); opt-in, see DESIGN.md.  Combinations: alone or with NGF_F_BAKE_DENSITY it
+                              covers layers 1 and 2 of the pre-composed formulation (levels 1 / 2); with NGF_F_BAKE_DENSITY | NGF_F_BAKE_COLOR
+                              (round 5) it is level 3 with LAYER 2 -- all the matrix work level 3 has left -- on the bf16 pipe; not with
+                              NGF_F_NO_FOLD, not with NGF_F_BAKE_COLOR alone. */
     NGF_F_BAKE_COLOR = 2    /* pre-compose rgb_decoder layer 1 (W1[:, :F] . basis, no activation in between:
                               networks.py:17,26-30) with the colour channels of each plane: colour planes
                               become 64-channel layer-1 pre-activation planes, the shade pass keeps only the
