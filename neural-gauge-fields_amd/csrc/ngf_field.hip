@@ -1158,6 +1158,7 @@ struct ngf_trainer {
     float *g_gb[3] = {};                     // gauge-plane gradients in the blocked layout the scatter writes (g_g: [texel][2])
     float *q_d[3] = {}, *d_d[3] = {};        // wd-projected density planes, scalar density-gradient images
     float *fwd_image = nullptr, *bwd_image = nullptr;      // LDS images of the colour MLP (train_fold_kernel)
+    float *fwd16_image = nullptr;                          // ... and the forward's image in the eval pass's layout (train_color_fwd16_kernel)
     float *g_dense[TP_COUNT] = {};          // reference-layout gradient buffers of the MLP parameters (index TP_*)
     int64_t dense_n[TP_COUNT] = {};
     uint8_t *mask = nullptr;
@@ -1339,7 +1340,7 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
     if ((rc = tr_alloc(t, &T.et, cap)) || (rc = tr_alloc(t, &T.sg, cap)) || (rc = tr_alloc(t, &T.w, cap)) || (rc = tr_alloc(t, &T.dx, cap)) || (rc = tr_alloc(t, &T.c, cap * 3)) ||
         (rc = tr_alloc(t, &T.dt, cap * 6)) || (rc = tr_alloc(t, &T.G, (size_t)d->max_rays * 3)) || (rc = tr_alloc(t, &T.count, (size_t)d->max_rays)) ||
         (rc = tr_alloc(t, &T.offset, (size_t)d->max_rays + 1)) || (rc = tr_alloc(t, &T.list, cap * 2)) || (rc = tr_alloc(t, &T.list_w, cap)) ||
-        (rc = tr_alloc(t, &t->fwd_image, (size_t)kFwdImage)) || (rc = tr_alloc(t, &t->bwd_image, (size_t)kBwdImage)) ||
+        (rc = tr_alloc(t, &t->fwd_image, (size_t)kFwdImage)) || (rc = tr_alloc(t, &t->bwd_image, (size_t)kBwdImage)) || (rc = tr_alloc(t, &t->fwd16_image, (size_t)MlpLayout16<48>::TOTAL)) ||
         (rc = tr_alloc(t, &T.bin_off, (size_t)nbins + 1)) || (rc = tr_alloc(t, &T.bin_unit, (size_t)nbins + 1)) || (rc = tr_alloc(t, &T.unit_total, (size_t)1)))
         return bail(rc);
     // The activation rows (576 floats per sample + the 18 of its scatter pairs).  If the whole-batch default does not fit the free HBM, fall back to round 1's chunked
@@ -1434,12 +1435,12 @@ static int train_forward_part(ngf_trainer *t, const float *rays, const float *ji
     hipLaunchKernelGGL(train_project_density_kernel, dim3(128, 3), dim3(256), 0, st, PJ);
     HIP_TRY(hipMemsetAsync(t->zero_arena, 0, t->zero_bytes, st));
     // the LDS images of the colour MLP are first read by the colour forward: built beside the density kernel and the scan
-    T.fwd_image = t->fwd_image; T.bwd_image = t->bwd_image;
+    T.fwd_image = t->fwd_image; T.bwd_image = t->bwd_image; T.fwd16_image = t->fwd16_image;
     if (fork) {
         HIP_TRY(hipEventRecord(t->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(sx, t->ev_fork, 0));
     }
-    hipLaunchKernelGGL(train_fold_kernel, dim3(48), dim3(256), 0, sx, T, t->fwd_image, t->bwd_image);
+    hipLaunchKernelGGL(train_fold_kernel, dim3(48), dim3(256), 0, sx, T, t->fwd_image, t->bwd_image, t->fwd16_image);
     if (fork) { HIP_TRY(hipEventRecord(t->ev_join[0], sx)); fs.fold = true; }
 
     const int64_t pairs = n * n_samples;
@@ -1467,6 +1468,8 @@ static int train_forward_part(ngf_trainer *t, const float *rays, const float *ji
     static_assert((((kFwdImage + 3) & ~3) + kTrainWaves * kFwdTileFloats) * 4 <= 160 * 1024, "colour forward LDS");
     static_assert((((kBwdImage + 3) & ~3) + kTrainWavesBwd * kBwdTileFloats) * 4 <= 160 * 1024, "colour backward LDS");
     HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(train_color_fwd_kernel), lds_f));
+    const size_t lds_f16 = (size_t)((MlpLayout16<48>::TOTAL + 3) & ~3) * sizeof(float);
+    HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(train_color_fwd16_kernel), lds_f16));
     HIP_TRY(ensure_dynamic_lds(reinterpret_cast<const void *>(train_color_bwd_kernel), lds_b));
     if (fork) { HIP_TRY(hipStreamWaitEvent(st, t->ev_join[0], 0)); fs.fold = false; }          // the images
     const int32_t *cnt = no_sync ? T.offset + n : nullptr;
@@ -1480,7 +1483,9 @@ static int train_forward_part(ngf_trainer *t, const float *rays, const float *ji
         T.chunk_base = (int32_t)base;
         T.chunk_n = (int32_t)std::min<int64_t>(t->chunk, list_len - base);
         T.store = single ? 1 : 0;
-        hipLaunchKernelGGL(train_color_fwd_kernel, dim3(tr_grid(t, (T.chunk_n + 15) / 16, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_f, st, T);
+        // round 5: the colour forward in the eval pass's shape (twelve waves per CU, rows stored from registers); ngf_debug_set("ablate", 1 << 23) = the LDS-tile kernel (A/B)
+        if (A.ablate & (1 << 23)) hipLaunchKernelGGL(train_color_fwd_kernel, dim3(tr_grid(t, (T.chunk_n + 15) / 16, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_f, st, T);
+        else hipLaunchKernelGGL(train_color_fwd16_kernel, dim3(tr_grid(t, (T.chunk_n + 15) / 16, kTrainWaves16, 1)), dim3(kTrainWaves16 * 64), lds_f16, st, T);
     }
     P.fork = fork; P.no_sync = no_sync; P.single = single; P.n = n; P.n_samples = n_samples; P.list_len = list_len;
     P.valid = true;
@@ -1526,7 +1531,8 @@ static int train_backward_part(ngf_trainer *t, ngf_trainer::Pending &P, double *
         if (int jrc = join()) return jrc;              // the previous chunk's chains read the rows this chunk overwrites
         if (!single) {
             T.store = 1;
-            hipLaunchKernelGGL(train_color_fwd_kernel, dim3(tr_grid(t, passes, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_f, st, T);
+            if (A.ablate & (1 << 23)) hipLaunchKernelGGL(train_color_fwd_kernel, dim3(tr_grid(t, passes, kTrainWaves, 1)), dim3(kTrainWaves * 64), lds_f, st, T);
+            else hipLaunchKernelGGL(train_color_fwd16_kernel, dim3(tr_grid(t, passes, kTrainWaves16, 1)), dim3(kTrainWaves16 * 64), (size_t)((MlpLayout16<48>::TOTAL + 3) & ~3) * sizeof(float), st, T);
         }
         T.bin_accumulate = base > 0 ? 1 : 0;
         if (base > 0) HIP_TRY(hipMemsetAsync(T.bin_count, 0, ((size_t)T.nbins + 1) * sizeof(int32_t), st));      // the first chunk's counters: the zero arena

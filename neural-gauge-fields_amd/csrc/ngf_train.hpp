@@ -80,6 +80,7 @@ struct TrainArgs {
     // activations of the current chunk, sample-major rows
     float *F, *V, *H1, *H2, *D3, *D2, *D1;          // [chunk, 144|16|64|64|16|64|64]  (V = the 15 view inputs + 0)
     const float *fwd_image, *bwd_image;             // LDS images built by train_fold_kernel
+    const float *fwd16_image;                       // the forward's image in the eval pass's layout (MlpLayout16<48>, ngf_shade16.hpp), train_color_fwd16_kernel
     float *M;                                       // [64,144] = Delta1^T F, accumulated over the chunks
     // colour-plane scatter by bins (section 5b): a bin = the cells of one 8x8 block of one colour plane
     float *DF;                                      // [chunk, 144]  d loss / d colour features of the chunk's samples
@@ -464,8 +465,12 @@ constexpr int kBwdTileFloats = 16 * kDfStride + 64 * kTs;
 static_assert(16 * kDfStride >= 2 * 64 * kTs, "DF^T must cover the H1 and D2 tiles it aliases");
 
 // ---- per-step weight images -------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) train_fold_kernel(const TrainArgs T, float *fwd, float *bwd)
+// fwd16 (round 5): the same W1' / W2 / W3 / biases in the eval pass's image layout MlpLayout16<48> (ngf_shade16.hpp: what build_rgb_image16 makes on
+// the host for a render handle) -- A operands [unit tile][k-step][lane], lane (i, kq) of k-step t = input kmap(t, kq) of unit mt * 16 + i;
+// hidden units in accumulator order n = mt * 16 + 4 kq + r.
+__global__ void __launch_bounds__(256) train_fold_kernel(const TrainArgs T, float *fwd, float *bwd, float *fwd16)
 {
+    using L16 = MlpLayout16<48>;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     for (int i = tid; i < 64 * kIn1Pad; i += nth) {                  // W1' and its transpose
         const int m = i / kIn1Pad, k = i % kIn1Pad;
@@ -479,16 +484,36 @@ __global__ void __launch_bounds__(256) train_fold_kernel(const TrainArgs T, floa
             v = T.w1[m * kIn1 + k];
         }
         fwd[kFwdW1 + m * kLd1 + k] = v;
+        {   // the one (k-step, lane) of the 16-wide image that multiplies input k into unit m
+            const int mt = m >> 4, iu = m & 15;
+            int t16, kq;
+            if (k < kFeat) { const int P = k / 48, c = k % 48; kq = (c & 15) >> 2; t16 = P * L16::QCH + 4 * (c >> 4) + (c & 3); }
+            else { const int e = k - kFeat; kq = e >> 2; t16 = 3 * L16::QCH + (e & 3); }
+            fwd16[L16::W1 + (mt * L16::KT + t16) * 64 + kq * 16 + iu] = v;
+        }
     }
     for (int i = tid; i < 64 * 64; i += nth) {
         const int m = i / 64, k = i % 64;
         const float v = T.w2[m * 64 + k];
         fwd[kFwdW2 + m * kLd2 + k] = v;
         bwd[kBwdW2T + k * kLd2 + m] = v;
+        {   // input hidden unit k = mt' * 16 + 4 kq + r is k-step t = 4 mt' + r of lane quarter kq
+            const int mt = m >> 4, iu = m & 15, kq = (k & 15) >> 2, t16 = 4 * (k >> 4) + (k & 3);
+            fwd16[L16::W2 + (mt * 16 + t16) * 64 + kq * 16 + iu] = v;
+        }
     }
-    for (int i = tid; i < 192; i += nth) { fwd[kFwdW3 + i] = T.w3[i]; bwd[kBwdW3 + i] = T.w3[i]; }
-    for (int i = tid; i < 64; i += nth) { fwd[kFwdB1 + i] = T.b1[i]; fwd[kFwdB2 + i] = T.b2[i]; }
-    for (int i = tid; i < 4; i += nth) fwd[kFwdB3 + i] = i < 3 ? T.b3[i] : 0.0f;
+    for (int i = tid; i < 192; i += nth) {
+        fwd[kFwdW3 + i] = T.w3[i]; bwd[kBwdW3 + i] = T.w3[i];
+        const int c = i / 64, n = i % 64, kq = (n & 15) >> 2, kk = 4 * (n >> 4) + (n & 3);         // unit n = (kk >> 2) * 16 + 4 kq + (kk & 3)
+        fwd16[L16::W3 + c * 64 + kq * 16 + kk] = T.w3[i];
+    }
+    for (int i = tid; i < 64; i += nth) {
+        fwd[kFwdB1 + i] = T.b1[i]; fwd[kFwdB2 + i] = T.b2[i];
+        const int kq = (i & 15) >> 2, kk = 4 * (i >> 4) + (i & 3);
+        fwd16[L16::B1 + kq * 16 + kk] = T.b1[i];
+        fwd16[L16::B2 + kq * 16 + kk] = T.b2[i];
+    }
+    for (int i = tid; i < 4; i += nth) { fwd[kFwdB3 + i] = i < 3 ? T.b3[i] : 0.0f; fwd16[L16::B3 + i] = i < 3 ? T.b3[i] : 0.0f; }
     // pad columns (never multiplied by a non-zero operand, but keep them defined)
     for (int i = tid; i < 64 * (kLd1 - kIn1Pad); i += nth) fwd[kFwdW1 + (i / (kLd1 - kIn1Pad)) * kLd1 + kIn1Pad + i % (kLd1 - kIn1Pad)] = 0.0f;
     for (int i = tid; i < 64 * (kLd2 - 64); i += nth) {
@@ -617,6 +642,165 @@ __global__ void __launch_bounds__(kTrainWaves * 64) __attribute__((amdgpu_waves_
             tile_to_rows(H2t, 64, T.H2, 64, row, live, lane);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        r_cur = r_nx; i_cur = i_nx;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[k] = t_nx[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dcur[k] = d_nx[k];
+    }
+}
+
+// ---- 3b. colour forward in the eval pass's shape (round 5) -----------------------------------------------------------------------------------
+// train_color_fwd_kernel above keeps its tiles in LDS ([k][17] transposes between MFMA operands and sample-major rows): 152 KB per workgroup, six
+// waves per CU, 200 us for ~170 k samples -- the render kernel's level-1 shade pass does the same arithmetic for 16 samples in ~1.6 us of a SIMD
+// shared by three waves, ten times the rate.  This kernel IS that pass (gather16_issue / mix16 / layer1_plane16 of ngf_shade16.hpp, twelve waves per
+// CU, the 58.6 KB MlpLayout16<48> image train_fold_kernel now also builds) with the activation rows stored straight from the registers that hold
+// them: lane (s, kq) has channels 16 q + 4 kq .. + 3 of every plane, its four view inputs and hidden units mt * 16 + 4 kq .. + 3 of its own sample --
+// 16-byte pieces of the rows F [144], V [16], H1 [64], H2 [64] (post-ReLU, as before).  Same features to the bit (same bil_setup / bil_mix);
+// layers 1-2 sum in the MFMA's k order of the eval pass instead of dense16's: last-bit differences in H1 / H2 / colours.
+constexpr int kTrainWaves16 = 12;
+__global__ void __launch_bounds__(kTrainWaves16 * 64) train_color_fwd16_kernel(const TrainArgs T)
+{
+    NGF_KARG_CONTRACT_T(&train_color_fwd16_kernel, TrainArgs);      // gather16_issue reads the colour-plane descriptors from the kernel-argument segment
+    using L = MlpLayout16<48>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const RenderArgs &A = T.R;
+    stage_blob(smem, T.fwd16_image, L::TOTAL);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const int chunk_n = chunk_rows(T);
+    const int passes = (chunk_n + 15) / 16;
+    const int stride = gridDim.x * kTrainWaves16;
+    auto want_list = [&](int ps, int &r_, int &i_) {
+        const int lc = ps * 16 + n;
+        const int64_t sl = T.chunk_base + (lc < chunk_n ? lc : 0);
+        r_ = T.list[2 * sl]; i_ = T.list[2 * sl + 1];
+    };
+    auto want_coords = [&](int r_, int i_, float (&t_)[6], float (&d_)[3]) {
+        float xn_[3];
+        list_sample_coords(A, r_, i_, t_, xn_);
+        d_[0] = A.rays[(int64_t)r_ * 6 + 3]; d_[1] = A.rays[(int64_t)r_ * 6 + 4]; d_[2] = A.rays[(int64_t)r_ * 6 + 5];
+    };
+    int pass = blockIdx.x * kTrainWaves16 + wave;
+    int r_cur = 0, i_cur = 0;
+    float t[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, dcur[3] = {0.0f, 0.0f, 1.0f};
+    if (pass < passes) {
+        want_list(pass, r_cur, i_cur);
+        want_coords(r_cur, i_cur, t, dcur);
+    }
+    for (; pass < passes; pass += stride) {
+        const float *blob = per_pass16(smem);
+        const int local = pass * 16 + n;
+        const bool live = local < chunk_n;
+        const bool keep = live && T.store;
+        const int64_t row = live ? local : 0;
+        const int64_t r = r_cur;
+        const int i = i_cur;
+        const int next = pass + stride < passes ? pass + stride : pass;
+        int r_nx, i_nx;
+        want_list(next, r_nx, i_nx);
+        const float rec[kRecFloats] = {0.0f, 0.0f, t[0], t[1], t[2], t[3], t[4], t[5]};
+        f32x4 v;
+        {
+            float d[3] = {dcur[0], dcur[1], dcur[2]}, v16[16];
+            view_inputs(d, v16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = kq == 0 ? v16[j] : (kq == 1 ? v16[4 + j] : (kq == 2 ? v16[8 + j] : v16[12 + j]));      // selects: a kq-indexed read would put v16 into scratch
+        }
+        if (keep) *reinterpret_cast<f32x4 *>(T.V + row * 16 + 4 * kq) = v;
+        Gather16<48> g;
+        float feat[L::QCH];
+        gather16_issue<48, 0>(A, rec, kq, g);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = *reinterpret_cast<const f32x4 *>(blob + L::B1 + kq * 16 + mt * 4);
+        {
+            const float *w1 = blob + L::W1 + lane;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = NGF_MFMA16(w1[(mt * L::KT + 3 * L::QCH + j) * 64], v[j], acc[mt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto keep_feat = [&](int P) {
+            if (keep) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    *reinterpret_cast<f32x4 *>(T.F + row * kFeat + P * 48 + 16 * q + 4 * kq) = f32x4{feat[4 * q], feat[4 * q + 1], feat[4 * q + 2], feat[4 * q + 3]};
+            }
+        };
+        mix16<48>(g, feat);
+        __builtin_amdgcn_sched_barrier(0);
+        gather16_issue<48, 1>(A, rec, kq, g);
+        __builtin_amdgcn_sched_barrier(0);
+        keep_feat(0);
+        layer1_plane16<48, 0>(blob, lane, feat, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        mix16<48>(g, feat);
+        __builtin_amdgcn_sched_barrier(0);
+        gather16_issue<48, 2>(A, rec, kq, g);
+        __builtin_amdgcn_sched_barrier(0);
+        keep_feat(1);
+        layer1_plane16<48, 1>(blob, lane, feat, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        mix16<48>(g, feat);
+        __builtin_amdgcn_sched_barrier(0);
+        keep_feat(2);
+        // the next pass's coordinates (three dependent reads) are requested here, behind plane 2's 48 MFMAs and layer 2
+        float t_nx[6], d_nx[3];
+        want_coords(r_nx, i_nx, t_nx, d_nx);
+        layer1_plane16<48, 2>(blob, lane, feat, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        // layer 2 on the lane's own 16 hidden units (accumulator order = B operand order), H1 / H2 rows from the registers
+        float h[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) h[k] = relu1(acc[k >> 2][k & 3]);
+        if (keep) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4 *>(T.H1 + row * 64 + mt * 16 + 4 * kq) = f32x4{h[4 * mt], h[4 * mt + 1], h[4 * mt + 2], h[4 * mt + 3]};
+        }
+        f32x4 c2[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) c2[mt] = *reinterpret_cast<const f32x4 *>(blob + L::B2 + kq * 16 + mt * 4);
+        {
+            const float *w2 = blob + L::W2 + lane;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) c2[mt] = NGF_MFMA16(w2[(mt * 16 + k) * 64], h[k], c2[mt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float hr[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) hr[k] = relu1(c2[k >> 2][k & 3]);
+        if (keep) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4 *>(T.H2 + row * 64 + mt * 16 + 4 * kq) = f32x4{hr[4 * mt], hr[4 * mt + 1], hr[4 * mt + 2], hr[4 * mt + 3]};
+        }
+        // layer 3 + sigmoid as train_color_fwd_kernel: the lane's 16 units, then the four quarters meet
+        const f32x4 *w3 = reinterpret_cast<const f32x4 *>(blob + L::W3 + kq * 16);
+        float c[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float sacc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w = w3[j * 16 + q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sacc = fmaf(w[e], hr[4 * q + e], sacc);
+            }
+            sacc += __shfl_xor(sacc, 16);
+            sacc += __shfl_xor(sacc, 32);
+            sacc += blob[L::B3 + j];
+            c[j] = 1.0f / (1.0f + expf(-sacc));
+        }
+        if (live && kq == 0) {
+            float *dst = T.c + ((int64_t)r * A.S + i) * 3;
+            dst[0] = c[0]; dst[1] = c[1]; dst[2] = c[2];
+        }
         r_cur = r_nx; i_cur = i_nx;
 #pragma unroll
         for (int k = 0; k < 6; ++k) t[k] = t_nx[k];

@@ -329,7 +329,12 @@ def test_full_size_batch_matches_autograd_oracle():
         want = grads[name].numpy()
         if k < 3:
             want = want - l1_term(params[name])
-        assert rel(got, want) < 2 * GRAD_TOL, (name, rel(got, want))
+        # 190 000 samples x 128 hidden units: now and then a pre-activation sits within rounding of zero and the MFMA's summation order decides its
+        # ReLU (seeds 9 and 10 of this batch have such samples for the round-5 forward kernel, seeds 11-14 none; round 4's kernel had none at seed 9:
+        # profiles/r05_train_relu_kinks.txt).  A flipped unit moves a handful of texels by ~1e-3 of the tensor's largest entry and nothing in norm:
+        # the gradient is held norm-wise at the tolerance and entry-wise at a bound no layout or indexing error stays below.
+        l2 = float(np.linalg.norm((got - want).ravel()) / max(np.linalg.norm(want.ravel()), 1e-30))
+        assert l2 < 2 * GRAD_TOL and rel(got, want) < 2e-2, (name, l2, rel(got, want))
 
 
 def test_scatter_takes_the_per_tap_path_when_a_ray_chunk_spans_too_many_blocks():
