@@ -10,7 +10,7 @@
 # Copy gpurun_out/r05_* into profiles/ afterwards (tracked).  Workload names: profiles/workload.py.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-WLS="triplane_R1_bdc triplane_R0_bdc triplane_R2_bdc triplane_R1_bd triplane_R1 triplane_R1_nofold triplane_R1_splitd triplane_R1_bdcs triplane_R2_bd triplane_R1_bdc_S884mask triplane_R2_bdc_S884mask triplane_R1_bdc_S884ball infoinv_R1 infoinv_R1_split"
+WLS="triplane_R1_bdc triplane_R0_bdc triplane_R2_bdc triplane_R1_bd triplane_R1 triplane_R1_nofold triplane_R1_splitd triplane_R1_bdcs triplane_R2_bd triplane_R1_bdc_S884mask triplane_R2_bdc_S884mask triplane_R1_bdc_S884ball infoinv_R1 infoinv_R1_split triplane_R1_split triplane_R0 triplane_R2_splitd triplane_R2_bdcs"
 [ "$1" = quick ] && WLS="triplane_R1_bdc"
 for wl in $WLS; do
   bash profiles/collect.sh r05_$wl $wl "ngf::render_kernel" > /dev/null 2>&1
@@ -40,5 +40,9 @@ fi
 SIZES="2000 4096 8000 16000 40000 80000 160000 640000" python profiles/exp_launch_size.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_shard_latency.txt
 LEVEL=2 python profiles/exp_launch_size.py 2>&1 | grep -v amdgpu.ids >> gpurun_out/r05_shard_latency.txt
 MODEL=infoinv python profiles/exp_launch_size.py 2>&1 | grep -v amdgpu.ids >> gpurun_out/r05_shard_latency.txt
+if [ "$1" != quick ]; then
+  timeout 600 python profiles/exp_rank_shards.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_rank_shards.txt
+  timeout 600 python profiles/exp_pipeline_gap.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_pipeline_gap.txt
+fi
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/r05_pytest_gpu.txt
 ls gpurun_out | grep r05_ | head -100
