@@ -813,8 +813,14 @@ __global__ void __launch_bounds__(kTrainWaves16 * 64) train_color_fwd16_kernel(c
 // kCompLanes lanes per ray.  d loss / d alpha_i = dL/dw_i T_i - (sum_{j>i} w_j dL/dw_j) / (1 - alpha_i + 1e-10) with
 // dL/dw_j = G . (c_j [active] - bg) is the cumprod backward; the suffix sum is accumulated from the END of the ray in float64
 // (what ATen's reverse cumsum does on the CPU), T_i was parked in dx by the scan.
-constexpr int kCompAhead = 4;
-constexpr int kCompLanes = 16;                   // lanes per ray (eight -- two waves per SIMD for a 4096-ray batch -- measured slower: 71 vs 64 us)
+#ifndef NGF_COMP_AHEAD
+#define NGF_COMP_AHEAD 4
+#endif
+constexpr int kCompAhead = NGF_COMP_AHEAD;
+#ifndef NGF_COMP_LANES
+#define NGF_COMP_LANES 32
+#endif
+constexpr int kCompLanes = NGF_COMP_LANES;                   // lanes per ray.  Round 5: 32 with the colours of active samples only (52 us; 16 lanes: 61, 64 lanes: 68; with every colour read 65 / 64 / 79; 8 blocks ahead instead of 4: 50.5).  Round 3: 16 (eight measured slower: 71 vs 64 us)
 // PHASE 0: the fused step (residual against T.target, loss, backward).  PHASE 1: the forward call of the two-call form -- the same sums, then
 // rgb_map (clamped) and depth_map are written and the kernel ends.  PHASE 2: its backward call -- the same sums again (they decide where the
 // clamp passes a gradient), G = T.d_rgb where it does.
@@ -839,8 +845,15 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
             const int i = i0 + kCompLanes * u;
             const int64_t idx = r * A.S + (i < A.S ? i : 0);
             wv[u] = i < A.S ? T.w[idx] : 0.0f;
+        }
+        // the colours of the ACTIVE samples only (4-5 % of the pairs, in runs along the ray: most 64-byte lines of T.c are never touched): the kernel
+        // moves ~190 MB per step at ~3 TB/s, a quarter of it were colours nothing reads
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) cv[u][ch] = T.c[idx * 3 + ch];
+        for (int u = 0; u < kCompAhead; ++u) {
+            const int i = i0 + kCompLanes * u;
+            const int64_t idx = r * A.S + (i < A.S ? i : 0);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) cv[u][ch] = wv[u] > A.thr ? T.c[idx * 3 + ch] : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < kCompAhead; ++u) {
@@ -899,8 +912,14 @@ __global__ void __launch_bounds__(64) train_composite_bwd_kernel(const TrainArgs
             sv[u] = inb ? T.sg[idx] : 0.0f;
             tv[u] = inb ? T.dx[idx] : 0.0f;
             wv[u] = inb ? T.w[idx] : 0.0f;
+        }
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) cv[u][ch] = T.c[idx * 3 + ch];
+        for (int u = 0; u < kCompAhead; ++u) {
+            const int i = j0 - kCompLanes * u + seg;
+            const bool inb = (j0 - kCompLanes * u >= 0) && (i < A.S);
+            const int64_t idx = r * A.S + (inb ? i : 0);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) cv[u][ch] = wv[u] > A.thr ? T.c[idx * 3 + ch] : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < kCompAhead; ++u) {

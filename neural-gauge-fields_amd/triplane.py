@@ -71,7 +71,8 @@ class TriPlane(Base):
         self.init_para((int(newSize[0]), int(newSize[1]), int(newSize[2])))
 
     def density_L1(self):
-        """Field.py:149-152 (value only; its gradient is fused into the Adam kernel of ngf_amd.train.Trainer)."""
+        """Field.py:149-152, differentiable like the reference's (the reference loop adds it to the loss, main.py:279-281); ngf_amd.train.Trainer fuses
+        its gradient into the planes' Adam kernel instead."""
         return torch.mean(torch.abs(self.plane_xy)) + torch.mean(torch.abs(self.plane_yz)) + torch.mean(torch.abs(self.plane_xz))
 
     def _fill_desc(self, d, dp):

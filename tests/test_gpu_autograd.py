@@ -142,6 +142,77 @@ def test_arbitrary_loss_two_batches_in_one_graph_and_the_fused_trainer_agree():
     tr.release()
 
 
+def test_the_references_loop_goes_through_alpha_mask_shrink_and_up_sampling():
+    """The structural steps of the reference's loop (TriPlane/main.py:329-356) on the AUTOGRAD path: ``updateAlphaMask`` installs a mask,
+    ``shrink`` crops the planes into new Parameters and moves the aabb (the mask keeps its own), ``up_sampling`` replaces the planes again,
+    and each time the reference builds a new ``torch.optim.Adam``.  ``forward`` rebuilds the field's gradient engine behind the scenes; after
+    every step the reference loop's gradients (MSE + density_L1) equal autograd of the eager port built from the field's CURRENT state."""
+    from oracle import train as otrain
+    from ngf_amd import synth
+    g, params, step, mask = load_case("triplane_r1_gauge")
+    field = field_for_case(g, params, None)
+    with torch.no_grad():       # the seeded fog fills the box: carve an occupied column (x, y in the middle half, every z) so that shrink has something to crop
+        w = field.density_decoder.weight[0, :16]                       # the xy plane's share of the linear density decoder (bias 10, then - 10)
+        H, W = field.plane_xy.shape[-2:]
+        yy, xx = torch.meshgrid(torch.arange(H, device="cuda"), torch.arange(W, device="cuda"), indexing="ij")
+        inside = ((yy - (H - 1) / 2).abs() < H / 4) & ((xx - (W - 1) / 2).abs() < W / 4)
+        field.plane_xy[0, :16] = torch.where(inside, -2.0, -25.0)[None] * torch.sign(w)[:, None, None] / w.abs().sum()      # pre-softplus -2 (alpha ~0.2 per step) / -25 (empty)
+        field.plane_yz[0, :16] = 0.0
+        field.plane_xz[0, :16] = 0.0
+    rays_np = synth.lookat_rays(36, 36)
+    rays_train = torch.from_numpy(rays_np).cuda()
+    n, nSamples = rays_np.shape[0], 80
+    rgb_np = synth.hash_uniform(57, 1, (n, 3))
+    rgb_train = torch.from_numpy(rgb_np).cuda()
+    L1_reg_weight = 8e-5
+
+    def one_iteration(tag, iteration, optimizer):
+        jit_np = synth.hash_uniform(57, 10 + iteration, (n,))
+        cur = {name: p.detach().cpu().numpy().copy() for name, p in zip(train.PARAM_NAMES, train._train_params(field))}
+        am = None
+        if field.alphaMask is not None:
+            am = (field.alphaMask.alpha_volume[0, 0].float().cpu().numpy(), field.alphaMask.aabb.cpu().numpy())
+        orc = otrain.EagerTrainer(cur, field.aabb.cpu().numpy(), float(field.stepSize), tuple(field.near_far), float(field.distance_scale),
+                                  float(field.rayMarch_weight_thres), alpha_mask=am)
+        want, want_loss, want_rgb, aux = orc.gradients(torch.from_numpy(rays_np), torch.from_numpy(rgb_np), nSamples, torch.from_numpy(jit_np), True, iteration)
+        assert int(aux["active"].sum()) > 50, tag                       # the colour path carries gradient in every phase
+        # main.py:272-296
+        output = field(rays_train, is_train=True, white_bg=True, N_samples=nSamples, iteration=iteration, jitter=torch.from_numpy(jit_np), coin=0.7)
+        rgb_map = output['rgb_map']
+        rgb_loss = torch.mean((rgb_map - rgb_train) ** 2)
+        mse = float(rgb_loss.detach())                                  # (the reference's `total_loss +=` below adds the L1 term into rgb_loss in place)
+        total_loss = rgb_loss
+        loss_reg_L1 = field.density_L1()
+        total_loss += L1_reg_weight * loss_reg_L1
+        optimizer.zero_grad()
+        total_loss.backward()
+        np.testing.assert_allclose(rgb_map.detach().cpu().numpy(), want_rgb.numpy(), rtol=1e-4, atol=2e-6, err_msg=tag)
+        assert abs(mse - want_loss) < 2e-6, tag
+        sd = dict(field.named_parameters())
+        for name in train.PARAM_NAMES:
+            got = sd[name].grad.cpu().numpy()
+            assert got.shape == cur[name].shape and rel(got, want[name].numpy()) < GRAD_TOL, (tag, name, rel(got, want[name].numpy()))
+        optimizer.step()
+
+    new_opt = lambda: torch.optim.Adam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))      # noqa: E731  (main.py:241, :354-356)
+    optimizer = new_opt()
+    one_iteration("fresh field", 0, optimizer)
+    one_iteration("after an Adam step", 1, optimizer)
+    new_aabb = field.updateAlphaMask((48, 48, 48))                       # main.py:334
+    one_iteration("alpha mask", 2, optimizer)
+    shape0 = tuple(field.plane_xy.shape)
+    field.shrink(new_aabb)                                               # main.py:336
+    assert tuple(field.plane_xy.shape) != shape0
+    optimizer = new_opt()            # (the reference keeps its old optimizer until the next up-sampling: the cropped planes get no updates and no zero_grad in
+                                     # between -- train.fit mirrors that; a new one here, so that .grad is this iteration's alone)
+    one_iteration("shrunk planes, mask on the old box", 3, optimizer)
+    res = [int(r) + 12 for r in field.gridSize]
+    field.up_sampling(res)                                               # main.py:350
+    optimizer = new_opt()                                                # main.py:354-356
+    one_iteration("up-sampled planes", 4, optimizer)
+    one_iteration("and one more step on them", 5, optimizer)
+
+
 def test_gauge_off_frozen_parameters_and_the_guards():
     g, params = load_train_case("train_r1")
     f = field_for_case(g, params, None)
