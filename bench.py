@@ -583,12 +583,14 @@ def main():
             # updateAlphaMask((256,)*3) builds from the seeded field (main.py:330); `ball`: occupancy = a ball of radius 0.8, 15 % of the box (an
             # object in empty space, as a trained lego is).  Module default level, whole frame in one launch.
             from ngf_amd.fieldbase import renderer as _renderer
-            for preset, shape in (("R1", "mask"), ("R2", "mask"), ("R1", "ball")):
-                key = f"triplane_{preset}_S884_{shape}"
+            for mdl, preset, shape in (("triplane", "R1", "mask"), ("triplane", "R2", "mask"), ("triplane", "R1", "ball"), ("infoinv", "R1", "mask")):
+                key = f"{mdl}_{preset}_S884_{shape}"
+                tri = mdl == "triplane"
+                fkw = {"iteration": 30001} if tri else {"infoinv": True}
                 try:
-                    fx, gx, _, _ = build_field("triplane", preset, device, True, True)
+                    fx, gx, _, _ = build_field(mdl, preset, device, True, True) if tri else build_field(mdl, preset, device)
                     if shape == "mask":
-                        fx.updateAlphaMask((256, 256, 256))
+                        fx.updateAlphaMask((256, 256, 256), **({} if tri else {"infoinv": True}))
                     else:
                         from ngf_amd import triplane as _tp
                         ax = torch.linspace(-1.5, 1.5, 128)
@@ -596,16 +598,21 @@ def main():
                         fx.alphaMask = _tp.AlphaGridMask(device, torch.tensor(np.asarray(gx["aabb"], np.float32)), ((xx ** 2 + yy ** 2 + zz ** 2) < 0.64).float().to(device))
                         fx.invalidate()
                     Sx = int(fx.nSamples)
-                    go = lambda: _renderer(rays, fx, chunk=4096, N_samples=-1, white_bg=True, device=device)
+                    go = lambda: _renderer(rays, fx, chunk=4096, N_samples=-1, white_bg=True, device=device, **({} if tri else fkw))
                     kernel_ms(go, 3, device)
                     ms = kernel_ms(go, 8, device)
-                    fx(rays, N_samples=-1, collect_stats=True, iteration=30001)
+                    fx(rays, N_samples=-1, collect_stats=True, **fkw)
                     sx = fx.last_stats.cpu().numpy().astype(np.float64)
-                    fl = sx[2] * 64 * 2048.0 + plan_tiles(n_total, 8, torch.cuda.get_device_properties(device).multi_processor_count * 12) * 16 * 2048.0
+                    pmx = load_pmc(f"triplane_{preset}_bdc_S884{shape}" if tri else f"infoinv_{preset}__S884{shape}")
+                    if tri:
+                        fl = sx[2] * 64 * 2048.0 + plan_tiles(n_total, 8, torch.cuda.get_device_properties(device).multi_processor_count * 12) * 16 * 2048.0
+                    else:
+                        fl = None if pmx is None else pmx.get("mfma_flops_per_dispatch")
                     extras[key] = {"Mray/s": n_total / ms / 1e3, "kernel_ms": ms, "samples_per_ray": Sx, "mask_occupancy": float(fx.alphaMask.alpha_volume.mean()),
                                    "evaluated_samples_per_ray": sx[0] / n_total, "active_samples_per_ray": sx[1] / n_total,
-                                   "executed_mfma_TFLOPs": fl / (ms * 1e-3) / 1e12, "mfma_frac_of_157.3": fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
-                                   "physical": physical_roofs(load_pmc(f"triplane_{preset}_bdc_S884{shape}"), ms)}
+                                   "executed_mfma_TFLOPs": None if fl is None else fl / (ms * 1e-3) / 1e12,
+                                   "mfma_frac_of_157.3": None if fl is None else fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                                   "physical": physical_roofs(pmx, ms)}
                     fx.release()
                 except Exception as ex:
                     extras[key] = {"error": repr(ex)}

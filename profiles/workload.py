@@ -49,7 +49,7 @@ if name.startswith(("triplane", "infoinv")):
     if shape.startswith("S884"):
         NS = -1                                                   # the model's own nSamples (884 for the 256^3 grid at step_ratio 0.5)
         if shape == "S884mask":
-            f.updateAlphaMask((256, 256, 256))
+            f.updateAlphaMask((256, 256, 256), **({} if model == "triplane" else {"infoinv": True}))
         else:
             from ngf_amd import triplane
             ax = torch.linspace(-1.5, 1.5, 128)

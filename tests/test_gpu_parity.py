@@ -683,37 +683,40 @@ def test_full_frame_properties(level):
     _close(depth[torch.from_numpy(pick).cuda()].cpu().numpy(), o_depth, "full-frame depth vs oracle", atol=5e-5)
 
 
-@pytest.mark.parametrize("preset", ["R1", "R2"])
-def test_full_frame_at_the_references_eval_shape(preset):
+@pytest.mark.parametrize("model,preset", [("triplane", "R1"), ("triplane", "R2"), ("infoinv", "R1")])
+def test_full_frame_at_the_references_eval_shape(model, preset):
     """What the reference's evaluation actually launches (VERDICT r4 missing #3): ``renderer(rays, field, chunk=4096, N_samples=-1, ...)``
     (TriPlane/main.py:94) -- N_samples = -1 resolves to the model's own nSamples = 884 (FieldBase.py:71-72,127) -- on a field that carries an
     alpha mask like every trained model (FieldBase.py:261-267), here the one the repo's own ``updateAlphaMask((256,256,256))`` (main.py:330-331)
     builds from the seeded field.  Full 800x800 frame at the module's default level: size-independent properties, the mask's effect, and a
-    strided check against the oracle marching the same 884 steps through the same mask."""
+    strided check against the oracle marching the same 884 steps through the same mask.  InfoInv: the same call in InfoInv/main.py (renderer with
+    N_samples=-1; its mask from ``updateAlphaMask(reso_mask, infoinv=infoinv)``, InfoInv/main.py:325)."""
     from ngf_amd import synth
     from ngf_amd.fieldbase import renderer
-    g, params, step = big_case("triplane", preset)
+    g, params, step = big_case(model, preset)
     g["gauge_on"] = np.array(1)
+    tri = model == "triplane"
+    kw = {"iteration": 30001} if tri else {"infoinv": True}
     rays_np = synth.lookat_rays(800, 800)
     rays = torch.from_numpy(rays_np).cuda()
-    f = field_for_case(g, params, None, bake=True, bake_color=True)
+    f = field_for_case(g, params, None, bake=True, bake_color=True) if tri else field_for_case(g, params, None)
     assert f.nSamples == 884
-    f.updateAlphaMask((256, 256, 256))
+    f.updateAlphaMask((256, 256, 256), **({} if tri else {"infoinv": True}))
     vol = f.alphaMask.alpha_volume
     occ = float(vol.mean())
     assert 0.0 < occ <= 1.0
-    rgb, depth = renderer(rays, f, chunk=4096, N_samples=-1, white_bg=True, device="cuda")
+    rgb, depth = renderer(rays, f, chunk=4096, N_samples=-1, white_bg=True, device="cuda", **({} if tri else kw))
     with torch.no_grad():
-        f(rays, N_samples=-1, white_bg=True, iteration=30001, collect_stats=True)
+        f(rays, N_samples=-1, white_bg=True, collect_stats=True, **kw)
     st = f.last_stats.cpu().numpy()
     assert st[3] == 640000 and st[1] <= st[0] <= 640000 * 884 and st[1] > 0
     assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(depth).all()) and float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0
     # rays are independent, whatever tile / launch they are in: the reference's own 4096-ray chunks give the same bits
     for c0 in (0, 4096 * 77, 640000 - 4096):
-        sub = f(rays[c0:c0 + 4096], N_samples=-1, white_bg=True, iteration=30001)
+        sub = f(rays[c0:c0 + 4096], N_samples=-1, white_bg=True, **kw)
         assert torch.equal(sub["rgb_map"], rgb[c0:c0 + 4096]) and torch.equal(sub["depth_map"], depth[c0:c0 + 4096])
     idx = torch.arange(0, 640000, 97, device="cuda")
-    sub = f(rays[idx], N_samples=-1, white_bg=True, iteration=30001)
+    sub = f(rays[idx], N_samples=-1, white_bg=True, **kw)
     assert torch.equal(sub["rgb_map"], rgb[idx]) and torch.equal(sub["depth_map"], depth[idx])
     # strided oracle check: the same 884 steps, the same packbits mask
     mask = (f.alphaMask.packed_bits(), tuple(int(v) for v in vol.shape[-3:]), f.alphaMask.aabb.cpu().numpy())
@@ -726,7 +729,7 @@ def test_full_frame_at_the_references_eval_shape(preset):
     # cell that matters) nearly the same picture
     f.alphaMask = None
     f.invalidate()
-    nomask = f(rays[idx], N_samples=-1, white_bg=True, iteration=30001, collect_stats=True)
+    nomask = f(rays[idx], N_samples=-1, white_bg=True, collect_stats=True, **kw)
     assert float((nomask["rgb_map"] - rgb[idx]).abs().max()) < 2e-2
     f.release()
 
