@@ -134,6 +134,7 @@ struct ngf_field {
     float *tex[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // dens[3], app[3], gau[3]
     float *blob = nullptr;
     float *basis_pack = nullptr;
+    float *w1p_tmp = nullptr;                 // create only: W1' = W1[:, :F] . basis folded on the device (freed before create returns; here so that an error exit frees it)
     uint8_t *mask = nullptr;
     unsigned int *counters = nullptr;
     mutable std::atomic<unsigned> next_counter{0};
@@ -173,19 +174,52 @@ __global__ void bake_density_kernel(const float *__restrict__ src, int H, int W,
 }
 
 // rgb_decoder layer 1 (pre-composed with basis) applied per texel: dst[(y,x)][j] = sum_c wp[j][c] * src[c0+c][y][x]
-// (fp64 accumulate); wp is [64][nc] with rows already in accumulator order (MlpLayout16Baked).
-__global__ void bake_color_kernel(const float *__restrict__ src, int H, int W, int c0, int nc, const float *__restrict__ wp,
-                                  float *__restrict__ dst)
+// (fp64 accumulate); wp = this plane's nc (<= 48) columns of W1' [64][ldw] (fold_w1_basis_kernel); channel n of a baked texel = unit n.
+// Round 5: a workgroup takes 64 consecutive padded texels (one per lane: every channel's read is one 256-byte run of the plane), wave w the outputs
+// 16 w .. 16 w + 15 -- sixteen independent fp64 chains per lane, wp as doubles in LDS (uniform reads: broadcasts).  12 us per 256^2 plane instead of 375
+// (one thread per output: 48 serial loads of one address per wave).  Same sums: a product of two floats is exact in fp64, so every partial sum is
+// rounded where the one-thread-per-output loop rounded it -- bit-identical planes.
+__global__ void __launch_bounds__(256) bake_color_kernel(const float *__restrict__ src, int H, int W, int c0, int nc, const float *__restrict__ wp, int ldw,
+                                                         float *__restrict__ dst)
 {
-    const size_t total = (size_t)(H + 2) * (W + 2) * 64;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(i & 63);
-        const size_t tx = i >> 6;
+    __shared__ double s_wp[64 * 48];
+    for (int i = threadIdx.x; i < 64 * nc; i += 256) s_wp[i] = (double)wp[(size_t)(i / nc) * ldw + i % nc];      // unit i / nc, channel i % nc of this plane's columns of W1'
+    __syncthreads();
+    const size_t texels = (size_t)(H + 2) * (W + 2), plane = (size_t)H * W;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const double *wr = s_wp + (size_t)(16 * w) * nc;
+    for (size_t t0 = (size_t)blockIdx.x * 64; t0 < texels; t0 += (size_t)gridDim.x * 64) {
+        const size_t tx = t0 + lane;
+        if (tx >= texels) continue;
         const int x = (int)(tx % (W + 2)), y = (int)(tx / (W + 2));
-        double v = 0.0;
-        if (x >= 1 && x <= W && y >= 1 && y <= H)
-            for (int c = 0; c < nc; ++c) v += (double)wp[j * nc + c] * (double)src[((size_t)(c0 + c) * H + (y - 1)) * W + (x - 1)];
-        dst[i] = (float)v;
+        double acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.0;
+        if (x >= 1 && x <= W && y >= 1 && y <= H) {
+            const float *sp = src + ((size_t)c0 * H + (y - 1)) * W + (x - 1);
+            for (int c = 0; c < nc; ++c) {
+                const double v = (double)sp[(size_t)c * plane];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] += wr[k * nc + c] * v;
+            }
+        }
+        f32x4 *o = reinterpret_cast<f32x4 *>(dst + tx * 64 + 16 * w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = f32x4{(float)acc[4 * q], (float)acc[4 * q + 1], (float)acc[4 * q + 2], (float)acc[4 * q + 3]};
+    }
+}
+
+// W1' = W1[:, :F] . basis, [64][F], fp64 accumulate with j ascending, rounded to fp32 once -- what every image builder below places (they used to fold
+// on the host: 1.3 M (TriPlane) / 3 M (InfoInv) fp64 multiply-adds of one thread, 0.5 / 1.2 ms of every create; the same sums to the bit: a product of
+// two floats is exact in fp64, one rounding per addition, -ffp-contract=off on both sides anyway).  Round 5.
+__global__ void __launch_bounds__(256) fold_w1_basis_kernel(const float *__restrict__ w1, const float *__restrict__ basis, int F, float *__restrict__ w1p)
+{
+    const int IN = F + 15, total = 64 * F;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int k = i % F, n = i / F;                       // lanes on consecutive k: basis rows are read in runs
+        double s = 0.0;
+        for (int j = 0; j < F; ++j) s += (double)w1[(size_t)n * IN + j] * (double)basis[(size_t)j * F + k];
+        w1p[i] = (float)s;
     }
 }
 
@@ -257,7 +291,7 @@ static void split3(float x, uint16_t out[3])
 
 // LDS image of ngf_shade_bf16.hpp: A fragments [mt][k-block][part][lane][8 bf16]; lane (i, kq), element e of k-block kb holds the
 // weight of output unit mt*16 + i for the (kb*8 + e)-th input that lane quarter kq supplies
-static void build_rgb_image_bf16(int F, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
+static void build_rgb_image_bf16(int F, const std::vector<float> &w1p, const std::vector<float> &w1, const std::vector<float> &b1,
                                  const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3, const std::vector<float> &b3,
                                  float *img)
 {
@@ -265,11 +299,7 @@ static void build_rgb_image_bf16(int F, const std::vector<float> &basis, const s
     const int IN = F + 15, APPc = F / 3;
     std::vector<double> w1f((size_t)64 * (F + 16), 0.0);       // W1' = [W1[:, :F] . basis | W1[:, F:F+15] | 0]
     for (int n = 0; n < 64; ++n) {
-        for (int k = 0; k < F; ++k) {
-            double s = 0.0;
-            for (int j = 0; j < F; ++j) s += (double)w1[(size_t)n * IN + j] * (double)basis[(size_t)j * F + k];
-            w1f[(size_t)n * (F + 16) + k] = s;
-        }
+        for (int k = 0; k < F; ++k) w1f[(size_t)n * (F + 16) + k] = (double)w1p[(size_t)n * F + k];      // W1[:, :F] . basis, folded on the device (fold_w1_basis_kernel)
         for (int k = 0; k < 15; ++k) w1f[(size_t)n * (F + 16) + F + k] = w1[(size_t)n * IN + F + k];
     }
     auto hidden = [](int mt, int r, int kq) { return mt * 16 + 4 * kq + r; };
@@ -337,7 +367,7 @@ static void rebuild_baked_image_bf16(const std::vector<float> &baked, const std:
 // k-block kb holds the weight of unit mt*16 + i for the lane quarter's (8 kb + e)-th input: 18 channels of each plane in the PACKED
 // channel order (infoinv_split_channel), its 4 view entries, 6 zero pads.  Layer 1: hi / mid parts in the LDS image
 // [mt][kb][2][lane][8 bf16], lo parts in the streamed image [kb][mt][lane][8 bf16]; layer 2: [mt][kb][3][lane][8 bf16].
-static void build_rgb_image_bf16_ii(int F, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
+static void build_rgb_image_bf16_ii(int F, const std::vector<float> &w1p, const std::vector<float> &w1, const std::vector<float> &b1,
                                     const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3, const std::vector<float> &b3,
                                     float *img, std::vector<float> &lopack)
 {
@@ -345,11 +375,7 @@ static void build_rgb_image_bf16_ii(int F, const std::vector<float> &basis, cons
     const int IN = F + 15, APPc = F / 3;
     std::vector<double> w1f((size_t)64 * (F + 16), 0.0);       // W1' = [W1[:, :F] . basis | W1[:, F:F+15] | 0]
     for (int n = 0; n < 64; ++n) {
-        for (int k = 0; k < F; ++k) {
-            double s = 0.0;
-            for (int j = 0; j < F; ++j) s += (double)w1[(size_t)n * IN + j] * (double)basis[(size_t)j * F + k];
-            w1f[(size_t)n * (F + 16) + k] = s;
-        }
+        for (int k = 0; k < F; ++k) w1f[(size_t)n * (F + 16) + k] = (double)w1p[(size_t)n * F + k];      // W1[:, :F] . basis, folded on the device (fold_w1_basis_kernel)
         for (int k = 0; k < 15; ++k) w1f[(size_t)n * (F + 16) + F + k] = w1[(size_t)n * IN + F + k];
     }
     auto hidden = [](int mt, int r, int kq) { return mt * 16 + 4 * kq + r; };
@@ -393,7 +419,7 @@ static void build_rgb_image_bf16_ii(int F, const std::vector<float> &basis, cons
 
 // InfoInv default (ngf_infoinv.hpp mlp_pass16_ii): MlpLayout16<72>; k-step t of lane quarter kq is its t-th input -- 18 channels of each
 // plane in the PACKED channel order (infoinv_split_channel), then its 4 view entries
-static void build_rgb_image16_ii(int F, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
+static void build_rgb_image16_ii(int F, const std::vector<float> &w1p, const std::vector<float> &w1, const std::vector<float> &b1,
                                  const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3, const std::vector<float> &b3,
                                  float *img)
 {
@@ -401,11 +427,7 @@ static void build_rgb_image16_ii(int F, const std::vector<float> &basis, const s
     const int IN = F + 15, APPc = F / 3;
     std::vector<double> w1f((size_t)64 * (F + 16), 0.0);       // W1' = [W1[:, :F] . basis | W1[:, F:F+15] | 0]
     for (int n = 0; n < 64; ++n) {
-        for (int k = 0; k < F; ++k) {
-            double s = 0.0;
-            for (int j = 0; j < F; ++j) s += (double)w1[(size_t)n * IN + j] * (double)basis[(size_t)j * F + k];
-            w1f[(size_t)n * (F + 16) + k] = s;
-        }
+        for (int k = 0; k < F; ++k) w1f[(size_t)n * (F + 16) + k] = (double)w1p[(size_t)n * F + k];      // W1[:, :F] . basis, folded on the device (fold_w1_basis_kernel)
         for (int k = 0; k < 15; ++k) w1f[(size_t)n * (F + 16) + F + k] = w1[(size_t)n * IN + F + k];
     }
     auto hidden = [](int mt, int r, int kq) { return mt * 16 + 4 * kq + r; };
@@ -473,18 +495,14 @@ static void build_rgb_image16_nofold(int F, const std::vector<float> &basis, con
             }
 }
 
-static void build_rgb_image16(int F, bool bake, const std::vector<float> &basis, const std::vector<float> &w1, const std::vector<float> &b1,
+static void build_rgb_image16(int F, bool bake, const std::vector<float> &w1p, const std::vector<float> &w1, const std::vector<float> &b1,
                               const std::vector<float> &w2, const std::vector<float> &b2, const std::vector<float> &w3,
-                              const std::vector<float> &b3, float *img, std::vector<float> &wp)
+                              const std::vector<float> &b3, float *img)
 {
     const int IN = F + 15, APPc = F / 3, QCH = APPc / 4, KT = 3 * QCH + 4;
     std::vector<double> w1f((size_t)64 * (F + 16), 0.0);       // W1' = [W1[:, :F] . basis | W1[:, F:F+15] | 0]
     for (int n = 0; n < 64; ++n) {
-        for (int k = 0; k < F; ++k) {
-            double s = 0.0;
-            for (int j = 0; j < F; ++j) s += (double)w1[(size_t)n * IN + j] * (double)basis[(size_t)j * F + k];
-            w1f[(size_t)n * (F + 16) + k] = s;
-        }
+        for (int k = 0; k < F; ++k) w1f[(size_t)n * (F + 16) + k] = (double)w1p[(size_t)n * F + k];      // W1[:, :F] . basis, folded on the device (fold_w1_basis_kernel)
         for (int k = 0; k < 15; ++k) w1f[(size_t)n * (F + 16) + F + k] = w1[(size_t)n * IN + F + k];
     }
     auto hidden = [](int mt, int r, int kq) { return mt * 16 + 4 * kq + r; };
@@ -492,13 +510,6 @@ static void build_rgb_image16(int F, bool bake, const std::vector<float> &basis,
     if (bake) {
         using L = MlpLayout16Baked;
         oW1 = L::W1V; oW2 = L::W2; oB1 = L::B1; oB2 = L::B2; oW3 = L::W3; oB3 = L::B3;
-        wp.assign((size_t)3 * 64 * APPc, 0.0f);
-        for (int kq = 0; kq < 4; ++kq)
-            for (int mt = 0; mt < 4; ++mt)
-                for (int r = 0; r < 4; ++r)
-                    for (int kk = 0; kk < F; ++kk)
-                        wp[((size_t)(kk / APPc) * 64 + hidden(mt, r, kq)) * APPc + (kk % APPc)] =
-                            (float)w1f[(size_t)hidden(mt, r, kq) * (F + 16) + kk];
         for (int mt = 0; mt < 4; ++mt)
             for (int j = 0; j < 4; ++j)
                 for (int l = 0; l < 64; ++l)
@@ -551,6 +562,7 @@ extern "C" int ngf_field_destroy(ngf_field *f)
         if (t) (void)hipFree(t);
     if (f->blob) (void)hipFree(f->blob);
     if (f->basis_pack) (void)hipFree(f->basis_pack);
+    if (f->w1p_tmp) (void)hipFree(f->w1p_tmp);
     if (f->mask) (void)hipFree(f->mask);
     if (f->counters) (void)hipFree(f->counters);
     delete f;
@@ -596,8 +608,17 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     const bool split_l3 = split_bf16 && bake_c;        // round 5: level 3, layer 2 as split bf16 products (layer 1 is folded into the planes there)
 
     // MLP weights: to the host once, pre-compose, permute, back to HBM as one LDS image
-    std::vector<float> basis, w1, b1, w2, b2, w3, b3;
-    if ((rc = d2h(basis, d->basis, (size_t)F * F, st)) || (rc = d2h(w1, d->w1, (size_t)64 * (F + 15), st)) ||
+    // W1' = W1[:, :F] . basis comes folded from the device (fold_w1_basis_kernel) for every formulation that pre-composes it; level 0 streams basis itself
+    std::vector<float> basis, w1p, w1, b1, w2, b2, w3, b3;
+    if (!d->basis || !d->w1) return bail(fail(NGF_E_ARG, "missing weight tensor"));
+    if (no_fold) {
+        if ((rc = d2h(basis, d->basis, (size_t)F * F, st))) return bail(rc);
+    } else {
+        if (hipMalloc((void **)&f->w1p_tmp, (size_t)64 * F * sizeof(float)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(W1') failed"));
+        fold_w1_basis_kernel<<<(64 * F + 255) / 256, 256, 0, st>>>(d->w1, d->basis, F, f->w1p_tmp);
+        if ((rc = d2h(w1p, f->w1p_tmp, (size_t)64 * F, st))) return bail(rc);
+    }
+    if ((rc = d2h(w1, d->w1, (size_t)64 * (F + 15), st)) ||
         (rc = d2h(b1, d->b1, 64, st)) || (rc = d2h(w2, d->w2, 64 * 64, st)) || (rc = d2h(b2, d->b2, 64, st)) ||
         (rc = d2h(w3, d->w3, 3 * 64, st)) || (rc = d2h(b3, d->b3, 3, st)))
         return bail(rc);
@@ -614,30 +635,22 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
 
     const int rgb_floats = tri ? (split_l3 ? MlpLayout16BakedBf16::TOTAL : split_bf16 ? MlpLayoutBf16::TOTAL : no_fold ? MlpLayout16NoFold::TOTAL : (bake_c ? MlpLayout16Baked::TOTAL : MlpLayout16<48>::TOTAL)) : (split_ii ? MlpLayoutBf16II::TOTAL : MlpLayout16<72>::TOTAL);
     const int dens_floats = tri ? 0 : (split_ii ? InfoInvDensLayoutBf16::TOTAL : InfoInvDensLayout::TOTAL);
-    std::vector<float> img((size_t)rgb_floats + dens_floats, 0.0f), wp;
+    std::vector<float> img((size_t)rgb_floats + dens_floats, 0.0f);
     std::vector<float> bpack;
     if (split_l3) {
         std::vector<float> baked((size_t)MlpLayout16Baked::TOTAL, 0.0f);
-        build_rgb_image16(F, true, basis, w1, b1, w2, b2, w3, b3, baked.data(), wp);
+        build_rgb_image16(F, true, w1p, w1, b1, w2, b2, w3, b3, baked.data());
         rebuild_baked_image_bf16(baked, w2, img.data());
-    } else if (split_bf16) build_rgb_image_bf16(F, basis, w1, b1, w2, b2, w3, b3, img.data());
+    } else if (split_bf16) build_rgb_image_bf16(F, w1p, w1, b1, w2, b2, w3, b3, img.data());
     else if (no_fold) build_rgb_image16_nofold(F, basis, w1, b1, w2, b2, w3, b3, img.data(), bpack);
-    else if (tri) build_rgb_image16(F, bake_c, basis, w1, b1, w2, b2, w3, b3, img.data(), wp);
-    else if (split_ii) build_rgb_image_bf16_ii(F, basis, w1, b1, w2, b2, w3, b3, img.data(), bpack);
-    else build_rgb_image16_ii(F, basis, w1, b1, w2, b2, w3, b3, img.data());
+    else if (tri) build_rgb_image16(F, bake_c, w1p, w1, b1, w2, b2, w3, b3, img.data());
+    else if (split_ii) build_rgb_image_bf16_ii(F, w1p, w1, b1, w2, b2, w3, b3, img.data(), bpack);
+    else build_rgb_image16_ii(F, w1p, w1, b1, w2, b2, w3, b3, img.data());
     if (!tri && split_ii) build_infoinv_density_image_bf16(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
     else if (!tri) build_infoinv_density_image(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
     if ((rc = alloc_f(&f->blob, img.size(), f, st))) return bail(rc);
     if (hipMemcpyAsync(f->blob, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess)
         return bail(fail(NGF_E_HIP, "uploading the MLP image failed"));
-    float *wp_dev = nullptr;
-    if (bake_c) {
-        if (hipMalloc((void **)&wp_dev, wp.size() * sizeof(float)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(wp) failed"));
-        if (hipMemcpyAsync(wp_dev, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) {
-            (void)hipFree(wp_dev);
-            return bail(fail(NGF_E_HIP, "uploading the pre-composed layer-1 matrix failed"));
-        }
-    }
     A.blob = f->blob;
     A.blob_floats = (int)img.size();
     if (no_fold || split_ii) {        // the matrix the shade streams from L2 (level-0 basis / lo parts of InfoInv's split layer 1)
@@ -658,31 +671,24 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
         const size_t texels = (size_t)(H + 2) * (W + 2);
         const int dc = bake ? 1 : d->dens_dim;
         if (texels * (size_t)(app_c > 96 ? app_c : 96) * sizeof(float) >= ((size_t)1 << 32)) {     // the kernels address a texture with 32-bit byte offsets (tex_at)
-            if (wp_dev) (void)hipFree(wp_dev);
             return bail(fail(NGF_E_UNSUPPORTED, "plane %d: %d x %d texels do not fit a 4 GiB packed texture", p, H, W));
         }
-        if ((rc = alloc_f(&f->tex[p], texels * dc, f, st)) || (rc = alloc_f(&f->tex[3 + p], texels * app_c, f, st))) {
-            if (wp_dev) (void)hipFree(wp_dev);
-            return bail(rc);
-        }
+        if ((rc = alloc_f(&f->tex[p], texels * dc, f, st)) || (rc = alloc_f(&f->tex[3 + p], texels * app_c, f, st))) return bail(rc);
         if (bake) bake_density_kernel<<<1024, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, d->dens_w1 + p * d->dens_dim, f->tex[p]);
         else pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, 0, d->dens_dim, f->tex[p]);
-        if (bake_c) bake_color_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, wp_dev + (size_t)p * 64 * f->app, f->tex[3 + p]);
+        if (bake_c) bake_color_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, f->w1p_tmp + (size_t)p * f->app, F, f->tex[3 + p]);
         else pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, f->tex[3 + p], tri ? 0 : 1);
         A.dens[p] = Tex{f->tex[p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
         A.app[p] = Tex{f->tex[3 + p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
         if (tri) {
             const int gh = d->gauge_h[p], gw = d->gauge_w[p];
-            if ((rc = alloc_f(&f->tex[6 + p], (size_t)(gh + 2) * (gw + 2) * 2, f, st))) {
-                if (wp_dev) (void)hipFree(wp_dev);
-                return bail(rc);
-            }
+            if ((rc = alloc_f(&f->tex[6 + p], (size_t)(gh + 2) * (gw + 2) * 2, f, st))) return bail(rc);
             pack_plane_kernel<<<256, 256, 0, st>>>(d->gauge[p], gh, gw, 0, 2, f->tex[6 + p]);
             A.gau[p] = Tex{f->tex[6 + p], gw, gh, gw + 2, (float)(gw - 1), (float)(gh - 1)};
         }
     }
     const bool launch_ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
-    if (wp_dev) (void)hipFree(wp_dev);
+    if (f->w1p_tmp) { (void)hipFree(f->w1p_tmp); f->w1p_tmp = nullptr; }
     if (!launch_ok) return bail(fail(NGF_E_HIP, "packing kernels failed"));
 
     for (int k = 0; k < 3; ++k) {
