@@ -355,8 +355,12 @@ const char *ngf_last_error(void);
 int ngf_abi_version(void);
 /* sizeof(ngf_field_desc) as compiled into the library (binding self-check) */
 int ngf_sizeof_field_desc(void);
-/* bytes of HBM the handle owns (packed textures + MLP image) */
+/* bytes of HBM the handle owns (packed textures + MLP image + mask + tile-queue heads) */
 int64_t ngf_field_bytes(const ngf_field *f);
+/* ngf_field_destroy parks a handle's device buffers in a per-process pool (exact-size reuse by the next ngf_field_create on the same device, at most
+ * 64 buffers / 4 GiB): a handle is rebuilt after every parameter change of an eval field, with the same shapes, and hipFree / hipMalloc cost more
+ * than the rebuild's own work.  This call returns the parked buffers to the driver (e.g. before another framework needs the memory). */
+int ngf_pool_trim(void);
 
 #ifdef __cplusplus
 }

@@ -141,6 +141,7 @@ struct ngf_field {
     RenderArgs proto;
     int64_t bytes = 0;
     int num_cus = 256;
+    std::vector<std::pair<void *, size_t>> allocs;      // every device buffer of the handle (pointer, bytes): ngf_field_destroy hands them to the pool
 };
 
 // ---- packing kernels -----------------------------------------------------------------------------
@@ -542,10 +543,76 @@ static void build_rgb_image16(int F, bool bake, const std::vector<float> &w1p, c
 }
 
 
+// ---- buffer pool of the field handles (round 5) ---------------------------------------------------------------------------------
+// A handle is rebuilt after every parameter change of an eval field (Base.handle()): same shapes, so the same ten buffer sizes.  hipFree
+// synchronises the device and cost 0.7 ms per destroy -- more than the create's own work (0.5 ms) -- and hipMalloc is not free either.
+// Destroyed handles therefore park their buffers here (exact-size reuse, per device; at most kPoolEntries buffers / kPoolBytes; the rest
+// goes back to the driver), after ONE hipDeviceSynchronize in ngf_field_destroy (what the first hipFree used to do implicitly: kernels
+// of any stream may still read the buffers).  ngf_pool_trim() returns everything to the driver.
+struct PoolEntry { void *p; size_t bytes; int dev; };
+static std::mutex g_pool_mu;
+static std::vector<PoolEntry> g_pool;
+static size_t g_pool_bytes = 0;
+constexpr size_t kPoolEntries = 64, kPoolBytes = (size_t)4 << 30;
+
+static hipError_t pool_malloc(void **p, size_t bytes)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i].bytes == bytes && g_pool[i].dev == dev) {
+                *p = g_pool[i].p;
+                g_pool_bytes -= bytes;
+                g_pool[i] = g_pool.back();
+                g_pool.pop_back();
+                return hipSuccess;
+            }
+    }
+    return hipMalloc(p, bytes);
+}
+
+static void pool_free(void *p, size_t bytes)          // the caller has made sure that nothing on the device still uses p
+{
+    if (!p) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_pool.size() < kPoolEntries && g_pool_bytes + bytes <= kPoolBytes) {
+            g_pool.push_back(PoolEntry{p, bytes, dev});
+            g_pool_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+extern "C" int ngf_pool_trim(void)
+{
+    std::vector<PoolEntry> out;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        out.swap(g_pool);
+        g_pool_bytes = 0;
+    }
+    for (const PoolEntry &e : out) (void)hipFree(e.p);
+    return NGF_OK;
+}
+
+static int field_alloc(ngf_field *f, void **p, size_t bytes, const char *what)
+{
+    if (pool_malloc(p, bytes) != hipSuccess) { *p = nullptr; return fail(NGF_E_HIP, "hipMalloc(%s, %zu bytes) failed", what, bytes); }
+    f->allocs.emplace_back(*p, bytes);
+    f->bytes += (int64_t)bytes;
+    return NGF_OK;
+}
+
 static int alloc_f(float **p, size_t n, ngf_field *f, hipStream_t st)
 {
-    HIP_TRY(hipMalloc((void **)p, n * sizeof(float)));
-    f->bytes += (int64_t)(n * sizeof(float));
+    int rc = field_alloc(f, (void **)p, n * sizeof(float), "texture / image");
+    if (rc) return rc;
     return poison_alloc(*p, n * sizeof(float), st);
 }
 
@@ -558,13 +625,8 @@ extern "C" int64_t ngf_field_bytes(const ngf_field *f) { return f ? f->bytes : 0
 extern "C" int ngf_field_destroy(ngf_field *f)
 {
     if (!f) return NGF_OK;
-    for (float *t : f->tex)
-        if (t) (void)hipFree(t);
-    if (f->blob) (void)hipFree(f->blob);
-    if (f->basis_pack) (void)hipFree(f->basis_pack);
-    if (f->w1p_tmp) (void)hipFree(f->w1p_tmp);
-    if (f->mask) (void)hipFree(f->mask);
-    if (f->counters) (void)hipFree(f->counters);
+    if (!f->allocs.empty()) (void)hipDeviceSynchronize();        // renders of any stream may still read the buffers (hipFree used to wait for them)
+    for (const auto &a : f->allocs) pool_free(a.first, a.second);
     delete f;
     return NGF_OK;
 }
@@ -583,6 +645,12 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     }
     if (!(d->step > 0.0f)) return fail(NGF_E_ARG, "step must be > 0");
     hipStream_t st = (hipStream_t)hip_stream;
+#ifdef NGF_EXP_CREATE_TIMES                    // experiment build (profiles/exp_create_phases.py): the phases of a create on stderr
+    auto tc0 = std::chrono::steady_clock::now();
+#define NGF_CT(label) do { auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "create %-28s %8.1f us\n", label, std::chrono::duration<double, std::micro>(t1 - tc0).count()); tc0 = t1; } while (0)
+#else
+#define NGF_CT(label) do { } while (0)
+#endif
     ngf_field *f = new (std::nothrow) ngf_field();
     if (!f) return fail(NGF_E_HIP, "out of host memory");
     f->model = d->model; f->flags = d->flags; f->plane_c = d->plane_c; f->dens_dim = d->dens_dim;
@@ -614,7 +682,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     if (no_fold) {
         if ((rc = d2h(basis, d->basis, (size_t)F * F, st))) return bail(rc);
     } else {
-        if (hipMalloc((void **)&f->w1p_tmp, (size_t)64 * F * sizeof(float)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(W1') failed"));
+        if ((rc = field_alloc(f, (void **)&f->w1p_tmp, (size_t)64 * F * sizeof(float), "W1'"))) return bail(rc);
         fold_w1_basis_kernel<<<(64 * F + 255) / 256, 256, 0, st>>>(d->w1, d->basis, F, f->w1p_tmp);
         if ((rc = d2h(w1p, f->w1p_tmp, (size_t)64 * F, st))) return bail(rc);
     }
@@ -632,6 +700,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
             return bail(rc);
     }
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "hipStreamSynchronize failed in ngf_field_create"));
+    NGF_CT("fold kernel + D2H + sync");
 
     const int rgb_floats = tri ? (split_l3 ? MlpLayout16BakedBf16::TOTAL : split_bf16 ? MlpLayoutBf16::TOTAL : no_fold ? MlpLayout16NoFold::TOTAL : (bake_c ? MlpLayout16Baked::TOTAL : MlpLayout16<48>::TOTAL)) : (split_ii ? MlpLayoutBf16II::TOTAL : MlpLayout16<72>::TOTAL);
     const int dens_floats = tri ? 0 : (split_ii ? InfoInvDensLayoutBf16::TOTAL : InfoInvDensLayout::TOTAL);
@@ -648,6 +717,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     else build_rgb_image16_ii(F, w1p, w1, b1, w2, b2, w3, b3, img.data());
     if (!tri && split_ii) build_infoinv_density_image_bf16(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
     else if (!tri) build_infoinv_density_image(dw1, db1, dw2, db2, dw3, db3, img.data() + rgb_floats);
+    NGF_CT("host images");
     if ((rc = alloc_f(&f->blob, img.size(), f, st))) return bail(rc);
     if (hipMemcpyAsync(f->blob, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess)
         return bail(fail(NGF_E_HIP, "uploading the MLP image failed"));
@@ -664,6 +734,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
         A.bd = db1[0];
     }
 
+    NGF_CT("image upload");
     // textures: channel-last, zero-bordered
     const int app_c = bake_c ? 64 : f->app;
     for (int p = 0; p < 3; ++p) {
@@ -687,8 +758,10 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
             A.gau[p] = Tex{f->tex[6 + p], gw, gh, gw + 2, (float)(gw - 1), (float)(gh - 1)};
         }
     }
+    NGF_CT("texture allocs + launches");
     const bool launch_ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
-    if (f->w1p_tmp) { (void)hipFree(f->w1p_tmp); f->w1p_tmp = nullptr; }
+    NGF_CT("sync (pack / bake kernels)");
+    f->w1p_tmp = nullptr;          // (the buffer stays in f->allocs: it goes to the pool with the handle -- the next create of these shapes takes it from there)
     if (!launch_ok) return bail(fail(NGF_E_HIP, "packing kernels failed"));
 
     for (int k = 0; k < 3; ++k) {
@@ -699,8 +772,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     A.near_ = d->near_; A.far_ = d->far_; A.step = d->step; A.dscale = d->distance_scale; A.thr = d->weight_thres;
     if (d->mask_bits) {
         const size_t nbytes = ((size_t)d->mask_d * d->mask_h * d->mask_w + 7) / 8;
-        if (hipMalloc((void **)&f->mask, nbytes) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(mask) failed"));
-        f->bytes += (int64_t)nbytes;
+        if ((rc = field_alloc(f, (void **)&f->mask, nbytes, "mask"))) return bail(rc);
         if (hipMemcpyAsync(f->mask, d->mask_bits, nbytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
             return bail(fail(NGF_E_HIP, "copying the alpha mask failed"));
         A.mask.bits = f->mask;
@@ -710,9 +782,10 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
             A.mask.inv[k] = 1.0f / (d->mask_aabb[3 + k] - d->mask_aabb[k]) * 2;   // invgridSize (FieldBase.py:29)
         }
     }
-    if (hipMalloc((void **)&f->counters, (size_t)kCounters * kQueueHeads * sizeof(unsigned)) != hipSuccess) return bail(fail(NGF_E_HIP, "hipMalloc(counters) failed"));
+    if ((rc = field_alloc(f, (void **)&f->counters, (size_t)kCounters * kQueueHeads * sizeof(unsigned), "counters"))) return bail(rc);
     if (hipMemsetAsync(f->counters, 0, (size_t)kCounters * kQueueHeads * sizeof(unsigned), st) != hipSuccess) return bail(fail(NGF_E_HIP, "zeroing the queue heads failed"));
     if (hipStreamSynchronize(st) != hipSuccess) return bail(fail(NGF_E_HIP, "packing failed: %s", hipGetErrorString(hipGetLastError())));
+    NGF_CT("mask + counters + sync");
     *out = f;
     return NGF_OK;
 }

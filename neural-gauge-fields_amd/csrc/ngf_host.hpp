@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>

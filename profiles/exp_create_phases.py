@@ -19,3 +19,13 @@ for k in range(5):
     sys.stderr.write(f"--- rebuild {k}\n"); sys.stderr.flush()
     f.handle(); torch.cuda.synchronize()
     sys.stderr.write(f"total {1e3 * (time.perf_counter() - t0):.2f} ms (python side included)\n")
+# the Python side of a rebuild: the key, the descriptor, the create call, the destroy of the previous handle
+import ctypes as C
+L = _lib.lib()
+for k in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    key = f._param_key(); t1 = time.perf_counter()
+    old, f._handle, f._handle_key = f._handle, None, None
+    f.handle(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    L.ngf_field_destroy(old); torch.cuda.synchronize(); t3 = time.perf_counter()
+    sys.stderr.write(f"python: _param_key {1e6 * (t1 - t0):.0f} us, descriptor + create {1e6 * (t2 - t1):.0f} us, destroy of the old handle {1e6 * (t3 - t2):.0f} us\n")
