@@ -134,6 +134,7 @@ struct ngf_field {
     float *tex[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // dens[3], app[3], gau[3]
     float *blob = nullptr;
     float *basis_pack = nullptr;
+    double *w1pd_tmp = nullptr;               // create only: the same values as doubles (bake_color_kernel's weights)
     float *w1p_tmp = nullptr;                 // create only: W1' = W1[:, :F] . basis folded on the device (freed before create returns; here so that an error exit frees it)
     uint8_t *mask = nullptr;
     unsigned int *counters = nullptr;
@@ -175,52 +176,55 @@ __global__ void bake_density_kernel(const float *__restrict__ src, int H, int W,
 }
 
 // rgb_decoder layer 1 (pre-composed with basis) applied per texel: dst[(y,x)][j] = sum_c wp[j][c] * src[c0+c][y][x]
-// (fp64 accumulate); wp = this plane's nc (<= 48) columns of W1' [64][ldw] (fold_w1_basis_kernel); channel n of a baked texel = unit n.
+// (fp64 accumulate); wp = this plane's nc (<= 48) columns of W1' [64][ldw], as doubles (fold_w1_basis_kernel's second output: the fp32-rounded values);
+// channel n of a baked texel = unit n.
 // Round 5: a workgroup takes 64 consecutive padded texels (one per lane: every channel's read is one 256-byte run of the plane), wave w the outputs
-// 16 w .. 16 w + 15 -- sixteen independent fp64 chains per lane, wp as doubles in LDS (uniform reads: broadcasts).  12 us per 256^2 plane instead of 375
-// (one thread per output: 48 serial loads of one address per wave).  Same sums: a product of two floats is exact in fp64, so every partial sum is
-// rounded where the one-thread-per-output loop rounded it -- bit-identical planes.
-__global__ void __launch_bounds__(256) bake_color_kernel(const float *__restrict__ src, int H, int W, int c0, int nc, const float *__restrict__ wp, int ldw,
+// 16 w .. 16 w + 15 -- sixteen independent fp64 chains per lane whose weights are wave-uniform (scalar loads, SGPR operands of v_fma_f64).  Round 4 had one
+// thread per output (48 serial loads of one address per wave): 375 us per 256^2 plane.  Same sums: a product of two floats is exact in fp64, so every
+// partial sum is rounded where the one-thread-per-output loop rounded it -- bit-identical planes.
+__global__ void __launch_bounds__(256) bake_color_kernel(const float *__restrict__ src, int H, int W, int c0, int nc, const double *__restrict__ wp, int ldw,
                                                          float *__restrict__ dst)
 {
-    __shared__ double s_wp[64 * 48];
-    for (int i = threadIdx.x; i < 64 * nc; i += 256) s_wp[i] = (double)wp[(size_t)(i / nc) * ldw + i % nc];      // unit i / nc, channel i % nc of this plane's columns of W1'
-    __syncthreads();
     const size_t texels = (size_t)(H + 2) * (W + 2), plane = (size_t)H * W;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const double *wr = s_wp + (size_t)(16 * w) * nc;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const double *wr = wp + (size_t)(16 * w) * ldw;            // wave-uniform
     for (size_t t0 = (size_t)blockIdx.x * 64; t0 < texels; t0 += (size_t)gridDim.x * 64) {
         const size_t tx = t0 + lane;
         if (tx >= texels) continue;
         const int x = (int)(tx % (W + 2)), y = (int)(tx / (W + 2));
+        const bool inside = x >= 1 && x <= W && y >= 1 && y <= H;
+        const float *sp = src + ((size_t)c0 * H + (inside ? y - 1 : 0)) * W + (inside ? x - 1 : 0);
         double acc[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = 0.0;
-        if (x >= 1 && x <= W && y >= 1 && y <= H) {
-            const float *sp = src + ((size_t)c0 * H + (y - 1)) * W + (x - 1);
-            for (int c = 0; c < nc; ++c) {
-                const double v = (double)sp[(size_t)c * plane];
+#pragma unroll 4
+        for (int c = 0; c < nc; ++c) {
+            const double v = (double)sp[(size_t)c * plane];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) acc[k] += wr[k * nc + c] * v;
-            }
+            for (int k = 0; k < 16; ++k) acc[k] += wr[(size_t)k * ldw + c] * v;
         }
         f32x4 *o = reinterpret_cast<f32x4 *>(dst + tx * 64 + 16 * w);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = f32x4{(float)acc[4 * q], (float)acc[4 * q + 1], (float)acc[4 * q + 2], (float)acc[4 * q + 3]};
+        for (int q = 0; q < 4; ++q)
+            o[q] = inside ? f32x4{(float)acc[4 * q], (float)acc[4 * q + 1], (float)acc[4 * q + 2], (float)acc[4 * q + 3]} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
 }
 
 // W1' = W1[:, :F] . basis, [64][F], fp64 accumulate with j ascending, rounded to fp32 once -- what every image builder below places (they used to fold
 // on the host: 1.3 M (TriPlane) / 3 M (InfoInv) fp64 multiply-adds of one thread, 0.5 / 1.2 ms of every create; the same sums to the bit: a product of
-// two floats is exact in fp64, one rounding per addition, -ffp-contract=off on both sides anyway).  Round 5.
-__global__ void __launch_bounds__(256) fold_w1_basis_kernel(const float *__restrict__ w1, const float *__restrict__ basis, int F, float *__restrict__ w1p)
+// two floats is exact in fp64, one rounding per addition, -ffp-contract=off on both sides anyway).  w1p_d (may be NULL): the same fp32 values as doubles,
+// what bake_color_kernel multiplies with.  Round 5.
+__global__ void __launch_bounds__(256) fold_w1_basis_kernel(const float *__restrict__ w1, const float *__restrict__ basis, int F, float *__restrict__ w1p,
+                                                            double *__restrict__ w1p_d)
 {
     const int IN = F + 15, total = 64 * F;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int k = i % F, n = i / F;                       // lanes on consecutive k: basis rows are read in runs
         double s = 0.0;
+#pragma unroll 8
         for (int j = 0; j < F; ++j) s += (double)w1[(size_t)n * IN + j] * (double)basis[(size_t)j * F + k];
         w1p[i] = (float)s;
+        if (w1p_d) w1p_d[i] = (double)(float)s;
     }
 }
 
@@ -683,7 +687,8 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
         if ((rc = d2h(basis, d->basis, (size_t)F * F, st))) return bail(rc);
     } else {
         if ((rc = field_alloc(f, (void **)&f->w1p_tmp, (size_t)64 * F * sizeof(float), "W1'"))) return bail(rc);
-        fold_w1_basis_kernel<<<(64 * F + 255) / 256, 256, 0, st>>>(d->w1, d->basis, F, f->w1p_tmp);
+        if (bake_c && (rc = field_alloc(f, (void **)&f->w1pd_tmp, (size_t)64 * F * sizeof(double), "W1' (fp64)"))) return bail(rc);
+        fold_w1_basis_kernel<<<(64 * F + 255) / 256, 256, 0, st>>>(d->w1, d->basis, F, f->w1p_tmp, f->w1pd_tmp);
         if ((rc = d2h(w1p, f->w1p_tmp, (size_t)64 * F, st))) return bail(rc);
     }
     if ((rc = d2h(w1, d->w1, (size_t)64 * (F + 15), st)) ||
@@ -747,7 +752,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
         if ((rc = alloc_f(&f->tex[p], texels * dc, f, st)) || (rc = alloc_f(&f->tex[3 + p], texels * app_c, f, st))) return bail(rc);
         if (bake) bake_density_kernel<<<1024, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, d->dens_w1 + p * d->dens_dim, f->tex[p]);
         else pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, 0, d->dens_dim, f->tex[p]);
-        if (bake_c) bake_color_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, f->w1p_tmp + (size_t)p * f->app, F, f->tex[3 + p]);
+        if (bake_c) bake_color_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, f->w1pd_tmp + (size_t)p * f->app, F, f->tex[3 + p]);
         else pack_plane_kernel<<<2048, 256, 0, st>>>(d->plane[p], H, W, d->dens_dim, f->app, f->tex[3 + p], tri ? 0 : 1);
         A.dens[p] = Tex{f->tex[p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
         A.app[p] = Tex{f->tex[3 + p], W, H, W + 2, (float)(W - 1), (float)(H - 1)};
@@ -761,7 +766,7 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     NGF_CT("texture allocs + launches");
     const bool launch_ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
     NGF_CT("sync (pack / bake kernels)");
-    f->w1p_tmp = nullptr;          // (the buffer stays in f->allocs: it goes to the pool with the handle -- the next create of these shapes takes it from there)
+    f->w1p_tmp = nullptr; f->w1pd_tmp = nullptr;          // (the buffers stay in f->allocs: it goes to the pool with the handle -- the next create of these shapes takes it from there)
     if (!launch_ok) return bail(fail(NGF_E_HIP, "packing kernels failed"));
 
     for (int k = 0; k < 3; ++k) {
