@@ -2,6 +2,7 @@
 """bench.py -- Mray/s of the TriPlane ray-march hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W           (N > 1 without a launcher: starts its own N ranks, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -307,6 +308,33 @@ def cpu_baseline(params, g, step, rays_np, budget_s, f, kw):
             "cpu_active_fraction": float(np.mean(act))}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch_command(n, argv, port):
+    """`python bench.py --gpus N ...` started WITHOUT a launcher (no WORLD_SIZE in the environment) re-executes itself as N ranks of one
+    node, one per GPU, exactly as the driver's own multi-GPU command line does; rank 0's JSON line is the job's last stdout line."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n)}", "--master-addr", "127.0.0.1",
+            "--master-port", str(int(port)), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def self_launch(n, argv):
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s) (torch.cuda.device_count()); nothing was launched")
+    env = dict(os.environ, NGF_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # RCCL across processes needs dmabuf IPC on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n, 1))))
+    cmd = self_launch_command(n, argv, free_port())
+    print("bench.py: no launcher in the environment, starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -323,20 +351,29 @@ def main():
     ap.add_argument("--knobs", default="", help="experiments only: comma-separated ngf_debug_set knobs, e.g. waves=12,tile_w=8,kernel=1")
     args = ap.parse_args()
 
+    if args.gpus < 1 or (args.gpus > 1 and H % (args.gpus * 10) != 0):
+        raise SystemExit(f"--gpus {args.gpus}: the frame's 800 rows are dealt out in 10-row blocks, so N must divide 80 (1, 2, 4, 5, 8, 10, 16 ...)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("NGF_BENCH_FORCE_LAUNCH") == "1"):
+        # no launcher: be the launcher (NGF_BENCH_FORCE_LAUNCH=1 takes this route at N = 1 too, so that one GPU can test it)
+        self_launch(args.gpus, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"LOCAL_RANK {local} but this node shows {torch.cuda.device_count()} GPU(s)")
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    dist_on = world > 1 or os.environ.get("NGF_BENCH_FORCE_DIST") == "1"     # the env knob exercises the RCCL path on one GPU
+    self_launched = os.environ.get("NGF_BENCH_SELF_LAUNCHED") == "1"
+    dist_on = world > 1 or os.environ.get("NGF_BENCH_FORCE_DIST") == "1" or (self_launched and "MASTER_PORT" in os.environ)     # the env knobs exercise the RCCL path on one GPU
     if dist_on:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=10))
 
     import ngf_amd  # noqa: F401
     from ngf_amd import dist as ndist
@@ -479,6 +516,7 @@ def main():
     }
     if args.knobs:
         result["config"]["knobs"] = args.knobs
+    result["config"]["launcher"] = "self (bench.py started its own torch.distributed.run)" if self_launched else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "none (single process)")
 
     if dist_on:
         # untimed: the gathered, re-ordered frame of the last step against a direct render of the whole frame on this rank

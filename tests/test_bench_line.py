@@ -88,3 +88,49 @@ def test_side_file_keeps_everything(monkeypatch, tmp_path):
     full = json.load(open(tmp_path / "bench_extras.json"))
     assert len(full["extras"]) == 26 and "simd_vector_datapath" in full["notes"]
     assert full["roofline"]["algorithmic_d3"]["bytes_per_launch"] == res["roofline"]["algorithmic_d3"]["bytes_per_launch"]
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_self_launch_command_line(n):
+    """`python bench.py --gpus N` without a launcher starts its own N ranks -- the command line is the driver's own
+    multi-GPU one (one node, N processes, loop-back rendezvous) with the caller's arguments passed through unchanged."""
+    argv = ["--gpus", str(n), "--steps", "7", "--warmup", "2"]
+    cmd = bench.self_launch_command(n, argv, 29617)
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and f"--nproc-per-node={n}" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29617"
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == argv and all(a.startswith("-") or a in ("torch.distributed.run", "127.0.0.1", "29617") for a in cmd[1:script])
+    p = bench.free_port()
+    assert 1024 < p < 65536
+
+
+def test_self_launch_refuses_more_ranks_than_gpus(monkeypatch):
+    """--gpus N on a node with fewer GPUs: a clear non-zero exit, nothing launched, no hang."""
+    import subprocess
+    import torch
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    called = []
+    monkeypatch.setattr(subprocess, "call", lambda *a, **k: called.append(a) or 0)
+    with pytest.raises(SystemExit) as ex:
+        bench.self_launch(8, ["--gpus", "8"])
+    assert "1 GPU" in str(ex.value) and "--gpus 8" in str(ex.value) and not called
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    with pytest.raises(SystemExit) as ex:
+        bench.self_launch(8, ["--gpus", "8", "--steps", "3"])
+    assert ex.value.code == 0 and len(called) == 1 and called[0][0][-4:] == ["--gpus", "8", "--steps", "3"]
+
+
+def test_bench_without_a_gpu_exits_with_a_message():
+    """The product path has no CPU fallback: on a box without a GPU the bench says so (rc != 0) whatever --gpus is, and never waits for a rendezvous."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for n in ("1", "8"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", n], env=env, capture_output=True, text=True, timeout=300)
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+        assert r.returncode != 0 and "MI355X" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "10-row blocks" in r.stderr

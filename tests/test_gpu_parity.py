@@ -621,6 +621,20 @@ def test_bench_rccl_path_single_gpu(tmp_path):
     assert d["launch_ms"]["min"] <= d["ms_per_step_median"] <= d["launch_ms"]["max"]
 
 
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment re-executes itself under torch.distributed.run
+    (the driver's N = 1 command line is launcher-less; an 8-GPU SCALE run started the same way must not die on a usage error).  One GPU can
+    only run N = 1, so NGF_BENCH_FORCE_LAUNCH=1 takes the self-launch route at N = 1: parent -> torchrun -> one rank over RCCL -> ONE JSON line."""
+    import os
+    env = {k: "" for k in ()}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        assert k not in os.environ, "this test must start from a launcher-less environment"
+    d, _ = _run_bench(["--steps", "2", "--warmup", "1", "--extras", "0", "--cpu-seconds", "0"], dict(env, NGF_BENCH_FORCE_LAUNCH="1"))
+    assert d["config"]["launcher"].startswith("self") and d["n_gpus"] == 1 and d["value"] > 1
+    assert d["gathered_frame_bit_identical_to_single_gpu_render"] is True and d["all_gather_ms"] > 0
+    assert d["critical_path_ms"]["render"] > 0
+
+
 def test_bench_default_line_is_parseable_with_extras():
     """The driver's command (`bench.py --gpus 1 --steps K --warmup W`, extras and CPU baseline ON): one final JSON line < 4 KB carrying
     value, roofline and cpu_baseline; the extras live in bench_extras.json (the 29 KB line left the round unmeasured)."""
