@@ -15,9 +15,18 @@
  *
  * Conventions: plain pointers and sizes only; every data pointer is a DEVICE pointer unless
  * stated otherwise; all work is enqueued on the caller's HIP stream (hipStream_t passed as
- * void*) and nothing synchronises except ngf_field_create (which copies ~150 KB of MLP weights
- * to the host once to pre-compose them).  Return value 0 = success, otherwise an NGF_E_* code
- * and ngf_last_error() holds a message for the calling thread.  No C++ exception crosses the ABI.
+ * void*).  What waits for the device today: ngf_field_create / ngf_uv_create wait for THEIR
+ * stream once (they copy ~150 KB of MLP weights to the host to permute them into the LDS image);
+ * ngf_field_destroy waits for the streams the handle was used on -- one event per stream, on the
+ * handle's own device, no device-wide synchronisation -- before it parks the buffers in the pool;
+ * ngf_uv_destroy / ngf_trainer_destroy / ngf_pool_trim call hipFree (which waits for the device);
+ * the *_host out-parameters of the training calls wait for their stream.  Every render / march /
+ * decode / alpha / filter / eval / ray-generation call is asynchronous.
+ * Devices: a handle belongs to the device that was current in the calling thread when it was
+ * created; its calls must be made with that device current (the launches go to the caller's
+ * stream), its destroy may be called under any current device.
+ * Return value 0 = success, otherwise an NGF_E_* code and ngf_last_error() holds a message for
+ * the calling thread.  No C++ exception crosses the ABI.
  */
 #ifndef NGF_H
 #define NGF_H
@@ -27,9 +36,10 @@
 extern "C" {
 #endif
 
-#define NGF_ABI_VERSION 4      /* 4: ngf_train_forward / ngf_train_backward_grad (the step in two calls, d loss / d rgb_map handed in), trainers without Adam moments; 3: ngf_train_overflow_count + speculative rows (ngf_train_desc.chunk_samples < 0), ngf_train_backward2 (loss_len travels with the call; ngf_train_backward is back to its ABI-1 contract of ONE double); 2: ngf_uv_desc.flags (was padding), ngf_uv_render_batch, ngf_debug_dirty_lds, trainer chunk_samples = 0 means the whole batch */
+#define NGF_ABI_VERSION 5      /* 5: handles remember their device and streams (ngf_field_destroy needs no current-device contract), ngf_pool_set_limit / ngf_pool_bytes, NGF_E_STALE from ngf_train_backward_grad; 4: ngf_train_forward / ngf_train_backward_grad (the step in two calls, d loss / d rgb_map handed in), trainers without Adam moments; 3: ngf_train_overflow_count + speculative rows (ngf_train_desc.chunk_samples < 0), ngf_train_backward2 (loss_len travels with the call; ngf_train_backward is back to its ABI-1 contract of ONE double); 2: ngf_uv_desc.flags (was padding), ngf_uv_render_batch, ngf_debug_dirty_lds, trainer chunk_samples = 0 means the whole batch */
 
-enum { NGF_OK = 0, NGF_E_ARG = 1, NGF_E_HIP = 2, NGF_E_UNSUPPORTED = 3 };
+enum { NGF_OK = 0, NGF_E_ARG = 1, NGF_E_HIP = 2, NGF_E_UNSUPPORTED = 3,
+       NGF_E_STALE = 4 /* ngf_train_backward_grad: the ticket is not the trainer's last forward -- run the forward again; nothing else returns it */ };
 enum { NGF_MODEL_TRIPLANE = 0, NGF_MODEL_INFOINV = 1 };
 
 /* ngf_field_desc.flags */
@@ -357,10 +367,16 @@ int ngf_abi_version(void);
 int ngf_sizeof_field_desc(void);
 /* bytes of HBM the handle owns (packed textures + MLP image + mask + tile-queue heads) */
 int64_t ngf_field_bytes(const ngf_field *f);
-/* ngf_field_destroy parks a handle's device buffers in a per-process pool (exact-size reuse by the next ngf_field_create on the same device, at most
- * 64 buffers / 4 GiB): a handle is rebuilt after every parameter change of an eval field, with the same shapes, and hipFree / hipMalloc cost more
- * than the rebuild's own work.  This call returns the parked buffers to the driver (e.g. before another framework needs the memory). */
+/* ngf_field_destroy parks a handle's device buffers in a per-process pool (exact-size reuse by the next ngf_field_create on the same device -- the
+ * device the HANDLE was created on, not the calling thread's current one): a handle is rebuilt after every parameter change of an eval field, with
+ * the same shapes, and hipFree / hipMalloc cost more than the rebuild's own work.  At most 64 buffers / ngf_pool_set_limit bytes (default 1 GiB) are
+ * parked; when a new buffer does not fit, the OLDEST parked ones go back to the driver (sizes that never match again after up_sampling / shrink age out),
+ * and a hipMalloc that fails inside ngf_field_create empties the pool and is tried once more.
+ * ngf_pool_trim returns every parked buffer to the driver (e.g. before another framework needs the memory); ngf_pool_set_limit changes the byte cap
+ * (0 = park nothing) and evicts down to it; ngf_pool_bytes reports what is parked on one device (device < 0: on all). */
 int ngf_pool_trim(void);
+int ngf_pool_set_limit(int64_t bytes);
+int64_t ngf_pool_bytes(int32_t device);
 
 #ifdef __cplusplus
 }

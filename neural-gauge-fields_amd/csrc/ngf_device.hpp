@@ -119,7 +119,10 @@ __device__ __forceinline__ void queue_done(unsigned int *slot, unsigned *wg_done
     if (lane != 0) return;
     const unsigned d = __hip_atomic_fetch_add(wg_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (d + 1u != waves_in_wg) return;
-    const unsigned done = __hip_atomic_fetch_add(slot + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // acq_rel: the report is ordered after this workgroup's queue atomics, and the last workgroup's zero stores after everybody's
+    // report -- on today's hardware the relaxed form worked because device-scope atomics resolve at the L2, but nothing promised it.  One atomic
+    // per workgroup and launch: the cache maintenance it implies is not measurable (profiles/r06_shard_latency.txt).
+    const unsigned done = __hip_atomic_fetch_add(slot + 8, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (done + 1u == workgroups) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) __hip_atomic_store(slot + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

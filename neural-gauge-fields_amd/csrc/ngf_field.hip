@@ -143,7 +143,24 @@ struct ngf_field {
     int64_t bytes = 0;
     int num_cus = 256;
     std::vector<std::pair<void *, size_t>> allocs;      // every device buffer of the handle (pointer, bytes): ngf_field_destroy hands them to the pool
+    // round 6: the device the handle lives on and every stream a launch that reads its buffers was put on -- ngf_field_destroy waits for
+    // THOSE streams (one event each) on THAT device instead of a hipDeviceSynchronize on whatever device is current in the calling thread
+    int dev = 0;
+    mutable std::mutex use_mu;
+    mutable std::vector<hipStream_t> streams;
+    mutable std::atomic<void *> last_stream{(void *)(intptr_t)-1};
 };
+
+// every launch that reads the handle's buffers reports its stream (a pointer compare in the steady state)
+static inline void field_use(const ngf_field *f, hipStream_t st)
+{
+    if (f->last_stream.load(std::memory_order_relaxed) == (void *)st) return;
+    std::lock_guard<std::mutex> lk(f->use_mu);
+    bool known = false;
+    for (hipStream_t s : f->streams) known |= s == st;
+    if (!known) f->streams.push_back(st);
+    f->last_stream.store((void *)st, std::memory_order_relaxed);
+}
 
 // ---- packing kernels -----------------------------------------------------------------------------
 // NCHW [C,H,W] channels [c0,c0+nc) -> zero-bordered channel-last [(H+2)][(W+2)][nc]
@@ -553,16 +570,40 @@ static void build_rgb_image16(int F, bool bake, const std::vector<float> &w1p, c
 // Destroyed handles therefore park their buffers here (exact-size reuse, per device; at most kPoolEntries buffers / kPoolBytes; the rest
 // goes back to the driver), after ONE hipDeviceSynchronize in ngf_field_destroy (what the first hipFree used to do implicitly: kernels
 // of any stream may still read the buffers).  ngf_pool_trim() returns everything to the driver.
-struct PoolEntry { void *p; size_t bytes; int dev; };
+struct PoolEntry { void *p; size_t bytes; int dev; uint64_t age; };
 static std::mutex g_pool_mu;
 static std::vector<PoolEntry> g_pool;
 static size_t g_pool_bytes = 0;
-constexpr size_t kPoolEntries = 64, kPoolBytes = (size_t)4 << 30;
+static uint64_t g_pool_clock = 0;
+static size_t g_pool_cap_bytes = (size_t)1 << 30;        // ngf_pool_set_limit; a level-3 TriPlane handle at 256^2 is 52 MB + 67 MB, a 300^2 one 160 MB
+constexpr size_t kPoolEntries = 64;
 
-static hipError_t pool_malloc(void **p, size_t bytes)
+static void pool_release(const std::vector<PoolEntry> &out)          // hipFree outside the lock, each on its own device
 {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+    for (const PoolEntry &e : out) {
+        DeviceScope ds(e.dev);
+        (void)hipFree(e.p);
+    }
+}
+
+// entries of `dev` (or of every device: dev < 0) leave the pool, oldest first, until at most keep_bytes / keep_entries are parked
+static void pool_evict_locked(std::vector<PoolEntry> &out, int dev, size_t keep_bytes, size_t keep_entries)
+{
+    while (!g_pool.empty() && (g_pool_bytes > keep_bytes || g_pool.size() > keep_entries)) {
+        size_t oldest = g_pool.size();
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if ((dev < 0 || g_pool[i].dev == dev) && (oldest == g_pool.size() || g_pool[i].age < g_pool[oldest].age)) oldest = i;
+        if (oldest == g_pool.size()) break;
+        out.push_back(g_pool[oldest]);
+        g_pool_bytes -= g_pool[oldest].bytes;
+        g_pool[oldest] = g_pool.back();
+        g_pool.pop_back();
+    }
+}
+
+// `dev` = the device the buffer is for (the handle's); the caller has made it the current one
+static hipError_t pool_malloc(void **p, size_t bytes, int dev)
+{
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         for (size_t i = 0; i < g_pool.size(); ++i)
@@ -574,23 +615,43 @@ static hipError_t pool_malloc(void **p, size_t bytes)
                 return hipSuccess;
             }
     }
-    return hipMalloc(p, bytes);
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        // out of memory while this pool sits on parked buffers nobody else can see (torch's caching allocator cannot): give them all back and try once more
+        (void)hipGetLastError();
+        std::vector<PoolEntry> out;
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            pool_evict_locked(out, -1, 0, 0);
+        }
+        if (out.empty()) return e;
+        pool_release(out);
+        e = hipMalloc(p, bytes);
+    }
+    return e;
 }
 
-static void pool_free(void *p, size_t bytes)          // the caller has made sure that nothing on the device still uses p
+static void pool_free(void *p, size_t bytes, int dev)          // the caller has made sure that nothing on device `dev` still uses p
 {
     if (!p) return;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+    std::vector<PoolEntry> out;
+    bool parked = false;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        if (g_pool.size() < kPoolEntries && g_pool_bytes + bytes <= kPoolBytes) {
-            g_pool.push_back(PoolEntry{p, bytes, dev});
+        if (bytes <= g_pool_cap_bytes) {
+            // full: the OLDEST parked buffers make room (after up_sampling / shrink the old sizes never match again -- round 5 refused the
+            // new ones instead and kept the stale ones for the life of the process)
+            pool_evict_locked(out, -1, g_pool_cap_bytes - bytes, kPoolEntries - 1);
+            g_pool.push_back(PoolEntry{p, bytes, dev, ++g_pool_clock});
             g_pool_bytes += bytes;
-            return;
+            parked = true;
         }
     }
-    (void)hipFree(p);
+    pool_release(out);
+    if (!parked) {
+        DeviceScope ds(dev);
+        (void)hipFree(p);
+    }
 }
 
 extern "C" int ngf_pool_trim(void)
@@ -598,16 +659,37 @@ extern "C" int ngf_pool_trim(void)
     std::vector<PoolEntry> out;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        out.swap(g_pool);
-        g_pool_bytes = 0;
+        pool_evict_locked(out, -1, 0, 0);
     }
-    for (const PoolEntry &e : out) (void)hipFree(e.p);
+    pool_release(out);
     return NGF_OK;
+}
+
+extern "C" int ngf_pool_set_limit(int64_t bytes)
+{
+    if (bytes < 0) return fail(NGF_E_ARG, "ngf_pool_set_limit: %lld", (long long)bytes);
+    std::vector<PoolEntry> out;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_pool_cap_bytes = (size_t)bytes;
+        pool_evict_locked(out, -1, g_pool_cap_bytes, kPoolEntries);
+    }
+    pool_release(out);
+    return NGF_OK;
+}
+
+extern "C" int64_t ngf_pool_bytes(int32_t device)          // parked bytes of one device (device < 0: of all) -- tests, memory reports
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int64_t b = 0;
+    for (const PoolEntry &e : g_pool)
+        if (device < 0 || e.dev == device) b += (int64_t)e.bytes;
+    return b;
 }
 
 static int field_alloc(ngf_field *f, void **p, size_t bytes, const char *what)
 {
-    if (pool_malloc(p, bytes) != hipSuccess) { *p = nullptr; return fail(NGF_E_HIP, "hipMalloc(%s, %zu bytes) failed", what, bytes); }
+    if (pool_malloc(p, bytes, f->dev) != hipSuccess) { *p = nullptr; return fail(NGF_E_HIP, "hipMalloc(%s, %zu bytes) failed on device %d", what, bytes, f->dev); }
     f->allocs.emplace_back(*p, bytes);
     f->bytes += (int64_t)bytes;
     return NGF_OK;
@@ -629,8 +711,28 @@ extern "C" int64_t ngf_field_bytes(const ngf_field *f) { return f ? f->bytes : 0
 extern "C" int ngf_field_destroy(ngf_field *f)
 {
     if (!f) return NGF_OK;
-    if (!f->allocs.empty()) (void)hipDeviceSynchronize();        // renders of any stream may still read the buffers (hipFree used to wait for them)
-    for (const auto &a : f->allocs) pool_free(a.first, a.second);
+    if (!f->allocs.empty()) {
+        // Launches may still read the buffers: wait for the streams the handle was used on -- on the handle's device, whatever device is
+        // current in the calling thread (round 5 synchronised the CURRENT device and parked the buffers under ITS id) -- and for nothing
+        // else: no device-wide synchronisation.  A stream the caller has destroyed in the meantime has finished its work (hipStreamDestroy
+        // drains it); if the runtime refuses it, or the event cannot be made, the device-wide wait is the fallback.
+        DeviceScope ds(f->dev);
+        std::vector<hipStream_t> used;
+        {
+            std::lock_guard<std::mutex> lk(f->use_mu);
+            used = f->streams;
+        }
+        bool waited = true;
+        hipEvent_t ev = nullptr;
+        if (!used.empty()) {
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ev = nullptr; waited = false; }
+            for (size_t i = 0; waited && i < used.size(); ++i)
+                waited = hipEventRecord(ev, used[i]) == hipSuccess && hipEventSynchronize(ev) == hipSuccess;
+            if (ev) (void)hipEventDestroy(ev);
+        }
+        if (!waited) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
+        for (const auto &a : f->allocs) pool_free(a.first, a.second, f->dev);
+    }
     delete f;
     return NGF_OK;
 }
@@ -663,6 +765,8 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) f->num_cus = prop.multiProcessorCount;
+    f->dev = dev;                   // the caller's current device: where the parameter tensors and the stream live
+    field_use(f, st);               // the packing kernels below write the handle's buffers on this stream
 
     int rc = NGF_OK;
     RenderArgs &A = f->proto;
@@ -1041,6 +1145,7 @@ static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
 
 static int render_common(const ngf_field *f, RenderArgs &A, hipStream_t st)
 {
+    field_use(f, st);
     if (f->model == NGF_MODEL_INFOINV) {
         const bool wide = knob(KNOB_TILE_W) > 16 || knob(KNOB_SPLIT) == 0;      // debug knobs only: launch_render never picks more than 16 rays per tile
         if (f->flags & NGF_F_SPLIT_BF16) {
@@ -1101,6 +1206,7 @@ extern "C" int ngf_field_decode_rgb(const ngf_field *f, const float *coords, con
     if (!f || !coords || !dirs || !rgb) return fail(NGF_E_ARG, "ngf_field_decode_rgb: null argument");
     if (n <= 0) return fail(NGF_E_ARG, "ngf_field_decode_rgb: n=%lld", (long long)n);
     hipStream_t st = (hipStream_t)hip_stream;
+    field_use(f, st);
     RenderArgs A = f->proto;
     A.mode = mode ? 1 : 0;
     const size_t lds = ((size_t)((A.blob_floats + 3) & ~3) + 4 * 32 * kViewFeat) * sizeof(float);
@@ -1127,6 +1233,7 @@ extern "C" int ngf_field_decode_rgb(const ngf_field *f, const float *coords, con
 
 static int launch_alpha(const ngf_field *f, const float *xyz, const Lattice &L, int64_t n, int32_t mode, float length, float *alpha, hipStream_t st)
 {
+    field_use(f, st);
     RenderArgs A = f->proto;
     A.mode = mode ? 1 : 0;
     if (int rc = poison_lds(st)) return rc;
@@ -1192,6 +1299,7 @@ extern "C" int ngf_field_ray_filter(const ngf_field *f, const float *rays, int64
     if (n_samples > 0 && !f->proto.mask.bits) return fail(NGF_E_ARG, "ngf_field_ray_filter: the field has no alpha mask");
     if (n < 0) return fail(NGF_E_ARG, "ngf_field_ray_filter: n=%lld", (long long)n);
     if (n == 0) return NGF_OK;
+    field_use(f, (hipStream_t)hip_stream);
     RenderArgs A = f->proto;
     int64_t grid = (n + 255) / 256;
     if (grid > 16 * (int64_t)f->num_cus) grid = 16 * (int64_t)f->num_cus;
@@ -1234,6 +1342,7 @@ enum { TP_PLANE = 0, TP_GAUGE = 3, TP_DENS_W = 6, TP_DENS_B = 7, TP_BASIS = 8, T
        TP_B3 = 14, TP_COUNT = 15 };
 
 struct ngf_trainer {
+    int dev = 0;                             // the device the trainer's buffers and streams live on
     ngf_train_desc d;
     TrainArgs proto;
     std::vector<void *> allocs;
@@ -1287,6 +1396,7 @@ static int tr_alloc(ngf_trainer *t, T **p, size_t count)
 extern "C" int ngf_trainer_destroy(ngf_trainer *t)
 {
     if (!t) return NGF_OK;
+    DeviceScope ds(t->dev);              // hipFree / stream teardown on the trainer's device, whatever is current in the calling thread
     for (void *q : t->allocs) (void)hipFree(q);
     for (int k = 0; k < ngf_trainer::kAux; ++k) {
         if (t->aux[k]) { (void)hipStreamSynchronize(t->aux[k]); (void)hipStreamDestroy(t->aux[k]); }
@@ -1324,6 +1434,7 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) t->num_cus = prop.multiProcessorCount;
+    t->dev = dev;
     int rc;
     for (int k = 0; k < ngf_trainer::kAux; ++k)
         if (hipStreamCreateWithFlags(&t->aux[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t->ev_join[k], hipEventDisableTiming) != hipSuccess)
@@ -1734,7 +1845,7 @@ extern "C" int ngf_train_backward_grad(ngf_trainer *t, int64_t ticket, const flo
 {
     if (!t || !d_rgb_map) return fail(NGF_E_ARG, "ngf_train_backward_grad: null argument");
     if (!t->pending.valid || t->pending.ticket != ticket)
-        return fail(NGF_E_ARG, "ngf_train_backward_grad: ticket %lld is not the trainer's last forward (%s) -- another forward or a fused step used the "
+        return fail(NGF_E_STALE, "ngf_train_backward_grad: ticket %lld is not the trainer's last forward (%s) -- another forward or a fused step used the "
                     "trainer's buffers since; run ngf_train_forward again", (long long)ticket, t->pending.valid ? "a newer one is pending" : "none is pending");
     ForkState fs;
     ngf_trainer::Pending &P = t->pending;

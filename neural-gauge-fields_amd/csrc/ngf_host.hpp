@@ -48,6 +48,17 @@ int poison_alloc(void *p, size_t bytes, hipStream_t st);     // no-op unless kno
 
 namespace ngf {
 
+// Scoped switch to the device a handle / a parked buffer lives on (hipFree, hipMalloc and events act on the calling thread's CURRENT device).
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
+
 // device -> host copy of n floats (weights are folded / packed on the host at create time)
 inline int d2h(std::vector<float> &dst, const float *src, size_t n, hipStream_t st)
 {

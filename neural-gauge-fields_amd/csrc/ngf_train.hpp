@@ -1655,7 +1655,7 @@ __device__ __forceinline__ int blocked_offset(int X, int Y, int bw)
 // (X, Y) = padded (column, row) of the cell's first tap, val[tap][channel] the contributions (tap = 2 * dy + dx), bw = blocks per row;
 // tile: kScatWaveFloats floats of wave-private LDS.  Every lane of the wave must call it (wave-uniform control flow inside).
 template <int BYS, int CH, int N = 4 * CH, int DEPTH = 0>
-__device__ __forceinline__ void scatter_blocked(float *tile, int lane, bool work, int X, int Y, float (&val)[N], float *gbuf, int bw, unsigned *lines = nullptr)        // lines: profiling counters {whole-line atomics, per-tap fallbacks}
+__device__ __forceinline__ void scatter_blocked(float *tile, int lane, bool work, int X, int Y, float (&val)[N], float *gbuf, int bw, bool lines, unsigned &n_line, unsigned &n_tap)        // lines: profiling -- n_line / n_tap count {whole-line atomics, per-tap fallbacks}.  Two scalars by reference, not an array behind a pointer that may be null: that form kept the counters in scratch (28 B per lane in every launch, round 5)
 {
     const int big = 1 << 20;
     const int bx0 = wave_min_i(work ? X >> 2 : big), bx1 = wave_max_i(work ? (X + 1) >> 2 : -big);
@@ -1669,11 +1669,11 @@ __device__ __forceinline__ void scatter_blocked(float *tile, int lane, bool work
             float v0[N], v1[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) v0[j] = v1[j] = val[j];
-            scatter_blocked<BYS, CH, N, DEPTH + 1>(tile, lane, work && !(lane & H), X, Y, v0, gbuf, bw, lines);
-            scatter_blocked<BYS, CH, N, DEPTH + 1>(tile, lane, work && (lane & H), X, Y, v1, gbuf, bw, lines);
+            scatter_blocked<BYS, CH, N, DEPTH + 1>(tile, lane, work && !(lane & H), X, Y, v0, gbuf, bw, lines, n_line, n_tap);
+            scatter_blocked<BYS, CH, N, DEPTH + 1>(tile, lane, work && (lane & H), X, Y, v1, gbuf, bw, lines, n_line, n_tap);
             return;
         }
-        if (lines) lines[1] += 1;
+        if (lines) n_tap += 1;
         if (work) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -1738,7 +1738,7 @@ __device__ __forceinline__ void scatter_blocked(float *tile, int lane, bool work
         if (lines) {                            // profiling: one transaction per 16-lane group with a non-zero float
             const unsigned long long ma = __ballot(va != 0.0f), mb = __ballot(vb != 0.0f);
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) lines[0] += (((ma >> (16 * gq)) & 0xffffull) ? 1u : 0u) + (((mb >> (16 * gq)) & 0xffffull) ? 1u : 0u);
+            for (int gq = 0; gq < 4; ++gq) n_line += (((ma >> (16 * gq)) & 0xffffull) ? 1u : 0u) + (((mb >> (16 * gq)) & 0xffffull) ? 1u : 0u);
         }
         if (va != 0.0f) {
             const int q = (int)(((unsigned)ba * magic) >> 16), r = ba - q * nbx;
@@ -1768,7 +1768,7 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
     float *tile = s_tile[wave];
     float bsum = 0.0f;
     const bool count_lines = (A.ablate & (1 << 21)) != 0;      // profiling: atomic line transactions -> T.prof[8]
-    unsigned n_lines[2] = {0, 0};
+    unsigned n_line = 0, n_tap = 0;
     // a wave item = 64 consecutive steps of ONE ray (the last chunk of a ray is short): its taps stay inside a small bounding box
     const int chunks = (A.S + 63) / 64;
     const int64_t items = A.n * chunks;
@@ -1796,7 +1796,7 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
             dt[2 * p + 1] = dx * (b.wx0 * (v01 - v00) + b.wx1 * (v11 - v10)) * b.sy;
             if (DENS && !(A.ablate & 256)) {
                 float dw[4] = {b.w00 * dx, b.w10 * dx, b.w01 * dx, b.w11 * dx};
-                scatter_blocked<2, 1>(tile, lane, work, b.cx, b.cy, dw, T.d_dens[p], T.d_bw[p], count_lines ? n_lines : nullptr);
+                scatter_blocked<2, 1>(tile, lane, work, b.cx, b.cy, dw, T.d_dens[p], T.d_bw[p], count_lines, n_line, n_tap);
             }
         }
         if (GAUGE && A.mode) {
@@ -1817,11 +1817,11 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
                 Bil b = bil_setup(u[p], v[p], A.gau[p]);
                 float gv[8] = {b.w00 * dg[p][0], b.w00 * dg[p][1], b.w10 * dg[p][0], b.w10 * dg[p][1],
                                b.w01 * dg[p][0], b.w01 * dg[p][1], b.w11 * dg[p][0], b.w11 * dg[p][1]};
-                if (!(A.ablate & 512)) scatter_blocked<1, 2>(tile, lane, work, b.cx, b.cy, gv, T.g_gau[p], T.g_bw[p], count_lines ? n_lines : nullptr);
+                if (!(A.ablate & 512)) scatter_blocked<1, 2>(tile, lane, work, b.cx, b.cy, gv, T.g_gau[p], T.g_bw[p], count_lines, n_line, n_tap);
             }
         }
     }
-    if (count_lines && lane == 0) { atomicAdd(T.prof + 8, (unsigned long long)n_lines[0]); atomicAdd(T.prof + 10, (unsigned long long)n_lines[1]); }
+    if (count_lines && lane == 0) { atomicAdd(T.prof + 8, (unsigned long long)n_line); atomicAdd(T.prof + 10, (unsigned long long)n_tap); }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) bsum += __shfl_xor(bsum, s);
     if (lane == 0) atomicAdd(&s_bd, bsum);

@@ -12,11 +12,13 @@ struct ngf_uv {
     mutable std::atomic<unsigned> next_counter{0};
     UvArgs proto;
     int num_cus = 256;
+    int dev = 0;                   // the device the handle's buffers live on (the caller's current device at create)
 };
 
 extern "C" int ngf_uv_destroy(ngf_uv *m)
 {
     if (!m) return NGF_OK;
+    DeviceScope ds(m->dev);        // hipFree waits for the device's work: on the handle's device, whatever is current in the calling thread
     if (m->w) (void)hipFree(m->w);
     if (m->tex) (void)hipFree(m->tex);
     if (m->counters) (void)hipFree(m->counters);
@@ -141,6 +143,7 @@ extern "C" int ngf_uv_create(const ngf_uv_desc *d, ngf_uv **out, void *hip_strea
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) m->num_cus = prop.multiProcessorCount;
+    m->dev = dev;
     UvArgs &A = m->proto;
     memset(&A, 0, sizeof(A));
     A.sphere = d->sphere ? 1 : 0;

@@ -200,11 +200,17 @@ class Base(torch.nn.Module):
     def _fill_desc(self, d: _lib.FieldDesc, keep: list):
         raise NotImplementedError
 
-    def release(self):
+    def release(self, trim=False):
+        """Destroy the packed device image.  The library waits for the streams the handle was used on (on the handle's own device) and parks
+        its buffers for the next ``handle()`` of the same shapes; ``trim=True`` also returns the parked buffers to the driver (after
+        up_sampling / shrink the old sizes never match again, and torch's caching allocator cannot see memory this pool holds)."""
         if self._handle is not None:
             _lib.lib().ngf_field_destroy(self._handle)
             self._handle = None
             self._handle_key = None
+            self._handle_shapes = None
+        if trim:
+            _lib.lib().ngf_pool_trim()
 
     def __del__(self):
         try:
@@ -256,12 +262,17 @@ class Base(torch.nn.Module):
             shp = self.alphaMask.alpha_volume.shape
             d.mask_d, d.mask_h, d.mask_w = int(shp[-3]), int(shp[-2]), int(shp[-1])
             d.mask_aabb = (C.c_float * 6)(*self.alphaMask.aabb.reshape(-1).tolist())
+        # the old image goes first: its buffers are what the new one is built in (same shapes after a parameter update -- exact-size reuse from
+        # the library's pool, no second image resident; other shapes after up_sampling / shrink / a new mask -- the stale sizes go back to the driver)
+        shapes = (tuple(int(x) for x in d.plane_h), tuple(int(x) for x in d.plane_w), tuple(int(x) for x in d.gauge_h), tuple(int(x) for x in d.gauge_w),
+                  int(d.flags), int(d.mask_d), int(d.mask_h), int(d.mask_w))
+        old = getattr(self, '_handle_shapes', None)
+        self.release(trim=old is not None and old != shapes)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
             out = C.c_void_p()
             _lib.check(L.ngf_field_create(C.byref(d), C.byref(out), C.c_void_p(stream)))
-        self.release()
-        self._handle, self._handle_key = out, key
+        self._handle, self._handle_key, self._handle_shapes = out, key, shapes
         return out
 
     def _mode(self, **kw) -> int:

@@ -413,11 +413,13 @@ class RenderGrad:
         return rgb, depth, int(ticket.value)
 
     def backward(self, ticket, d_rgb, want):
-        """``want[k]``: return parameter k's gradient (else None).  -1 = the ticket is stale (another forward used the buffers): re-run forward."""
+        """``want[k]``: return parameter k's gradient (else None).  None = the ticket is stale (NGF_E_STALE: another forward used the buffers) -- re-run forward; every other failure raises."""
         with torch.cuda.device(self.dev):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            if self.L.ngf_train_backward_grad(self._h, int(ticket), d_rgb.data_ptr(), st) != 0:
+            rc = self.L.ngf_train_backward_grad(self._h, int(ticket), d_rgb.data_ptr(), st)
+            if rc == _lib.E_STALE:
                 return None
+            _lib.check(rc)              # anything else is an error of this call (a HIP / launch failure must not be retried away)
             grads = []
             for k in range(15):
                 if not want[k]:

@@ -22,12 +22,12 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for s in declared:
         assert hasattr(L, s), s
-    assert L.ngf_abi_version() == 4
+    assert L.ngf_abi_version() == 5
     import ctypes as C
     assert L.ngf_sizeof_field_desc() == C.sizeof(_lib.FieldDesc)
     # the experiment library (product kernels + the experiment kernels; tests and profiles/ only) exports the same ABI
     with _lib.library("exp") as X:
-        assert X is not L and all(hasattr(X, s) for s in declared) and X.ngf_abi_version() == 4
+        assert X is not L and all(hasattr(X, s) for s in declared) and X.ngf_abi_version() == 5
     assert _lib.lib() is L
 
 

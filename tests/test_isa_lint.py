@@ -70,7 +70,12 @@ def test_shipped_hot_kernels_use_no_scratch(asm):
             "render_kernelINS_14TriPlanePolicyILb1ELb1ELi12ELi1ELb0EEELb1ELb0E",      # level 3 (module default), production instantiation
             "render_kernelINS_14TriPlanePolicyILb1ELb0ELi12ELi1ELb0EEELb1ELb0E",      # level 2
             "render_kernelINS_14InfoInvPolicyTILb0ELb0EEELb1ELb0E",                   # InfoInv fp32
-            "render_kernelINS_14InfoInvPolicyTILb1ELb0EEELb1ELb0E"]                   # InfoInv split bf16
+            "render_kernelINS_14InfoInvPolicyTILb1ELb0EEELb1ELb0E",                   # InfoInv split bf16
+            # round 6: the kernels of a training step -- train_density_bwd_kernel<true, true> carried 28 B per lane through round 5
+            # (its two profiling counters lived in an array behind a maybe-null pointer)
+            "train_density_kernel", "train_scan_kernel", "train_color_fwd16_kernel", "train_composite_bwd_kernel", "train_color_bwd_kernel",
+            "train_bin_scatter_kernel", "train_bin_gather_kernel", "xty_all_kernel", "train_density_bwd_kernel", "train_density_finish_kernel",
+            "adam_plane_kernel", "adam_dense_all_kernel"]
     for needle in want:
         hits = {k: v for k, v in scratch.items() if needle in k}
         assert hits, f"no kernel matches {needle}"
