@@ -178,6 +178,9 @@ def compact_line(result: dict) -> str:
         tr = result["extras"].get("train_step_R1", {})
         if "ms_per_iteration" in tr:
             out["train_ms_per_iteration"] = _r(tr["ms_per_iteration"], 4)
+        ta = result["extras"].get("train_step_R1_autograd", {})
+        if "ms_per_iteration" in ta:
+            out["train_autograd_ms_per_iteration"] = _r(ta["ms_per_iteration"], 4)
         hbm = result["extras"].get("handle_build_ms", {})
         if hbm and "error" not in hbm:
             out["handle_build_ms"] = {k.replace("triplane_", ""): _r(v, 3) for k, v in hbm.items() if isinstance(v, float)}
@@ -416,6 +419,10 @@ def main():
     # ... copied there on a stream of their own: the render stream never waits for an exchange or a reorder (the timed region ends with a device-wide synchronise)
     side = torch.cuda.Stream(device) if dist_on else None
 
+    # the frame IS an image (W rays per row; at N > 1 a rank's rows are whole image rows too): the launch may walk it in screen-space blocks
+    # (ngf_field_render_image -- what ngf_amd.evalout.evaluation passes to renderer; same pixels bit for bit, tests/test_gpu_parity.py)
+    kw = dict(kw, row_width=W)
+
     def render_only():
         f(rays, N_samples=S, white_bg=True, out=(rgb_view, depth_view), **kw)
 
@@ -609,7 +616,7 @@ def main():
             for mdl, preset, flags, tag, ptag_sfx in variants:
                 try:
                     fx, _, _, _ = build_field(mdl, preset, device, **flags)
-                    kx = {"iteration": 30001} if mdl == "triplane" else {"infoinv": True}
+                    kx = dict({"iteration": 30001} if mdl == "triplane" else {"infoinv": True}, row_width=W)
                     ms = kernel_ms(lambda: fx(rays, N_samples=S, white_bg=True, **kx), 5, device)      # includes 1st-call warm-up
                     ms = kernel_ms(lambda: fx(rays, N_samples=S, white_bg=True, **kx), 10, device)
                     fx(rays, N_samples=S, collect_stats=True, **kx)
@@ -656,7 +663,7 @@ def main():
                         fx.alphaMask = _tp.AlphaGridMask(device, torch.tensor(np.asarray(gx["aabb"], np.float32)), ((xx ** 2 + yy ** 2 + zz ** 2) < 0.64).float().to(device))
                         fx.invalidate()
                     Sx = int(fx.nSamples)
-                    go = lambda: _renderer(rays, fx, chunk=4096, N_samples=-1, white_bg=True, device=device, **({} if tri else fkw))
+                    go = lambda: _renderer(rays, fx, chunk=4096, N_samples=-1, white_bg=True, device=device, row_width=W, **({} if tri else fkw))
                     kernel_ms(go, 3, device)
                     ms = kernel_ms(go, 8, device)
                     fx(rays, N_samples=-1, collect_stats=True, **fkw)
@@ -674,6 +681,24 @@ def main():
                     fx.release()
                 except Exception as ex:
                     extras[key] = {"error": repr(ex)}
+            # the screen-space tile order against the list's own (row-major) order, alternating launches of one field
+            try:
+                ab = {}
+                for mdl, preset, shape in (("triplane", "R1", ""), ("triplane", "R2", ""), ("triplane", "R2", "S884_mask")):
+                    fx, _, _, _ = build_field(mdl, preset, device, True, True)
+                    ns = S
+                    if shape:
+                        fx.updateAlphaMask((256, 256, 256))
+                        ns = -1
+                    t = {0: [], W: []}
+                    for rep in range(6):
+                        for rw in (0, W):
+                            t[rw].append(kernel_ms(lambda: fx(rays, N_samples=ns, white_bg=True, iteration=30001, row_width=rw), 2, device))
+                    ab[f"{mdl}_{preset}{'_' + shape if shape else ''}"] = {"row_major_ms": float(np.median(t[0][1:])), "image_blocks_ms": float(np.median(t[W][1:]))}
+                    fx.release()
+                extras["tile_order_ab"] = ab
+            except Exception as ex:
+                extras["tile_order_ab"] = {"error": repr(ex)}
             # What a parameter change costs before the next render: ngf_field_create = texture packing, the pre-compositions of
             # the level (fp64 folds), the MLP image; timed from invalidate() to the handle being ready, median of 5 (the render itself excluded).
             try:
@@ -800,29 +825,34 @@ def main():
                     fs_.release()
                 except Exception as ex:
                     tr_extra["speculative_rows_ms_per_iteration"] = repr(ex)
-                try:    # TriPlane/main.py:272-299 unchanged on the drop-in field: differentiable forward, torch's MSE + density_L1, torch.optim.Adam
-                    fa_, _, _, _ = build_field("triplane", args.preset, device, True, False)
-                    opt_ = torch.optim.Adam(fa_.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
-                    def ref_iter(it):
-                        out_ = fa_(tr_rays, is_train=True, white_bg=True, N_samples=Str, iteration=it)
-                        loss_ = torch.mean((out_["rgb_map"] - tr_rgb) ** 2)
-                        tot_ = loss_ + 8e-5 * fa_.density_L1()
-                        opt_.zero_grad()
-                        tot_.backward()
-                        opt_.step()
-                        return loss_
-                    for it in range(3):
-                        ref_iter(it)
-                    torch.cuda.synchronize(device)
-                    t0 = time.perf_counter()
-                    for it in range(10):
-                        ref_iter(3 + it).item()                      # the reference reads the loss every iteration (main.py:297)
-                    torch.cuda.synchronize(device)
-                    tr_extra["reference_loop_on_autograd_path_ms_per_iteration"] = (time.perf_counter() - t0) / 10 * 1e3
-                    fa_._grad_engine.release()
-                    fa_.release()
-                except Exception as ex:
-                    tr_extra["reference_loop_on_autograd_path_ms_per_iteration"] = repr(ex)
+                # TriPlane/main.py:272-299 unchanged on the drop-in field: differentiable forward, torch's MSE + density_L1, total_loss.backward(), and
+                # optimizer.step() of (a) torch.optim.Adam, as the reference writes it, (b) ngf_amd.optim.Adam -- the same constructor and state, one
+                # fused C-ABI call per step that also keeps the engine's packed planes current
+                for key_, cls_ in (("reference_loop_on_autograd_path_ms_per_iteration", "torch"), ("reference_loop_with_ngf_optim_ms_per_iteration", "ngf")):
+                    try:
+                        from ngf_amd import optim as noptim
+                        fa_, _, _, _ = build_field("triplane", args.preset, device, True, False)
+                        opt_ = (torch.optim.Adam if cls_ == "torch" else noptim.Adam)(fa_.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+                        def ref_iter(it):
+                            out_ = fa_(tr_rays, is_train=True, white_bg=True, N_samples=Str, iteration=it)
+                            loss_ = torch.mean((out_["rgb_map"] - tr_rgb) ** 2)
+                            tot_ = loss_ + 8e-5 * fa_.density_L1()
+                            opt_.zero_grad()
+                            tot_.backward()
+                            opt_.step()
+                            return loss_
+                        for it in range(3):
+                            ref_iter(it)
+                        torch.cuda.synchronize(device)
+                        t0 = time.perf_counter()
+                        for it in range(10):
+                            ref_iter(3 + it).item()                      # the reference reads the loss every iteration (main.py:297)
+                        torch.cuda.synchronize(device)
+                        tr_extra[key_] = (time.perf_counter() - t0) / 10 * 1e3
+                        fa_._grad_engine.release()
+                        fa_.release()
+                    except Exception as ex:
+                        tr_extra[key_] = repr(ex)
                 # A/B of the trainer's streams (it forks onto two streams of its own after the colour backward: DESIGN.md section 8 N3): ten
                 # more iterations, alternately forked and with the whole step on the caller's stream -- the active count falls as the field
                 # trains, so the two are interleaved; every step is synchronised here, which the headline figure above is not
@@ -886,6 +916,11 @@ def main():
                     tr_extra["cpu_port_forward_backward_s"] = time.perf_counter() - t0
                     tr_extra["cpu_threads"] = torch.get_num_threads()
                 extras["train_step_R1"] = tr_extra
+                if isinstance(tr_extra.get("reference_loop_with_ngf_optim_ms_per_iteration"), float):
+                    extras["train_step_R1_autograd"] = {"ms_per_iteration": tr_extra["reference_loop_with_ngf_optim_ms_per_iteration"],
+                                                        "with_torch_optim_Adam_ms": tr_extra.get("reference_loop_on_autograd_path_ms_per_iteration"),
+                                                        "what": "TriPlane/main.py:272-299 as written on the drop-in field (differentiable forward, torch MSE + density_L1, "
+                                                                "backward), optimizer = ngf_amd.optim.Adam(field.get_optparam_groups(), betas=(0.9, 0.99))"}
                 trn.release()
                 ft.release()
             except Exception as ex:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define NGF_ABI_VERSION 5      /* 5: handles remember their device and streams (ngf_field_destroy needs no current-device contract), ngf_pool_set_limit / ngf_pool_bytes, NGF_E_STALE from ngf_train_backward_grad; 4: ngf_train_forward / ngf_train_backward_grad (the step in two calls, d loss / d rgb_map handed in), trainers without Adam moments; 3: ngf_train_overflow_count + speculative rows (ngf_train_desc.chunk_samples < 0), ngf_train_backward2 (loss_len travels with the call; ngf_train_backward is back to its ABI-1 contract of ONE double); 2: ngf_uv_desc.flags (was padding), ngf_uv_render_batch, ngf_debug_dirty_lds, trainer chunk_samples = 0 means the whole batch */
+#define NGF_ABI_VERSION 5      /* 5: handles remember their device and streams (ngf_field_destroy needs no current-device contract), ngf_pool_set_limit / ngf_pool_bytes, NGF_E_STALE from ngf_train_backward_grad, ngf_train_get_grads / ngf_train_adam_ext, ngf_field_render_image; 4: ngf_train_forward / ngf_train_backward_grad (the step in two calls, d loss / d rgb_map handed in), trainers without Adam moments; 3: ngf_train_overflow_count + speculative rows (ngf_train_desc.chunk_samples < 0), ngf_train_backward2 (loss_len travels with the call; ngf_train_backward is back to its ABI-1 contract of ONE double); 2: ngf_uv_desc.flags (was padding), ngf_uv_render_batch, ngf_debug_dirty_lds, trainer chunk_samples = 0 means the whole batch */
 
 enum { NGF_OK = 0, NGF_E_ARG = 1, NGF_E_HIP = 2, NGF_E_UNSUPPORTED = 3,
        NGF_E_STALE = 4 /* ngf_train_backward_grad: the ticket is not the trainer's last forward -- run the forward again; nothing else returns it */ };
@@ -120,6 +120,12 @@ int ngf_field_destroy(ngf_field *f);
 int ngf_field_render(const ngf_field *f, const float *rays, int64_t n, int32_t n_samples, int32_t white_bg,
                      int32_t mode, const float *jitter, float *rgb, float *depth, uint64_t *stats,
                      void *hip_stream);
+/* ABI 5: the same call for a ray list that is an IMAGE -- rays [n,6] row-major with row_width rays per image row, which is what the reference's
+ * evaluation hands renderer (samples.view(-1, 6) of an H x W frame, TriPlane/main.py:88-94).  Pixels are bit-identical to ngf_field_render; the
+ * launch walks the image in screen-space blocks (80 rows x 80 pixels) instead of row by row, which keeps the colour-plane taps of the tiles in flight
+ * inside an XCD's L2 (dense scenes: -4 ... -6 % frame time, profiles/r06_r2_locality.txt).  row_width <= 0 or not a multiple of 8: ngf_field_render. */
+int ngf_field_render_image(const ngf_field *f, const float *rays, int64_t n, int32_t row_width, int32_t n_samples, int32_t white_bg,
+                           int32_t mode, const float *jitter, float *rgb, float *depth, uint64_t *stats, void *hip_stream);
 
 /* Pieces of the path exposed for parity tests (same device code as ngf_field_render):
  *   ngf_field_decode_rgb : compute_rgb + rgb_decoder (Field.py:93-105, networks.py:25-32) for n samples
@@ -281,6 +287,17 @@ int ngf_train_adam(ngf_trainer *t, int32_t which, int32_t step_count, float lr, 
  * parameter whose .grad is None).  The six plane updates are one launch each, the nine MLP parameters share one. */
 int ngf_train_adam_all(ngf_trainer *t, const int32_t step_count[NGF_TRAIN_PARAMS], const float lr[NGF_TRAIN_PARAMS], float beta1,
                        float beta2, float eps, float l1_weight, void *hip_stream);
+/* ABI 5 -- the two calls behind the reference's own loop on the drop-in field (TriPlane/main.py:234-242,294-302: torch's loss, total_loss.backward(),
+ * optimizer.step() with ngf_amd.optim.Adam in torch.optim.Adam's place):
+ * ngf_train_get_grads: every wanted gradient of the last ngf_train_backward_grad / ngf_train_backward in its reference layout, out[k] NULL = skip
+ * (one call and at most seven launches instead of fifteen ngf_train_get_grad calls).
+ * ngf_train_adam_ext: torch.optim.Adam's update of the trainer's parameters from the CALLER's gradient tensors and moments (reference layouts:
+ * p.grad, state['exp_avg'], state['exp_avg_sq']); step_count[k] <= 0 or grad[k] NULL leaves parameter k alone; the plane kernels also write the
+ * trainer's channel-last copies, so the next forward needs no re-pack.  No L1 term is added (the caller's loss carries it). */
+int ngf_train_get_grads(ngf_trainer *t, float *const out[NGF_TRAIN_PARAMS], void *hip_stream);
+int ngf_train_adam_ext(ngf_trainer *t, const float *const grad[NGF_TRAIN_PARAMS], float *const exp_avg[NGF_TRAIN_PARAMS],
+                       float *const exp_avg_sq[NGF_TRAIN_PARAMS], const int32_t step_count[NGF_TRAIN_PARAMS], const float lr[NGF_TRAIN_PARAMS],
+                       float beta1, float beta2, float eps, void *hip_stream);
 /* The trainer keeps channel-last copies of the planes and gauge planes; ngf_train_adam keeps them current.  After writing to a
  * plane's memory by any other means (checkpoint load, in-place edit) call this: the next backward re-packs all of them. */
 int ngf_train_params_changed(ngf_trainer *t);
@@ -360,6 +377,9 @@ int ngf_debug_xcd_histogram(unsigned *out8, int32_t workgroups, void *hip_stream
  * tiles.  Returns the number of segments (1..4); unused entries are zeroed.  (Why: a persistent grid ends when its last wave does -- narrow
  * tiles for the last rays let the waves run dry together.) */
 int ngf_debug_tile_plan(int64_t n, int32_t wide, int64_t resident, int32_t tail16, int64_t *seg_rays, int32_t *seg_shift);
+/* test hook: the queue-position -> tile map of ngf_field_render_image evaluated on the host for `count` positions (RenderArgs::ord_*: ord_n positions
+ * re-ordered, tpr tiles per image row, blocks of bw tiles x bh rows) */
+int ngf_debug_tile_order(const uint32_t *q, int64_t count, uint32_t ord_n, uint32_t tpr, uint32_t bw, uint32_t bh, uint32_t *out);
 
 const char *ngf_last_error(void);
 int ngf_abi_version(void);

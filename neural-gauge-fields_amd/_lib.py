@@ -19,12 +19,12 @@ F_BAKE_COLOR = 2
 F_NO_FOLD = 4
 F_SPLIT_BF16 = 8
 
-SYMBOLS = ["ngf_field_create", "ngf_field_destroy", "ngf_field_render", "ngf_field_decode_rgb", "ngf_field_march",
+SYMBOLS = ["ngf_field_create", "ngf_field_destroy", "ngf_field_render", "ngf_field_render_image", "ngf_field_decode_rgb", "ngf_field_march",
            "ngf_generate_rays", "ngf_generate_rays_dtu", "ngf_last_error", "ngf_abi_version", "ngf_field_bytes", "ngf_sizeof_field_desc",
            "ngf_uv_create", "ngf_uv_destroy", "ngf_uv_render", "ngf_uv_render_batch", "ngf_field_alpha", "ngf_field_ray_filter",
            "ngf_eval_workspace_bytes", "ngf_eval_frame_u8", "ngf_eval_depth_range", "ngf_eval_depth_colormap", "ngf_eval_mse",
            "ngf_eval_ssim", "ngf_trainer_create", "ngf_trainer_destroy", "ngf_trainer_bytes", "ngf_sizeof_train_desc", "ngf_train_backward", "ngf_train_backward2",
-           "ngf_train_forward", "ngf_train_backward_grad", "ngf_train_get_grad", "ngf_train_get_active", "ngf_train_overflow_count", "ngf_train_adam", "ngf_train_adam_all", "ngf_train_params_changed", "ngf_train_debug_sections", "ngf_resize_bilinear", "ngf_uv_set_texture", "ngf_uv_texture_edit", "ngf_field_alpha_mask_build", "ngf_pack_mask_bits", "ngf_debug_set", "ngf_debug_get", "ngf_debug_dirty_lds", "ngf_debug_xcd_histogram", "ngf_debug_tile_plan", "ngf_pool_trim", "ngf_pool_set_limit", "ngf_pool_bytes"]
+           "ngf_train_forward", "ngf_train_backward_grad", "ngf_train_get_grad", "ngf_train_get_active", "ngf_train_overflow_count", "ngf_train_adam", "ngf_train_adam_all", "ngf_train_adam_ext", "ngf_train_get_grads", "ngf_train_params_changed", "ngf_train_debug_sections", "ngf_resize_bilinear", "ngf_uv_set_texture", "ngf_uv_texture_edit", "ngf_field_alpha_mask_build", "ngf_pack_mask_bits", "ngf_debug_set", "ngf_debug_get", "ngf_debug_dirty_lds", "ngf_debug_xcd_histogram", "ngf_debug_tile_plan", "ngf_debug_tile_order", "ngf_pool_trim", "ngf_pool_set_limit", "ngf_pool_bytes"]
 
 
 class FieldDesc(C.Structure):
@@ -82,6 +82,8 @@ def _load(path):
         L.ngf_field_destroy.argtypes = [C.c_void_p]
         L.ngf_field_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ngf_field_render_image.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ngf_field_decode_rgb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
         L.ngf_field_march.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
@@ -120,6 +122,7 @@ def _load(path):
         L.ngf_pool_set_limit.argtypes = [C.c_int64]
         L.ngf_pool_bytes.argtypes = [C.c_int32]
         L.ngf_pool_bytes.restype = C.c_int64
+        L.ngf_debug_tile_order.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         if L.ngf_abi_version() != 5 or L.ngf_sizeof_field_desc() != C.sizeof(FieldDesc):
             raise RuntimeError("libngf_hip.so ABI mismatch (version or ngf_field_desc layout)")
         _LIBS[path] = L

@@ -66,6 +66,15 @@ struct RenderArgs {
     int32_t waves_active;  // waves of a workgroup that take tiles (the others leave after the LDS image barrier): < WAVES for launches with fewer tiles than
                            // resident waves, so that the working waves are spread over all CUs and SIMDs
     uint32_t tiles;        // number of tiles of the launch
+    // Screen-space tile order (round 6; ngf_field_render_image: the caller says that the ray list is an image of `row_width` rays per row).  The queue
+    // hands out positions 0, 1, 2 ...; position q < ord_n is the tile tile_order(q): the launch walks the image in blocks of ord_bh rows x ord_bw
+    // tiles instead of row by row, so that the tiles in flight together cover a compact window -- narrow frusta whose footprints on the planes
+    // are strips an XCD's L2 can hold -- instead of a fan over the whole plane.  Every tile still is 8 consecutive rays of one row and computes
+    // what it always did: pixels are bit-identical, only the order changes.  ord_n = 0: the list's own order.
+    uint32_t ord_n;        // queue positions that are re-ordered: the full bands of segment 0 (whole rows, ord_bh at a time)
+    uint32_t ord_tpr;      // tiles per image row (row_width >> seg_shift[0])
+    uint32_t ord_bw;       // block width in tiles
+    uint32_t ord_bh;       // block height in rows
     uint32_t queue_waves;  // workgroups of the launch (each reports once, when its last working wave found the queue empty): what tile_counter[8] counts up to
     int32_t ablate;        // debug instantiations only (render_kernel<.., DBG = true>): 32 no early termination, 64 no empty-iteration skip -- both
                            // EXACT (A/B timing and the bit-identity tests).  Round 1-2's bits 1 / 2 / 4 / 16 (skip collect, skip layers 2-3, cached
@@ -107,6 +116,22 @@ __device__ __forceinline__ bool next_tile(const RenderArgs &A, int xcd, int lane
         if (t < hi - lo) { tile = lo + t; return true; }
     }
     return false;
+}
+
+// queue position -> tile (RenderArgs::ord_*): bands of ord_bh image rows, each walked block by block (the last block of a band may be narrower).
+// Wave-uniform scalar arithmetic, once per tile.
+__host__ __device__ __forceinline__ unsigned tile_order(unsigned q, unsigned n, unsigned tpr, unsigned bw, unsigned bh)
+{
+    if (q >= n) return q;
+    const unsigned band_tiles = tpr * bh, full = bw * bh;
+    const unsigned band = q / band_tiles, p = q - band * band_tiles;
+    const unsigned last = (tpr - 1) / bw;                   // index of the band's last block
+    unsigned b = p / full;
+    b = b < last ? b : last;
+    const unsigned inb = p - b * full;
+    const unsigned wb = b == last ? tpr - last * bw : bw;
+    const unsigned r = inb / wb, c = b * bw + (inb - r * wb);
+    return (band * bh + r) * tpr + c;
 }
 
 // A wave that found the queue empty reports to its workgroup's LDS counter; the workgroup's last wave reports to the launch's slot, and the last

@@ -31,7 +31,7 @@ int ngf::fail(int code, const char *fmt, ...)
 }
 
 static std::atomic<int> g_knob[ngf::KNOB_COUNT];
-static const char *const g_knob_name[ngf::KNOB_COUNT] = {"tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage", "poison", "grid", "xcd", "tail"};
+static const char *const g_knob_name[ngf::KNOB_COUNT] = {"tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage", "poison", "grid", "xcd", "tail", "ord_rows", "ord_px"};
 static bool g_knob_init = [] { for (auto &k : g_knob) k.store(-1); return true; }();
 
 int ngf::knob(int id) { return g_knob[id].load(std::memory_order_relaxed); }
@@ -950,6 +950,14 @@ static int make_tile_plan(int64_t n, int wide, int64_t resident, int tail16, int
     return nseg;
 }
 
+// the device's queue-position -> tile map of ngf_field_render_image, on the host (CPU test: a bijection of [0, ord_n) for every plan)
+extern "C" int ngf_debug_tile_order(const uint32_t *q, int64_t count, uint32_t ord_n, uint32_t tpr, uint32_t bw, uint32_t bh, uint32_t *out)
+{
+    if (!q || !out || count < 0 || !tpr || !bw || !bh) return fail(NGF_E_ARG, "ngf_debug_tile_order: bad argument");
+    for (int64_t i = 0; i < count; ++i) out[i] = tile_order(q[i], ord_n, tpr, bw, bh);
+    return NGF_OK;
+}
+
 extern "C" int ngf_debug_tile_plan(int64_t n, int32_t wide, int64_t resident, int32_t tail16, int64_t *seg_rays, int32_t *seg_shift)
 {
     int64_t r[4] = {0, 0, 0, 0};
@@ -1013,6 +1021,26 @@ static int launch_render(K kernel, K kernel_split, K kernel_prod, const ngf_fiel
         if (k < 3) {
             if (tiles >= ((int64_t)1 << 32)) return fail(NGF_E_ARG, "render launch of %lld tiles: split the ray list", (long long)tiles);
             A.seg_end[k] = (uint32_t)tiles;
+        }
+    }
+    // Screen-space tile order (ngf_field_render_image): the caller declared the list an image of A.ord_tpr (= row_width here) rays per row.  Blocks of
+    // 80 rows x 80 pixels measured best on the MLP-stress frames (profiles/r06_r2_locality.txt: R2 -3.8 %, R2 at S = 884 -6.1 %; R1 and InfoInv
+    // within 0.6 %); only whole rows of the widest segment take part, the plan's narrow tail keeps the list's order.
+    {
+        const int64_t row_w = A.ord_tpr;
+        A.ord_n = A.ord_tpr = A.ord_bw = A.ord_bh = 0;
+        const int sft0 = seg_shift[0];
+        if (split && row_w > 0 && (row_w & ((1 << sft0) - 1)) == 0 && (seg_rays[0] >> sft0) < ((int64_t)1 << 31)) {
+            const int64_t tpr = row_w >> sft0, rows = seg_rays[0] / row_w;
+            int64_t bh = knob(KNOB_ORD_ROWS) > 0 ? knob(KNOB_ORD_ROWS) : 80;
+            int64_t bw = (knob(KNOB_ORD_PX) > 0 ? knob(KNOB_ORD_PX) : 80) >> sft0;
+            if (bw < 1) bw = 1;
+            if (bw > tpr) bw = tpr;
+            if (knob(KNOB_ORD_ROWS) != 0 && tpr > bw && rows >= 2 && bh >= 2) {          // knob ord_rows = 0: the list's order
+                if (bh > rows) bh = rows;
+                A.ord_tpr = (uint32_t)tpr; A.ord_bw = (uint32_t)bw; A.ord_bh = (uint32_t)bh;
+                A.ord_n = (uint32_t)((rows / bh) * bh * tpr);
+            }
         }
     }
     K k = split ? kernel_split : kernel;
@@ -1181,6 +1209,23 @@ extern "C" int ngf_field_render(const ngf_field *f, const float *rays, int64_t n
     A.rays = rays; A.jitter = jitter; A.rgb = rgb; A.depth = depth; A.n = n; A.S = n_samples;
     A.white_bg = white_bg ? 1 : 0; A.mode = mode ? 1 : 0; A.stats = (unsigned long long *)stats;
     if (knob(KNOB_ABLATE) > 0) A.ablate = knob(KNOB_ABLATE);          // ngf_debug_set("ablate", bits): A/B timing and bit-identity tests only
+    return render_common(f, A, (hipStream_t)hip_stream);
+}
+
+// ABI 5: ngf_field_render for a ray list that IS an image -- rays [n,6] row-major, row_width rays per image row (the reference's evaluation hands
+// `renderer` exactly that: samples.view(-1, 6) of an H x W frame, TriPlane/main.py:88-94).  Same pixels, bit for bit; the launch walks the image in
+// screen-space blocks (RenderArgs::ord_*).  row_width <= 0, or a width the tile plan cannot use (not a multiple of the 8-ray tile): ngf_field_render.
+extern "C" int ngf_field_render_image(const ngf_field *f, const float *rays, int64_t n, int32_t row_width, int32_t n_samples, int32_t white_bg,
+                                      int32_t mode, const float *jitter, float *rgb, float *depth, uint64_t *stats, void *hip_stream)
+{
+    if (!f || !rays || !rgb || !depth) return fail(NGF_E_ARG, "ngf_field_render_image: null argument");
+    if (n < 0 || n_samples <= 0) return fail(NGF_E_ARG, "ngf_field_render_image: n=%lld n_samples=%d", (long long)n, n_samples);
+    if (n == 0) return NGF_OK;
+    RenderArgs A = f->proto;
+    A.rays = rays; A.jitter = jitter; A.rgb = rgb; A.depth = depth; A.n = n; A.S = n_samples;
+    A.white_bg = white_bg ? 1 : 0; A.mode = mode ? 1 : 0; A.stats = (unsigned long long *)stats;
+    if (knob(KNOB_ABLATE) > 0) A.ablate = knob(KNOB_ABLATE);
+    A.ord_tpr = row_width > 0 && (int64_t)row_width < n ? (uint32_t)row_width : 0u;          // launch_render turns the width into the plan (or drops it)
     return render_common(f, A, (hipStream_t)hip_stream);
 }
 
@@ -1893,6 +1938,101 @@ extern "C" int ngf_train_get_grad(ngf_trainer *t, int32_t which, float *out, voi
     } else {
         HIP_TRY(hipMemcpyAsync(out, t->g_dense[which], (size_t)t->dense_n[which] * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+// ABI 5: every requested gradient in ONE call (out[k] NULL = not wanted): three tiled transposes for the planes, the gauge planes, one launch for
+// the nine MLP parameters -- the autograd path (ngf_amd.train.RenderGrad.backward) made fifteen calls of ngf_train_get_grad per step.
+extern "C" int ngf_train_get_grads(ngf_trainer *t, float *const *out, void *hip_stream)
+{
+    if (!t || !out) return fail(NGF_E_ARG, "ngf_train_get_grads: null argument");
+    hipStream_t st = (hipStream_t)hip_stream;
+    for (int p = 0; p < 3; ++p) {
+        if (out[p]) {
+            const int H = t->d.plane_h[p], W = t->d.plane_w[p];
+            hipLaunchKernelGGL((unpack_plane_tiled_kernel<64, 16>), dim3(H * ((W + 63) / 64)), dim3(256), 0, st, (const float *)t->g_d[p], (const float *)t->g_a[p], H, W, out[p]);
+        }
+        if (out[3 + p])
+            hipLaunchKernelGGL(unpack_plane_kernel, dim3(256), dim3(256), 0, st, (const float *)t->g_g[p], 2, (const float *)nullptr, 2, t->d.gauge_h[p], t->d.gauge_w[p], out[3 + p]);
+    }
+    CopyDenseAll D;
+    int32_t at = 0;
+    for (int j = 0; j < kDenseParams; ++j) {
+        const int k = TP_DENS_W + j;
+        D.src[j] = t->g_dense[k]; D.dst[j] = out[k]; D.begin[j] = at;
+        if (out[k]) at += (int32_t)t->dense_n[k];
+    }
+    D.begin[kDenseParams] = at;
+    if (at > 0) hipLaunchKernelGGL(copy_dense_all_kernel, dim3((at + 255) / 256), dim3(256), 0, st, D);
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
+// ABI 5: torch.optim.Adam's update for the trainer's fifteen parameters from the CALLER'S gradient tensors and moments (reference layouts: what
+// p.grad, state['exp_avg'], state['exp_avg_sq'] are after total_loss.backward()), planes in one pass that also writes the trainer's packed
+// copy -- the next ngf_train_forward reads it without a re-pack.  step_count[k] <= 0 or grad[k] NULL = parameter k is left alone.  The arithmetic
+// is ngf_train_adam's (adam_one); no L1 term is added here: the caller's loss put it into the gradient.  Works on trainers with or without
+// their own moments.  ngf_amd.optim.Adam is the Python face (TriPlane/main.py:234-242,294-302 unchanged).
+extern "C" int ngf_train_adam_ext(ngf_trainer *t, const float *const *grad, float *const *exp_avg, float *const *exp_avg_sq, const int32_t *step_count,
+                                  const float *lr, float beta1, float beta2, float eps, void *hip_stream)
+{
+    if (!t || !grad || !exp_avg || !exp_avg_sq || !step_count || !lr) return fail(NGF_E_ARG, "ngf_train_adam_ext: null argument");
+    const ngf_train_desc &d = t->d;
+    hipStream_t st = (hipStream_t)hip_stream;
+    auto args = [&](int k) {
+        AdamArgs a;
+        a.lr = lr[k]; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.l1 = 0.0f;
+        a.bc1 = (float)(1.0 - pow((double)beta1, (double)step_count[k]));
+        a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step_count[k]));
+        return a;
+    };
+    for (int k = 0; k < TP_COUNT; ++k)
+        if (step_count[k] > 0 && grad[k] && (!exp_avg[k] || !exp_avg_sq[k])) return fail(NGF_E_ARG, "ngf_train_adam_ext: parameter %d has a gradient but no moments", k);
+    const bool fork = !(knob(KNOB_ABLATE) > 0 && (knob(KNOB_ABLATE) & (1 << 19)));
+    const bool big[3] = {step_count[0] > 0 && grad[0], step_count[1] > 0 && grad[1], step_count[2] > 0 && grad[2]};
+    const bool forked = fork && (big[1] || big[2]);
+    if (forked) {
+        HIP_TRY(hipEventRecord(t->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(t->aux[0], t->ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(t->aux[1], t->ev_fork, 0));
+    }
+    for (int p : {1, 2, 0}) {
+        if (!big[p]) continue;
+        const int H = d.plane_h[p], W = d.plane_w[p];
+        hipStream_t sk = (forked && p > 0) ? t->aux[p - 1] : st;
+        // a stale packed copy (ngf_train_params_changed since the last forward) is simply rewritten: the kernel stores every interior texel and the
+        // zero border was written when the copy was first packed
+        hipLaunchKernelGGL((adam_plane_kernel<64, 16, true>), dim3(H * ((W + 63) / 64)), dim3(256), 0, sk, d.plane[p], exp_avg[p], exp_avg_sq[p], H, W,
+                           (const float *)nullptr, (const float *)nullptr, t->tex_d[p], t->tex_a[p], args(p), (const int32_t *)nullptr, grad[p]);
+        t->tex_fresh[p] = true;
+    }
+    for (int p = 0; p < 3; ++p) {
+        const int k = 3 + p;
+        if (!(step_count[k] > 0 && grad[k])) continue;
+        hipLaunchKernelGGL((adam_plane_kernel<2, 2, true>), dim3(d.gauge_h[p] * ((d.gauge_w[p] + 63) / 64)), dim3(256), 0, st, d.gauge[p], exp_avg[k], exp_avg_sq[k],
+                           d.gauge_h[p], d.gauge_w[p], (const float *)nullptr, (const float *)nullptr, t->tex_g[p], (float *)nullptr, args(k), (const int32_t *)nullptr, grad[k]);
+        t->tex_fresh[k] = true;
+    }
+    float *params[TP_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d.dens_w, d.dens_b, d.basis, d.w1, d.b1, d.w2, d.b2, d.w3, d.b3};
+    AdamDenseAll D;
+    int32_t at = 0;
+    for (int j = 0; j < kDenseParams; ++j) {
+        const int k = TP_DENS_W + j;
+        D.p[j] = params[k]; D.m[j] = exp_avg[k]; D.v[j] = exp_avg_sq[k]; D.g[j] = grad[k];
+        D.begin[j] = at;
+        D.a[j] = args(k);
+        if (step_count[k] > 0 && grad[k]) at += (int32_t)t->dense_n[k];
+        else { D.a[j].bc1 = 1.0f; D.a[j].bc2_sqrt = 1.0f; }          // empty segment
+    }
+    D.begin[kDenseParams] = at;
+    D.skip = nullptr;
+    if (at > 0) hipLaunchKernelGGL(adam_dense_all_kernel, dim3((at + 255) / 256), dim3(256), 0, st, D);
+    if (forked)
+        for (int j = 0; j < 2; ++j) {
+            HIP_TRY(hipEventRecord(t->ev_join[j], t->aux[j]));
+            HIP_TRY(hipStreamWaitEvent(st, t->ev_join[j], 0));
+        }
     HIP_TRY(hipGetLastError());
     return NGF_OK;
 }

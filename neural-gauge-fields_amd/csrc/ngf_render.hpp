@@ -469,6 +469,10 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
     for (;;) {
         unsigned int tile = 0;
         if (!next_tile(A, xcd, lane, q_first, tile)) break;
+        if constexpr (SPLIT) {          // screen-space tile order (ngf_field_render_image): the queue position becomes a tile of the image-blocked walk
+            const uint32_t ord_n = NGF_KARG(ord_n);
+            if (tile < ord_n) tile = tile_order(tile, ord_n, NGF_KARG(ord_tpr), NGF_KARG(ord_bw), NGF_KARG(ord_bh));
+        }
 #ifdef NGF_EXP_TIMELINE
         if (!tl_tiles) tl_first = wall_clock64();
         ++tl_tiles;

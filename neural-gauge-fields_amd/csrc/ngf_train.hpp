@@ -1945,11 +1945,50 @@ __global__ void __launch_bounds__(256) adam_dense_all_kernel(const AdamDenseAll 
 // (CS per texel), [CS,C) in gb / tb (C-CS per texel).  A workgroup takes 64 texels of one row: the packed gradient rows go through LDS
 // so that every global access is a contiguous run (the parameter / moments along x, the packed arrays along the channels), and the
 // updated values leave the same way into the packed copy -- the next step's kernels read it without a re-pack.
-template <int C, int CS>
+// EXT (round 6, ngf_train_adam_ext): the gradient is the caller's tensor `gext` in the parameter's own NCHW layout (torch's p.grad after
+// total_loss.backward(): render gradient + whatever else the caller's loss added, e.g. density_L1) instead of the trainer's packed buffers.
+template <int C, int CS, bool EXT = false>
 __global__ void __launch_bounds__(256) adam_plane_kernel(float *p, float *m, float *v, int H, int W, const float *ga, const float *gb, float *ta, float *tb,
-                                                         const AdamArgs a, const int32_t *skip)
+                                                         const AdamArgs a, const int32_t *skip, const float *gext = nullptr)
 {
     if (skip && *skip) return;
+    constexpr int CB = C - CS;
+    __shared__ float sg[64 * (C + 1)];
+    const int tiles_x = (W + 63) / 64;
+    for (int tile = blockIdx.x; tile < H * tiles_x; tile += gridDim.x) {
+        const int y = tile / tiles_x, x0 = (tile - y * tiles_x) * 64, nx = min(64, W - x0);
+        const size_t texel0 = (size_t)(y + 1) * (W + 2) + (x0 + 1);
+        if (!EXT) {
+            for (int e = threadIdx.x; e < nx * CS; e += 256) sg[(e / CS) * (C + 1) + e % CS] = ga[texel0 * CS + e];
+            if (CB > 0)
+                for (int e = threadIdx.x; e < nx * CB; e += 256) sg[(e / (CB > 0 ? CB : 1)) * (C + 1) + CS + e % (CB > 0 ? CB : 1)] = gb[texel0 * CB + e];
+            __syncthreads();
+        }
+        for (int e = threadIdx.x; e < C * 64; e += 256) {
+            const int c = e >> 6, x = e & 63;
+            if (x < nx) {
+                const size_t i = ((size_t)c * H + y) * W + x0 + x;
+                const float pv = p[i];
+                const float g = (EXT ? gext[i] : sg[x * (C + 1) + c]) + a.l1 * (pv > 0.0f ? 1.0f : (pv < 0.0f ? -1.0f : 0.0f));
+                float mi = m[i], vi = v[i];
+                const float pn = adam_one(pv, g, mi, vi, a);
+                p[i] = pn; m[i] = mi; v[i] = vi;
+                sg[x * (C + 1) + c] = pn;
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < nx * CS; e += 256) ta[texel0 * CS + e] = sg[(e / CS) * (C + 1) + e % CS];
+        if (CB > 0)
+            for (int e = threadIdx.x; e < nx * CB; e += 256) tb[texel0 * CB + e] = sg[(e / (CB > 0 ? CB : 1)) * (C + 1) + CS + e % (CB > 0 ? CB : 1)];
+        __syncthreads();
+    }
+}
+
+// packed gradient -> NCHW through LDS, 64 texels of one row per workgroup pass: contiguous runs on both sides (ngf_train_get_grads: the autograd
+// path copies every plane gradient out once per step; unpack_plane_kernel below reads its source 4 bytes per 64 / 192-byte stride)
+template <int C, int CS>
+__global__ void __launch_bounds__(256) unpack_plane_tiled_kernel(const float *ga, const float *gb, int H, int W, float *dst)
+{
     constexpr int CB = C - CS;
     __shared__ float sg[64 * (C + 1)];
     const int tiles_x = (W + 63) / 64;
@@ -1962,21 +2001,22 @@ __global__ void __launch_bounds__(256) adam_plane_kernel(float *p, float *m, flo
         __syncthreads();
         for (int e = threadIdx.x; e < C * 64; e += 256) {
             const int c = e >> 6, x = e & 63;
-            if (x < nx) {
-                const size_t i = ((size_t)c * H + y) * W + x0 + x;
-                const float pv = p[i];
-                const float g = sg[x * (C + 1) + c] + a.l1 * (pv > 0.0f ? 1.0f : (pv < 0.0f ? -1.0f : 0.0f));
-                float mi = m[i], vi = v[i];
-                const float pn = adam_one(pv, g, mi, vi, a);
-                p[i] = pn; m[i] = mi; v[i] = vi;
-                sg[x * (C + 1) + c] = pn;
-            }
+            if (x < nx) dst[((size_t)c * H + y) * W + x0 + x] = sg[x * (C + 1) + c];
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < nx * CS; e += 256) ta[texel0 * CS + e] = sg[(e / CS) * (C + 1) + e % CS];
-        if (CB > 0)
-            for (int e = threadIdx.x; e < nx * CB; e += 256) tb[texel0 * CB + e] = sg[(e / (CB > 0 ? CB : 1)) * (C + 1) + CS + e % (CB > 0 ? CB : 1)];
-        __syncthreads();
+    }
+}
+
+// the MLP parameters' gradients (reference layout already) to the caller's tensors in one launch: segment k = [begin[k], begin[k+1])
+struct CopyDenseAll { const float *src[kDenseParams]; float *dst[kDenseParams]; int32_t begin[kDenseParams + 1]; };
+__global__ void __launch_bounds__(256) copy_dense_all_kernel(const CopyDenseAll D)
+{
+    const int total = D.begin[kDenseParams];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < kDenseParams; ++j) k += (i >= D.begin[j]) ? 1 : 0;
+        D.dst[k][i - D.begin[k]] = D.src[k][i - D.begin[k]];
     }
 }
 

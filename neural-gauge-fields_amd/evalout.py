@@ -179,7 +179,7 @@ def evaluation(test_dataset, field, args=None, savePath=None, N_vis=5, prtx='', 
     for idx, samples in enumerate(test_dataset.all_rays[0::interval]):
         W, H = test_dataset.img_wh
         rays = samples.view(-1, samples.shape[-1])
-        rgb_map, depth_map = renderer(rays, field, chunk=4096, N_samples=N_samples, white_bg=white_bg, device=device)
+        rgb_map, depth_map = renderer(rays, field, chunk=4096, N_samples=N_samples, white_bg=white_bg, device=device, row_width=W)
         gt = test_dataset.all_rgbs[idxs[idx]].view(H, W, 3) if len(test_dataset.all_rgbs) else None
         o = frame_outputs(rgb_map, depth_map, H, W, near_far, gt, compute_extra_metrics)
         if gt is not None:
@@ -215,7 +215,7 @@ def evaluation_path(test_dataset, field, c2ws, savePath=None, N_vis=5, prtx='', 
     rgb_maps, depth_maps = [], []
     for idx, c2w in enumerate(c2ws):
         rays = generate_rays(H, W, f, torch.as_tensor(c2w, dtype=torch.float32)[:3, :4], device=device)
-        rgb_map, depth_map = renderer(rays, field, chunk=8192, N_samples=N_samples, white_bg=white_bg, device=device)
+        rgb_map, depth_map = renderer(rays, field, chunk=8192, N_samples=N_samples, white_bg=white_bg, device=device, row_width=W)
         o = frame_outputs(rgb_map, depth_map, H, W, near_far)
         rgb_maps.append(o["rgb8"])
         depth_maps.append(o["depth8"])

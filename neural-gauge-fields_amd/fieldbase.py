@@ -280,9 +280,11 @@ class Base(torch.nn.Module):
 
     # --- Base.forward (FieldBase.py:251-312) ---------------------------------------------------------
     @torch.no_grad()
-    def _render(self, rays_chunk, white_bg, is_train, N_samples, mode, collect_stats=False, out=None, jitter=None, coin=None):
+    def _render(self, rays_chunk, white_bg, is_train, N_samples, mode, collect_stats=False, out=None, jitter=None, coin=None, row_width=0):
         """``jitter`` [n] and ``coin`` (a float in [0,1)) replace the torch.rand_like of sample_ray (FieldBase.py:128-130) and the
-        torch.rand((1,)) of the random background (FieldBase.py:299) in training mode -- parity tests against captured reference forwards."""
+        torch.rand((1,)) of the random background (FieldBase.py:299) in training mode -- parity tests against captured reference forwards.
+        ``row_width`` > 0: the ray list is an image with that many rays per row (ngf_field_render_image: the same pixels, the launch walks the image
+        in screen-space blocks; ``renderer(..., row_width=W)`` / ``evalout.evaluation`` pass it)."""
         dev = torch.device(self.device)
         rays = rays_chunk.to(device=dev, dtype=torch.float32).contiguous()
         if rays.dim() != 2 or rays.shape[1] != 6:
@@ -309,8 +311,8 @@ class Base(torch.nn.Module):
         stats = torch.zeros(16, dtype=torch.int64, device=dev) if collect_stats else None   # [4:] = section cycles under the profile knob
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
-            _lib.check(_lib.lib().ngf_field_render(
-                h, rays.data_ptr(), n, S, int(white_bg), int(mode), None if jitter is None else jitter.data_ptr(),
+            _lib.check(_lib.lib().ngf_field_render_image(
+                h, rays.data_ptr(), n, int(row_width or 0), S, int(white_bg), int(mode), None if jitter is None else jitter.data_ptr(),
                 rgb.data_ptr(), depth.data_ptr(), None if stats is None else stats.data_ptr(), C.c_void_p(stream)))
         if collect_stats:
             self.last_stats = stats
@@ -454,7 +456,8 @@ class density_decoder(torch.nn.Module):
 def renderer(rays, field, chunk=1024, N_samples=-1, white_bg=True, is_train=False, device='cuda', **field_kw):
     """TriPlane/main.py:60-71 (InfoInv/main.py:61-72).  ``chunk`` existed to bound the reference's
     [chunk, S, C] intermediates; the fused kernel has none, so the whole batch goes down in one launch
-    (``chunk`` is accepted and ignored).  Extra keyword arguments (``infoinv=...``) reach the field."""
+    (``chunk`` is accepted and ignored).  Extra keyword arguments (``infoinv=...``) reach the field; ``row_width=W`` tells the launch that ``rays``
+    is an H x W image in row-major order (evaluation's ``samples.view(-1, 6)``, main.py:88-94): the same pixels from a screen-space tile order."""
     kw = dict(field_kw)
     if 'infoinv' not in kw and 'iteration' not in kw and field.MODEL == _lib.MODEL_TRIPLANE:
         kw['iteration'] = 30001

@@ -41,11 +41,11 @@ class TriPlane(Base):
         """compute_alpha / getDenseAlpha / updateAlphaMask(..., infoinv=True) of InfoInv/models/FieldBase.py:140,161,180."""
         return int(bool(infoinv))
 
-    def forward(self, rays_chunk, white_bg=True, is_train=False, N_samples=-1, infoinv=True, collect_stats=False, out=None, jitter=None, coin=None):
+    def forward(self, rays_chunk, white_bg=True, is_train=False, N_samples=-1, infoinv=True, collect_stats=False, out=None, jitter=None, coin=None, row_width=0):
         """InfoInv/models/FieldBase.py:228.  Training the InfoInv tree is outside SURVEY.md section 8: a call that the
         reference would record for autograd (is_train=True, grad enabled, parameters requiring gradients) raises instead of returning pixels
         without a graph -- a loss built on them would otherwise only train its regularisers."""
         if self._wants_grad(is_train):
             raise NotImplementedError("ngf_amd.infoinv.TriPlane has no backward (InfoInv training is out of scope, DESIGN.md section 7): call it "
                                       "under torch.no_grad() for a training-mode render, or train with the TriPlane tree")
-        return self._render(rays_chunk, white_bg, is_train, N_samples, mode=int(bool(infoinv)), collect_stats=collect_stats, out=out, jitter=jitter, coin=coin)
+        return self._render(rays_chunk, white_bg, is_train, N_samples, mode=int(bool(infoinv)), collect_stats=collect_stats, out=out, jitter=jitter, coin=coin, row_width=row_width)

@@ -58,6 +58,8 @@ def _bind(L):
     L.ngf_train_adam.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
     L.ngf_train_adam_all.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
     L.ngf_train_params_changed.argtypes = [C.c_void_p]
+    L.ngf_train_get_grads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ngf_train_adam_ext.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
     if L.ngf_sizeof_train_desc() != C.sizeof(TrainDesc):
         raise RuntimeError("libngf_hip.so ABI mismatch (ngf_train_desc layout)")
     L._ngf_train_bound = True
@@ -378,6 +380,8 @@ class RenderGrad:
         self.key = _field_key(field, self.params)
         self._versions = tuple(int(p._version) for p in self.params[:6])
         self.last_active = 0
+        from . import optim
+        optim.register(field, self.params)          # ngf_amd.optim.Adam finds the engine behind a parameter (fused update, no re-pack)
 
     def fits(self, n, S):
         return n <= self.max_rays and S <= self.max_samples and self.key == _field_key(self.field, _train_params(self.field))
@@ -420,14 +424,9 @@ class RenderGrad:
             if rc == _lib.E_STALE:
                 return None
             _lib.check(rc)              # anything else is an error of this call (a HIP / launch failure must not be retried away)
-            grads = []
-            for k in range(15):
-                if not want[k]:
-                    grads.append(None)
-                    continue
-                g = torch.empty_like(self.params[k])
-                _lib.check(self.L.ngf_train_get_grad(self._h, k, g.data_ptr(), st))
-                grads.append(g)
+            grads = [torch.empty_like(self.params[k]) if want[k] else None for k in range(15)]
+            ptrs = (C.c_void_p * 15)(*[None if g is None else g.data_ptr() for g in grads])
+            _lib.check(self.L.ngf_train_get_grads(self._h, ptrs, st))          # one call: three tiled transposes, the gauge planes, one launch for the nine MLP tensors
         return grads
 
 

@@ -82,7 +82,7 @@ class TriPlane(Base):
             d.gauge_h[k], d.gauge_w[k] = g.shape[2], g.shape[3]
         d.dens_w1, d.dens_b1 = dp(self.density_decoder.weight), dp(self.density_decoder.bias)
 
-    def forward(self, rays_chunk, white_bg=True, is_train=False, N_samples=-1, iteration=0, collect_stats=False, out=None, jitter=None, coin=None):
+    def forward(self, rays_chunk, white_bg=True, is_train=False, N_samples=-1, iteration=0, collect_stats=False, out=None, jitter=None, coin=None, row_width=0):
         """FieldBase.py:251: gauge is applied iff iteration >= gauge_start (Field.py:58).  With ``is_train=True``, autograd enabled and
         parameters that require gradients -- the reference's training loop, TriPlane/main.py:272 -- the result is differentiable with respect to
         the fifteen parameters (``Base._render_train``); everything else is the fused eval launch (no graph, like the reference under its
@@ -92,4 +92,4 @@ class TriPlane(Base):
                 raise ValueError("collect_stats / out= belong to the eval launch; wrap the call in torch.no_grad() to use them with is_train=True")
             return self._render_train(rays_chunk, white_bg, N_samples, int(iteration >= self.gauge_start), jitter=jitter, coin=coin)
         return self._render(rays_chunk, white_bg, is_train, N_samples, mode=int(iteration >= self.gauge_start),
-                            collect_stats=collect_stats, out=out, jitter=jitter, coin=coin)
+                            collect_stats=collect_stats, out=out, jitter=jitter, coin=coin, row_width=row_width)

@@ -25,15 +25,22 @@ def rel(a, b):
     return float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-30)
 
 
-def test_the_references_training_loop_runs_unchanged_and_matches_its_gradients():
+def _adam(which):
+    from ngf_amd import optim
+    return {"torch": torch.optim.Adam, "ngf": optim.Adam}[which]
+
+
+@pytest.mark.parametrize("opt", ["torch", "ngf"])
+def test_the_references_training_loop_runs_unchanged_and_matches_its_gradients(opt):
     """The loop body below is main.py:272-299 line for line (names kept); only the two random draws of the forward are pinned to the captured
-    ones (jitter=, coin=: keyword extras of the drop-in's forward) so that the reference's numbers can be compared."""
+    ones (jitter=, coin=: keyword extras of the drop-in's forward) so that the reference's numbers can be compared.  ``opt = ngf``: the one
+    changed line is the optimizer's class (ngf_amd.optim.Adam, same constructor): the same trajectory from one fused C-ABI call per step."""
     g, params = load_train_case("train_r1")
     field = field_for_case(g, params, None)
     nSamples = int(g["S"])
     rays_train, rgb_train = torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["rgb_train"]).cuda()
     grad_vars = field.get_optparam_groups(0.02, 1e-3)                       # main.py:234 (args.lr_init, args.lr_basis)
-    optimizer = torch.optim.Adam(grad_vars, betas=(0.9, 0.99))              # main.py:241
+    optimizer = _adam(opt)(grad_vars, betas=(0.9, 0.99))                    # main.py:241
     lr_factor = float(g["lr_factor"])
     L1_reg_weight = 8e-5
     PSNRs = []
@@ -70,10 +77,63 @@ def test_the_references_training_loop_runs_unchanged_and_matches_its_gradients()
         d = np.abs(sd[name].cpu().numpy() - g[f"after.{name}"])
         assert not np.array_equal(sd[name].cpu().numpy(), params[name])
         assert np.median(d) < 1e-5 and np.mean(d > 1e-3) < 0.02, (name, float(np.median(d)), float(np.mean(d > 1e-3)))
-    # the eval launch sees torch.optim's in-place updates (Parameter._version moved: the packed image is rebuilt)
+    # the eval launch sees the optimizer's in-place updates (torch.optim: Parameter._version moved; ngf_amd.optim: it invalidates the image itself)
     with torch.no_grad():
         out = field(rays_train, N_samples=nSamples, iteration=30001)
+        fresh = field_for_case(g, {k: v.cpu().numpy() for k, v in field.state_dict().items()}, None)(rays_train, N_samples=nSamples, iteration=30001)
     assert torch.isfinite(out["rgb_map"]).all() and not out["rgb_map"].requires_grad
+    assert torch.equal(out["rgb_map"], fresh["rgb_map"])
+
+
+def test_fused_adam_follows_torch_adam_step_for_step():
+    """ngf_amd.optim.Adam against torch.optim.Adam on two copies of one field, the reference's loop for six iterations (gauge planes join at
+    iteration 3: gauge_start): parameters and optimizer state agree after every step; the state dict of one loads into the other; a parameter
+    that is not the field's (an extra tensor in its own group) takes torch's path inside the same step; the differentiable engine's packed
+    planes stay current without a re-pack (the next forward's rgb_map equals a freshly built field's)."""
+    from ngf_amd import optim, synth
+    g, params = load_train_case("train_r1")
+    S = int(g["S"])
+    rays, tgt = torch.from_numpy(g["rays"]).cuda(), torch.from_numpy(g["rgb_train"]).cuda()
+    fa, fb = field_for_case(g, params, None), field_for_case(g, params, None)
+    fa.gauge_start = fb.gauge_start = 3
+    ea, eb = torch.nn.Parameter(torch.ones(5, device="cuda")), torch.nn.Parameter(torch.ones(5, device="cuda"))
+    oa = torch.optim.Adam(fa.get_optparam_groups(0.02, 1e-3) + [{'params': [ea], 'lr': 0.1}], betas=(0.9, 0.99))
+    ob = optim.Adam(fb.get_optparam_groups(0.02, 1e-3) + [{'params': [eb], 'lr': 0.1}], betas=(0.9, 0.99))
+    for it in range(6):
+        jit = torch.from_numpy(synth.hash_uniform(77, it, (rays.shape[0],)))
+        for f, o, e in ((fa, oa, ea), (fb, ob, eb)):
+            out = f(rays, is_train=True, white_bg=True, N_samples=S, iteration=it, jitter=jit)
+            total = torch.mean((out["rgb_map"] - tgt) ** 2) + 8e-5 * f.density_L1() + (e ** 2).sum()
+            o.zero_grad()
+            total.backward()
+            o.step()
+            for gr in o.param_groups:
+                gr['lr'] = gr['lr'] * 0.999
+        assert torch.allclose(ea, eb)
+        for (na, pa), (nb, pb) in zip(fa.named_parameters(), fb.named_parameters()):
+            d = float((pa - pb).abs().max())
+            assert d <= 2e-6 * max(float(pa.abs().max()), 1e-3) + 1e-7, (it, na, d)      # the same arithmetic; a few ulp where ReLU kinks give last-bit gradient differences
+            if pa.grad is None:
+                assert pb.grad is None and pb not in ob.state, na
+            else:
+                sa, sb = oa.state[pa], ob.state[pb]
+                assert float(sa['step']) == float(sb['step'])
+                assert float((sa['exp_avg'] - sb['exp_avg']).abs().max()) <= 1e-5 * max(float(sa['exp_avg'].abs().max()), 1e-12), (it, na)
+                assert float((sa['exp_avg_sq'] - sb['exp_avg_sq']).abs().max()) <= 1e-5 * max(float(sa['exp_avg_sq'].abs().max()), 1e-20), (it, na)
+    # no re-pack happened on the fused side and none was needed: the engine renders the current parameters
+    jit = torch.from_numpy(synth.hash_uniform(77, 99, (rays.shape[0],)))
+    got = fb(rays, is_train=True, white_bg=True, N_samples=S, iteration=9, jitter=jit)["rgb_map"].detach()
+    sdb = {k: v.cpu().numpy() for k, v in fb.state_dict().items()}
+    fc = field_for_case(g, sdb, None)
+    fc.gauge_start = 3
+    want = fc(rays, is_train=True, white_bg=True, N_samples=S, iteration=9, jitter=jit)["rgb_map"].detach()
+    assert torch.equal(got, want)
+    # checkpoints move between the two classes
+    oc = torch.optim.Adam(fb.get_optparam_groups(0.02, 1e-3) + [{'params': [eb], 'lr': 0.1}], betas=(0.9, 0.99))
+    oc.load_state_dict(ob.state_dict())
+    od = optim.Adam(fa.get_optparam_groups(0.02, 1e-3) + [{'params': [ea], 'lr': 0.1}], betas=(0.9, 0.99))
+    od.load_state_dict(oa.state_dict())
+    assert float(oc.state[fb.plane_xy]['step']) == 6 and float(od.state[fa.gauge_xy]['step']) == 3
 
 
 @pytest.mark.parametrize("name", ["triplane_r1_train_white", "triplane_r1_train_black"])

@@ -907,6 +907,48 @@ def test_tile_queue_slots_are_clean_after_every_kind_of_launch():
     f.release()
 
 
+def test_image_tile_order_renders_the_same_bits():
+    """Round 6: ngf_field_render_image walks an image-shaped ray list in screen-space blocks (80 rows x 80 pixels: the tiles in
+    flight together cover a compact window, so their colour-plane taps stay inside an XCD's L2).  A tile computes what it always did: the pixels of
+    the blocked walk are the row-major walk's bit for bit -- full frame, a width the blocks do not divide, a frame with a ragged last row, widths
+    the plan cannot use (not a multiple of the 8-ray tile: silently the list's order), the per-XCD queues on top, InfoInv, and the statistics."""
+    from ngf_amd import _lib, synth
+    from ngf_amd.fieldbase import renderer
+    g, params, step = big_case("triplane", "R2")
+    f = field_for_case(g, params, None, bake=True, bake_color=True)
+    kw = dict(N_samples=96, white_bg=True, iteration=30001)
+    for H, W, extra in ((400, 800, 0), (203, 424, 0), (150, 200, 77), (64, 100, 0), (32, 4096, 0)):
+        rays = torch.from_numpy(np.concatenate([synth.lookat_rays(H, W), synth.lookat_rays(1, W)[:extra]], 0)).cuda()
+        ref = f(rays, collect_stats=True, **kw)
+        st0 = f.last_stats.clone()
+        out = f(rays, row_width=W, collect_stats=True, **kw)
+        assert torch.equal(out["rgb_map"], ref["rgb_map"]) and torch.equal(out["depth_map"], ref["depth_map"]), (H, W)
+        assert torch.equal(f.last_stats[:4], st0[:4])
+        prod = f(rays, row_width=W, **kw)                     # the production instantiation (no statistics)
+        assert torch.equal(prod["rgb_map"], ref["rgb_map"]) and torch.equal(prod["depth_map"], ref["depth_map"]), (H, W)
+        with _lib.knobs(xcd=1):
+            x = f(rays, row_width=W, **kw)
+        assert torch.equal(x["rgb_map"], ref["rgb_map"])
+        with _lib.knobs(ord_rows=16, ord_px=32):
+            y = f(rays, row_width=W, **kw)
+        assert torch.equal(y["rgb_map"], ref["rgb_map"]) and torch.equal(y["depth_map"], ref["depth_map"])
+        with _lib.knobs(ord_rows=0):                          # knob: the list's own order
+            z = f(rays, row_width=W, **kw)
+        assert torch.equal(z["rgb_map"], ref["rgb_map"])
+    rays = torch.from_numpy(synth.lookat_rays(120, 160)).cuda()
+    rgb, depth = renderer(rays, f, chunk=4096, N_samples=96, white_bg=True, row_width=160)           # the reference's call, plus the hint
+    ref = f(rays, **kw)
+    assert torch.equal(rgb, ref["rgb_map"]) and torch.equal(depth, ref["depth_map"])
+    f.release()
+    gi, pi, _ = big_case("infoinv", "R1")
+    fi = field_for_case(gi, pi, None)
+    rays = torch.from_numpy(synth.lookat_rays(160, 320)).cuda()
+    a = fi(rays, N_samples=64, infoinv=True)
+    b = fi(rays, N_samples=64, infoinv=True, row_width=320)
+    assert torch.equal(a["rgb_map"], b["rgb_map"]) and torch.equal(a["depth_map"], b["depth_map"])
+    fi.release()
+
+
 def test_xcd_tile_queues_are_bit_identical_and_xcds_are_visible():
     """Round 3: with knob xcd = 1 a render launch keeps one tile queue per XCD (each XCD has its own L2; its waves then
     work on ONE compact ray range and steal from the other chunks at the end).  Which wave renders a tile does not change the tile: knob xcd = 0 / 1 give the same bits, on the

@@ -284,3 +284,30 @@ def test_tile_plan_covers_every_ray_once_with_whole_tiles():
         assert sum((r + w - 1) // w for r, w in p) <= 3072, (n, p)
     assert plan(640000, 8, 3072, 0) == [(640000, 8)]
     assert plan(80000, 8, 3072, 16) == [(58496, 8), (12288, 4), (6144, 2), (3072, 1)]
+
+
+def test_screen_space_tile_order_is_a_bijection():
+    """ngf_field_render_image re-orders the queue positions of the widest plan segment into an image-blocked walk (RenderArgs::ord_*): for every
+    plan -- block widths that do not divide the row, bands of every height, a tail the map leaves alone -- the map is a bijection of the tiles,
+    the identity behind ord_n, and consecutive positions of one block stay inside that block's bh x bw window."""
+    import ctypes as C
+    from ngf_amd import _lib
+    L = _lib.lib()
+    for tpr, bw, bh, rows, extra in ((100, 10, 80, 800, 0), (100, 10, 80, 790, 37), (53, 10, 7, 40, 5), (7, 3, 2, 9, 0), (10, 10, 4, 8, 3), (25, 4, 80, 3, 0), (1, 1, 2, 16, 0)):
+        bh_eff = min(bh, rows)
+        ord_n = (rows // bh_eff) * bh_eff * tpr
+        total = rows * tpr + extra
+        q = np.arange(total, dtype=np.uint32)
+        out = np.empty_like(q)
+        assert L.ngf_debug_tile_order(q.ctypes.data_as(C.c_void_p), total, ord_n, tpr, bw, bh_eff, out.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(np.sort(out[:ord_n]), np.arange(ord_n, dtype=np.uint32)), (tpr, bw, bh_eff)
+        assert np.array_equal(out[ord_n:], q[ord_n:])
+        r, c = out[:ord_n] // tpr, out[:ord_n] % tpr
+        # the first block of the first band: its bw x bh positions cover exactly columns [0, bw) of rows [0, bh)
+        w0 = min(bw, tpr)
+        first = slice(0, w0 * bh_eff)
+        if ord_n >= w0 * bh_eff:
+            assert r[first].max() == bh_eff - 1 and c[first].max() == w0 - 1 and len(set(zip(r[first].tolist(), c[first].tolist()))) == w0 * bh_eff
+        # a band never leaves its rows
+        band = np.arange(ord_n) // (tpr * bh_eff)
+        assert np.array_equal(r // bh_eff, band)
