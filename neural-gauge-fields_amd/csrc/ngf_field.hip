@@ -932,7 +932,9 @@ static int make_tile_plan(int64_t n, int wide, int64_t resident, int tail16, int
     int64_t left = n, want[4] = {0, 0, 0, 0};
     for (int k = 3; k >= 1; --k) {      // the narrow segments are sized from the END of the ray list
         if (widths[k] >= wide) continue;
-        want[k] = std::min<int64_t>(left, (resident * tail16 / 16) * widths[k]);
+        // tail16 < 256: the same count for every narrow width; >= 256 (sweeps): one byte per width -- bits 0-7 one-ray, 8-15 two-ray, 16-23 four-ray tiles
+        const int tk = tail16 < 256 ? tail16 : (tail16 >> (8 * (3 - k))) & 0xff;
+        want[k] = std::min<int64_t>(left, (resident * tk / 16) * widths[k]);
         left -= want[k];
     }
     want[0] = left;
@@ -1225,7 +1227,7 @@ extern "C" int ngf_field_render_image(const ngf_field *f, const float *rays, int
     A.rays = rays; A.jitter = jitter; A.rgb = rgb; A.depth = depth; A.n = n; A.S = n_samples;
     A.white_bg = white_bg ? 1 : 0; A.mode = mode ? 1 : 0; A.stats = (unsigned long long *)stats;
     if (knob(KNOB_ABLATE) > 0) A.ablate = knob(KNOB_ABLATE);
-    A.ord_tpr = row_width > 0 && (int64_t)row_width < n ? (uint32_t)row_width : 0u;          // launch_render turns the width into the plan (or drops it)
+    A.ord_tpr = row_width > 0 && (int64_t)row_width < n && f->model == NGF_MODEL_TRIPLANE ? (uint32_t)row_width : 0u;          // launch_render turns the width into the plan (or drops it); InfoInv: the list's order (its kernels do not re-order)
     return render_common(f, A, (hipStream_t)hip_stream);
 }
 

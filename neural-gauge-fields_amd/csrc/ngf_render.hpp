@@ -431,6 +431,8 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
 #ifdef NGF_EXP_TIMELINE     // experiment build (profiles/exp_timeline.py): per-wave wall-clock marks of the production kernel -> A.stats[16 + 8 * wave id ..]
     const unsigned long long tl_t0 = wall_clock64();
     unsigned long long tl_tiles = 0, tl_pass = 0, tl_iter = 0, tl_first = 0;
+    unsigned long long tl_seg_t0 = 0, tl_seg_t1 = 0, tl_seg_t2 = 0, tl_seg_t3 = 0, tl_seg_n = 0, tl_tile_t = 0;      // round 6: wall clock per plan segment, tiles per segment (16 bits each)
+    int tl_seg = 0;
 #endif
     __shared__ unsigned wg_done;          // working waves of this workgroup that found the tile queue empty (queue_done)
     if (threadIdx.x == 0) wg_done = 0;
@@ -469,7 +471,9 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
     for (;;) {
         unsigned int tile = 0;
         if (!next_tile(A, xcd, lane, q_first, tile)) break;
-        if constexpr (SPLIT) {          // screen-space tile order (ngf_field_render_image): the queue position becomes a tile of the image-blocked walk
+        if constexpr (SPLIT && !P::INFOINV) {          // screen-space tile order (ngf_field_render_image): the queue position becomes a tile of the image-blocked walk.
+            // (TriPlane only: the InfoInv frames do not move with it -- +-0.7 %, profiles/r06_r2_locality.txt -- and its fp32 kernel sits at its register
+            // budget: the four scalar divisions of the map cost it 12 B of scratch)
             const uint32_t ord_n = NGF_KARG(ord_n);
             if (tile < ord_n) tile = tile_order(tile, ord_n, NGF_KARG(ord_tpr), NGF_KARG(ord_bw), NGF_KARG(ord_bh));
         }
@@ -487,6 +491,11 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
             if (tile >= e1) { ts = NGF_KARG_AT(seg_shift, 2); base = NGF_KARG_AT(seg_ray0, 2) + ((int64_t)(tile - e1) << ts); }
             if (tile >= e2) { ts = NGF_KARG_AT(seg_shift, 3); base = NGF_KARG_AT(seg_ray0, 3) + ((int64_t)(tile - e2) << ts); }
         }
+#ifdef NGF_EXP_TIMELINE
+        tl_tile_t = wall_clock64();
+        tl_seg = 0;
+        if constexpr (SPLIT) tl_seg = (tile >= NGF_KARG_AT(seg_end, 0)) + (tile >= NGF_KARG_AT(seg_end, 1)) + (tile >= NGF_KARG_AT(seg_end, 2));
+#endif
         const int tile_w = 1 << ts;
         // split tile of >= 4 rays: a 16-lane row holds M = tile_w / 4 rays, lane-in-row = seg * M + r (split_chain above), ray slot = row * M + r;
         // of 2 / 1 rays: a ray takes R = 2 / 4 whole rows, seg = its lane index inside them (split_chain_rows)
@@ -765,12 +774,20 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
             depth_p[ray] = dep + (1.0f - acc) * d[2];
         }
         if constexpr (DBG) st_rays += __popcll(__ballot(live && seg == 0));
+#ifdef NGF_EXP_TIMELINE
+        {
+            const unsigned long long dt_tile = wall_clock64() - tl_tile_t;
+            tl_seg_t0 += tl_seg == 0 ? dt_tile : 0; tl_seg_t1 += tl_seg == 1 ? dt_tile : 0; tl_seg_t2 += tl_seg == 2 ? dt_tile : 0; tl_seg_t3 += tl_seg == 3 ? dt_tile : 0;
+            tl_seg_n += 1ull << (16 * tl_seg);
+        }
+#endif
     }
     queue_done(A.tile_counter, &wg_done, (unsigned)A.waves_active, A.queue_waves, lane);
 #ifdef NGF_EXP_TIMELINE
     if (!DBG && A.stats && lane == 0) {
-        unsigned long long *row = A.stats + 16 + 8 * ((size_t)blockIdx.x * P::WAVES + wave);
+        unsigned long long *row = A.stats + 16 + 16 * ((size_t)blockIdx.x * P::WAVES + wave);
         row[0] = tl_t0; row[1] = tl_t1; row[2] = tl_first; row[3] = wall_clock64(); row[4] = tl_tiles; row[5] = tl_pass; row[6] = tl_iter; row[7] = (unsigned long long)xcd;
+        row[8] = tl_seg_t0; row[9] = tl_seg_t1; row[10] = tl_seg_t2; row[11] = tl_seg_t3; row[12] = tl_seg_n;
     }
 #endif
     if (DBG && A.stats && lane == 0) {

@@ -155,10 +155,12 @@ class Base(torch.nn.Module):
     # --- differentiable training-mode forward (FieldBase.py:251-312 under autograd; the loop of TriPlane/main.py:272-296) ------------------
     def _render_grad_engine(self, n, S):
         """The device trainer behind ``forward(is_train=True)`` with autograd on (ngf_amd.train.RenderGrad); rebuilt when the batch outgrows it
-        or the parameter tensors were re-allocated (up_sampling / shrink / load)."""
+        or the parameter tensors were re-allocated (up_sampling / shrink / load).  One key computation per call (the loop of main.py:272-296 pays
+        it once per iteration: ``_render_train`` takes the parameter list from the engine, the backward checks the engine's identity)."""
         from . import train
         eng = getattr(self, '_grad_engine', None)
-        if eng is not None and eng._h is not None and eng.fits(n, S):
+        params = train._train_params(self)
+        if eng is not None and eng._h is not None and eng.fits(n, S, params):
             return eng
         if eng is not None:
             eng.release()
@@ -185,7 +187,8 @@ class Base(torch.nn.Module):
         S = int(N_samples) if N_samples > 0 else int(self.nSamples)
         jitter = torch.rand((n,), device=dev) if jitter is None else jitter.detach().to(device=dev, dtype=torch.float32).reshape(n).contiguous()
         white = bool(white_bg or ((torch.rand((1,)) if coin is None else torch.tensor([float(coin)])) < 0.5))
-        rgb, depth = train._TrainRender.apply(self, rays, jitter, S, white, bool(gauge_on), *train._train_params(self))
+        eng = self._render_grad_engine(n, S)
+        rgb, depth = train._TrainRender.apply(self, eng, rays, jitter, S, white, bool(gauge_on), *eng.params)
         return {'rgb_map': rgb, 'depth_map': depth}
 
     def invalidate(self):

@@ -383,8 +383,8 @@ class RenderGrad:
         from . import optim
         optim.register(field, self.params)          # ngf_amd.optim.Adam finds the engine behind a parameter (fused update, no re-pack)
 
-    def fits(self, n, S):
-        return n <= self.max_rays and S <= self.max_samples and self.key == _field_key(self.field, _train_params(self.field))
+    def fits(self, n, S, params=None):
+        return n <= self.max_rays and S <= self.max_samples and self.key == _field_key(self.field, _train_params(self.field) if params is None else params)
 
     def release(self):
         if getattr(self, "_h", None) is not None:
@@ -435,8 +435,7 @@ class _TrainRender(torch.autograd.Function):
     (the reference computes it under torch.no_grad(), FieldBase.py:304-306); rays carry no gradient (the reference's are data)."""
 
     @staticmethod
-    def forward(ctx, field, rays, jitter, S, white_bg, gauge_on, *params):
-        eng = field._render_grad_engine(rays.shape[0], S)
+    def forward(ctx, field, eng, rays, jitter, S, white_bg, gauge_on, *params):
         rgb, depth, ticket = eng.forward(rays, jitter, S, white_bg, gauge_on)
         ctx.field, ctx.engine, ctx.ticket = field, eng, ticket
         ctx.cfg = (int(S), bool(white_bg), bool(gauge_on))
@@ -449,12 +448,15 @@ class _TrainRender(torch.autograd.Function):
         saved = ctx.saved_tensors
         rays, jitter = saved[0], saved[1]
         S, white_bg, gauge_on = ctx.cfg
-        # the field's CURRENT engine: the one of the forward, unless a larger batch had it rebuilt in between (then this batch is rendered again below)
-        eng = ctx.field._render_grad_engine(rays.shape[0], S)
+        # the field's CURRENT engine: the one of the forward (the common case: its identity is the whole check), unless a larger batch or a
+        # re-allocation had it rebuilt in between (then this batch is rendered again below)
+        eng = ctx.engine
+        if getattr(ctx.field, '_grad_engine', None) is not eng or eng._h is None:
+            eng = ctx.field._render_grad_engine(rays.shape[0], S)
         if any(a.data_ptr() != b.data_ptr() or a.shape != b.shape for a, b in zip(saved[2:], eng.params)):
             raise RuntimeError("the field's parameter tensors were re-allocated (up_sampling / shrink / load) between forward and backward")
         d = d_rgb.to(dtype=torch.float32).contiguous()
-        want = [bool(w) for w in ctx.needs_input_grad[6:]]
+        want = [bool(w) for w in ctx.needs_input_grad[7:]]
         if not gauge_on:                                   # compute_gauge was not evaluated (Field.py:58,73): the gauge planes are not in the graph
             want[3:6] = [False, False, False]
         grads = eng.backward(ctx.ticket, d, want) if eng is ctx.engine else None
@@ -463,7 +465,7 @@ class _TrainRender(torch.autograd.Function):
             grads = eng.backward(ticket, d, want)
             if grads is None:
                 raise RuntimeError(_lib.lib().ngf_last_error().decode())
-        return (None,) * 6 + tuple(grads)
+        return (None,) * 7 + tuple(grads)
 
 
 class SimpleSampler:

@@ -106,13 +106,22 @@ def test_fused_adam_follows_torch_adam_step_for_step():
             total = torch.mean((out["rgb_map"] - tgt) ** 2) + 8e-5 * f.density_L1() + (e ** 2).sum()
             o.zero_grad()
             total.backward()
+            if f is fb:
+                # the density / gauge gradients are sums of float atomics (order-dependent last bits) and Adam divides by sqrt(v): two runs of ONE
+                # optimizer drift apart by ~1e-4 x lr where a gradient nearly cancels.  This test is about the update's arithmetic, so both
+                # optimizers get the same gradient tensors (the trajectory against the reference's own is the loop test above)
+                for (na, pa), (nb, pb) in zip(fa.named_parameters(), fb.named_parameters()):
+                    assert (pa.grad is None) == (pb.grad is None), na
+                    if pa.grad is not None:
+                        assert float((pa.grad - pb.grad).abs().max()) <= 2e-3 * max(float(pa.grad.abs().max()), 1e-30), na      # (the density bias's is a cancelling sum of 600 k atomics: 1e-4 of itself between two runs)
+                        pb.grad.copy_(pa.grad)
             o.step()
             for gr in o.param_groups:
                 gr['lr'] = gr['lr'] * 0.999
         assert torch.allclose(ea, eb)
         for (na, pa), (nb, pb) in zip(fa.named_parameters(), fb.named_parameters()):
-            d = float((pa - pb).abs().max())
-            assert d <= 2e-6 * max(float(pa.abs().max()), 1e-3) + 1e-7, (it, na, d)      # the same arithmetic; a few ulp where ReLU kinks give last-bit gradient differences
+            d = float((pa.detach() - pb.detach()).abs().max())
+            assert d <= 1e-6 * max(float(pa.detach().abs().max()), 1e-3) + 1e-8, (it, na, d)      # the same arithmetic on the same gradients: rounding of lr / (1 - beta1^t) only
             if pa.grad is None:
                 assert pb.grad is None and pb not in ob.state, na
             else:
@@ -122,6 +131,7 @@ def test_fused_adam_follows_torch_adam_step_for_step():
                 assert float((sa['exp_avg_sq'] - sb['exp_avg_sq']).abs().max()) <= 1e-5 * max(float(sa['exp_avg_sq'].abs().max()), 1e-20), (it, na)
     # no re-pack happened on the fused side and none was needed: the engine renders the current parameters
     jit = torch.from_numpy(synth.hash_uniform(77, 99, (rays.shape[0],)))
+    fb.zero_grad()
     got = fb(rays, is_train=True, white_bg=True, N_samples=S, iteration=9, jitter=jit)["rgb_map"].detach()
     sdb = {k: v.cpu().numpy() for k, v in fb.state_dict().items()}
     fc = field_for_case(g, sdb, None)
