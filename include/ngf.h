@@ -298,6 +298,11 @@ int ngf_train_get_grads(ngf_trainer *t, float *const out[NGF_TRAIN_PARAMS], void
 int ngf_train_adam_ext(ngf_trainer *t, const float *const grad[NGF_TRAIN_PARAMS], float *const exp_avg[NGF_TRAIN_PARAMS],
                        float *const exp_avg_sq[NGF_TRAIN_PARAMS], const int32_t step_count[NGF_TRAIN_PARAMS], const float lr[NGF_TRAIN_PARAMS],
                        float beta1, float beta2, float eps, void *hip_stream);
+/* ABI 5: TriPlane.density_L1 (TriPlane/models/Field.py:149-152: mean|plane_xy| + mean|plane_yz| + mean|plane_xz|) as two launches, and its gradient
+ * sign(p) * upstream / n as one, for the reference's `total_loss += L1_reg_weight * field.density_L1()` (main.py:279-281).  planes[k]: contiguous float32,
+ * 16-byte aligned, n[k] values; out / upstream: one float on the device; workspace: 3 * 256 doubles on the device; grads[k] NULL = not wanted. */
+int ngf_planes_l1(const float *const planes[3], const int64_t n[3], float *out, void *workspace, void *hip_stream);
+int ngf_planes_l1_backward(const float *const planes[3], const int64_t n[3], const float *upstream, float *const grads[3], void *hip_stream);
 /* The trainer keeps channel-last copies of the planes and gauge planes; ngf_train_adam keeps them current.  After writing to a
  * plane's memory by any other means (checkpoint load, in-place edit) call this: the next backward re-packs all of them. */
 int ngf_train_params_changed(ngf_trainer *t);

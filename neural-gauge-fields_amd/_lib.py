@@ -24,7 +24,7 @@ SYMBOLS = ["ngf_field_create", "ngf_field_destroy", "ngf_field_render", "ngf_fie
            "ngf_uv_create", "ngf_uv_destroy", "ngf_uv_render", "ngf_uv_render_batch", "ngf_field_alpha", "ngf_field_ray_filter",
            "ngf_eval_workspace_bytes", "ngf_eval_frame_u8", "ngf_eval_depth_range", "ngf_eval_depth_colormap", "ngf_eval_mse",
            "ngf_eval_ssim", "ngf_trainer_create", "ngf_trainer_destroy", "ngf_trainer_bytes", "ngf_sizeof_train_desc", "ngf_train_backward", "ngf_train_backward2",
-           "ngf_train_forward", "ngf_train_backward_grad", "ngf_train_get_grad", "ngf_train_get_active", "ngf_train_overflow_count", "ngf_train_adam", "ngf_train_adam_all", "ngf_train_adam_ext", "ngf_train_get_grads", "ngf_train_params_changed", "ngf_train_debug_sections", "ngf_resize_bilinear", "ngf_uv_set_texture", "ngf_uv_texture_edit", "ngf_field_alpha_mask_build", "ngf_pack_mask_bits", "ngf_debug_set", "ngf_debug_get", "ngf_debug_dirty_lds", "ngf_debug_xcd_histogram", "ngf_debug_tile_plan", "ngf_debug_tile_order", "ngf_pool_trim", "ngf_pool_set_limit", "ngf_pool_bytes"]
+           "ngf_train_forward", "ngf_train_backward_grad", "ngf_train_get_grad", "ngf_train_get_active", "ngf_train_overflow_count", "ngf_train_adam", "ngf_train_adam_all", "ngf_train_adam_ext", "ngf_train_get_grads", "ngf_train_params_changed", "ngf_train_debug_sections", "ngf_resize_bilinear", "ngf_uv_set_texture", "ngf_uv_texture_edit", "ngf_field_alpha_mask_build", "ngf_pack_mask_bits", "ngf_debug_set", "ngf_debug_get", "ngf_debug_dirty_lds", "ngf_debug_xcd_histogram", "ngf_debug_tile_plan", "ngf_debug_tile_order", "ngf_planes_l1", "ngf_planes_l1_backward", "ngf_pool_trim", "ngf_pool_set_limit", "ngf_pool_bytes"]
 
 
 class FieldDesc(C.Structure):
@@ -122,6 +122,8 @@ def _load(path):
         L.ngf_pool_set_limit.argtypes = [C.c_int64]
         L.ngf_pool_bytes.argtypes = [C.c_int32]
         L.ngf_pool_bytes.restype = C.c_int64
+        L.ngf_planes_l1.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ngf_planes_l1_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ngf_debug_tile_order.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         if L.ngf_abi_version() != 5 or L.ngf_sizeof_field_desc() != C.sizeof(FieldDesc):
             raise RuntimeError("libngf_hip.so ABI mismatch (version or ngf_field_desc layout)")

@@ -92,6 +92,39 @@ extern "C" int ngf_eval_ssim(const float *img0, const float *img1, int32_t H, in
     return NGF_OK;
 }
 
+// ABI 5: TriPlane.density_L1 (Field.py:149-152) and its gradient, three planes per launch.  planes[k] / n[k]: the k-th plane's values (any layout:
+// the mean runs over all of them) -- contiguous float32, 16-byte aligned; out: one float (device); workspace: 3 * 256 doubles (device).
+extern "C" int ngf_planes_l1(const float *const *planes, const int64_t *n, float *out, void *workspace, void *hip_stream)
+{
+    if (!planes || !n || !out || !workspace) return fail(NGF_E_ARG, "ngf_planes_l1: null argument");
+    PlanesL1 a;
+    for (int k = 0; k < 3; ++k) {
+        if (!planes[k] || n[k] <= 0 || ((uintptr_t)planes[k] & 15)) return fail(NGF_E_ARG, "ngf_planes_l1: plane %d missing, empty or not 16-byte aligned", k);
+        a.p[k] = planes[k]; a.n[k] = n[k]; a.g[k] = nullptr;
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(planes_l1_partial_kernel, dim3(kL1Blocks, 3), dim3(kEvalThreads), 0, st, a, (double *)workspace);
+    hipLaunchKernelGGL(planes_l1_final_kernel, dim3(1), dim3(kEvalThreads), 0, st, (const double *)workspace, a, out);
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+// grads[k] (NULL = not wanted) <- sign(planes[k]) * upstream[0] / n[k]; upstream: one float on the device (d loss / d density_L1)
+extern "C" int ngf_planes_l1_backward(const float *const *planes, const int64_t *n, const float *upstream, float *const *grads, void *hip_stream)
+{
+    if (!planes || !n || !upstream || !grads) return fail(NGF_E_ARG, "ngf_planes_l1_backward: null argument");
+    PlanesL1 a;
+    bool any = false;
+    for (int k = 0; k < 3; ++k) {
+        if (!planes[k] || n[k] <= 0 || ((uintptr_t)planes[k] & 15) || ((uintptr_t)grads[k] & 15)) return fail(NGF_E_ARG, "ngf_planes_l1_backward: plane %d missing, empty or not 16-byte aligned", k);
+        a.p[k] = planes[k]; a.n[k] = n[k]; a.g[k] = grads[k];
+        any |= grads[k] != nullptr;
+    }
+    if (!any) return NGF_OK;
+    hipLaunchKernelGGL(planes_l1_backward_kernel, dim3(1024, 3), dim3(kEvalThreads), 0, (hipStream_t)hip_stream, a, upstream);
+    HIP_TRY(hipGetLastError());
+    return NGF_OK;
+}
+
 extern "C" int ngf_pack_mask_bits(const float *volume, int64_t n, uint8_t *bits, void *hip_stream)
 {
     if (!volume || !bits || n <= 0) return fail(NGF_E_ARG, "ngf_pack_mask_bits: bad argument");

@@ -16,6 +16,7 @@
 
 namespace ngf {
 
+typedef float f32x4e __attribute__((ext_vector_type(4)));
 constexpr int kEvalThreads = 256;
 constexpr int kEvalMaxBlocks = 1024;
 constexpr int kSsimMaxTaps = 33;
@@ -127,6 +128,61 @@ __global__ void __launch_bounds__(kEvalThreads) mean_final_kernel(const double *
     for (int i = threadIdx.x; i < blocks; i += blockDim.x) s += partial[i];
     s = block_reduce(s, [](double x, double y) { return x + y; }, sh);
     if (threadIdx.x == 0) out[0] = s / count;
+}
+
+// ---- density_L1 (Field.py:149-152): sum over the three planes of mean(|plane|), and its gradient ---------------------------------------------
+// The reference's loop adds L1_reg_weight * field.density_L1() to its loss (main.py:279-281); as torch ops that is abs + mean per plane and, in the
+// backward, sign x scale per plane with a 16.7 MB |plane| intermediate each -- ~14 launches over 150 MB.  Here: a partial-sum launch over the three
+// planes (blockIdx.y = plane; float32 |x| summed in double per thread, fixed order: deterministic), a one-block finish, and ONE backward launch.
+struct PlanesL1 { const float *p[3]; int64_t n[3]; float *g[3]; };
+constexpr int kL1Blocks = 256;
+__global__ void __launch_bounds__(kEvalThreads) planes_l1_partial_kernel(const PlanesL1 a, double *partial)
+{
+    __shared__ double sh[kEvalThreads];
+    const int pl = blockIdx.y;
+    const float *__restrict__ x = a.p[pl];
+    const int64_t n = a.n[pl], n4 = n >> 2;
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4e v = reinterpret_cast<const f32x4e *>(x)[i];
+        s += (double)((fabsf(v[0]) + fabsf(v[1])) + (fabsf(v[2]) + fabsf(v[3])));
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s += (double)fabsf(x[i]);
+    s = block_reduce(s, [](double u, double w) { return u + w; }, sh);
+    if (threadIdx.x == 0) partial[pl * kL1Blocks + blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(kEvalThreads) planes_l1_final_kernel(const double *partial, const PlanesL1 a, float *out)
+{
+    __shared__ double sh[kEvalThreads];
+    double total = 0.0;
+    for (int pl = 0; pl < 3; ++pl) {
+        double s = threadIdx.x < kL1Blocks ? partial[pl * kL1Blocks + threadIdx.x] : 0.0;
+        s = block_reduce(s, [](double u, double w) { return u + w; }, sh);
+        __syncthreads();
+        total += (double)(float)(s / (double)a.n[pl]);          // each plane's mean is a float32 in the reference; their sum is a float32 addition chain
+        if (pl == 1) total = (double)(float)total;
+    }
+    if (threadIdx.x == 0) out[0] = (float)total;
+}
+// d/dp [mean(|p|)] * upstream = sign(p) * (upstream / n): torch's abs backward (grad * sgn(p), sgn(0) = 0) after mean's (grad / n)
+__global__ void __launch_bounds__(kEvalThreads) planes_l1_backward_kernel(const PlanesL1 a, const float *upstream)
+{
+    const int pl = blockIdx.y;
+    float *__restrict__ g = a.g[pl];
+    if (!g) return;
+    const float *__restrict__ x = a.p[pl];
+    const int64_t n = a.n[pl], n4 = n >> 2;
+    const float sc = upstream[0] * (1.0f / (float)n);          // torch's mean backward divides by a host scalar as a * (1 / b) in float32 (its div kernel's scalar path): the same bits
+    auto sg = [sc](float v) { return v > 0.0f ? sc : (v < 0.0f ? -sc : (v == 0.0f ? 0.0f * sc : v)); };          // NaN stays NaN like torch.sgn
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4e v = reinterpret_cast<const f32x4e *>(x)[i];
+        reinterpret_cast<f32x4e *>(g)[i] = f32x4e{sg(v[0]), sg(v[1]), sg(v[2]), sg(v[3])};
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) g[i] = sg(x[i]);
 }
 
 // vertical blur of the five moment images (img0, img1, img0^2, img1^2, img0*img1; the products are float32 as in the

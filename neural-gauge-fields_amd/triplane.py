@@ -7,6 +7,36 @@ from . import _lib
 from .fieldbase import AlphaGridMask, Base, renderer, rgb_decoder  # noqa: F401
 
 
+class _DensityL1(torch.autograd.Function):
+    """mean|plane_xy| + mean|plane_yz| + mean|plane_xz| (Field.py:149-152) and sign(p) * upstream / numel as its gradient."""
+
+    @staticmethod
+    def forward(ctx, pxy, pyz, pxz):
+        import ctypes as C
+        planes = (pxy.detach(), pyz.detach(), pxz.detach())
+        out = torch.empty((), device=pxy.device, dtype=torch.float32)
+        ws = torch.empty((3 * 256,), device=pxy.device, dtype=torch.float64)
+        ptrs = (C.c_void_p * 3)(*[p.data_ptr() for p in planes])
+        ns = (C.c_int64 * 3)(*[p.numel() for p in planes])
+        with torch.cuda.device(pxy.device):
+            _lib.check(_lib.lib().ngf_planes_l1(ptrs, ns, out.data_ptr(), ws.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ctx.save_for_backward(pxy, pyz, pxz)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        planes = ctx.saved_tensors
+        g = g.to(dtype=torch.float32).contiguous()
+        grads = [torch.empty_like(p) if need else None for p, need in zip(planes, ctx.needs_input_grad)]
+        ptrs = (C.c_void_p * 3)(*[p.data_ptr() for p in planes])
+        ns = (C.c_int64 * 3)(*[p.numel() for p in planes])
+        gp = (C.c_void_p * 3)(*[None if x is None else x.data_ptr() for x in grads])
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().ngf_planes_l1_backward(ptrs, ns, g.data_ptr(), gp, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return tuple(grads)
+
+
 class TriPlane(Base):
     MODEL = _lib.MODEL_TRIPLANE
     PLANE_C = 64
@@ -72,7 +102,11 @@ class TriPlane(Base):
 
     def density_L1(self):
         """Field.py:149-152, differentiable like the reference's (the reference loop adds it to the loss, main.py:279-281); ngf_amd.train.Trainer fuses
-        its gradient into the planes' Adam kernel instead."""
+        its gradient into the planes' Adam kernel instead.  On the device: ngf_planes_l1 / ngf_planes_l1_backward (three planes per launch, no |plane|
+        intermediates) behind one autograd node; anything else (CPU tensors, other dtypes) is the reference's torch expression."""
+        planes = (self.plane_xy, self.plane_yz, self.plane_xz)
+        if all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.data_ptr() % 16 == 0 and p.numel() > 0 for p in planes):
+            return _DensityL1.apply(*planes)
         return torch.mean(torch.abs(self.plane_xy)) + torch.mean(torch.abs(self.plane_yz)) + torch.mean(torch.abs(self.plane_xz))
 
     def _fill_desc(self, d, dp):

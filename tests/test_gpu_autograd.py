@@ -336,3 +336,27 @@ def test_full_size_batch_through_the_autograd_path_matches_the_fused_trainer():
         a, b = sd[name].grad, tr.gradient(k)
         assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-30), name
     tr.release()
+
+
+def test_density_l1_matches_torchs_expression_and_gradient():
+    """TriPlane.density_L1 (Field.py:149-152) on the device: ngf_planes_l1 / ngf_planes_l1_backward behind one autograd node against the
+    reference's torch expression -- the value to float32 rounding of a 4 M-term mean, the gradient sign(p) * upstream / numel bit for bit
+    (zeros get a zero gradient like torch.sgn); rectangular planes whose size is not a multiple of four; a frozen plane gets no gradient."""
+    g, params, step, mask = load_case("triplane_r1_gauge")
+    f = field_for_case(g, params, None)
+    with torch.no_grad():
+        f.plane_xy[0, 3, 5:9, :] = 0.0
+    ref = torch.mean(torch.abs(f.plane_xy)) + torch.mean(torch.abs(f.plane_yz)) + torch.mean(torch.abs(f.plane_xz))
+    got = f.density_L1()
+    assert got.shape == ref.shape and got.requires_grad
+    assert abs(float(got) - float(ref)) <= 2e-6 * float(ref)
+    w = torch.tensor(8e-5, device="cuda")
+    want = torch.autograd.grad(ref * w, [f.plane_xy, f.plane_yz, f.plane_xz])
+    have = torch.autograd.grad(got * w, [f.plane_xy, f.plane_yz, f.plane_xz])
+    for a, b in zip(have, want):
+        assert torch.equal(a, b)
+    assert int((have[0] == 0).sum()) == 4 * f.plane_xy.shape[3]
+    f.plane_yz.requires_grad_(False)
+    (f.density_L1() * 3.0).backward()
+    assert f.plane_yz.grad is None and f.plane_xy.grad is not None
+    assert torch.allclose(f.plane_xy.grad, want[0] * (3.0 / 8e-5), rtol=1e-6, atol=0)
