@@ -49,7 +49,7 @@ def so_sha16():
     return hashlib.sha256(open(_lib.SO_PATH, "rb").read()).hexdigest()[:16]
 
 
-PMC_ROUNDS = ("r05", "r04", "r03", "r02")
+PMC_ROUNDS = ("r06", "r05", "r04", "r03", "r02")
 
 
 def load_pmc(tag):

@@ -189,6 +189,6 @@ def knobs_from_env():
     if any(os.environ.get("NGF_" + k.upper()) not in (None, "", "-1") for k in ("waves", "nstep", "profile", "kernel", "stage")):
         _LIB = _load(SO_PATH_EXP)          # these knobs select experiment kernels: the whole script runs on libngf_hip_exp.so
     L = lib()
-    for k in ("tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage", "xcd", "grid", "tail"):
+    for k in ("tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage", "xcd", "grid", "tail", "ord_rows", "ord_px", "train_dwg"):
         v = os.environ.get("NGF_" + k.upper())
         check(L.ngf_debug_set(k.encode(), int(v) if v not in (None, "") else -1))

@@ -31,7 +31,7 @@ int ngf::fail(int code, const char *fmt, ...)
 }
 
 static std::atomic<int> g_knob[ngf::KNOB_COUNT];
-static const char *const g_knob_name[ngf::KNOB_COUNT] = {"tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage", "poison", "grid", "xcd", "tail", "ord_rows", "ord_px"};
+static const char *const g_knob_name[ngf::KNOB_COUNT] = {"tile_w", "split", "waves", "nstep", "profile", "ablate", "uv_tiles", "kernel", "stage", "poison", "grid", "xcd", "tail", "ord_rows", "ord_px", "train_dwg"};
 static bool g_knob_init = [] { for (auto &k : g_knob) k.store(-1); return true; }();
 
 int ngf::knob(int id) { return g_knob[id].load(std::memory_order_relaxed); }
@@ -1752,7 +1752,7 @@ static int train_backward_part(ngf_trainer *t, ngf_trainer::Pending &P, double *
     const size_t lds_f = (size_t)(((kFwdImage + 3) & ~3) + kTrainWaves * kFwdTileFloats) * sizeof(float),
                  lds_b = (size_t)(((kBwdImage + 3) & ~3) + kTrainWavesBwd * kBwdTileFloats) * sizeof(float);
     const int32_t *cnt = no_sync ? T.offset + n : nullptr;
-    const dim3 dgrid(tr_grid(t, n * ((n_samples + 63) / 64), 4, kDensBwdGroupsPerCu + 1));
+    const dim3 dgrid(tr_grid(t, n * ((n_samples + 63) / 64), 4, knob(KNOB_TRAIN_DWG) > 0 ? knob(KNOB_TRAIN_DWG) : kDensBwdGroupsPerCu + 1));          // knob train_dwg (sweeps): workgroups per CU
     // After the colour backward of a chunk the step forks: the weight-gradient GEMMs (sx) and the colour-plane scatter (sb) leave the
     // caller's stream, which goes on with the density / gauge backward and waits for both before it returns to the caller's order.  None of
     // these chains fills the device alone (LDS transposes, LDS latency, the atomic unit).  (Tried: the density / gauge backward beside the

@@ -26,7 +26,7 @@ static constexpr int kQueueHeads = 16;     // unsigned ints per launch slot: 8 p
 
 // Experiment / test knobs (ngf_debug_set, include/ngf.h).  Process-wide, set ONLY through the explicit ABI call -- never read
 // from the environment, so a stray variable in a user's shell cannot change what a launch computes.  -1 = library default.
-enum Knob { KNOB_TILE_W = 0, KNOB_SPLIT, KNOB_WAVES, KNOB_NSTEP, KNOB_PROFILE, KNOB_ABLATE, KNOB_UV_TILES, KNOB_KERNEL, KNOB_STAGE, KNOB_POISON, KNOB_GRID, KNOB_XCD, KNOB_TAIL, KNOB_ORD_ROWS, KNOB_ORD_PX, KNOB_COUNT };
+enum Knob { KNOB_TILE_W = 0, KNOB_SPLIT, KNOB_WAVES, KNOB_NSTEP, KNOB_PROFILE, KNOB_ABLATE, KNOB_UV_TILES, KNOB_KERNEL, KNOB_STAGE, KNOB_POISON, KNOB_GRID, KNOB_XCD, KNOB_TAIL, KNOB_ORD_ROWS, KNOB_ORD_PX, KNOB_TRAIN_DWG, KNOB_COUNT };
 int knob(int id);                          // current value (ngf_field.hip)
 // hipFuncSetAttribute(kernel, MaxDynamicSharedMemorySize, bytes) once per (device, kernel) and size, not on every launch (ngf_field.hip)
 hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);

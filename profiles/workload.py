@@ -56,6 +56,8 @@ if name.startswith(("triplane", "infoinv")):
             zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
             f.alphaMask = triplane.AlphaGridMask(dev, torch.tensor(np.asarray(g["aabb"], np.float32)), ((xx ** 2 + yy ** 2 + zz ** 2) < 0.8 ** 2).float().to(dev))
             f.invalidate()
+    if int(os.environ.get("NGF_ROW_WIDTH", "800")) > 0 and model == "triplane":
+        kw["row_width"] = int(os.environ.get("NGF_ROW_WIDTH", "800"))       # the frame is an image: screen-space tile order (round 6), as bench.py and evalout.evaluation run it; NGF_ROW_WIDTH=0: the list's order
     run = lambda: f(rays, N_samples=NS, white_bg=True, **kw)
     with torch.no_grad():
         run(); run()
