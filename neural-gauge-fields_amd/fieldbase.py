@@ -169,7 +169,12 @@ class Base(torch.nn.Module):
         return eng
 
     def _wants_grad(self, is_train):
-        return bool(is_train) and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if not (is_train and torch.is_grad_enabled()):
+            return False
+        slots = getattr(self, '_tp_slots', None)          # the fifteen parameters without walking the module tree (train._train_params)
+        if slots is not None:
+            return any(m._parameters[a].requires_grad for m, a in slots)
+        return any(p.requires_grad for p in self.parameters())
 
     def _render_train(self, rays_chunk, white_bg, N_samples, gauge_on, jitter=None, coin=None):
         """``forward(is_train=True)`` with gradients: the same random draws as ``_render`` (jitter: torch.rand_like of sample_ray,
@@ -187,6 +192,19 @@ class Base(torch.nn.Module):
         S = int(N_samples) if N_samples > 0 else int(self.nSamples)
         jitter = torch.rand((n,), device=dev) if jitter is None else jitter.detach().to(device=dev, dtype=torch.float32).reshape(n).contiguous()
         white = bool(white_bg or ((torch.rand((1,)) if coin is None else torch.tensor([float(coin)])) < 0.5))
+        # Memory of a differentiable forward: the engine keeps per-(ray, sample) buffers (136 B per pair) and activation rows for a third
+        # of the pairs (2.4 KB each) -- 3.4 GiB at the reference's 4096 x 884 batch, growing with n x S.  A call beyond ``grad_max_pairs`` pairs
+        # (default 2^24 = 4.6 batches of that size, ~16 GiB) is cut into ray chunks, one autograd node each: the engine holds ONE chunk, so the
+        # backward renders every chunk but the last again (what two forwards before one backward always did) -- bounded memory for twice the forward.
+        cap = max(int(getattr(self, 'grad_max_pairs', 1 << 24)), S)
+        per = max(1, cap // S)
+        if n > per:
+            outs = []
+            for a in range(0, n, per):
+                r, j = rays[a:a + per], jitter[a:a + per]
+                eng = self._render_grad_engine(r.shape[0], S)
+                outs.append(train._TrainRender.apply(self, eng, r, j, S, white, bool(gauge_on), *eng.params))
+            return {'rgb_map': torch.cat([o[0] for o in outs], 0), 'depth_map': torch.cat([o[1] for o in outs], 0)}
         eng = self._render_grad_engine(n, S)
         rgb, depth = train._TrainRender.apply(self, eng, rays, jitter, S, white, bool(gauge_on), *eng.params)
         return {'rgb_map': rgb, 'depth_map': depth}

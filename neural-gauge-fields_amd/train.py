@@ -67,13 +67,25 @@ def _bind(L):
 
 def _train_params(field):
     """The fifteen parameters in ngf_train_desc order (PARAM_NAMES), checked for what the kernels read: contiguous float32 device tensors."""
-    sd = dict(field.named_parameters())
-    params = []
-    for name in PARAM_NAMES:
-        p = sd[name]
-        if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
-            raise RuntimeError(f"parameter {name} must be a contiguous float32 device tensor")
-        params.append(p)
+    # (module, attribute) of every name resolved once per field; a call is fifteen dictionary look-ups, and the checks run again only when one of
+    # the Parameter OBJECTS changed (up_sampling / shrink / load replace them) -- this sits in front of every differentiable forward
+    slots = getattr(field, '_tp_slots', None)
+    if slots is None:
+        slots = []
+        for name in PARAM_NAMES:
+            *path, attr = name.split('.')
+            m = field
+            for part in path:
+                m = getattr(m, part)
+            slots.append((m, attr))
+        field._tp_slots = slots
+    params = [m._parameters[attr] for m, attr in slots]
+    last = getattr(field, '_tp_checked', None)
+    if last is None or any(a is not b for a, b in zip(params, last)):
+        for name, p in zip(PARAM_NAMES, params):
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise RuntimeError(f"parameter {name} must be a contiguous float32 device tensor")
+        field._tp_checked = params
     return params
 
 
@@ -356,9 +368,14 @@ class RenderGrad:
     gradients of the fifteen parameters in their reference layouts.  ``Base.forward`` owns one per field (``_TrainRender`` below is the
     torch.autograd.Function around it); the caller's own loss, ``density_L1`` and ``torch.optim.Adam`` do the rest, unchanged.
 
-    Activation rows: a third of the batch's (ray, sample) pairs (at least 262 144) and the active count read on the host in ``forward`` -- one
-    stream synchronisation per step, like the reference's own ``rgb_mask.any()`` (FieldBase.py:291) -- so the gradient is always complete: a
-    batch with more active samples than rows is worked through chunk by chunk, never truncated."""
+    Activation rows (2.4 KB each), never a truncated gradient either way:
+    * when the device has the memory for it (rows for EVERY (ray, sample) pair of the largest batch take less than a quarter of the free HBM: 8.7 GiB
+      at the reference's 4096 x 884 on a 288 GB MI355X) the rows cover every pair and the forward NEVER waits for the host -- the colour kernels read
+      the active count on the device.  Round 6: the host round trip in the middle of the forward left the GPU idle while Python caught up (the
+      loop reads its loss every iteration, so every iteration starts with an empty queue); without it the reference's loop runs ~0.2 ms faster;
+    * otherwise a third of the pairs (at least 262 144) and the active count read on the host in ``forward`` -- one stream synchronisation per step, like
+      the reference's own ``rgb_mask.any()`` (FieldBase.py:291): a batch with more active samples than rows is worked through chunk by chunk.
+    ``field.grad_rows = "all" | "third"`` forces one or the other."""
 
     def __init__(self, field, max_rays, max_samples):
         self.field = field
@@ -372,6 +389,12 @@ class RenderGrad:
         pairs = self.max_rays * self.max_samples
         rows = min(pairs, max(1 << 18, -(-pairs // 3)))
         self.chunk_samples = (rows + 15) // 16 * 16
+        want = getattr(field, 'grad_rows', None)
+        with torch.cuda.device(self.dev):
+            free = torch.cuda.mem_get_info()[0]
+        self.host_count = not (want == "all" or (want != "third" and pairs * 2600 * 4 <= free))
+        if not self.host_count:
+            self.chunk_samples = 0                  # ngf_train_desc: rows for every pair -- no host count, no chunks
         d, self._keep = _train_desc(field, self.params, None, None, self.max_rays, self.max_samples, self.chunk_samples)
         out = C.c_void_p()
         with torch.cuda.device(self.dev):
@@ -379,9 +402,19 @@ class RenderGrad:
         self._h = out
         self.key = _field_key(field, self.params)
         self._versions = tuple(int(p._version) for p in self.params[:6])
-        self.last_active = 0
+        self._last_active, self._last_n = 0, 0
+        self._active_dev = torch.zeros((1,), dtype=torch.int32, device=self.dev)
         from . import optim
         optim.register(field, self.params)          # ngf_amd.optim.Adam finds the engine behind a parameter (fused update, no re-pack)
+
+    @property
+    def last_active(self) -> int:
+        """Active samples of the last forward (read from the device on demand when the forward did not bring it to the host)."""
+        if not self.host_count and self._last_n > 0 and self._h is not None:
+            with torch.cuda.device(self.dev):
+                _lib.check(self.L.ngf_train_get_active(self._h, self._last_n, self._active_dev.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            return int(self._active_dev.item())
+        return self._last_active
 
     def fits(self, n, S, params=None):
         return n <= self.max_rays and S <= self.max_samples and self.key == _field_key(self.field, _train_params(self.field) if params is None else params)
@@ -412,8 +445,8 @@ class RenderGrad:
         with torch.cuda.device(self.dev):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             _lib.check(self.L.ngf_train_forward(self._h, rays.data_ptr(), jitter.data_ptr(), n, int(S), int(bool(white_bg)), int(bool(gauge_on)),
-                                                rgb.data_ptr(), depth.data_ptr(), C.byref(n_active), C.byref(ticket), st))
-        self.last_active = int(n_active.value)
+                                                rgb.data_ptr(), depth.data_ptr(), C.byref(n_active) if self.host_count else None, C.byref(ticket), st))
+        self._last_active, self._last_n = int(n_active.value), n
         return rgb, depth, int(ticket.value)
 
     def backward(self, ticket, d_rgb, want):

@@ -360,3 +360,25 @@ def test_density_l1_matches_torchs_expression_and_gradient():
     (f.density_L1() * 3.0).backward()
     assert f.plane_yz.grad is None and f.plane_xy.grad is not None
     assert torch.allclose(f.plane_xy.grad, want[0] * (3.0 / 8e-5), rtol=1e-6, atol=0)
+
+
+def test_a_differentiable_forward_beyond_grad_max_pairs_is_chunked_and_gives_the_same_gradients():
+    """``field(rays, is_train=True)`` under autograd keeps activation rows that grow with n x S.  Beyond ``field.grad_max_pairs`` the
+    call is cut into ray chunks (one autograd node each, the engine holds one chunk, earlier chunks are rendered again in the backward): same
+    rgb_map bit for bit, the same gradients up to the order of their sums, the engine sized for a chunk and not for the batch."""
+    g, params, step, mask = load_case("triplane_r1_gauge")
+    from ngf_amd import synth
+    rays = torch.from_numpy(g["rays"]).cuda()
+    n, S = rays.shape[0], 48
+    tgt = torch.from_numpy(synth.hash_uniform(41, 1, (n, 3))).cuda()
+    jit = torch.from_numpy(synth.hash_uniform(41, 2, (n,)))
+    fa, fb = field_for_case(g, params, None), field_for_case(g, params, None)
+    fb.grad_max_pairs = S * 37                       # 37 rays per chunk
+    oa = fa(rays, is_train=True, N_samples=S, iteration=5, jitter=jit)
+    ob = fb(rays, is_train=True, N_samples=S, iteration=5, jitter=jit)
+    assert torch.equal(oa["rgb_map"], ob["rgb_map"]) and torch.equal(oa["depth_map"], ob["depth_map"])
+    assert fb._grad_engine.max_rays == 37 and fa._grad_engine.max_rays == n
+    ((oa["rgb_map"] - tgt) ** 2).mean().backward()
+    ((ob["rgb_map"] - tgt) ** 2).mean().backward()
+    for (na, pa), (nb, pb) in zip(fa.named_parameters(), fb.named_parameters()):
+        assert float((pa.grad - pb.grad).abs().max()) <= 2e-5 * max(float(pa.grad.abs().max()), 1e-30), na
