@@ -1835,6 +1835,7 @@ static int train_backward_part(ngf_trainer *t, ngf_trainer::Pending &P, double *
         FA.texels[p] = (int64_t)(d.plane_h[p] + 2) * (d.plane_w[p] + 2); FA.g_dens[p] = t->g_d[p];
         U.src[p] = t->g_gb[p]; U.dst[p] = t->g_g[p]; U.w2[p] = d.gauge_w[p] + 2; U.h2[p] = d.gauge_h[p] + 2; U.bw[p] = T.g_bw[p];
     }
+    U.g_bd = T.g_bd;
     U.loss_src = T.loss; U.loss_dst = rgb_loss; U.loss_len = loss_len; U.inv_count = 1.0 / (3.0 * (double)n); U.overflow = t->overflow;        // the loss travels with the last kernel of the caller's stream (a copy of 8 bytes is a launch of its own)
     hipLaunchKernelGGL(train_density_finish_kernel, dim3(128, 3), dim3(256), 0, st, FA);
     hipLaunchKernelGGL(train_unblock_gauge_kernel, dim3(128, 3), dim3(256), 0, st, U);

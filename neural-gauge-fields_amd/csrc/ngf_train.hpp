@@ -94,7 +94,7 @@ struct TrainArgs {
     float *slab;                                    // [unit_cap][81][48]  the units' texel sums (train_bin_gather_kernel adds them up)
     int32_t bin_base[3], bin_nbx[3], nbins, bin_cap;
     int32_t bin_accumulate;                         // train_bin_gather_kernel adds to the planes' gradients (chunks after the first) instead of writing them
-    double *loss;            // [2]: sum of squared residuals, (unused)
+    double *loss;            // [2]: [0] sum of squared residuals, [1] d loss / d density bias accumulated in double (train_density_bwd_kernel; rounded to g_bd once, by train_unblock_gauge_kernel)
     int32_t chunk_base, chunk_n;      // the slice of the active list this launch works on
     const int32_t *n_active_dev;      // non-NULL: the active count lives on the device (offset[n]); chunk_n is then only the capacity and
                                       // the kernels clip it themselves -- no host round trip between the scan and the colour kernels
@@ -1761,12 +1761,16 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
     NGF_KARG_CONTRACT_T((&train_density_bwd_kernel<DENS, GAUGE>), TrainArgs);
     const RenderArgs &A = T.R;
     __shared__ __attribute__((aligned(16))) float s_tile[4][kScatWaveFloats];
-    __shared__ float s_bd;
-    if (threadIdx.x == 0) s_bd = 0.0f;
+    __shared__ double s_bd;
+    if (threadIdx.x == 0) s_bd = 0.0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *tile = s_tile[wave];
-    float bsum = 0.0f;
+    // d loss / d density bias = the sum of d loss / d sigma' over every sample: hundreds of thousands of terms of both signs that cancel to ~1e-3 of
+    // their absolute sum.  As float atomics in arrival order two runs of one batch differed by 1e-4 of the result (round 6: a gradient test at 1e-4 failed
+    // once in ~10 suite runs); accumulated in double -- per lane, per wave, per workgroup, one double atomic per workgroup into T.loss[1] -- the order no
+    // longer reaches the float result, which train_unblock_gauge_kernel rounds once at the end of the step.
+    double bsum = 0.0;
     const bool count_lines = (A.ablate & (1 << 21)) != 0;      // profiling: atomic line transactions -> T.prof[8]
     unsigned n_line = 0, n_tap = 0;
     // a wave item = 64 consecutive steps of ONE ray (the last chunk of a ray is short): its taps stay inside a small bounding box
@@ -1785,7 +1789,7 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
         float t[6], xn[3];
         list_sample_coords(A, r, i, t, xn);
         float dt[6];
-        if (DENS) bsum += dx;
+        if (DENS) bsum += (double)dx;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const Tex &tx = A.dens[p];
@@ -1826,15 +1830,16 @@ __global__ void __launch_bounds__(256) train_density_bwd_kernel(const TrainArgs 
     for (int s = 32; s > 0; s >>= 1) bsum += __shfl_xor(bsum, s);
     if (lane == 0) atomicAdd(&s_bd, bsum);
     __syncthreads();
-    if (DENS && threadIdx.x == 0) atomicAdd(T.g_bd, s_bd);
+    if (DENS && threadIdx.x == 0 && s_bd != 0.0) atomicAdd(T.loss + 1, s_bd);
 }
 
 // blocked gauge-gradient plane -> [texel][2] (what the Adam kernel and ngf_train_get_grad read); blockIdx.y = plane
-struct UnblockArgs { const float *src[3]; float *dst[3]; int32_t w2[3], h2[3], bw[3]; const double *loss_src; double *loss_dst; int32_t loss_len; double inv_count; const int32_t *overflow; };   // + the step's loss to the caller's buffer: [0] sum of squared residuals, [1] their mean -- NaN when the step overflowed its speculative rows (train_prefix_kernel): the colour forward of such a step was truncated, its loss means nothing
+struct UnblockArgs { const float *src[3]; float *dst[3]; int32_t w2[3], h2[3], bw[3]; const double *loss_src; double *loss_dst; int32_t loss_len; double inv_count; const int32_t *overflow; float *g_bd; };   // g_bd: d loss / d density bias, rounded once from the double sum at loss_src[1]   // + the step's loss to the caller's buffer: [0] sum of squared residuals, [1] their mean -- NaN when the step overflowed its speculative rows (train_prefix_kernel): the colour forward of such a step was truncated, its loss means nothing
 __global__ void __launch_bounds__(256) train_unblock_gauge_kernel(const UnblockArgs U)
 {
     const int p = blockIdx.y;
     const int total = U.w2[p] * U.h2[p];
+    if (U.g_bd && blockIdx.x == 0 && p == 0 && threadIdx.x == 0) U.g_bd[0] = (float)U.loss_src[1];
     if (U.loss_dst && blockIdx.x == 0 && p == 0 && threadIdx.x == 0) {
         const double sum = (U.overflow && U.overflow[0]) ? __longlong_as_double(0x7FF8000000000000ll) : *U.loss_src;
         U.loss_dst[0] = sum;
