@@ -681,6 +681,36 @@ def main():
                     fx.release()
                 except Exception as ex:
                     extras[key] = {"error": repr(ex)}
+            # The reference's renderer is handed HOST rays and its drivers read the pixels on the host (TriPlane/main.py:60-71,93-106: `rays.to(device)`
+            # per chunk, `.cpu()` of rgb / depth).  The headline `value` starts with the rays in HBM (the contract of the metric); this is the same
+            # frame with the 15.4 MB H2D copy of the ray list and the 10.2 MB D2H of rgb + depth inside the clock -- pageable tensors (what
+            # torch.from_numpy gives the reference's loop) and pinned ones -- and with the rays made on the device instead (N1: ngf_generate_rays).
+            try:
+                hbnd = {}
+                rays_pageable = torch.from_numpy(rays_np)
+                rays_pinned = rays_pageable.pin_memory()
+                out_pinned = (torch.empty((n_total, 3)).pin_memory(), torch.empty((n_total,)).pin_memory())
+                def frame_from_host(src, pinned_out):
+                    rgb_d, dep_d = _renderer(src.to(device, non_blocking=True), f, chunk=4096, N_samples=S, white_bg=True, device=device, row_width=W)
+                    if pinned_out:
+                        out_pinned[0].copy_(rgb_d, non_blocking=True); out_pinned[1].copy_(dep_d, non_blocking=True)
+                        torch.cuda.synchronize(device)
+                    else:
+                        rgb_d.cpu(); dep_d.cpu()
+                for label, src, po in (("pageable", rays_pageable, False), ("pinned", rays_pinned, True)):
+                    frame_from_host(src, po)
+                    ts = []
+                    for _ in range(10):
+                        torch.cuda.synchronize(device)
+                        t0 = time.perf_counter()
+                        frame_from_host(src, po)
+                        ts.append((time.perf_counter() - t0) * 1e3)
+                    hbnd[label] = {"ms_per_frame": float(np.median(ts)), "Mray/s": n_total / float(np.median(ts)) / 1e3}
+                hbnd["bytes"] = {"h2d_rays": int(rays_np.nbytes), "d2h_rgb_depth": int(n_total * 16)}
+                hbnd["note"] = "wall clock of one frame: H2D of the ray list + render + D2H of rgb and depth; never `value` (inputs resident in HBM there)"
+                extras["host_boundary_frame"] = hbnd
+            except Exception as ex:
+                extras["host_boundary_frame"] = {"error": repr(ex)}
             # the screen-space tile order against the list's own (row-major) order, alternating launches of one field
             try:
                 ab = {}
