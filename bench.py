@@ -410,7 +410,7 @@ def main():
     rays = torch.from_numpy(rays_np).to(device)
     n_local = rays.shape[0]
     assert n_local == per
-    pipe = ndist.PipelinedGather(per, world, device) if dist_on else None
+    pipe = ndist.PipelinedGather(per, world, device, depth=3) if dist_on else None          # three buffers: with frames on two render streams the exchange of frame k may finish while frame k + 2 is already marched
     send, rgb_view, depth_view = ndist.shard_buffers(per, device)
     frame_no = [0]
     last_frame = [None]
@@ -418,6 +418,11 @@ def main():
     frame_out = [(torch.empty((n_total, 3), device=device), torch.empty((n_total,), device=device)) for _ in range(2)] if dist_on else None
     # ... copied there on a stream of their own: the render stream never waits for an exchange or a reorder (the timed region ends with a device-wide synchronise)
     side = torch.cuda.Stream(device) if dist_on else None
+    # ... and consecutive frames are marched on TWO alternating render streams (round 6): on one stream frame k + 1 starts when the LAST wave of
+    # frame k has ended, so every frame pays its launch's tail (wave slots idle at the ends: ~45 us of a 0.61 ms shard, profiles/r06_timeline.txt)
+    # and the launch gap; on two streams the next frame's workgroups take the CUs the previous frame has already left.  One rank's shard of eight:
+    # 0.658 -> 0.627 ms per step, same pixels (profiles/r06_two_streams.txt).  Launches of one handle may overlap (a queue slot per launch, 256 in flight).
+    render_streams = ndist.render_streams(device) if dist_on else None
 
     # the frame IS an image (W rays per row; at N > 1 a rank's rows are whole image rows too): the launch may walk it in screen-space blocks
     # (ngf_field_render_image -- what ngf_amd.evalout.evaluation passes to renderer; same pixels bit for bit, tests/test_gpu_parity.py)
@@ -435,12 +440,13 @@ def main():
             return
         # frame k: march into send buffer k%2, start its all-gather on RCCL's stream, hand out frame k-1 (whose
         # exchange overlapped this march) in image order.  Every frame is complete when the timed region ends.
+        # (the per-step event pair is not recorded here: on alternating streams a pair would span the other stream's frame as well -- the
+        # shard's launch time is measured by a serial loop after the timed region)
         k = frame_no[0]
-        out_k = pipe.buffers(k)
-        if pair: pair[0].record()
-        f(rays, N_samples=S, white_bg=True, out=out_k, **kw)
-        if pair: pair[1].record()
-        pipe.submit(k)
+        with torch.cuda.stream(render_streams[k % len(render_streams)]):
+            out_k = pipe.buffers(k)
+            f(rays, N_samples=S, white_bg=True, out=out_k, **kw)
+            pipe.submit(k)
         if k > 0:
             last_frame[0] = pipe.frame_in_image_order(k - 1, H, W, ROW_BLOCK, out=frame_out[(k - 1) % 2], stream=side)
         frame_no[0] = k + 1
@@ -450,10 +456,20 @@ def main():
             last_frame[0] = pipe.frame_in_image_order(frame_no[0] - 1, H, W, ROW_BLOCK, out=frame_out[(frame_no[0] - 1) % 2], stream=side)
 
     marks = []
-    elapsed = time_steps(step_fn, args.steps, args.warmup, device, dist_on, finish, marks)
+    elapsed = time_steps(step_fn, args.steps, args.warmup, device, dist_on, finish, None if dist_on else marks)
     ms_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed / 1e6
-    # per-step launch durations of the TIMED loop (HIP events on the launch stream around every render launch)
+    # per-step launch durations of the TIMED loop (HIP events on the launch stream around every render launch); at N > 1 the frames of the timed
+    # loop overlap on two render streams, so the shard's launch is timed afterwards: the same K launches one after the other on one stream
+    if dist_on:
+        pipe.drain()
+        torch.cuda.synchronize(device)
+        marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a, b in marks:
+            a.record()
+            f(rays, N_samples=S, white_bg=True, out=(pipe.send[0][1], pipe.send[0][2]), **kw)
+            b.record()
+        torch.cuda.synchronize(device)
     launch_ms = np.array([a.elapsed_time(b) for a, b in marks], np.float64)
     launch_stats = {"min": float(launch_ms.min()), "median": float(np.median(launch_ms)), "max": float(launch_ms.max())}
 
@@ -531,7 +547,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{'TriPlane' if model == 'triplane' else 'InfoInv'} 800x800 frame, S=192, preset {args.preset} "
                                f"(seeded random planes 256^2, dense density preset), gauge on, white_bg",
-                   "rays_per_step": n_total, "samples_per_ray": S, "sharding": f"rays x{world} (10-row blocks, round robin) + double-buffered RCCL all_gather",
+                   "rays_per_step": n_total, "samples_per_ray": S, "sharding": f"rays x{world} (10-row blocks, round robin) + double-buffered RCCL all_gather" + (", frames on two alternating render streams" if dist_on else ""),
                    "level": ("3 (module default: SURVEY 7 folds (i)-(iii) -- layer 1 o basis folded into 64-channel pre-activation planes, density_decoder into "
                              "1-channel planes, per-ray view fold)" if args.bake_color else "2 (layer 1 o basis, per-ray view fold, density_decoder folded into "
                              "1-channel planes)" if args.bake_density else "1 (layer 1 o basis, per-ray view fold)") if model == "triplane" else "default",
@@ -541,6 +557,9 @@ def main():
         "ms_per_step_median": launch_stats["median"], "launch_ms": launch_stats,
         "value_from_median_launch": n_local / launch_stats["median"] / 1e3,
     }
+    if dist_on:
+        result["launch_ms_note"] = ("N > 1: the timed loop's frames overlap on two render streams; launch_ms / roofline.kernel_ms are the same K shard launches "
+                                    "run one after the other on one stream after the timed region")
     if args.knobs:
         result["config"]["knobs"] = args.knobs
     result["config"]["launcher"] = "self (bench.py started its own torch.distributed.run)" if self_launched else ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "none (single process)")

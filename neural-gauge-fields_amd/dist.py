@@ -43,6 +43,19 @@ def deinterleave(rgb, depth, H: int, W: int, world: int, block: int):
     return rgb, depth
 
 
+def render_streams(device, n: int = 2):
+    """``n`` HIP streams to march consecutive frames on in turn (frame k on stream k % n), each ordered behind the caller's current stream.
+    A render launch is a persistent grid of one workgroup per CU; on ONE stream frame k + 1 starts when the last wave of frame k has ended, so
+    every frame pays the launch's tail (wave slots idle while the last tiles finish) and the launch gap.  On two streams the next frame's
+    workgroups start on the CUs the previous frame has left: one rank's 80 000-ray shard of eight 0.658 -> 0.627 ms per pipelined step
+    (profiles/r06_two_streams.txt).  A field handle supports overlapping launches (one tile-queue slot per launch, 256 in flight)."""
+    cur = torch.cuda.current_stream(device)
+    out = [torch.cuda.Stream(device) for _ in range(n)]
+    for s in out:
+        s.wait_stream(cur)
+    return out
+
+
 class PipelinedGather:
     """Double-buffered all-gather of a rank's pixels: frame k's exchange runs on RCCL's stream while frame k+1 is
     marched on the render stream.  ``buffers(k)`` gives the (rgb, depth) views frame k must be rendered into;

@@ -43,6 +43,8 @@ MODEL=infoinv python profiles/exp_launch_size.py 2>&1 | grep -v amdgpu.ids >> gp
 if [ "$1" != quick ]; then
   timeout 600 python profiles/exp_rank_shards.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_rank_shards.txt
   timeout 600 python profiles/exp_pipeline_gap.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_pipeline_gap.txt
+  # one render stream against two alternating ones (what bench.py runs at N > 1), 80 000-ray shards and whole frames; tail knob under both
+  (TAILS=8,12,16,24 timeout 600 python profiles/exp_two_streams.py; SHARDS=1 timeout 600 python profiles/exp_two_streams.py) 2>&1 | grep -v "amdgpu.ids\|socket\|version\|Hostname\|Librccl" > gpurun_out/r06_two_streams.txt
 fi
 python profiles/exp_autograd_loop.py both 20 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_autograd_loop.txt
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/r06_pytest_gpu.txt
