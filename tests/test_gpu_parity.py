@@ -949,6 +949,32 @@ def test_image_tile_order_renders_the_same_bits():
     fi.release()
 
 
+def test_overlapping_launches_on_two_render_streams_give_the_same_bits():
+    """Round 6: bench.py at N > 1 (and ngf_amd.dist.render_streams for any caller) marches consecutive frames on two alternating HIP streams, so the
+    launches of ONE field handle overlap -- the next frame's workgroups start on the CUs the previous frame has left.  Every launch takes its own
+    tile-queue slot (256 in flight per handle) and writes its own output buffers: twelve frames of three shapes on alternating streams, both
+    models, are the serial frames bit for bit, and the queue slots are clean afterwards (the next serial frames are right as well)."""
+    from ngf_amd import dist as ndist, synth
+    for model, kw in (("triplane", dict(N_samples=96, white_bg=True, iteration=30001)), ("infoinv", dict(N_samples=64, white_bg=True, infoinv=True))):
+        g, params, step = big_case(model, "R1")
+        f = field_for_case(g, params, None, bake=True, bake_color=True) if model == "triplane" else field_for_case(g, params, None)
+        shapes = [torch.from_numpy(synth.lookat_rays(h, w)).cuda() for h, w in ((100, 800), (37, 264), (3, 1000))]
+        refs = [f(r, **kw) for r in shapes]
+        streams = ndist.render_streams(torch.device("cuda"))
+        outs = [(torch.full((shapes[k % 3].shape[0], 3), -1.0, device="cuda"), torch.full((shapes[k % 3].shape[0],), -1.0, device="cuda")) for k in range(12)]
+        torch.cuda.synchronize()
+        for k in range(12):
+            with torch.cuda.stream(streams[k % 2]):
+                f(shapes[k % 3], out=outs[k], row_width=(800, 264, 1000)[k % 3], **kw)
+        torch.cuda.synchronize()
+        for k in range(12):
+            assert torch.equal(outs[k][0], refs[k % 3]["rgb_map"]) and torch.equal(outs[k][1], refs[k % 3]["depth_map"]), (model, k)
+        again = [f(r, **kw) for r in shapes]
+        for a, b in zip(again, refs):
+            assert torch.equal(a["rgb_map"], b["rgb_map"]) and torch.equal(a["depth_map"], b["depth_map"])
+        f.release()
+
+
 def test_xcd_tile_queues_are_bit_identical_and_xcds_are_visible():
     """Round 3: with knob xcd = 1 a render launch keeps one tile queue per XCD (each XCD has its own L2; its waves then
     work on ONE compact ray range and steal from the other chunks at the end).  Which wave renders a tile does not change the tile: knob xcd = 0 / 1 give the same bits, on the
