@@ -438,7 +438,7 @@ def main():
             render_only()
             if pair: pair[1].record()
             return
-        # frame k: march into send buffer k%2, start its all-gather on RCCL's stream, hand out frame k-1 (whose
+        # frame k: march into send buffer k%3 on render stream k%2, start its all-gather on RCCL's stream, hand out frame k-1 (whose
         # exchange overlapped this march) in image order.  Every frame is complete when the timed region ends.
         # (the per-step event pair is not recorded here: on alternating streams a pair would span the other stream's frame as well -- the
         # shard's launch time is measured by a serial loop after the timed region)
