@@ -170,7 +170,7 @@ def compact_line(result: dict) -> str:
     if "parity" in result:
         out["parity"] = _r(result["parity"], 4)
     for k in ("ms_per_step_median", "launch_ms", "gathered_frame_bit_identical_to_single_gpu_render", "all_gather_ms", "all_gather_bytes_per_rank",
-              "shard_kernel_ms", "critical_path_ms", "speedup_vs_cpu_port"):
+              "shard_kernel_ms", "critical_path_ms", "speedup_vs_cpu_port", "launch_ms_note"):
         if k in result:
             out[k] = _r(result[k], 5)
     if "extras" in result:      # headline numbers of the other configs only; the full entries are in the side file
@@ -226,12 +226,28 @@ def build_field(model, preset, device, bake=False, bake_color=False, no_fold=Fal
     return f, g, params, step
 
 
+CLOCK_PREAMBLE_MS = 80.0          # untimed device work ahead of the W warm-up steps (time_steps): the GPU's clocks ramp for 25-30 ms after an idle period
+PREAMBLE_REPORT = {}
+
+
 def time_steps(fn, steps, warmup, device, dist_on, finish=lambda: None, marks=None):
     """The timed region of the contract: W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over
     ranks.  `marks` (a list) receives one (start, end) HIP-event pair per timed step, recorded by `fn(pair)` around its render launch on
     the launch stream INSIDE the timed loop: their durations are the per-step launch times the line reports (median / min / max) and
     what roofline.kernel_ms is taken from -- the same launches the wall clock saw, not a second loop."""
     import torch.distributed as dist
+    # Clock preamble (round 6, profiles/r06_clock_ramp.txt): after an idle period -- the seconds this process spent building the field on the host --
+    # the GPU's first 25-30 ms of work run up to 1.3x slower while its clocks ramp (every launch of a block that follows a pause, whatever the
+    # launch size; the steady state is flat to 0.1 %).  W = 3 warm-up steps of an eight-rank shard are 2 ms and K = 20 timed steps 13 ms: the whole
+    # timed region would sit on the ramp.  So the device is kept busy with the very step that is measured for CLOCK_PREAMBLE_MS before the contract's W
+    # warm-up steps; nothing of it is timed, and the line reports it (config.clock_preamble).
+    pre_t0, pre_n = time.perf_counter(), 0
+    while (time.perf_counter() - pre_t0) * 1e3 < CLOCK_PREAMBLE_MS:
+        for _ in range(4):
+            fn(None)
+        pre_n += 4
+        torch.cuda.synchronize(device)
+    PREAMBLE_REPORT.update({"launches": pre_n, "ms": (time.perf_counter() - pre_t0) * 1e3})
     for _ in range(warmup):
         fn(None)
     finish()
@@ -557,6 +573,8 @@ def main():
         "ms_per_step_median": launch_stats["median"], "launch_ms": launch_stats,
         "value_from_median_launch": n_local / launch_stats["median"] / 1e3,
     }
+    result["config"]["clock_preamble"] = {"launches": PREAMBLE_REPORT.get("launches"), "ms": _r(PREAMBLE_REPORT.get("ms", 0.0), 3),
+                                          "what": "untimed steps before the W warm-up steps (GPU clocks ramp 25-30 ms after idle)"}
     if dist_on:
         result["launch_ms_note"] = ("N > 1: the timed loop's frames overlap on two render streams; launch_ms / roofline.kernel_ms are the same K shard launches "
                                     "run one after the other on one stream after the timed region")
