@@ -22,11 +22,19 @@ frame = torch.from_numpy(synth.lookat_rays(800, 800)).cuda().view(800, 800, 6)
 
 
 def timed(rays, rep=20):
-    for _ in range(3):
-        f(rays, N_samples=192, white_bg=True, iteration=30001)
+    """Median launch of `rep`, outputs owned by the caller (torch's caching allocator may map a new segment for a new output size in the middle of a timed
+    block: one 60 ms stall, then 12 launches on the clock ramp -- profiles/r06_clock_ramp.txt) and the clocks up before the first event."""
+    import time
+    out = (torch.empty((rays.shape[0], 3), device="cuda"), torch.empty((rays.shape[0],), device="cuda"))
+    kw = dict(N_samples=192, white_bg=True, iteration=30001, out=out, row_width=800)          # as bench.py renders a rank's rows
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.06:
+        for _ in range(3):
+            f(rays, **kw)
+        torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(rep)]
     for a, b in ev:
-        a.record(); f(rays, N_samples=192, white_bg=True, iteration=30001); b.record()
+        a.record(); f(rays, **kw); b.record()
     torch.cuda.synchronize()
     return float(np.median([a.elapsed_time(b) for a, b in ev]))
 
