@@ -230,21 +230,32 @@ CLOCK_PREAMBLE_MS = 80.0          # untimed device work ahead of the W warm-up s
 PREAMBLE_REPORT = {}
 
 
-def time_steps(fn, steps, warmup, device, dist_on, finish=lambda: None, marks=None):
+def time_steps(fn, steps, warmup, device, dist_on, finish=lambda: None, marks=None, preamble=None):
     """The timed region of the contract: W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over
     ranks.  `marks` (a list) receives one (start, end) HIP-event pair per timed step, recorded by `fn(pair)` around its render launch on
     the launch stream INSIDE the timed loop: their durations are the per-step launch times the line reports (median / min / max) and
-    what roofline.kernel_ms is taken from -- the same launches the wall clock saw, not a second loop."""
+    what roofline.kernel_ms is taken from -- the same launches the wall clock saw, not a second loop.
+    `preamble`: the launch the clock preamble repeats.  It MUST NOT contain a collective: the preamble runs for a wall-clock time, so its
+    trip count differs from rank to rank (at N = 1 it defaults to fn(None))."""
     import torch.distributed as dist
     # Clock preamble (round 6, profiles/r06_clock_ramp.txt): after an idle period -- the seconds this process spent building the field on the host --
     # the GPU's first 25-30 ms of work run up to 1.3x slower while its clocks ramp (every launch of a block that follows a pause, whatever the
     # launch size; the steady state is flat to 0.1 %).  W = 3 warm-up steps of an eight-rank shard are 2 ms and K = 20 timed steps 13 ms: the whole
-    # timed region would sit on the ramp.  So the device is kept busy with the very step that is measured for CLOCK_PREAMBLE_MS before the contract's W
+    # timed region would sit on the ramp.  So the device is kept busy with the very launch that is measured for CLOCK_PREAMBLE_MS before the contract's W
     # warm-up steps; nothing of it is timed, and the line reports it (config.clock_preamble).
+    # At N > 1 the ranks meet at a barrier FIRST (they arrive seconds apart: a rank that ran its preamble and then waited for a late one in the warm-up's
+    # exchange would be idle again when the timed region starts), and the preamble is the shard's render launch alone -- every rank stops by its own clock,
+    # so a collective in this loop would be issued a different number of times per rank and pair up with the warm-up's (or the barrier's) collectives.
+    if preamble is None:
+        if dist_on:
+            raise ValueError("time_steps(dist_on=True) needs a collective-free `preamble` launch")
+        preamble = lambda: fn(None)          # noqa: E731
+    if dist_on:
+        dist.barrier()
     pre_t0, pre_n = time.perf_counter(), 0
     while (time.perf_counter() - pre_t0) * 1e3 < CLOCK_PREAMBLE_MS:
         for _ in range(4):
-            fn(None)
+            preamble()
         pre_n += 4
         torch.cuda.synchronize(device)
     PREAMBLE_REPORT.update({"launches": pre_n, "ms": (time.perf_counter() - pre_t0) * 1e3})
@@ -472,7 +483,7 @@ def main():
             last_frame[0] = pipe.frame_in_image_order(frame_no[0] - 1, H, W, ROW_BLOCK, out=frame_out[(frame_no[0] - 1) % 2], stream=side)
 
     marks = []
-    elapsed = time_steps(step_fn, args.steps, args.warmup, device, dist_on, finish, None if dist_on else marks)
+    elapsed = time_steps(step_fn, args.steps, args.warmup, device, dist_on, finish, None if dist_on else marks, preamble=render_only)
     ms_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed / 1e6
     # per-step launch durations of the TIMED loop (HIP events on the launch stream around every render launch); at N > 1 the frames of the timed

@@ -134,3 +134,68 @@ def test_bench_without_a_gpu_exits_with_a_message():
         assert r.returncode != 0 and "MI355X" in r.stderr
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "10-row blocks" in r.stderr
+
+
+def _worker_time_steps(rank, world, port, tmp):
+    """bench.time_steps at world 2 without a device (gloo; the device calls are stubbed): rank 1 arrives 0.4 s late, every step's exchange carries
+    the step's sequence number, and every rank must see ITS number from every other rank -- i.e. all ranks issued the same collectives in the same order."""
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class _Ev:
+        def __init__(self, enable_timing=False): pass
+        def record(self, *a): pass
+    bench.torch.cuda.synchronize = lambda *a, **k: None
+    bench.torch.cuda.Event = _Ev
+    bench.CLOCK_PREAMBLE_MS = 60.0
+    if rank == 1:
+        time.sleep(0.4)                                   # a rank that built its field more slowly
+    seq, pre, bad, works = [0], [0], [], []
+
+    def step(pair):
+        mine = torch.tensor([float(seq[0])])
+        got = torch.empty(world)
+        works.append((dist.all_gather_into_tensor(got, mine, async_op=True), got, seq[0]))
+        seq[0] += 1
+
+    def finish():
+        while works:
+            w, got, k = works.pop(0)
+            w.wait()
+            if not bool((got == float(k)).all()):
+                bad.append((k, got.tolist()))
+
+    def preamble():
+        pre[0] += 1
+        time.sleep(0.001 * (1 + 2 * rank))                # ranks get through a different number of preamble launches
+
+    try:
+        bench.time_steps(step, 5, 2, torch.device("cpu"), True, finish)
+        refused = False
+    except ValueError:
+        refused = True                                    # no collective-free preamble launch given at N > 1: refused before anything is issued
+    el = bench.time_steps(step, 5, 2, torch.device("cpu"), True, finish, None, preamble=preamble)
+    finish()
+    counts = [None] * world
+    dist.all_gather_object(counts, (seq[0], pre[0]))
+    ok = refused and not bad and seq[0] == 7 and all(c[0] == 7 for c in counts) and pre[0] >= 4 and el > 0
+    open(os.path.join(tmp, f"ok{rank}"), "w").write(f"{int(ok)} refused={refused} bad={bad} counts={counts} elapsed={el}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_timed_region_issues_the_same_collectives_on_every_rank(tmp_path):
+    """The clock preamble of bench.time_steps runs for a wall-clock time, so its trip count is rank-local: it must not contain a collective (as first
+    written in round 6 it repeated the whole pipelined step, exchange included -- at N > 1 the ranks would have issued different numbers of
+    all-gathers and paired them with the warm-up's or the barrier's; one GPU cannot show that).  World 2 over gloo, rank 1 late, different preamble
+    trip counts per rank: every step's exchange pairs with the same step on the other rank, and a missing preamble launch is refused."""
+    import torch.multiprocessing as mp
+    port = bench.free_port()
+    mp.spawn(_worker_time_steps, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [open(tmp_path / f"ok{r}").read() for r in range(2)]
+    assert all(r.startswith("1 ") for r in res), res
+    pre = [eval(r.split("counts=")[1].split(" elapsed")[0]) for r in res]
+    assert pre[0][0][1] != pre[0][1][1], "the test meant the ranks to run different numbers of preamble launches"
