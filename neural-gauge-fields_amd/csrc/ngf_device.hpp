@@ -34,6 +34,8 @@ struct Tex {
 
 struct MaskVol {
     const uint8_t *bits;  // np.packbits image of [D,H,W]; NULL = none
+    const uint8_t *cells; // [(D+1)][(H+1)][(W+1)]: per trilinear cell (base corner -1 .. D-1 per axis) the bits of its 8 corners, bit dz*4 + dy*2 + dx,
+                          // corners outside the volume 0 (grid_sample's zeros padding) -- built from `bits` by mask_cells_kernel at create (round 6)
     int32_t D, H, W;
     float a0[3], inv[3];  // mask aabb[0], invgridSize = 1/(aabb1-aabb0)*2
 };
@@ -361,6 +363,11 @@ __device__ __forceinline__ int mask_bit(const MaskVol &m, int z, int y, int x)
     return (m.bits[idx >> 3] >> (7 - (int)(idx & 7))) & 1;
 }
 
+// One byte per sample (round 6): the 8 corner bits of the sample's cell come from `cells` in ONE gather (the packbits image cost eight dependent
+// byte gathers + bounds tests per sample: 0.94 ms of the 5.25 ms S = 884 frame).  Cells with no corner set (empty space) and cells with all eight
+// set (inside the object) are decided by the byte alone -- exactly: with every corner set the sum holds the product of the three weights >= 1/2
+// (w0 + w1 = 1 per axis), so it is > 0 whatever the other terms round to; only boundary cells evaluate the weighted sum, with the same expression
+// as before.
 __device__ __forceinline__ bool mask_occupied(const MaskVol &m, const float p[3])
 {
     float q[3];
@@ -370,10 +377,13 @@ __device__ __forceinline__ bool mask_occupied(const MaskVol &m, const float p[3]
     float iy = ((q[1] + 1.0f) / 2.0f) * (float)(m.H - 1);
     float iz = ((q[2] + 1.0f) / 2.0f) * (float)(m.D - 1);
     float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-    if (!(fx >= -2.0f && fx <= (float)m.W + 1.0f && fy >= -2.0f && fy <= (float)m.H + 1.0f && fz >= -2.0f &&
-          fz <= (float)m.D + 1.0f))
+    // a cell with at least one corner inside the volume has its base corner in -1 .. size - 1 (NaN fails every compare)
+    if (!(fx >= -1.0f && fx <= (float)(m.W - 1) && fy >= -1.0f && fy <= (float)(m.H - 1) && fz >= -1.0f && fz <= (float)(m.D - 1)))
         return false;
-    int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const unsigned x1 = (unsigned)((int)fx + 1), y1 = (unsigned)((int)fy + 1), z1 = (unsigned)((int)fz + 1);
+    const unsigned c = m.cells[(z1 * (unsigned)(m.H + 1) + y1) * (unsigned)(m.W + 1) + x1];
+    if (c == 0u) return false;
+    if (c == 255u) return true;
     float wx[2] = {(fx + 1.0f) - ix, ix - fx}, wy[2] = {(fy + 1.0f) - iy, iy - fy}, wz[2] = {(fz + 1.0f) - iz, iz - fz};
     float acc = 0.0f;
 #pragma unroll
@@ -382,7 +392,7 @@ __device__ __forceinline__ bool mask_occupied(const MaskVol &m, const float p[3]
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx)
-                if (mask_bit(m, z0 + dz, y0 + dy, x0 + dx)) acc += wx[dx] * wy[dy] * wz[dz];
+                if ((c >> (dz * 4 + dy * 2 + dx)) & 1u) acc += wx[dx] * wy[dy] * wz[dz];
     return acc > 0.0f;
 }
 

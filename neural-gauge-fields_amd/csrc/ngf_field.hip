@@ -137,6 +137,7 @@ struct ngf_field {
     double *w1pd_tmp = nullptr;               // create only: the same values as doubles (bake_color_kernel's weights)
     float *w1p_tmp = nullptr;                 // create only: W1' = W1[:, :F] . basis folded on the device (freed before create returns; here so that an error exit frees it)
     uint8_t *mask = nullptr;
+    uint8_t *mask_cells = nullptr;            // the mask's corner bytes per trilinear cell (mask_cells_kernel)
     unsigned int *counters = nullptr;
     mutable std::atomic<unsigned> next_counter{0};
     RenderArgs proto;
@@ -175,6 +176,22 @@ __global__ void pack_plane_kernel(const float *__restrict__ src, int H, int W, i
         float v = 0.0f;
         if (x >= 1 && x <= W && y >= 1 && y <= H) v = src[((size_t)(c0 + (perm ? infoinv_split_channel(c) : c)) * H + (y - 1)) * W + (x - 1)];
         dst[i] = v;
+    }
+}
+
+// Alpha mask, second image (round 6): per trilinear cell -- base corner (z, y, x) in -1 .. D-1 / H-1 / W-1 -- one byte with the bits of its 8 corners
+// (bit dz*4 + dy*2 + dx; corners outside the volume are 0 = grid_sample's zeros padding), so that mask_occupied needs ONE gather per sample.
+__global__ void __launch_bounds__(256) mask_cells_kernel(const uint8_t *__restrict__ bits, int D, int H, int W, uint8_t *__restrict__ cells)
+{
+    ngf::MaskVol m{};
+    m.bits = bits; m.D = D; m.H = H; m.W = W;
+    const size_t total = (size_t)(D + 1) * (H + 1) * (W + 1);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % (size_t)(W + 1)) - 1, y = (int)((i / (size_t)(W + 1)) % (size_t)(H + 1)) - 1, z = (int)(i / ((size_t)(W + 1) * (H + 1))) - 1;
+        unsigned c = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c |= (unsigned)ngf::mask_bit(m, z + (k >> 2), y + ((k >> 1) & 1), x + (k & 1)) << k;
+        cells[i] = (uint8_t)c;
     }
 }
 
@@ -886,6 +903,12 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
             return bail(fail(NGF_E_HIP, "copying the alpha mask failed"));
         A.mask.bits = f->mask;
         A.mask.D = d->mask_d; A.mask.H = d->mask_h; A.mask.W = d->mask_w;
+        const size_t ncells = (size_t)(d->mask_d + 1) * (d->mask_h + 1) * (d->mask_w + 1);
+        if (ncells >= ((size_t)1 << 32)) return bail(fail(NGF_E_ARG, "alpha mask of %d x %d x %d cells: the cell image is indexed with 32 bits", d->mask_d, d->mask_h, d->mask_w));
+        if ((rc = field_alloc(f, (void **)&f->mask_cells, ncells, "mask cells"))) return bail(rc);
+        hipLaunchKernelGGL(mask_cells_kernel, dim3(2048), dim3(256), 0, st, (const uint8_t *)f->mask, d->mask_d, d->mask_h, d->mask_w, f->mask_cells);
+        if (hipGetLastError() != hipSuccess) return bail(fail(NGF_E_HIP, "mask_cells_kernel failed to launch"));
+        A.mask.cells = f->mask_cells;
         for (int k = 0; k < 3; ++k) {
             A.mask.a0[k] = d->mask_aabb[k];
             A.mask.inv[k] = 1.0f / (d->mask_aabb[3 + k] - d->mask_aabb[k]) * 2;   // invgridSize (FieldBase.py:29)
@@ -1402,6 +1425,7 @@ struct ngf_trainer {
     float *g_dense[TP_COUNT] = {};          // reference-layout gradient buffers of the MLP parameters (index TP_*)
     int64_t dense_n[TP_COUNT] = {};
     uint8_t *mask = nullptr;
+    uint8_t *mask_cells = nullptr;
     bool tex_fresh[6] = {};                 // the packed copy of plane / gauge plane k holds the parameter's current values
     char *zero_arena = nullptr;             // every buffer a step accumulates into (gradients, M, loss): one memset per step
     size_t zero_bytes = 0;
@@ -1560,6 +1584,12 @@ extern "C" int ngf_trainer_create(const ngf_train_desc *d, ngf_trainer **out, vo
         if (hipMemcpyAsync(t->mask, d->mask_bits, nbytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return bail(fail(NGF_E_HIP, "copying the alpha mask failed"));
         A.mask.bits = t->mask;
         A.mask.D = d->mask_d; A.mask.H = d->mask_h; A.mask.W = d->mask_w;
+        const size_t ncells = (size_t)(d->mask_d + 1) * (d->mask_h + 1) * (d->mask_w + 1);
+        if (ncells >= ((size_t)1 << 32)) return bail(fail(NGF_E_ARG, "alpha mask of %d x %d x %d cells: the cell image is indexed with 32 bits", d->mask_d, d->mask_h, d->mask_w));
+        if ((rc = tr_alloc(t, &t->mask_cells, ncells))) return bail(rc);
+        hipLaunchKernelGGL(mask_cells_kernel, dim3(2048), dim3(256), 0, st, (const uint8_t *)t->mask, d->mask_d, d->mask_h, d->mask_w, t->mask_cells);
+        if (hipGetLastError() != hipSuccess) return bail(fail(NGF_E_HIP, "mask_cells_kernel failed to launch"));
+        A.mask.cells = t->mask_cells;
         for (int k = 0; k < 3; ++k) {
             A.mask.a0[k] = d->mask_aabb[k];
             A.mask.inv[k] = 1.0f / (d->mask_aabb[3 + k] - d->mask_aabb[k]) * 2;

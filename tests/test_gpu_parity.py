@@ -1071,6 +1071,61 @@ def test_alpha_mask_build_and_ray_filter():
     assert bool(torch.isfinite(out["rgb_map"]).all())
 
 
+@pytest.mark.parametrize("dhw,keep", [((5, 6, 7), None), ((9, 4, 13), 0.6), ((3, 3, 3), 2.0), ((4, 5, 2), -1.0), ((16, 16, 16), 0.9)])
+def test_alpha_mask_sign_at_arbitrary_points(dhw, keep):
+    """Row A4 on its own: `sample_alpha(xyz) > 0` (FieldBase.py:33-40, 263-267 -- the sign of ATen's 3-D grid_sample on the {0,1} volume) at arbitrary
+    points through compute_alpha (alpha = 0 exactly where the mask is empty), against the reference's own grid_sample outputs
+    (tests/golden/ops_grid_sample.npz: a blobby 5 x 6 x 7 volume, points in and around it) and against the C oracle on blobby, full and empty
+    volumes of other shapes: random points, points far outside, and the lattice points themselves (weights exactly 0 / 1: boundary cells decided
+    by the weighted sum).  The kernels read ONE byte per sample -- the 8 corner bits of the sample's cell (mask_cells_kernel) -- so none / all / mixed
+    cells and the one-cell border with zero-padded corners are all in here."""
+    import ctypes as C
+    from oracle import oracle as O
+    from ngf_amd import synth
+    fx = np.load(os.path.join(GOLDEN, "ops_grid_sample.npz"))
+    if keep is None:
+        bits, q_fix, want_fix = np.ascontiguousarray(fx["mask_bits"]), fx["q"], fx["out3"] > 0
+        assert tuple(int(v) for v in fx["mask_dhw"]) == dhw
+    else:
+        _, bits = synth.alpha_mask_bits(17, dhw, keep=keep)          # keep = 2: every voxel set (the coarse pattern still carves holes); keep = -1: empty
+        if keep >= 2.0:
+            bits = np.packbits(np.ones(int(np.prod(dhw)), np.uint8))
+        q_fix, want_fix = None, None
+    d, h, w = dhw
+    # not the field's box, not symmetric -- except for the fixture's volume, whose points are normalised coordinates: the box [-1, 1]^3 hands most of them through unchanged
+    maabb = np.array([[-1.0, -0.8, -1.1], [1.0, 0.9, 1.3]] if keep is not None else [[-1.0] * 3, [1.0] * 3], np.float32)
+    g0, params, _ = big_case("triplane", "R1", res=32)
+    f = field_for_case(g0, params, (bits, dhw, maabb))
+    rng = np.random.default_rng(5)
+    pts = [rng.uniform(-1.45, 1.45, (20000, 3)).astype(np.float32)]
+    lat = np.stack(np.meshgrid(np.linspace(maabb[0, 0], maabb[1, 0], w, dtype=np.float32), np.linspace(maabb[0, 1], maabb[1, 1], h, dtype=np.float32),
+                               np.linspace(maabb[0, 2], maabb[1, 2], d, dtype=np.float32), indexing="ij"), -1).reshape(-1, 3)
+    pts += [lat, lat + np.float32(1e-6), lat - np.float32(1e-6)]
+    pts.append(np.array([[1e6, 0, 0], [-1e6, 0, 0], [0, 3e38, 0], [0, 0, -3e38], [1.0, 0.9, 1.3], [-1.0, -0.8, -1.1]], np.float32))
+    if q_fix is not None:
+        pts.append(q_fix.astype(np.float32))
+    p = np.ascontiguousarray(np.concatenate(pts, 0).astype(np.float32))
+    alpha = f.compute_alpha(torch.from_numpy(p), length=1000.0).cpu().numpy()
+    got = alpha != 0
+    # the reference's normalisation (AlphaGridMask.normalize_coord, FieldBase.py:39-40) in IEEE fp32, then the oracle's grid_sample
+    inv = (np.float32(1.0) / (maabb[1] - maabb[0]) * np.float32(2.0)).astype(np.float32)
+    qn = np.ascontiguousarray(((p - maabb[0]) * inv - np.float32(1.0)).astype(np.float32))
+    out3 = np.zeros((p.shape[0],), np.float32)
+    O.lib().ngf_oracle_mask_sample(bits.ctypes.data_as(C.c_void_p), d, h, w, qn.ctypes.data_as(C.c_void_p), C.c_int64(p.shape[0]), out3.ctypes.data_as(C.c_void_p))
+    want = out3 > 0
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {p.shape[0]} points differ"
+    if keep is not None and keep < 0:
+        assert not got.any()
+    else:
+        assert got.any() and not got.all()
+    if q_fix is not None:
+        # where the normalisation (p + 1) * 1 - 1 reproduces the fixture's point bit for bit, the REFERENCE's own sign must come out
+        back = qn[-q_fix.shape[0]:]
+        same = np.all(back == q_fix, axis=1)
+        assert same.sum() > 50
+        assert np.array_equal(got[-q_fix.shape[0]:][same], want_fix[same])
+
+
 def test_split_bf16_fields_build_the_same_alpha_mask():
     """Density queries of NGF_F_SPLIT_BF16 fields (compute_alpha / getDenseAlpha): TriPlane's density path is untouched by the flag
     (bit-identical); InfoInv's density MLP runs on split bf16 products too -- the reference's own dense alpha at the usual tolerance."""
