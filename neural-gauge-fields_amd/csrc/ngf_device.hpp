@@ -38,6 +38,10 @@ struct MaskVol {
                           // corners outside the volume 0 (grid_sample's zeros padding) -- built from `bits` by mask_cells_kernel at create (round 6)
     int32_t D, H, W;
     float a0[3], inv[3];  // mask aabb[0], invgridSize = 1/(aabb1-aabb0)*2
+    const uint8_t *coarse; // [cD][cH][cW], cX = ((X + 32) >> 3) + 1: blocks of 8^3 cells over the cell indices -16 .. X + 16 (block = (cell index + 16) >> 3: two blocks of
+                           // margin per side, so that a position far outside lands in a block whose neighbours are outside too); 1 = the block and its 26 neighbours
+                           // hold no occupied corner, i.e. every cell within +-8 cells per axis of a cell of this block is empty (mask_clear_around)
+    int32_t cD, cH, cW;
 };
 
 struct RenderArgs {
@@ -78,7 +82,7 @@ struct RenderArgs {
     uint32_t ord_bw;       // block width in tiles
     uint32_t ord_bh;       // block height in rows
     uint32_t queue_waves;  // workgroups of the launch (each reports once, when its last working wave found the queue empty): what tile_counter[8] counts up to
-    int32_t ablate;        // debug instantiations only (render_kernel<.., DBG = true>): 32 no early termination, 64 no empty-iteration skip -- both
+    int32_t ablate;        // debug instantiations only (render_kernel<.., DBG = true>): 32 no early termination, 64 no empty-iteration skip, 128 no empty-space skipping through the mask's block image -- both
                            // EXACT (A/B timing and the bit-identity tests).  Round 1-2's bits 1 / 2 / 4 / 16 (skip collect, skip layers 2-3, cached
                            // gathers, wave priority) produced wrong images and are gone; the trainer keeps its own bits (ngf_train.hpp)
     float a0[3], a1[3], inv[3];
@@ -194,6 +198,19 @@ __device__ __forceinline__ T karg(size_t off)
     ptr_t q = (ptr_t)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + off);
     asm volatile("" : "+s"(q));
     return *q;
+}
+// The alpha mask's descriptor re-read the same way (member by member, like karg_tex).
+__device__ __forceinline__ MaskVol karg_mask(size_t off)
+{
+    typedef const __attribute__((address_space(4))) MaskVol *mptr_t;
+    mptr_t t = (mptr_t)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + off);
+    asm volatile("" : "+s"(t));
+    MaskVol r;
+    r.bits = t->bits; r.cells = t->cells; r.D = t->D; r.H = t->H; r.W = t->W;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r.a0[k] = t->a0[k]; r.inv[k] = t->inv[k]; }
+    r.coarse = t->coarse; r.cD = t->cD; r.cH = t->cH; r.cW = t->cW;
+    return r;
 }
 #define NGF_KARG(field) karg<decltype(RenderArgs::field)>(offsetof(RenderArgs, field))
 #define NGF_KARG_AT(field, k) karg<std::remove_extent_t<decltype(RenderArgs::field)>>(offsetof(RenderArgs, field) + (k) * sizeof(std::remove_extent_t<decltype(RenderArgs::field)>))
@@ -394,6 +411,22 @@ __device__ __forceinline__ bool mask_occupied(const MaskVol &m, const float p[3]
             for (int dx = 0; dx < 2; ++dx)
                 if ((c >> (dz * 4 + dy * 2 + dx)) & 1u) acc += wx[dx] * wy[dy] * wz[dz];
     return acc > 0.0f;
+}
+
+// Empty-space skipping (round 6).  True = every sample whose cell lies within 8 cells (per axis) of the cell of p samples the mask as 0: cells outside
+// the volume are empty (zeros padding), so the cell index is clamped into the blocks around the volume.  A NaN position certifies nothing.
+__device__ __forceinline__ bool mask_clear_around(const MaskVol &m, const float p[3])
+{
+    float q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) q[k] = (p[k] - m.a0[k]) * m.inv[k] - 1.0f;
+    const float fx = floorf(((q[0] + 1.0f) / 2.0f) * (float)(m.W - 1)), fy = floorf(((q[1] + 1.0f) / 2.0f) * (float)(m.H - 1)),
+                fz = floorf(((q[2] + 1.0f) / 2.0f) * (float)(m.D - 1));
+    if (!(fx == fx && fy == fy && fz == fz)) return false;
+    // cell index + 16 = floor + 17, clamped to 0 .. size + 32 (beyond the clamp every neighbour within 8 cells is outside the volume, like those of the clamped cell)
+    const int X = (int)fminf(fmaxf(fx + 17.0f, 0.0f), (float)(m.W + 32)) >> 3, Y = (int)fminf(fmaxf(fy + 17.0f, 0.0f), (float)(m.H + 32)) >> 3,
+              Z = (int)fminf(fmaxf(fz + 17.0f, 0.0f), (float)(m.D + 32)) >> 3;
+    return m.coarse[(Z * m.cH + Y) * m.cW + X] != 0;
 }
 
 // feature2density (Field.py:48-50): F.softplus(x - 10), threshold 20.

@@ -138,6 +138,7 @@ struct ngf_field {
     float *w1p_tmp = nullptr;                 // create only: W1' = W1[:, :F] . basis folded on the device (freed before create returns; here so that an error exit frees it)
     uint8_t *mask = nullptr;
     uint8_t *mask_cells = nullptr;            // the mask's corner bytes per trilinear cell (mask_cells_kernel)
+    uint8_t *mask_any = nullptr, *mask_clear = nullptr;   // blocks of 8^3 cells: occupied at all / nothing within 8 cells (mask_coarse_*_kernel)
     unsigned int *counters = nullptr;
     mutable std::atomic<unsigned> next_counter{0};
     RenderArgs proto;
@@ -193,6 +194,41 @@ __global__ void __launch_bounds__(256) mask_cells_kernel(const uint8_t *__restri
         for (int k = 0; k < 8; ++k) c |= (unsigned)ngf::mask_bit(m, z + (k >> 2), y + ((k >> 1) & 1), x + (k & 1)) << k;
         cells[i] = (uint8_t)c;
     }
+}
+
+// Alpha mask, third image (round 6): empty-space skipping.  Blocks of 8^3 cells over the cell indices -16 .. size + 16 per axis (block = (cell index + 16) >> 3).
+// Pass 1: any[block] = some cell of the block has an occupied corner (one wave per block, a lane per (z, y) row of 8 cells).
+__global__ void __launch_bounds__(64) mask_coarse_any_kernel(const uint8_t *__restrict__ cells, int D, int H, int W, int cH, int cW, uint8_t *__restrict__ any)
+{
+    const int b = blockIdx.x, X = b % cW, Y = (b / cW) % cH, Z = b / (cW * cH);
+    const int z = Z * 8 - 16 + ((int)threadIdx.x >> 3), y = Y * 8 - 16 + ((int)threadIdx.x & 7);
+    unsigned acc = 0;
+    if (z >= 0 && z <= D && y >= 0 && y <= H) {
+        const uint8_t *row = cells + ((size_t)z * (H + 1) + y) * (W + 1);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int x = X * 8 - 16 + t;
+            if (x >= 0 && x <= W) acc |= row[x];
+        }
+    }
+    const unsigned long long m = __ballot(acc != 0);
+    if (threadIdx.x == 0) any[b] = m ? 1 : 0;
+}
+
+// Pass 2: clear[block] = the block and its 26 neighbours hold nothing (blocks outside the grid are empty space).
+__global__ void __launch_bounds__(256) mask_coarse_clear_kernel(const uint8_t *__restrict__ any, int cD, int cH, int cW, uint8_t *__restrict__ clear)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= cD * cH * cW) return;
+    const int X = b % cW, Y = (b / cW) % cH, Z = b / (cW * cH);
+    unsigned acc = 0;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int x = X + dx, y = Y + dy, z = Z + dz;
+                if (x >= 0 && x < cW && y >= 0 && y < cH && z >= 0 && z < cD) acc |= any[(z * cH + y) * cW + x];
+            }
+    clear[b] = acc ? 0 : 1;
 }
 
 // density_decoder Linear(48,1) pre-composed with the density channels of one plane (fp64 accumulate)
@@ -909,6 +945,13 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
         hipLaunchKernelGGL(mask_cells_kernel, dim3(2048), dim3(256), 0, st, (const uint8_t *)f->mask, d->mask_d, d->mask_h, d->mask_w, f->mask_cells);
         if (hipGetLastError() != hipSuccess) return bail(fail(NGF_E_HIP, "mask_cells_kernel failed to launch"));
         A.mask.cells = f->mask_cells;
+        const int cD = ((d->mask_d + 32) >> 3) + 1, cH = ((d->mask_h + 32) >> 3) + 1, cW = ((d->mask_w + 32) >> 3) + 1;
+        if ((rc = field_alloc(f, (void **)&f->mask_any, (size_t)cD * cH * cW, "mask blocks"))) return bail(rc);
+        if ((rc = field_alloc(f, (void **)&f->mask_clear, (size_t)cD * cH * cW, "mask blocks"))) return bail(rc);
+        hipLaunchKernelGGL(mask_coarse_any_kernel, dim3((unsigned)(cD * cH * cW)), dim3(64), 0, st, (const uint8_t *)f->mask_cells, d->mask_d, d->mask_h, d->mask_w, cH, cW, f->mask_any);
+        hipLaunchKernelGGL(mask_coarse_clear_kernel, dim3((unsigned)((cD * cH * cW + 255) / 256)), dim3(256), 0, st, (const uint8_t *)f->mask_any, cD, cH, cW, f->mask_clear);
+        if (hipGetLastError() != hipSuccess) return bail(fail(NGF_E_HIP, "mask_coarse kernels failed to launch"));
+        A.mask.coarse = f->mask_clear; A.mask.cD = cD; A.mask.cH = cH; A.mask.cW = cW;
         for (int k = 0; k < 3; ++k) {
             A.mask.a0[k] = d->mask_aabb[k];
             A.mask.inv[k] = 1.0f / (d->mask_aabb[3 + k] - d->mask_aabb[k]) * 2;   // invgridSize (FieldBase.py:29)
@@ -1141,6 +1184,9 @@ static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
     // product library: the fused kernel, twelve waves per CU, one march step per lane (measured best, profiles/r01_sweep.txt)
     if (knob(KNOB_KERNEL) > 0 || knob(KNOB_STAGE) > 0 || knob(KNOB_PROFILE) > 0 || knob(KNOB_NSTEP) > 1 || (knob(KNOB_WAVES) >= 0 && knob(KNOB_WAVES) != 12))
         return fail(NGF_E_UNSUPPORTED, "knobs kernel / stage / profile / nstep / waves select experiment kernels: load libngf_hip_exp.so (built with -DNGF_EXPERIMENTS)");
+    if constexpr (BD) {
+        if (A.mask.coarse) return launch_policy<MaskSkip<TriPlanePolicy<BD, BC, 12, 1>>>(f, A, st);      // a field with an alpha mask: the march skips empty space (levels 2 and 3)
+    }
     return launch_policy<TriPlanePolicy<BD, BC, 12, 1>>(f, A, st);
 #else
     // default: the fused kernel (every wave marches and shades).  ngf_debug_set("kernel", 1) selects the specialised march / shade
@@ -1189,7 +1235,11 @@ static int launch_triplane(const ngf_field *f, RenderArgs &A, hipStream_t st)
     }
     switch (w) {
     case 8: return launch_policy<TriPlanePolicy<BD, BC, 8, 1>>(f, A, st);
-    case 12: return launch_policy<TriPlanePolicy<BD, BC, 12, 1>>(f, A, st);
+    case 12:
+        if constexpr (BD) {
+            if (A.mask.coarse) return launch_policy<MaskSkip<TriPlanePolicy<BD, BC, 12, 1>>>(f, A, st);
+        }
+        return launch_policy<TriPlanePolicy<BD, BC, 12, 1>>(f, A, st);
     case 16: return launch_policy<TriPlanePolicy<BD, BC, 16, 1>>(f, A, st);
     default: return fail(NGF_E_ARG, "knob waves must be 8, 12 or 16");
     }
@@ -1203,12 +1253,13 @@ static int render_common(const ngf_field *f, RenderArgs &A, hipStream_t st)
         const bool wide = knob(KNOB_TILE_W) > 16 || knob(KNOB_SPLIT) == 0;      // debug knobs only: launch_render never picks more than 16 rays per tile
         if (f->flags & NGF_F_SPLIT_BF16) {
             if (wide) return fail(NGF_E_ARG, "InfoInv NGF_F_SPLIT_BF16 renders with split tiles of at most 16 rays");
-            return launch_policy<InfoInvSplitPolicy>(f, A, st);
+            return A.mask.coarse ? launch_policy<MaskSkip<InfoInvSplitPolicy>>(f, A, st) : launch_policy<InfoInvSplitPolicy>(f, A, st);
         }
-        return wide ? launch_policy<InfoInvWidePolicy>(f, A, st) : launch_policy<InfoInvPolicy>(f, A, st);
+        if (wide) return launch_policy<InfoInvWidePolicy>(f, A, st);
+        return A.mask.coarse ? launch_policy<MaskSkip<InfoInvPolicy>>(f, A, st) : launch_policy<InfoInvPolicy>(f, A, st);
     }
     if (f->flags & NGF_F_NO_FOLD) return launch_policy<TriPlaneNoFoldPolicy>(f, A, st);
-    if ((f->flags & NGF_F_SPLIT_BF16) && (f->flags & NGF_F_BAKE_COLOR)) return launch_policy<TriPlaneBakedBf16Policy>(f, A, st);
+    if ((f->flags & NGF_F_SPLIT_BF16) && (f->flags & NGF_F_BAKE_COLOR)) return A.mask.coarse ? launch_policy<MaskSkip<TriPlaneBakedBf16Policy>>(f, A, st) : launch_policy<TriPlaneBakedBf16Policy>(f, A, st);
     if (f->flags & NGF_F_SPLIT_BF16) {
         if (knob(KNOB_TILE_W) > 8 || knob(KNOB_SPLIT) == 0) return fail(NGF_E_ARG, "NGF_F_SPLIT_BF16 renders with split tiles of 4 or 8 rays");
         // 8 waves per CU: the pass keeps 48 registers of A fragments next to the gather buffer -- at the 168 registers that 12 waves

@@ -583,6 +583,7 @@ struct InfoInvPolicyT {
     static constexpr int RGB_FLOATS = SPLIT ? MlpLayoutBf16II::TOTAL : MlpLayout16<72>::TOTAL;      // the density image follows the colour image in LDS
     static constexpr int APP = 72;
     static constexpr bool INFOINV = true;
+    static constexpr bool MASK_SKIP = false;                      // ngf_render.hpp: MaskSkip<P> is the instantiation with the march's empty-space skipping
     static constexpr int WAVES = (SPLIT || WIDE) ? kInfoInvSplitWaves : kInfoInvWaves;        // 8 (split: 247 registers; wide tiles: LDS) / 12
     static constexpr bool PROFILE = false;
     static constexpr bool PROD = !WIDE;                           // has a production (DBG = false) instantiation of the split kernel

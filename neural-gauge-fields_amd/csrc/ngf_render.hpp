@@ -199,6 +199,7 @@ struct TriPlanePolicy {
     static constexpr bool PROFILE = PROFILE_;
     static constexpr bool PROD = WAVES_ == 12 && NSTEP_ == 1 && !PROFILE_;      // has a production (DBG = false) instantiation of the split kernel
     static constexpr bool INFOINV = false;
+    static constexpr bool MASK_SKIP = false;                    // empty-space skipping through the mask's block image (march loop): MaskSkip<P> below
     static constexpr bool STAGED = false;                       // ngf_stage.hpp: LDS-staged texture strips
     static constexpr int STAGE_FLOATS = 0;
     static constexpr int WAVES = WAVES_;
@@ -255,6 +256,18 @@ struct TriPlanePolicy {
         if constexpr (BAKE_C) mlp_pass16_baked(A, smem, rec, v, lane, c, pre, &cells);
         else mlp_pass16<48>(A, smem, rec, v, lane, c, nullptr, pre, &cells);
     }
+};
+
+// The same kernel with the march's empty-space skipping compiled in (round 6): launched for fields that carry an alpha mask.  A second instantiation
+// rather than a run-time branch in one: the level-3 kernel sits at its 168-register budget, and with the skip's branch in its march loop the frame
+// WITHOUT a mask measured 0.2-0.4 % slower (profiles/r06_mask_skip.txt) -- the headline launch keeps the code it had.
+template <typename P>
+struct MaskSkip : P {
+#ifdef NGF_EXP_NO_MASK_SKIP
+    static constexpr bool MASK_SKIP = false;                    // A/B builds (profiles/r06_mask_skip.txt)
+#else
+    static constexpr bool MASK_SKIP = true;
+#endif
 };
 
 // NGF_F_SPLIT_BF16: the colour MLP on the bf16 matrix pipe with 3-term split operands (ngf_shade_bf16.hpp).  Split tiles of <= 8 rays
@@ -603,7 +616,45 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                     if constexpr (DBG) st_valid += __popcll(__ballot(valid));
                 }
                 if (empty_step) {
-                    i += NSTEP * K;
+                    // Empty-space skipping (round 6).  The iteration held no valid sample; before the next one is evaluated, lane (ray, seg) looks at the
+                    // step i + K + m + seg (2m + 1) of its ray: when the mask's block image says that nothing is occupied within 8 cells of that sample's
+                    // cell, the 2m + 1 steps around it sample empty cells too -- m steps move a cell index by at most m r + 1 <= 8, r = the cells per step
+                    // of the wave's fastest ray -- so a leading run of n passing lanes on EVERY ray certifies n (2m + 1) steps and the tile jumps over the
+                    // whole iterations in them.  Certified samples have sigma = alpha = w = 0: T, acc, depth and the queue are what they would have been.
+                    // The same test runs the march out of the box (blocks beyond the volume are empty).  DBG: ablate bit 128 switches it off.
+                    int skip = 0;
+                    if constexpr (NSTEP == 1 && P::MASK_SKIP) {
+                        if (A.mask.coarse && !(DBG && (A.ablate & 128))) {
+                            // (the mask's descriptor re-read from the kernel-argument segment HERE: what hipcc derives from it -- the clamps' float bounds -- it otherwise
+                            // hoists to the kernel's entry and spills in the kernels that sit at their register budget: 52 B per lane at level 3)
+                            const MaskVol mk = karg_mask(offsetof(RenderArgs, mask));
+                            const float sz[3] = {(float)(mk.W - 1), (float)(mk.H - 1), (float)(mk.D - 1)};
+                            float r = 0.0f;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) r = fmaxf(r, fabsf(d[k]) * (A.step * 0.5f * mk.inv[k] * sz[k]));
+                            bool sane = !live || (r == r && r < 1e30f);          // a NaN / infinite direction certifies nothing
+                            r = live && sane ? r : 0.0f;
+#pragma unroll
+                            for (int off = 32; off >= 1; off >>= 1) r = fmaxf(r, __shfl_xor(r, off));
+                            const int m = (int)fminf(6.9f / fmaxf(r, 1e-6f), 2048.0f), gsteps = 2 * m + 1;
+                            const int stest = i + K + m + seg * gsteps;
+                            const float zt = tmin + A.step * ((float)stest + jit);
+                            float pt[3];
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) pt[k] = o[k] + d[k] * zt;
+                            const bool pass = !live || (sane && (stest - m >= S || mask_clear_around(mk, pt)));
+                            const unsigned long long fm = __ballot(!pass);
+                            int nrun = K;
+                            if (fm) {
+                                if (!SPLIT) nrun = 0;
+                                else if (ts >= 2) nrun = __builtin_ctz((unsigned)((fm | (fm >> 16) | (fm >> 32) | (fm >> 48)) & 0xffffu)) >> mshift;
+                                else if (ts == 1) nrun = __builtin_ctz((unsigned)(fm | (fm >> 32)));
+                                else nrun = __builtin_ctzll(fm);
+                            }
+                            skip = (nrun * gsteps) / K;
+                        }
+                    }
+                    i += NSTEP * K * (1 + skip);
                     if constexpr (P::PROFILE) prof[0] += __builtin_readcyclecounter() - t_sec;
                     continue;
                 }

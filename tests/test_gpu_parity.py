@@ -1126,6 +1126,79 @@ def test_alpha_mask_sign_at_arbitrary_points(dhw, keep):
         assert np.array_equal(got[-q_fix.shape[0]:][same], want_fix[same])
 
 
+def _sparse_masks(name):
+    """Occupancy volumes with real empty space, [D,H,W] on the field's +-1.5 box: a ball (an object in empty space), two small slabs near opposite
+    corners (long empty runs between them), and a blobby random volume (little to skip: the test of the conservative side)."""
+    if name == "ball":
+        ax = np.linspace(-1.5, 1.5, 128, dtype=np.float32)
+        zz, yy, xx = np.meshgrid(ax, ax, ax, indexing="ij")
+        return (xx ** 2 + yy ** 2 + zz ** 2) < 0.8 ** 2
+    if name == "slabs":
+        vol = np.zeros((200, 96, 256), bool)          # anisotropic: cells per step differ per axis
+        vol[10:24, 8:30, 20:60] = True
+        vol[150:190, 60:90, 180:250] = True
+        vol[100, 48, 128] = True                       # a single voxel in the middle of nowhere
+        return vol
+    from ngf_amd import synth
+    return synth.alpha_mask_bits(23, (64, 64, 64), keep=0.35)[0]
+
+
+@pytest.mark.parametrize("model,level", [("triplane", 3), ("triplane", 2), ("triplane", "bf16"), ("infoinv", "split")])
+@pytest.mark.parametrize("mask_name", ["ball", "slabs", "blobby"])
+def test_empty_space_skipping_is_bit_identical(model, level, mask_name):
+    """Round 6: after an iteration without a valid sample the march asks the mask's block image (8^3 cells per block, a block is `clear` when it and its 26
+    neighbours hold no occupied corner) how many of the next steps sample empty cells for certain, and jumps over whole iterations of them
+    (ngf_render.hpp, mask_clear_around).  Skipped samples have sigma = alpha = w = 0 in the reference too (FieldBase.py:261-270), so nothing may change:
+    the frame with the skip against the frame without it (DBG knob ablate = 128) bit for bit, for every tile shape (rays per wave tile 64 ... 1: the run
+    length is read from the ballot differently per shape), with per-ray jitter (train-mode forward), the same number of evaluated samples, the
+    production instantiation the same bits again, and a strided subset against the oracle at the reference's S = 884."""
+    from ngf_amd import synth, triplane
+    from ngf_amd._lib import knobs
+    g, params, step = big_case(model, "R1")
+    kw_f = {3: dict(bake=True, bake_color=True), 2: dict(bake=True), "bf16": dict(bake=True, bake_color=True, split_bf16=True), "split": dict(split_bf16=True)}[level]
+    f = field_for_case(g, params, None, **kw_f)
+    vol = _sparse_masks(mask_name)
+    f.alphaMask = triplane.AlphaGridMask("cuda", torch.tensor(np.asarray(g["aabb"], np.float32)), torch.from_numpy(vol.astype(np.float32)).cuda())
+    f.invalidate()
+    full = synth.lookat_rays(800, 800).reshape(800, 800, 6)
+    rays_np = np.ascontiguousarray(full[3::11, 5::11].reshape(-1, 6))          # 73 x 73 rays over the whole frame (many miss the object, many graze it)
+    rays = torch.from_numpy(rays_np).cuda()
+    kw = {"iteration": 30001} if model == "triplane" else {"infoinv": True}
+    S = -1                                                                      # the model's own nSamples: 884
+    jit = torch.from_numpy(synth.hash_uniform(31, 7, (rays_np.shape[0],)).astype(np.float32))
+    ref = None
+    for tw in ((8, 64, 32, 16, 4, 2, 1) if model == "triplane" else (8, 16, 4, 2, 1)):          # (the InfoInv bf16 kernel takes tiles of at most 16 rays)
+        with knobs(ablate=128, tile_w=tw):
+            off = f(rays, N_samples=S, white_bg=True, collect_stats=True, **kw)
+        n_off = f.last_stats.cpu().numpy().copy()
+        with knobs(tile_w=tw):
+            on = f(rays, N_samples=S, white_bg=True, collect_stats=True, **kw)
+            prod = f(rays, N_samples=S, white_bg=True, **kw)
+        n_on = f.last_stats.cpu().numpy().copy()
+        for a, b in ((off, on), (off, prod)):
+            assert torch.equal(a["rgb_map"], b["rgb_map"]) and torch.equal(a["depth_map"], b["depth_map"]), f"tile_w {tw}"
+        assert n_on[0] == n_off[0] and n_on[1] == n_off[1], f"tile_w {tw}: evaluated / active samples {n_on[:2]} vs {n_off[:2]}"
+        if ref is None:
+            ref = off
+        if tw <= 8:          # the tile shapes of a production launch give the same bits (wider tiles fold the view inputs differently: other last bits of the colours)
+            assert torch.equal(ref["rgb_map"], on["rgb_map"]) and torch.equal(ref["depth_map"], on["depth_map"]), f"tile_w {tw} vs 8"
+        with torch.no_grad():
+            with knobs(ablate=128, tile_w=tw):
+                t_off = f(rays, N_samples=S, white_bg=True, is_train=True, jitter=jit, coin=0.9, collect_stats=True, **kw)
+            with knobs(tile_w=tw):
+                t_on = f(rays, N_samples=S, white_bg=True, is_train=True, jitter=jit, coin=0.9, **kw)
+        assert torch.equal(t_off["rgb_map"], t_on["rgb_map"]) and torch.equal(t_off["depth_map"], t_on["depth_map"]), f"tile_w {tw}, jitter"
+    assert 0 < n_on[0] < 0.5 * rays_np.shape[0] * 884          # there IS empty space in these volumes
+    # ... and the oracle on a subset (its mask test is the restated grid_sample)
+    sub = slice(0, rays_np.shape[0], 9)
+    bits = np.packbits(vol.reshape(-1))
+    orc = oracle_for_case(dict(g, model=np.array(model)), params, step, (bits, vol.shape, np.asarray(g["aabb"], np.float32)))
+    o_rgb, o_depth = orc.render(rays_np[sub], 884, white_bg=True)
+    tol = dict(rtol=1e-4, atol=1e-5) if level in (2, 3) else dict(rtol=2e-4, atol=4e-5)
+    np.testing.assert_allclose(ref["rgb_map"].cpu().numpy()[sub], o_rgb, **tol)
+    np.testing.assert_allclose(ref["depth_map"].cpu().numpy()[sub], o_depth, rtol=1e-4, atol=5e-5)
+
+
 def test_split_bf16_fields_build_the_same_alpha_mask():
     """Density queries of NGF_F_SPLIT_BF16 fields (compute_alpha / getDenseAlpha): TriPlane's density path is untouched by the flag
     (bit-identical); InfoInv's density MLP runs on split bf16 products too -- the reference's own dense alpha at the usual tolerance."""
