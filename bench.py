@@ -696,7 +696,7 @@ def main():
             # updateAlphaMask((256,)*3) builds from the seeded field (main.py:330); `ball`: occupancy = a ball of radius 0.8, 15 % of the box (an
             # object in empty space, as a trained lego is).  Module default level, whole frame in one launch.
             from ngf_amd.fieldbase import renderer as _renderer
-            for mdl, preset, shape in (("triplane", "R1", "mask"), ("triplane", "R2", "mask"), ("triplane", "R1", "ball"), ("infoinv", "R1", "mask")):
+            for mdl, preset, shape in (("triplane", "R1", "mask"), ("triplane", "R2", "mask"), ("triplane", "R1", "ball"), ("infoinv", "R1", "mask"), ("infoinv", "R1", "ball")):
                 key = f"{mdl}_{preset}_S884_{shape}"
                 tri = mdl == "triplane"
                 fkw = {"iteration": 30001} if tri else {"infoinv": True}

@@ -17,3 +17,15 @@ for model in ("triplane", "infoinv"):
             f.handle(); torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
         print(f"{model} bake={bake}: handle rebuild {np.median(ts) * 1e3:.2f} ms")
+# ... and with a 256^3 alpha mask on the field (round 6: the create path also builds the mask's cell bytes -- 17 MB -- and its block image)
+g, params, step = big_case("triplane", "R1")
+f = field_for_case(g, params, None, bake=True, bake_color=True)
+f.updateAlphaMask((256, 256, 256))
+f.handle(); torch.cuda.synchronize()
+ts = []
+for _ in range(5):
+    f._handle_key = None
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    f.handle(); torch.cuda.synchronize()
+    ts.append(time.perf_counter() - t0)
+print(f"triplane bake=3 + 256^3 alpha mask: handle rebuild {np.median(ts) * 1e3:.2f} ms")
