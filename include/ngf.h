@@ -91,7 +91,9 @@ typedef struct ngf_field_desc {
     float step;                    /* stepSize (FieldBase.py:70) -- computed by the caller in float32 */
     float distance_scale;          /* 25 */
     float weight_thres;            /* rayMarch_weight_thres, 1e-4 */
-    /* optional alpha mask: the checkpoint's np.packbits image of the [D,H,W] volume (bit = occupied) */
+    /* optional alpha mask: the checkpoint's np.packbits image of the [D,H,W] volume (bit = occupied).  ngf_field_create derives two device images
+     * from it (the 8 corner bits of every trilinear cell as one byte, (D+1)(H+1)(W+1) bytes -- one gather per sample decides sample_alpha > 0,
+     * FieldBase.py:33-40,263-267 -- and a block image for the march's empty-space skipping); (D+1)(H+1)(W+1) must stay below 2^32 */
     const uint8_t *mask_bits;      /* NULL = no mask */
     int32_t mask_d, mask_h, mask_w;
     float mask_aabb[6];
@@ -390,7 +392,7 @@ const char *ngf_last_error(void);
 int ngf_abi_version(void);
 /* sizeof(ngf_field_desc) as compiled into the library (binding self-check) */
 int ngf_sizeof_field_desc(void);
-/* bytes of HBM the handle owns (packed textures + MLP image + mask + tile-queue heads) */
+/* bytes of HBM the handle owns (packed textures + MLP image + the mask's three images + tile-queue heads) */
 int64_t ngf_field_bytes(const ngf_field *f);
 /* ngf_field_destroy parks a handle's device buffers in a per-process pool (exact-size reuse by the next ngf_field_create on the same device -- the
  * device the HANDLE was created on, not the calling thread's current one): a handle is rebuilt after every parameter change of an eval field, with
