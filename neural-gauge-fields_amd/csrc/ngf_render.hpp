@@ -595,7 +595,9 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                         p[k] = o[k] + d[k] * z[u];
                         valid = valid && !(A.a0[k] > p[k] || p[k] > A.a1[k]);
                     }
+#ifndef NGF_EXP_NO_ALPHA_MASK          // timing experiment: the march without the alpha-mask test compiled in (what a no-mask instantiation would be)
                     if (A.mask.bits && valid) valid = mask_occupied(A.mask, p);
+#endif
 #pragma unroll
                     for (int k = 0; k < 6; ++k) t[u][k] = 0.0f;
 #pragma unroll
