@@ -38,10 +38,12 @@ struct MaskVol {
                           // corners outside the volume 0 (grid_sample's zeros padding) -- built from `bits` by mask_cells_kernel at create (round 6)
     int32_t D, H, W;
     float a0[3], inv[3];  // mask aabb[0], invgridSize = 1/(aabb1-aabb0)*2
-    const uint8_t *coarse; // [cD][cH][cW], cX = ((X + 32) >> 3) + 1: blocks of 8^3 cells over the cell indices -16 .. X + 16 (block = (cell index + 16) >> 3: two blocks of
-                           // margin per side, so that a position far outside lands in a block whose neighbours are outside too); 1 = the block and its 26 neighbours
-                           // hold no occupied corner, i.e. every cell within +-8 cells per axis of a cell of this block is empty (mask_clear_around)
-    int32_t cD, cH, cW;
+    // Block images for the march's empty-space skipping (mask_clear_around): blocks of B^3 cells over the cell indices -16 .. X + 16 (block = (cell index + 16) >> log2 B; the
+    // margin lands a position far outside in a block whose neighbours are outside too), dimensions ((X + 32) >> log2 B) + 1 per axis; 1 = the block and its 26 neighbours
+    // hold no occupied corner, i.e. every cell within B cells per axis of a cell of this block is empty.
+    const uint8_t *coarse; // B = 8: open space (up to 27 iterations of 8 steps per test at the headline geometry)
+    const uint8_t *fine;   // B = 4: asked when the coarse image certifies nothing -- the gaps of cluttered occupancy, the approach to a surface
+    int32_t cD, cH, cW;    // the coarse image's dimensions (host side; the kernels derive both from D, H, W)
 };
 
 struct RenderArgs {
@@ -209,7 +211,7 @@ __device__ __forceinline__ MaskVol karg_mask(size_t off)
     r.bits = t->bits; r.cells = t->cells; r.D = t->D; r.H = t->H; r.W = t->W;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { r.a0[k] = t->a0[k]; r.inv[k] = t->inv[k]; }
-    r.coarse = t->coarse; r.cD = t->cD; r.cH = t->cH; r.cW = t->cW;
+    r.coarse = t->coarse; r.fine = t->fine; r.cD = t->cD; r.cH = t->cH; r.cW = t->cW;
     return r;
 }
 #define NGF_KARG(field) karg<decltype(RenderArgs::field)>(offsetof(RenderArgs, field))
@@ -413,9 +415,10 @@ __device__ __forceinline__ bool mask_occupied(const MaskVol &m, const float p[3]
     return acc > 0.0f;
 }
 
-// Empty-space skipping (round 6).  True = every sample whose cell lies within 8 cells (per axis) of the cell of p samples the mask as 0: cells outside
+// Empty-space skipping (round 6).  True = every sample whose cell lies within B = 2^LOG cells (per axis) of the cell of p samples the mask as 0: cells outside
 // the volume are empty (zeros padding), so the cell index is clamped into the blocks around the volume.  A NaN position certifies nothing.
-__device__ __forceinline__ bool mask_clear_around(const MaskVol &m, const float p[3])
+template <int LOG>
+__device__ __forceinline__ bool mask_clear_around(const MaskVol &m, const uint8_t *image, const float p[3])
 {
     float q[3];
 #pragma unroll
@@ -423,10 +426,11 @@ __device__ __forceinline__ bool mask_clear_around(const MaskVol &m, const float 
     const float fx = floorf(((q[0] + 1.0f) / 2.0f) * (float)(m.W - 1)), fy = floorf(((q[1] + 1.0f) / 2.0f) * (float)(m.H - 1)),
                 fz = floorf(((q[2] + 1.0f) / 2.0f) * (float)(m.D - 1));
     if (!(fx == fx && fy == fy && fz == fz)) return false;
-    // cell index + 16 = floor + 17, clamped to 0 .. size + 32 (beyond the clamp every neighbour within 8 cells is outside the volume, like those of the clamped cell)
-    const int X = (int)fminf(fmaxf(fx + 17.0f, 0.0f), (float)(m.W + 32)) >> 3, Y = (int)fminf(fmaxf(fy + 17.0f, 0.0f), (float)(m.H + 32)) >> 3,
-              Z = (int)fminf(fmaxf(fz + 17.0f, 0.0f), (float)(m.D + 32)) >> 3;
-    return m.coarse[(Z * m.cH + Y) * m.cW + X] != 0;
+    // cell index + 16 = floor + 17, clamped to 0 .. size + 32 (beyond the clamp every neighbour within B cells is outside the volume, like those of the clamped cell)
+    const int X = (int)fminf(fmaxf(fx + 17.0f, 0.0f), (float)(m.W + 32)) >> LOG, Y = (int)fminf(fmaxf(fy + 17.0f, 0.0f), (float)(m.H + 32)) >> LOG,
+              Z = (int)fminf(fmaxf(fz + 17.0f, 0.0f), (float)(m.D + 32)) >> LOG;
+    const int bH = ((m.H + 32) >> LOG) + 1, bW = ((m.W + 32) >> LOG) + 1;
+    return image[(Z * bH + Y) * bW + X] != 0;
 }
 
 // feature2density (Field.py:48-50): F.softplus(x - 10), threshold 20.

@@ -138,7 +138,7 @@ struct ngf_field {
     float *w1p_tmp = nullptr;                 // create only: W1' = W1[:, :F] . basis folded on the device (freed before create returns; here so that an error exit frees it)
     uint8_t *mask = nullptr;
     uint8_t *mask_cells = nullptr;            // the mask's corner bytes per trilinear cell (mask_cells_kernel)
-    uint8_t *mask_any = nullptr, *mask_clear = nullptr;   // blocks of 8^3 cells: occupied at all / nothing within 8 cells (mask_coarse_*_kernel)
+    uint8_t *mask_any = nullptr, *mask_clear = nullptr, *mask_clear4 = nullptr;   // blocks of 8^3 (4^3) cells: occupied at all (scratch of the build) / nothing within 8 (4) cells (mask_block_*_kernel)
     unsigned int *counters = nullptr;
     mutable std::atomic<unsigned> next_counter{0};
     RenderArgs proto;
@@ -196,18 +196,20 @@ __global__ void __launch_bounds__(256) mask_cells_kernel(const uint8_t *__restri
     }
 }
 
-// Alpha mask, third image (round 6): empty-space skipping.  Blocks of 8^3 cells over the cell indices -16 .. size + 16 per axis (block = (cell index + 16) >> 3).
-// Pass 1: any[block] = some cell of the block has an occupied corner (one wave per block, a lane per (z, y) row of 8 cells).
-__global__ void __launch_bounds__(64) mask_coarse_any_kernel(const uint8_t *__restrict__ cells, int D, int H, int W, int cH, int cW, uint8_t *__restrict__ any)
+// Alpha mask, block images (round 6): empty-space skipping.  Blocks of B^3 cells, B = 2^LOG, over the cell indices -16 .. size + 16 per axis (block = (cell index + 16) >> LOG).
+// Pass 1: any[block] = some cell of the block has an occupied corner (one wave per block, a lane per (z, y) row of B cells).
+template <int LOG>
+__global__ void __launch_bounds__(64) mask_block_any_kernel(const uint8_t *__restrict__ cells, int D, int H, int W, int bH, int bW, uint8_t *__restrict__ any)
 {
-    const int b = blockIdx.x, X = b % cW, Y = (b / cW) % cH, Z = b / (cW * cH);
-    const int z = Z * 8 - 16 + ((int)threadIdx.x >> 3), y = Y * 8 - 16 + ((int)threadIdx.x & 7);
+    constexpr int B = 1 << LOG;
+    const int b = blockIdx.x, X = b % bW, Y = (b / bW) % bH, Z = b / (bW * bH);
+    const int z = Z * B - 16 + ((int)threadIdx.x >> LOG), y = Y * B - 16 + ((int)threadIdx.x & (B - 1));
     unsigned acc = 0;
-    if (z >= 0 && z <= D && y >= 0 && y <= H) {
+    if ((int)threadIdx.x < B * B && z >= 0 && z <= D && y >= 0 && y <= H) {
         const uint8_t *row = cells + ((size_t)z * (H + 1) + y) * (W + 1);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int x = X * 8 - 16 + t;
+        for (int t = 0; t < B; ++t) {
+            const int x = X * B - 16 + t;
             if (x >= 0 && x <= W) acc |= row[x];
         }
     }
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(64) mask_coarse_any_kernel(const uint8_t *__re
 }
 
 // Pass 2: clear[block] = the block and its 26 neighbours hold nothing (blocks outside the grid are empty space).
-__global__ void __launch_bounds__(256) mask_coarse_clear_kernel(const uint8_t *__restrict__ any, int cD, int cH, int cW, uint8_t *__restrict__ clear)
+__global__ void __launch_bounds__(256) mask_block_clear_kernel(const uint8_t *__restrict__ any, int cD, int cH, int cW, uint8_t *__restrict__ clear)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= cD * cH * cW) return;
@@ -946,11 +948,16 @@ extern "C" int ngf_field_create(const ngf_field_desc *d, ngf_field **out, void *
         if (hipGetLastError() != hipSuccess) return bail(fail(NGF_E_HIP, "mask_cells_kernel failed to launch"));
         A.mask.cells = f->mask_cells;
         const int cD = ((d->mask_d + 32) >> 3) + 1, cH = ((d->mask_h + 32) >> 3) + 1, cW = ((d->mask_w + 32) >> 3) + 1;
-        if ((rc = field_alloc(f, (void **)&f->mask_any, (size_t)cD * cH * cW, "mask blocks"))) return bail(rc);
+        const int fD = ((d->mask_d + 32) >> 2) + 1, fH = ((d->mask_h + 32) >> 2) + 1, fW = ((d->mask_w + 32) >> 2) + 1;
+        if ((rc = field_alloc(f, (void **)&f->mask_any, (size_t)fD * fH * fW, "mask blocks"))) return bail(rc);          // scratch of both builds (the finer image is the larger one)
         if ((rc = field_alloc(f, (void **)&f->mask_clear, (size_t)cD * cH * cW, "mask blocks"))) return bail(rc);
-        hipLaunchKernelGGL(mask_coarse_any_kernel, dim3((unsigned)(cD * cH * cW)), dim3(64), 0, st, (const uint8_t *)f->mask_cells, d->mask_d, d->mask_h, d->mask_w, cH, cW, f->mask_any);
-        hipLaunchKernelGGL(mask_coarse_clear_kernel, dim3((unsigned)((cD * cH * cW + 255) / 256)), dim3(256), 0, st, (const uint8_t *)f->mask_any, cD, cH, cW, f->mask_clear);
-        if (hipGetLastError() != hipSuccess) return bail(fail(NGF_E_HIP, "mask_coarse kernels failed to launch"));
+        if ((rc = field_alloc(f, (void **)&f->mask_clear4, (size_t)fD * fH * fW, "mask blocks"))) return bail(rc);
+        hipLaunchKernelGGL(mask_block_any_kernel<3>, dim3((unsigned)(cD * cH * cW)), dim3(64), 0, st, (const uint8_t *)f->mask_cells, d->mask_d, d->mask_h, d->mask_w, cH, cW, f->mask_any);
+        hipLaunchKernelGGL(mask_block_clear_kernel, dim3((unsigned)((cD * cH * cW + 255) / 256)), dim3(256), 0, st, (const uint8_t *)f->mask_any, cD, cH, cW, f->mask_clear);
+        hipLaunchKernelGGL(mask_block_any_kernel<2>, dim3((unsigned)(fD * fH * fW)), dim3(64), 0, st, (const uint8_t *)f->mask_cells, d->mask_d, d->mask_h, d->mask_w, fH, fW, f->mask_any);
+        hipLaunchKernelGGL(mask_block_clear_kernel, dim3((unsigned)((fD * fH * fW + 255) / 256)), dim3(256), 0, st, (const uint8_t *)f->mask_any, fD, fH, fW, f->mask_clear4);
+        if (hipGetLastError() != hipSuccess) return bail(fail(NGF_E_HIP, "mask_block kernels failed to launch"));
+        A.mask.fine = f->mask_clear4;
         A.mask.coarse = f->mask_clear; A.mask.cD = cD; A.mask.cH = cH; A.mask.cW = cW;
         for (int k = 0; k < 3; ++k) {
             A.mask.a0[k] = d->mask_aabb[k];

@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                 if (empty_step) {
                     // Empty-space skipping (round 6).  The iteration held no valid sample; before the next one is evaluated, lane (ray, seg) looks at the
                     // step i + K + m + seg (2m + 1) of its ray: when the mask's block image says that nothing is occupied within 8 cells of that sample's
-                    // cell, the 2m + 1 steps around it sample empty cells too -- m steps move a cell index by at most m r + 1 <= 8, r = the cells per step
+                    // cell, the 2m + 1 steps around it sample empty cells too -- m steps move a cell index by at most m r + 1 <= 8 (<= 4 for the finer image), r = the cells per step
                     // of the wave's fastest ray -- so a leading run of n passing lanes on EVERY ray certifies n (2m + 1) steps and the tile jumps over the
                     // whole iterations in them.  Certified samples have sigma = alpha = w = 0: T, acc, depth and the queue are what they would have been.
                     // The same test runs the march out of the box (blocks beyond the volume are empty).  DBG: ablate bit 128 switches it off.
@@ -634,26 +634,32 @@ __global__ void __launch_bounds__(P::WAVES * 64) render_kernel(const RenderArgs 
                             float r = 0.0f;
 #pragma unroll
                             for (int k = 0; k < 3; ++k) r = fmaxf(r, fabsf(d[k]) * (A.step * 0.5f * mk.inv[k] * sz[k]));
-                            bool sane = !live || (r == r && r < 1e30f);          // a NaN / infinite direction certifies nothing
+                            const bool sane = !live || (r == r && r < 1e30f);          // a NaN / infinite direction certifies nothing
                             r = live && sane ? r : 0.0f;
 #pragma unroll
                             for (int off = 32; off >= 1; off >>= 1) r = fmaxf(r, __shfl_xor(r, off));
-                            const int m = (int)fminf(6.9f / fmaxf(r, 1e-6f), 2048.0f), gsteps = 2 * m + 1;
-                            const int stest = i + K + m + seg * gsteps;
-                            const float zt = tmin + A.step * ((float)stest + jit);
-                            float pt[3];
+                            // whole iterations behind this one that the block image of 2^LOG-cell blocks certifies as empty
+                            auto certified = [&](auto logc, const uint8_t *image) -> int {
+                                constexpr int LOG = decltype(logc)::value;
+                                const int m = (int)fminf(((float)(1 << LOG) - 1.1f) / fmaxf(r, 1e-6f), 2048.0f), gsteps = 2 * m + 1;
+                                const int stest = i + K + m + seg * gsteps;
+                                const float zt = tmin + A.step * ((float)stest + jit);
+                                float pt[3];
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) pt[k] = o[k] + d[k] * zt;
-                            const bool pass = !live || (sane && (stest - m >= S || mask_clear_around(mk, pt)));
-                            const unsigned long long fm = __ballot(!pass);
-                            int nrun = K;
-                            if (fm) {
-                                if (!SPLIT) nrun = 0;
-                                else if (ts >= 2) nrun = __builtin_ctz((unsigned)((fm | (fm >> 16) | (fm >> 32) | (fm >> 48)) & 0xffffu)) >> mshift;
-                                else if (ts == 1) nrun = __builtin_ctz((unsigned)(fm | (fm >> 32)));
-                                else nrun = __builtin_ctzll(fm);
-                            }
-                            skip = (nrun * gsteps) / K;
+                                for (int k = 0; k < 3; ++k) pt[k] = o[k] + d[k] * zt;
+                                const bool pass = !live || (sane && (stest - m >= S || mask_clear_around<LOG>(mk, image, pt)));
+                                const unsigned long long fm = __ballot(!pass);
+                                int nrun = K;
+                                if (fm) {
+                                    if (!SPLIT) nrun = 0;
+                                    else if (ts >= 2) nrun = __builtin_ctz((unsigned)((fm | (fm >> 16) | (fm >> 32) | (fm >> 48)) & 0xffffu)) >> mshift;
+                                    else if (ts == 1) nrun = __builtin_ctz((unsigned)(fm | (fm >> 32)));
+                                    else nrun = __builtin_ctzll(fm);
+                                }
+                                return (nrun * gsteps) / K;
+                            };
+                            skip = certified(std::integral_constant<int, 3>{}, mk.coarse);
+                            if (skip == 0 && mk.fine) skip = certified(std::integral_constant<int, 2>{}, mk.fine);      // nothing in reach of the 8-cell blocks: the 4-cell ones (clutter, the approach to a surface)
                         }
                     }
                     i += NSTEP * K * (1 + skip);

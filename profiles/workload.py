@@ -50,6 +50,21 @@ if name.startswith(("triplane", "infoinv")):
         NS = -1                                                   # the model's own nSamples (884 for the 256^3 grid at step_ratio 0.5)
         if shape == "S884mask":
             f.updateAlphaMask((256, 256, 256), **({} if model == "triplane" else {"infoinv": True}))
+        elif shape in ("S884lattice", "S884shell"):
+            # cluttered occupancy (the adversarial side of the empty-space skipping): thin walls every 32 cells along all three axes inside a ball of radius 1.1
+            # (empty cells everywhere, almost no block with 8 clear cells around it) | a thin spherical shell (an object's surface: empty inside and outside)
+            from ngf_amd import triplane
+            ax = torch.linspace(-1.5, 1.5, 256)
+            zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+            r2 = xx ** 2 + yy ** 2 + zz ** 2
+            if shape == "S884lattice":
+                ii = torch.arange(256)
+                wall = (ii % 32) < 2
+                vol = (wall[:, None, None] | wall[None, :, None] | wall[None, None, :]) & (r2 < 1.1 ** 2)
+            else:
+                vol = (r2 < 0.85 ** 2) & (r2 > 0.80 ** 2)
+            f.alphaMask = triplane.AlphaGridMask(dev, torch.tensor(np.asarray(g["aabb"], np.float32)), vol.float().to(dev))
+            f.invalidate()
         else:
             from ngf_amd import triplane
             ax = torch.linspace(-1.5, 1.5, 128)
