@@ -1139,14 +1139,19 @@ def _sparse_masks(name):
         vol[150:190, 60:90, 180:250] = True
         vol[100, 48, 128] = True                       # a single voxel in the middle of nowhere
         return vol
+    if name == "lattice":                              # thin walls every 24 cells inside a ball: empty cells everywhere, hardly an 8-cell block that is clear -- the 4-cell image's case
+        ax = np.linspace(-1.5, 1.5, 160, dtype=np.float32)
+        zz, yy, xx = np.meshgrid(ax, ax, ax, indexing="ij")
+        wall = (np.arange(160) % 24) < 1
+        return (wall[:, None, None] | wall[None, :, None] | wall[None, None, :]) & ((xx ** 2 + yy ** 2 + zz ** 2) < 1.2 ** 2)
     from ngf_amd import synth
     return synth.alpha_mask_bits(23, (64, 64, 64), keep=0.35)[0]
 
 
 @pytest.mark.parametrize("model,level", [("triplane", 3), ("triplane", 2), ("triplane", "bf16"), ("infoinv", "split")])
-@pytest.mark.parametrize("mask_name", ["ball", "slabs", "blobby"])
+@pytest.mark.parametrize("mask_name", ["ball", "slabs", "blobby", "lattice"])
 def test_empty_space_skipping_is_bit_identical(model, level, mask_name):
-    """Round 6: after an iteration without a valid sample the march asks the mask's block image (8^3 cells per block, a block is `clear` when it and its 26
+    """Round 6: after an iteration without a valid sample the march asks the mask's block images (8^3 and, when those certify nothing, 4^3 cells per block; a block is `clear` when it and its 26
     neighbours hold no occupied corner) how many of the next steps sample empty cells for certain, and jumps over whole iterations of them
     (ngf_render.hpp, mask_clear_around).  Skipped samples have sigma = alpha = w = 0 in the reference too (FieldBase.py:261-270), so nothing may change:
     the frame with the skip against the frame without it (DBG knob ablate = 128) bit for bit, for every tile shape (rays per wave tile 64 ... 1: the run
