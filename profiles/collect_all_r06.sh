@@ -10,7 +10,7 @@
 # Copy gpurun_out/r06_* into profiles/ afterwards (tracked).  Workload names: profiles/workload.py.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-WLS="triplane_R1_bdc triplane_R0_bdc triplane_R2_bdc triplane_R1_bd triplane_R1 triplane_R1_nofold triplane_R1_splitd triplane_R1_bdcs triplane_R2_bd triplane_R1_bdc_S884mask triplane_R2_bdc_S884mask triplane_R1_bdc_S884ball infoinv_R1 infoinv_R1_split triplane_R1_split triplane_R0 triplane_R2_splitd triplane_R2_bdcs infoinv_R1__S884mask infoinv_R1__S884ball"
+WLS="triplane_R1_bdc triplane_R0_bdc triplane_R2_bdc triplane_R1_bd triplane_R1 triplane_R1_nofold triplane_R1_splitd triplane_R1_bdcs triplane_R2_bd triplane_R1_bdc_S884mask triplane_R2_bdc_S884mask triplane_R1_bdc_S884ball infoinv_R1 infoinv_R1_split triplane_R1_split triplane_R0 triplane_R2_splitd triplane_R2_bdcs infoinv_R1__S884mask infoinv_R1__S884ball triplane_R1_bdc_S884lattice"
 [ "$1" = quick ] && WLS="triplane_R1_bdc"
 for wl in $WLS; do
   bash profiles/collect.sh r06_$wl $wl "ngf::render_kernel" > /dev/null 2>&1
