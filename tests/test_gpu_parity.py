@@ -1194,6 +1194,21 @@ def test_empty_space_skipping_is_bit_identical(model, level, mask_name):
                 t_on = f(rays, N_samples=S, white_bg=True, is_train=True, jitter=jit, coin=0.9, **kw)
         assert torch.equal(t_off["rgb_map"], t_on["rgb_map"]) and torch.equal(t_off["depth_map"], t_on["depth_map"]), f"tile_w {tw}, jitter"
     assert 0 < n_on[0] < 0.5 * rays_np.shape[0] * 884          # there IS empty space in these volumes
+    # rays that are not a camera's: origins inside and outside the box, directions of any length (0.2 ... 3: the cells-per-step bound uses |d|), some with
+    # zero components, some pointing away from the box -- with and without the skip, same bits
+    rng = np.random.default_rng(3)
+    ro = rng.uniform(-2.5, 2.5, (6000, 3)).astype(np.float32)
+    rd = rng.normal(size=(6000, 3)).astype(np.float32)
+    rd *= (rng.uniform(0.2, 3.0, (6000, 1)) / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+    rd[::7, 0] = 0.0
+    rd[::11, 1:] = 0.0
+    odd = torch.from_numpy(np.concatenate([ro, rd], 1)).cuda()
+    for tw in (8, 1) if model == "triplane" else (16, 1):
+        with knobs(ablate=128, tile_w=tw):
+            a = f(odd, N_samples=S, white_bg=False, collect_stats=True, **kw)
+        with knobs(tile_w=tw):
+            b = f(odd, N_samples=S, white_bg=False, **kw)
+        assert torch.equal(a["rgb_map"], b["rgb_map"]) and torch.equal(a["depth_map"], b["depth_map"]), f"odd rays, tile_w {tw}"
     # ... and the oracle on a subset (its mask test is the restated grid_sample)
     sub = slice(0, rays_np.shape[0], 9)
     bits = np.packbits(vol.reshape(-1))
