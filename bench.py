@@ -226,6 +226,11 @@ def build_field(model, preset, device, bake=False, bake_color=False, no_fold=Fal
     return f, g, params, step
 
 
+# TEST knobs (tests/test_gpu_parity.py::test_bench_with_real_ranks_on_one_gpu): RCCL refuses two ranks on one device, gloo moves CUDA tensors through the host -- with
+# NGF_BENCH_BACKEND=gloo NGF_BENCH_ONE_DEVICE=1 the N > 1 path runs as N real processes on ONE GPU (every rank its own row blocks, the exchange between processes,
+# the ranks arriving at different times), which no single-rank run can show.  The line says so (config.test_backend); it is never a measurement.
+BACKEND = os.environ.get("NGF_BENCH_BACKEND", "nccl")
+ONE_DEVICE = os.environ.get("NGF_BENCH_ONE_DEVICE") == "1"
 CLOCK_PREAMBLE_MS = 80.0          # untimed device work ahead of the W warm-up steps (time_steps): the GPU's clocks ramp for 25-30 ms after an idle period
 PREAMBLE_REPORT = {}
 
@@ -363,7 +368,7 @@ def self_launch_command(n, argv, port):
 def self_launch(n, argv):
     import subprocess
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < n:
+    if have < n and not (ONE_DEVICE and have >= 1):
         raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s) (torch.cuda.device_count()); nothing was launched")
     env = dict(os.environ, NGF_BENCH_SELF_LAUNCHED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # RCCL across processes needs dmabuf IPC on this driver
@@ -401,6 +406,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
+    if ONE_DEVICE:
+        local = 0
     if local >= torch.cuda.device_count():
         raise SystemExit(f"LOCAL_RANK {local} but this node shows {torch.cuda.device_count()} GPU(s)")
     device = torch.device("cuda", local)
@@ -411,7 +418,10 @@ def main():
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=10))
+        if BACKEND == "nccl":
+            dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=10))
+        else:
+            dist.init_process_group(BACKEND, timeout=datetime.timedelta(minutes=10))
 
     import ngf_amd  # noqa: F401
     from ngf_amd import dist as ndist
@@ -586,6 +596,8 @@ def main():
     }
     result["config"]["clock_preamble"] = {"launches": PREAMBLE_REPORT.get("launches"), "ms": _r(PREAMBLE_REPORT.get("ms", 0.0), 3),
                                           "what": "untimed steps before the W warm-up steps (GPU clocks ramp 25-30 ms after idle)"}
+    if BACKEND != "nccl" or ONE_DEVICE:
+        result["config"]["test_backend"] = f"{BACKEND}, {'all ranks on one GPU' if ONE_DEVICE else 'one GPU per rank'}: a test of the N > 1 path, not a measurement"
     if dist_on:
         result["launch_ms_note"] = ("N > 1: the timed loop's frames overlap on two render streams; launch_ms / roofline.kernel_ms are the same K shard launches "
                                     "run one after the other on one stream after the timed region")

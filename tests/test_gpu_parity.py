@@ -635,6 +635,33 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert d["critical_path_ms"]["render"] > 0
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_with_real_ranks_on_one_gpu(world):
+    """The N > 1 path of bench.py with REAL ranks: `python bench.py --gpus N` (no launcher: it starts its own torch.distributed.run) as N processes that share the
+    one GPU of this box -- RCCL refuses two ranks on a device, so the exchange runs over gloo (CUDA tensors through the host; NGF_BENCH_BACKEND / NGF_BENCH_ONE_DEVICE,
+    test knobs).  Everything else is the code an 8-GPU node runs: every rank marches ITS interleaved row blocks on two alternating render streams, the
+    double-buffered all-gather crosses process boundaries, the ranks reach the timed region at different times (clock preamble behind a barrier, no collective
+    inside it), rank 0 prints ONE line -- and the gathered, re-ordered frame is bit-identical to a single-launch render on every rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        assert k not in os.environ, "this test must start from a launcher-less environment"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NGF_BENCH_BACKEND="gloo", NGF_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 6 and d["value"] > 0.1 and d["scaling"] == "strong"
+    assert d["config"]["launcher"].startswith("self") and "gloo" in d["config"]["test_backend"]
+    assert d["gathered_frame_bit_identical_to_single_gpu_render"] is True
+    assert 0 < d["shard_kernel_ms"]["min"] <= d["shard_kernel_ms"]["max"] and d["all_gather_ms"] > 0
+    assert "cpu_baseline" not in d          # rank 0 at N = 1 only
+
+
 def test_bench_default_line_is_parseable_with_extras():
     """The driver's command (`bench.py --gpus 1 --steps K --warmup W`, extras and CPU baseline ON): one final JSON line < 4 KB carrying
     value, roofline and cpu_baseline; the extras live in bench_extras.json (the 29 KB line left the round unmeasured)."""
