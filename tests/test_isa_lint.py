@@ -72,7 +72,7 @@ def test_shipped_hot_kernels_use_no_scratch(asm):
             "render_kernelINS_8MaskSkipINS_14TriPlanePolicyILb1ELb1ELi12ELi1ELb0EEEEELb1ELb0E",      # level 3 for fields with an alpha mask (empty-space skipping, round 6)
             "render_kernelINS_8MaskSkipINS_14TriPlanePolicyILb1ELb0ELi12ELi1ELb0EEEEELb1ELb0E",      # level 2, the same
             "render_kernelINS_8MaskSkipINS_23TriPlaneBakedBf16PolicyEEELb1ELb0E",                     # level 3 + bf16 layer 2, the same
-            "render_kernelINS_8MaskSkipINS_14InfoInvPolicyTILb1ELb0EEEEELb1ELb0E",                    # InfoInv split bf16, the same (the fp32 one carries 20 B there: DESIGN 4.1)
+            "render_kernelINS_8MaskSkipINS_14InfoInvPolicyTILb1ELb0EEEEELb1ELb0E",                    # InfoInv split bf16, the same (the fp32 one carries 52 B there: profiles/r06_mask_skip.txt)
             "render_kernelINS_14InfoInvPolicyTILb0ELb0EEELb1ELb0E",                   # InfoInv fp32
             "render_kernelINS_14InfoInvPolicyTILb1ELb0EEELb1ELb0E",                   # InfoInv split bf16
             # round 6: the kernels of a training step -- train_density_bwd_kernel<true, true> carried 28 B per lane through round 5
