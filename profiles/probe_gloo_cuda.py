@@ -1,3 +1,5 @@
+"""Probe (round 6, session 7): do gloo's collectives take CUDA tensors when two ranks share ONE GPU?  (all_gather_into_tensor async, all_reduce, barrier,
+all_gather of a list: yes, through the host) -- what bench.py's test knobs NGF_BENCH_BACKEND=gloo NGF_BENCH_ONE_DEVICE=1 rest on.   python profiles/probe_gloo_cuda.py"""
 import os, sys, torch, torch.distributed as dist, torch.multiprocessing as mp
 def w(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
