@@ -706,9 +706,9 @@ def main():
             # The reference's own evaluation shape: renderer(rays, field, chunk=4096, N_samples=-1) = 884 steps (TriPlane/main.py:94,
             # FieldBase.py:71-72) through an alpha mask like every trained model carries (FieldBase.py:261-267) -- `mask`: the one the repo's own
             # updateAlphaMask((256,)*3) builds from the seeded field (main.py:330); `ball`: occupancy = a ball of radius 0.8, 15 % of the box (an
-            # object in empty space, as a trained lego is).  Module default level, whole frame in one launch.
+            # object in empty space, as a trained lego is); `lattice`: thin walls every 32 cells inside a ball (clutter: the finer block image's case).  Module default level, whole frame in one launch.
             from ngf_amd.fieldbase import renderer as _renderer
-            for mdl, preset, shape in (("triplane", "R1", "mask"), ("triplane", "R2", "mask"), ("triplane", "R1", "ball"), ("infoinv", "R1", "mask"), ("infoinv", "R1", "ball")):
+            for mdl, preset, shape in (("triplane", "R1", "mask"), ("triplane", "R2", "mask"), ("triplane", "R1", "ball"), ("triplane", "R1", "lattice"), ("infoinv", "R1", "mask"), ("infoinv", "R1", "ball")):
                 key = f"{mdl}_{preset}_S884_{shape}"
                 tri = mdl == "triplane"
                 fkw = {"iteration": 30001} if tri else {"infoinv": True}
@@ -716,6 +716,14 @@ def main():
                     fx, gx, _, _ = build_field(mdl, preset, device, True, True) if tri else build_field(mdl, preset, device)
                     if shape == "mask":
                         fx.updateAlphaMask((256, 256, 256), **({} if tri else {"infoinv": True}))
+                    elif shape == "lattice":          # cluttered occupancy: thin walls every 32 cells along all three axes inside a ball of radius 1.1 (profiles/workload.py _S884lattice)
+                        from ngf_amd import triplane as _tp
+                        ax = torch.linspace(-1.5, 1.5, 256)
+                        zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+                        wall = (torch.arange(256) % 32) < 2
+                        vol = (wall[:, None, None] | wall[None, :, None] | wall[None, None, :]) & ((xx ** 2 + yy ** 2 + zz ** 2) < 1.1 ** 2)
+                        fx.alphaMask = _tp.AlphaGridMask(device, torch.tensor(np.asarray(gx["aabb"], np.float32)), vol.float().to(device))
+                        fx.invalidate()
                     else:
                         from ngf_amd import triplane as _tp
                         ax = torch.linspace(-1.5, 1.5, 128)
