@@ -5,7 +5,7 @@
 names: triplane_R0 | triplane_R1 | triplane_R2 | triplane_R1_bd (bake density) | triplane_R1_bdc (both bakes) | triplane_R1_nofold | infoinv_R1
        (800x800 frame, S = 192, BASELINE configs 2 / 3) | <any triplane name>_S884mask: the reference's own evaluation shape -- renderer(..., N_samples=-1)
        = 884 steps (TriPlane/main.py:94, FieldBase.py:71-72) through the alpha mask updateAlphaMask((256,)*3) builds from the field (main.py:330) --
-       | ..._S884ball: the same steps, occupancy = a ball of radius 0.8 (15 % of the box: an object, like a trained lego) | uv_sphere (BASELINE config 4: 76 800 DTU-camera rays x 64 samples)
+       | ..._S884ball: the same steps, occupancy = a ball of radius 0.8 (15 % of the box: an object, like a trained lego) | ..._S884lattice / _S884shell: thin walls every 32 cells inside a ball / a thin spherical shell (cluttered occupancy, a bare surface: round 6's empty-space skipping) | uv_sphere (BASELINE config 4: 76 800 DTU-camera rays x 64 samples)
        | train_R1 (4096-ray training iteration)
 Optional knobs through the environment of THIS script (mapped to ngf_debug_set): NGF_KERNEL, NGF_TILE_W, NGF_STAGE, ..."""
 import os
