@@ -23,6 +23,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL between the ranks of one node moves memory handles as dmabuf on this driver; the runtime reads the switch when it starts (the first
+# torch.cuda call), so it is set before torch is imported -- also for ranks a foreign launcher started with an environment that lacks it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
