@@ -450,7 +450,7 @@ def main():
     rays = torch.from_numpy(rays_np).to(device)
     n_local = rays.shape[0]
     assert n_local == per
-    pipe = ndist.PipelinedGather(per, world, device, depth=3) if dist_on else None          # three buffers: with frames on two render streams the exchange of frame k may finish while frame k + 2 is already marched
+    pipe = ndist.PipelinedGather(per, world, device, depth=ndist.PIPELINE_DEPTH) if dist_on else None          # four buffers: with frames on two render streams the exchange of frame k may finish while frame k + 2 or k + 3 is already marched (ngf_amd/dist.py)
     send, rgb_view, depth_view = ndist.shard_buffers(per, device)
     frame_no = [0]
     last_frame = [None]
@@ -478,7 +478,7 @@ def main():
             render_only()
             if pair: pair[1].record()
             return
-        # frame k: march into send buffer k%3 on render stream k%2, start its all-gather on RCCL's stream, hand out frame k-1 (whose
+        # frame k: march into send buffer k % depth on render stream k % 2, start its all-gather on RCCL's stream, hand out frame k-1 (whose
         # exchange overlapped this march) in image order.  Every frame is complete when the timed region ends.
         # (the per-step event pair is not recorded here: on alternating streams a pair would span the other stream's frame as well -- the
         # shard's launch time is measured by a serial loop after the timed region)

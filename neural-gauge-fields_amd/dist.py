@@ -43,6 +43,13 @@ def deinterleave(rgb, depth, H: int, W: int, world: int, block: int):
     return rgb, depth
 
 
+# Exchange buffers bench.py keeps in flight at N > 1.  A render launch is a persistent grid that fills every CU (three waves per SIMD at 168 registers),
+# so RCCL's all-gather kernel of frame k gets its workgroups placed only where a render workgroup has left -- while the NEXT frame's grid (the other
+# render stream) is waiting for the same CUs: the exchange of frame k may complete as late as during the march of frame k + 2 or k + 3.  ``buffers(k)``
+# makes the march of frame k wait for the reorder of frame k - depth, so four buffers leave the render streams three frames of slack (1.3 MB + 10 MB each).
+PIPELINE_DEPTH = 4
+
+
 def render_streams(device, n: int = 2):
     """``n`` HIP streams to march consecutive frames on in turn (frame k on stream k % n), each ordered behind the caller's current stream.
     A render launch is a persistent grid of one workgroup per CU; on ONE stream frame k + 1 starts when the last wave of frame k has ended, so
