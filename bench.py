@@ -234,7 +234,7 @@ def build_field(model, preset, device, bake=False, bake_color=False, no_fold=Fal
 # the ranks arriving at different times), which no single-rank run can show.  The line says so (config.test_backend); it is never a measurement.
 BACKEND = os.environ.get("NGF_BENCH_BACKEND", "nccl")
 ONE_DEVICE = os.environ.get("NGF_BENCH_ONE_DEVICE") == "1"
-CLOCK_PREAMBLE_MS = 80.0          # untimed device work ahead of the W warm-up steps (time_steps): the GPU's clocks ramp for 25-30 ms after an idle period
+CLOCK_PREAMBLE_MS = 80.0          # untimed device work between the W warm-up steps and the timed region (time_steps): the GPU's clocks ramp for 25-30 ms after an idle period
 PREAMBLE_REPORT = {}
 
 
@@ -249,15 +249,26 @@ def time_steps(fn, steps, warmup, device, dist_on, finish=lambda: None, marks=No
     # Clock preamble (round 6, profiles/r06_clock_ramp.txt): after an idle period -- the seconds this process spent building the field on the host --
     # the GPU's first 25-30 ms of work run up to 1.3x slower while its clocks ramp (every launch of a block that follows a pause, whatever the
     # launch size; the steady state is flat to 0.1 %).  W = 3 warm-up steps of an eight-rank shard are 2 ms and K = 20 timed steps 13 ms: the whole
-    # timed region would sit on the ramp.  So the device is kept busy with the very launch that is measured for CLOCK_PREAMBLE_MS before the contract's W
-    # warm-up steps; nothing of it is timed, and the line reports it (config.clock_preamble).
-    # At N > 1 the ranks meet at a barrier FIRST (they arrive seconds apart: a rank that ran its preamble and then waited for a late one in the warm-up's
-    # exchange would be idle again when the timed region starts), and the preamble is the shard's render launch alone -- every rank stops by its own clock,
-    # so a collective in this loop would be issued a different number of times per rank and pair up with the warm-up's (or the barrier's) collectives.
+    # timed region would sit on the ramp.  So the device is kept busy with the very launch that is measured for CLOCK_PREAMBLE_MS right in front of the
+    # timed region; nothing of it is timed, and the line reports it (config.clock_preamble).
+    # Order (last session of round 6): barrier, the contract's W warm-up steps, barrier, preamble, barrier + synchronize, K timed steps.  The warm-up
+    # comes FIRST because at N > 1 it holds the first collectives of the job -- RCCL sets up its channels on a communicator's first exchange and first
+    # barrier, host-side work of unknown length during which the GPU runs dry: with the preamble in front of the warm-up (as first written) the timed
+    # region of a real multi-GPU run would have started on the ramp again.  The ranks meet at a barrier before the preamble (they arrive seconds apart),
+    # run it by their own clocks for the same wall-clock time, and each leaves a few launches in its queue behind which the closing barrier's exchange
+    # is enqueued, so the device stays busy while the host waits for the other ranks (they differ by less than one 4-launch batch).
+    # The preamble is the shard's render launch alone -- every rank stops by its own clock, so a collective in this loop would be issued a different
+    # number of times per rank and pair up with the warm-up's (or the barrier's) collectives.
     if preamble is None:
         if dist_on:
             raise ValueError("time_steps(dist_on=True) needs a collective-free `preamble` launch")
         preamble = lambda: fn(None)          # noqa: E731
+    if dist_on:
+        dist.barrier()
+    for _ in range(warmup):
+        fn(None)
+    finish()
+    torch.cuda.synchronize(device)
     if dist_on:
         dist.barrier()
     pre_t0, pre_n = time.perf_counter(), 0
@@ -266,10 +277,11 @@ def time_steps(fn, steps, warmup, device, dist_on, finish=lambda: None, marks=No
             preamble()
         pre_n += 4
         torch.cuda.synchronize(device)
+    if dist_on:
+        for _ in range(8):
+            preamble()
+        pre_n += 8
     PREAMBLE_REPORT.update({"launches": pre_n, "ms": (time.perf_counter() - pre_t0) * 1e3})
-    for _ in range(warmup):
-        fn(None)
-    finish()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -598,7 +610,7 @@ def main():
         "value_from_median_launch": n_local / launch_stats["median"] / 1e3,
     }
     result["config"]["clock_preamble"] = {"launches": PREAMBLE_REPORT.get("launches"), "ms": _r(PREAMBLE_REPORT.get("ms", 0.0), 3),
-                                          "what": "untimed steps before the W warm-up steps (GPU clocks ramp 25-30 ms after idle)"}
+                                          "what": "untimed render launches between the W warm-up steps and the timed region (GPU clocks ramp 25-30 ms after idle)"}
     if BACKEND != "nccl" or ONE_DEVICE:
         result["config"]["test_backend"] = f"{BACKEND}, {'all ranks on one GPU' if ONE_DEVICE else 'one GPU per rank'}: a test of the N > 1 path, not a measurement"
     if dist_on:
