@@ -483,6 +483,19 @@ def main():
     def render_only():
         f(rays, N_samples=S, white_bg=True, out=(rgb_view, depth_view), **kw)
 
+    if dist_on:
+        # every stream of the pipeline sees one launch before anything is timed: a HIP stream gets its hardware queue on its first use (milliseconds), and with
+        # W = 1 the second render stream's first launch would otherwise fall into the timed region
+        for s_ in list(render_streams) + [side]:
+            with torch.cuda.stream(s_):
+                if s_ is side:
+                    frame_out[0][1][:1].zero_()
+                else:
+                    render_only()
+        # ... and the communicator its first exchange of this size (RCCL sets up its channels on it): once on every rank, whatever W is
+        dist.all_gather_into_tensor(pipe.recv[0], pipe.send[0][0])
+        torch.cuda.synchronize(device)
+
     def step_fn(pair):
         # pair: (start, end) HIP events recorded around THIS step's render launch on the launch stream (None in the warm-up)
         if not dist_on:
