@@ -434,7 +434,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if BACKEND == "nccl":
-            dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=10))
+            # RCCL's stream at high priority: a render launch is a persistent grid on every CU, and while frame k's exchange waits for CUs the next frame's
+            # grid (the other render stream) is waiting for the same ones -- the exchange's few workgroups go first when a render workgroup leaves
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=10), pg_options=opts)
+            except (AttributeError, TypeError):
+                dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=10))
         else:
             dist.init_process_group(BACKEND, timeout=datetime.timedelta(minutes=10))
 
