@@ -26,6 +26,10 @@ sys.path.insert(0, ROOT)
 # RCCL between the ranks of one node moves memory handles as dmabuf on this driver; the runtime reads the switch when it starts (the first
 # torch.cuda call), so it is set before torch is imported -- also for ranks a foreign launcher started with an environment that lacks it
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# The exchange is 1.3 MB per rank and rides beside the next frame's march; RCCL's kernel holds one CU per channel -- CUs the persistent render grid wants (a
+# stand-in kernel that holds 16 / 32 / 64 CU slots behind every frame costs the pipelined step 0.6 / 2.5 / 4.4 %: profiles/r06_exchange_contention.txt).
+# Eight channels move the 10 MB of a frame in well under a step; whoever launches the job may set another count.
+os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -630,6 +634,8 @@ def main():
     }
     result["config"]["clock_preamble"] = {"launches": PREAMBLE_REPORT.get("launches"), "ms": _r(PREAMBLE_REPORT.get("ms", 0.0), 3),
                                           "what": "untimed render launches between the W warm-up steps and the timed region (GPU clocks ramp 25-30 ms after idle)"}
+    if dist_on:
+        result["config"]["rccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
     if BACKEND != "nccl" or ONE_DEVICE:
         result["config"]["test_backend"] = f"{BACKEND}, {'all ranks on one GPU' if ONE_DEVICE else 'one GPU per rank'}: a test of the N > 1 path, not a measurement"
     if dist_on:
