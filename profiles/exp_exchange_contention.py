@@ -128,6 +128,18 @@ if os.environ.get("STREAMS"):
     for c in cfgs:
         print(f"{c[0]} render stream(s), depth {c[1]}: " + "   ".join(f"{w[0]:2d} x {w[1]:3d} us {np.median([r[0] for r in res[(c, w)]]):.4f}" for w in loads), flush=True)
     sys.exit(0)
+if os.environ.get("CAPPED"):
+    # eight held CUs (RCCL capped at eight channels, as bench.py sets it): one render stream against two, four buffers
+    loads = ((0, 0), (8, 50), (8, 150), (8, 400), (8, 1000))
+    cfgs = [(1, 4), (2, 4), (1, 3), (2, 3)]
+    res = {(c, w): [] for c in cfgs for w in loads}
+    for rep in range(4):
+        for c in cfgs:
+            for w in loads:
+                res[(c, w)].append(run(100, w[0], w[1], "high", c[1], nstreams=c[0]))
+    for c in cfgs:
+        print(f"{c[0]} render stream(s), depth {c[1]}: " + "   ".join(f"{w[0]:2d} x {w[1]:4d} us {np.median([r[0] for r in res[(c, w)]]):.4f}" for w in loads), flush=True)
+    sys.exit(0)
 for depth in (4, 3, 2):
     for wgs, us in ((0, 0), (16, 50), (16, 150), (32, 50), (32, 150), (64, 150), (32, 400)):
         line = f"depth {depth}  exchange {wgs:3d} workgroups x {us:3d} us: "
