@@ -30,6 +30,11 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # stand-in kernel that holds 16 / 32 / 64 CU slots behind every frame costs the pipelined step 0.6 / 2.5 / 4.4 %: profiles/r06_exchange_contention.txt).
 # Eight channels move the 10 MB of a frame in well under a step; whoever launches the job may set another count.
 os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
+# The N > 1 pipeline keeps five streams busy (two render streams, RCCL's, the reorder's, the caller's); the HIP runtime maps a process's streams onto FOUR
+# hardware queues unless told otherwise, and two streams that share a queue run one behind the other: beside an exchange that holds CUs one rank's pipelined
+# step is 0.637 / 0.640 / 0.653 / 0.688 ms on four queues and 0.611 / 0.625 / 0.614 / 0.650 ms on eight (profiles/r06_exchange_contention.txt, section 7).
+# Read when the runtime starts, so it is set before torch is imported; the single-stream N = 1 frame does not change.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -472,7 +477,7 @@ def main():
     rays = torch.from_numpy(rays_np).to(device)
     n_local = rays.shape[0]
     assert n_local == per
-    pipe = ndist.PipelinedGather(per, world, device, depth=ndist.PIPELINE_DEPTH) if dist_on else None          # four buffers: with frames on two render streams the exchange of frame k may finish while frame k + 2 or k + 3 is already marched (ngf_amd/dist.py)
+    pipe = ndist.PipelinedGather(per, world, device, depth=ndist.PIPELINE_DEPTH) if dist_on else None          # six buffers: with frames on two render streams the exchange of frame k may finish while frame k + 2 or k + 3 is already marched (ngf_amd/dist.py)
     send, rgb_view, depth_view = ndist.shard_buffers(per, device)
     frame_no = [0]
     last_frame = [None]
@@ -636,6 +641,7 @@ def main():
                                           "what": "untimed render launches between the W warm-up steps and the timed region (GPU clocks ramp 25-30 ms after idle)"}
     if dist_on:
         result["config"]["rccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
+        result["config"]["hip_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
     if BACKEND != "nccl" or ONE_DEVICE:
         result["config"]["test_backend"] = f"{BACKEND}, {'all ranks on one GPU' if ONE_DEVICE else 'one GPU per rank'}: a test of the N > 1 path, not a measurement"
     if dist_on:

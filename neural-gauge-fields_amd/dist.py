@@ -45,9 +45,11 @@ def deinterleave(rgb, depth, H: int, W: int, world: int, block: int):
 
 # Exchange buffers bench.py keeps in flight at N > 1.  A render launch is a persistent grid that fills every CU (three waves per SIMD at 168 registers),
 # so RCCL's all-gather kernel of frame k gets its workgroups placed only where a render workgroup has left -- while the NEXT frame's grid (the other
-# render stream) is waiting for the same CUs: the exchange of frame k may complete as late as during the march of frame k + 2 or k + 3.  ``buffers(k)``
-# makes the march of frame k wait for the reorder of frame k - depth, so four buffers leave the render streams three frames of slack (1.3 MB + 10 MB each).
-PIPELINE_DEPTH = 4
+# render stream) is waiting for the same CUs: the exchange of frame k may complete during the march of frame k + 2 or k + 3.  ``buffers(k)`` makes the
+# march of frame k wait for the reorder of frame k - depth.  Measured with a stand-in exchange kernel that holds CUs (profiles/r06_exchange_contention.txt):
+# three buffers -- tuned beside a free local-copy exchange -- lose 8-24 % once the exchange holds CUs for 150-400 us, four or six do not; on eight hardware
+# queues (GPU_MAX_HW_QUEUES=8, see ``render_streams``) six are never worse than four and 2.5 % better beside a short exchange.  11.5 MB per buffer pair.
+PIPELINE_DEPTH = 6
 
 
 def render_streams(device, n: int = 2):
@@ -55,7 +57,11 @@ def render_streams(device, n: int = 2):
     A render launch is a persistent grid of one workgroup per CU; on ONE stream frame k + 1 starts when the last wave of frame k has ended, so
     every frame pays the launch's tail (wave slots idle while the last tiles finish) and the launch gap.  On two streams the next frame's
     workgroups start on the CUs the previous frame has left: one rank's 80 000-ray shard of eight 0.658 -> 0.627 ms per pipelined step
-    (profiles/r06_two_streams.txt).  A field handle supports overlapping launches (one tile-queue slot per launch, 256 in flight)."""
+    (profiles/r06_two_streams.txt).  A field handle supports overlapping launches (one tile-queue slot per launch, 256 in flight).
+    The pipeline's five streams (these two, RCCL's, the reorder's, the caller's) need hardware queues of their own: the HIP runtime maps a process's streams
+    onto FOUR unless GPU_MAX_HW_QUEUES says otherwise (read when the runtime starts), and two streams that share a queue run one behind the other -- one
+    rank's pipelined step beside an exchange that holds CUs: 0.64-0.69 ms on four queues, 0.61-0.65 on eight (profiles/r06_exchange_contention.txt).
+    Set GPU_MAX_HW_QUEUES=8 in the environment of a multi-GPU job (bench.py does)."""
     cur = torch.cuda.current_stream(device)
     out = [torch.cuda.Stream(device) for _ in range(n)]
     for s in out:

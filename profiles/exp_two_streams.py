@@ -27,7 +27,7 @@ frame = torch.from_numpy(synth.lookat_rays(800, 800)).cuda().view(800, 800, 6)
 rows = ndist.interleaved_rows(800, WORLD, 0, 10)
 rays = torch.cat([frame[a:b] for a, b in rows]).reshape(-1, 6).contiguous()
 per = rays.shape[0]
-DEPTH = 3          # as bench.py: PipelinedGather(depth=3)
+DEPTH = int(os.environ.get("DEPTH", ndist.PIPELINE_DEPTH))          # as bench.py: PipelinedGather(depth=ndist.PIPELINE_DEPTH)
 pipe = ndist.PipelinedGather(per, 1, dev, depth=DEPTH)
 side = torch.cuda.Stream(dev)
 rstreams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]

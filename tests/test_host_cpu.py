@@ -133,7 +133,7 @@ def test_sharded_render_world2_gloo(tmp_path):
 def _worker_rows(rank, world, port, tmp):
     """The bench's data path at world 4 / 8 without a device: every rank fills its interleaved 10-row blocks of an 800 x 800 frame with
     a value that encodes (row, column), the exchange is PipelinedGather's double-buffered all_gather (gloo), and the re-ordered frames
-    must be the row-major frame -- for six frames in flight, i.e. every buffer of the pipeline is reused (depth ndist.PIPELINE_DEPTH = what bench.py runs since its frames
+    must be the row-major frame -- for depth + 2 frames in flight, i.e. every buffer of the pipeline is reused (depth ndist.PIPELINE_DEPTH = what bench.py runs since its frames
     alternate between two render streams, depth 2 = the class default)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
@@ -155,12 +155,13 @@ def _worker_rows(rank, world, port, tmp):
         o_rgb.copy_(torch.stack([base, base + 0.25, base + 0.5], 1) + 1000000.0 * k)
         o_depth.copy_(base + 0.75 + 1000000.0 * k)
 
-    for k in range(6):
+    nfr = len(pipe.send) + 2
+    for k in range(nfr):
         fill(k)
         pipe.submit(k)
         if k > 0:
             got.append(pipe.frame_in_image_order(k - 1, H, W, blk))          # what bench.py calls per step
-    got.append(ndist.deinterleave(*pipe.frame(5), H, W, world, blk))          # and the two-step form: the same frame
+    got.append(ndist.deinterleave(*pipe.frame(nfr - 1), H, W, world, blk))          # and the two-step form: the same frame
     pix = torch.arange(H * W, dtype=torch.float32)
     for k, (g_rgb, g_depth) in enumerate(got):
         ok = ok and torch.equal(g_rgb[:, 0], pix + 1000000.0 * k) and torch.equal(g_rgb[:, 2], pix + 0.5 + 1000000.0 * k)
