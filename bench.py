@@ -32,9 +32,12 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
 # The N > 1 pipeline keeps five streams busy (two render streams, RCCL's, the reorder's, the caller's); the HIP runtime maps a process's streams onto FOUR
 # hardware queues unless told otherwise, and two streams that share a queue run one behind the other: beside an exchange that holds CUs one rank's pipelined
-# step is 0.637 / 0.640 / 0.653 / 0.688 ms on four queues and 0.611 / 0.625 / 0.614 / 0.650 ms on eight (profiles/r06_exchange_contention.txt, section 7).
-# Read when the runtime starts, so it is set before torch is imported; the single-stream N = 1 frame does not change.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# step is 0.637 / 0.640 / 0.653 / 0.688 ms on four queues and 0.611 / 0.609 / 0.616 / 0.650 ms on eight (profiles/r06_exchange_contention.txt, sections 7-9).
+# Read when the runtime starts, so it is set before torch is imported -- for the ranks of an N > 1 job only (the launcher's WORLD_SIZE is in the environment by
+# then): the single-stream N = 1 frame and its extras stay on the runtime's default (measured indifferent: 148.4-148.6 Mray/s, training step 1.15 ms either way).
+# The gain is not the same on every box / run (one of four runs showed none at 32 x 400 us); it was never a loss for two render streams and four or more buffers.
+if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 or os.environ.get("NGF_BENCH_FORCE_DIST") == "1" or os.environ.get("NGF_BENCH_SELF_LAUNCHED") == "1":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -641,7 +644,7 @@ def main():
                                           "what": "untimed render launches between the W warm-up steps and the timed region (GPU clocks ramp 25-30 ms after idle)"}
     if dist_on:
         result["config"]["rccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
-        result["config"]["hip_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
+        result["config"]["hip_hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)")
     if BACKEND != "nccl" or ONE_DEVICE:
         result["config"]["test_backend"] = f"{BACKEND}, {'all ranks on one GPU' if ONE_DEVICE else 'one GPU per rank'}: a test of the N > 1 path, not a measurement"
     if dist_on:

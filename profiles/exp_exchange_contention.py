@@ -18,6 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
+if os.environ.get("LATE_QUEUES"):          # does the HIP runtime still read GPU_MAX_HW_QUEUES after torch has been imported (before the first torch.cuda call)?
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ["LATE_QUEUES"]
 import ngf_amd  # noqa: F401
 from ngf_amd import cases, dist as ndist, synth
 
@@ -139,6 +141,10 @@ if os.environ.get("CAPPED"):
                 res[(c, w)].append(run(100, w[0], w[1], "high", c[1], nstreams=c[0]))
     for c in cfgs:
         print(f"{c[0]} render stream(s), depth {c[1]}: " + "   ".join(f"{w[0]:2d} x {w[1]:4d} us {np.median([r[0] for r in res[(c, w)]]):.4f}" for w in loads), flush=True)
+    sys.exit(0)
+if os.environ.get("QUICK"):
+    rs = [run(100, 32, 400, "high", 4) for _ in range(5)]
+    print(f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')} (late: {os.environ.get('LATE_QUEUES')}): two streams, depth 4, 32 x 400 us: {np.median([r[0] for r in rs]):.4f} ms per step", flush=True)
     sys.exit(0)
 for depth in (4, 3, 2):
     for wgs, us in ((0, 0), (16, 50), (16, 150), (32, 50), (32, 150), (64, 150), (32, 400)):
