@@ -199,3 +199,23 @@ def test_timed_region_issues_the_same_collectives_on_every_rank(tmp_path):
     assert all(r.startswith("1 ") for r in res), res
     pre = [eval(r.split("counts=")[1].split(" elapsed")[0]) for r in res]
     assert pre[0][0][1] != pre[0][1][1], "the test meant the ranks to run different numbers of preamble launches"
+
+
+def test_environment_defaults_are_set_before_the_runtime_starts():
+    """bench.py fixes three switches BEFORE torch is imported (the HIP runtime / RCCL read them when they start): dmabuf IPC handles, RCCL's channel cap,
+    and -- for the ranks of an N > 1 job only -- eight HIP hardware queues (the pipeline's five streams must not share one: profiles/r06_exchange_contention.txt).
+    A value the launcher set wins."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.argv = ['bench.py']; import importlib.util as u; s = u.spec_from_file_location('bench_env', %r); m = u.module_from_spec(s); s.loader.exec_module(m); "
+            "print(os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'), os.environ.get('NCCL_MAX_NCHANNELS'), os.environ.get('GPU_MAX_HW_QUEUES'))" % os.path.join(ROOT, "bench.py"))
+
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "GPU_MAX_HW_QUEUES", "NCCL_MAX_NCHANNELS", "HSA_ENABLE_IPC_MODE_LEGACY", "NGF_BENCH_FORCE_DIST", "NGF_BENCH_SELF_LAUNCHED")}
+        e.update(env)
+        return subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300).stdout.split()
+
+    assert run() == ["0", "8", "None"]                                        # N = 1: the runtime's default queue count
+    assert run(WORLD_SIZE="8") == ["0", "8", "8"]                             # a rank of an 8-GPU job
+    assert run(NGF_BENCH_SELF_LAUNCHED="1", WORLD_SIZE="1") == ["0", "8", "8"]
+    assert run(WORLD_SIZE="8", GPU_MAX_HW_QUEUES="4", NCCL_MAX_NCHANNELS="16") == ["0", "16", "4"]      # the launcher's values win
