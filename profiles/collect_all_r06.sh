@@ -46,6 +46,11 @@ if [ "$1" != quick ]; then
   # one render stream against two alternating ones (what bench.py runs at N > 1), 80 000-ray shards and whole frames; tail knob under both
   (TAILS=8,12,16,24 timeout 600 python profiles/exp_two_streams.py; SHARDS=1 timeout 600 python profiles/exp_two_streams.py) 2>&1 | grep -v "amdgpu.ids\|socket\|version\|Hostname\|Librccl" > gpurun_out/r06_two_streams.txt
 fi
+if [ "$1" != quick ]; then
+  # an exchange kernel that NEEDS CUs behind every frame (stand-in for RCCL's all-gather on a real node), four against eight hardware queues
+  [ -f profiles/micro/libcu_holder.so ] || hipcc --offload-arch=gfx950 -O2 -shared -fPIC -o profiles/micro/libcu_holder.so profiles/micro/cu_holder.hip
+  for q in 4 8; do echo "GPU_MAX_HW_QUEUES=$q"; GPU_MAX_HW_QUEUES=$q STREAMS=1 timeout 300 python profiles/exp_exchange_contention.py 2>&1 | grep -v amdgpu.ids; done > gpurun_out/r06_exchange_contention_streams.txt
+fi
 python profiles/exp_autograd_loop.py both 20 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_autograd_loop.txt
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/r06_pytest_gpu.txt
 ls gpurun_out | grep r06_ | head -100
